@@ -1,0 +1,685 @@
+// engine.hip -- gscan context: streams, pinned/HBM buffers, double-buffered chunk
+// pipeline, device-resident batch scans, and the C ABI of include/gscan.h.
+//
+// Data flow of the host-chunk path (what FileGrep::find drives, replacing the
+// mmap -> pcre_exec loop of /root/reference/src/grab.cc:154-215):
+//
+//   read(2) into slot.pinned ──copy stream: hipMemcpyAsync──► slot.d_text (HBM)
+//        event `copied` ──compute stream waits──► scan kernel ──► d_recs/d_desc/d_counter
+//        ──compute stream: async D2H of counter + descriptors + first records──► event `done`
+//   gscan_wait: sync `done`, fetch the rest if needed, stitch runs in tile order.
+//
+// With GSCAN_SLOTS = 2 the copy of chunk k+1 overlaps the scan and report of chunk k.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "scan_args.h"
+
+
+using gscan::Database;
+using gscan::DevProgram;
+using gscan::ScanArgs;
+
+struct gscan_db {
+    Database db;
+};
+
+namespace {
+
+constexpr size_t kPad = 4096;          // slack behind every text buffer
+constexpr size_t kSpecRecs = 16384;    // records fetched speculatively with the header
+constexpr size_t kCopyPiece = 32u << 20; // memcpy/H2D pipelining granule for foreign host buffers
+constexpr size_t kMaxChunk = (1ull << 30) + 4096;
+
+enum SlotState { FREE = 0, ACQUIRED, INFLIGHT };
+
+struct Meta { // per-slot launch metadata, lives in pinned memory, copied as one block
+    gscan_seg seg;
+    uint32_t tile_first[2];
+};
+
+struct Slot {
+    SlotState state = FREE;
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+    uint8_t *d_text = nullptr;
+    size_t d_text_cap = 0;
+    uint32_t *d_recs = nullptr;
+    size_t rec_cap = 0;
+    unsigned long long *d_desc = nullptr;
+    uint32_t *d_tile_seg = nullptr; // all zero: one segment
+    size_t tiles_cap = 0;
+    uint32_t *d_counter = nullptr;
+    Meta *h_meta = nullptr; // pinned
+    Meta *d_meta = nullptr;
+    uint32_t *h_counter = nullptr;        // pinned, 2 words
+    unsigned long long *h_desc = nullptr; // pinned
+    size_t h_desc_cap = 0;
+    uint32_t *h_spec = nullptr; // pinned, kSpecRecs
+    std::vector<uint32_t> raw, sorted;
+    hipEvent_t copied = nullptr, done = nullptr;
+    uint64_t tag = 0;
+    size_t len = 0;
+    uint32_t n_tiles = 0;
+    const gscan_db *db = nullptr;
+    uint64_t seq = 0;
+};
+
+struct EvPair {
+    hipEvent_t a, b;
+};
+
+} // namespace
+
+struct gscan_ctx {
+    int device = 0;
+    int cus = 256;
+    size_t max_chunk = 0;
+    hipStream_t copy = nullptr, compute = nullptr;
+    Slot slot[GSCAN_SLOTS];
+    uint64_t next_seq = 1;
+    std::string err;
+    // compiled program on the device
+    DevProgram *d_prog = nullptr;
+    DevProgram *h_prog = nullptr; // pinned staging
+    uint64_t prog_id = 0;
+    // options
+    int variant = 0;
+    int blocks_per_cu = 8;
+    // device-resident path
+    size_t dev_cap_req = 0;
+    uint32_t *dv_recs = nullptr;
+    size_t dv_rec_cap = 0;
+    unsigned long long *dv_desc = nullptr;
+    uint32_t *dv_tile_seg = nullptr, *dv_tile_first = nullptr;
+    gscan_seg *dv_segs = nullptr;
+    size_t dv_tiles_cap = 0, dv_segs_cap = 0;
+    uint32_t *dv_counter = nullptr;
+    std::vector<gscan_seg> dv_last_segs;
+    std::vector<uint32_t> dv_tile_first_h;
+    uint32_t dv_last_tile_bytes = 0;
+    hipStream_t dv_stream = nullptr;
+    // kernel timing
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(gscan_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) return fail((c), GSCAN_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure_prog(gscan_ctx *c, const gscan_db *db, hipStream_t st)
+{
+    if (c->prog_id == db->db.id) return 0;
+    // The staging copy is overwritten: every earlier upload must have left it.  Uploads are
+    // rare (one per pattern), so a stream sync here costs nothing measurable.
+    HIPCHK(c, hipStreamSynchronize(c->compute));
+    if (c->dv_stream && c->dv_stream != c->compute) HIPCHK(c, hipStreamSynchronize(c->dv_stream));
+    memcpy(c->h_prog, &db->db.prog, sizeof(DevProgram));
+    HIPCHK(c, hipMemcpyAsync(c->d_prog, c->h_prog, sizeof(DevProgram), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->prog_id = db->db.id;
+    return 0;
+}
+
+uint32_t grid_for(const gscan_ctx *c, uint32_t n_tiles)
+{
+    if (c->blocks_per_cu <= 0) return n_tiles;
+    uint64_t g = (uint64_t)c->cus * (uint64_t)c->blocks_per_cu;
+    return (uint32_t)std::min<uint64_t>(g, n_tiles);
+}
+
+int slot_reserve(gscan_ctx *c, Slot &s, size_t len)
+{
+    if (len > s.pinned_cap) {
+        if (s.pinned) hipHostFree(s.pinned);
+        s.pinned = nullptr;
+        s.pinned_cap = 0;
+        size_t cap = std::max<size_t>((len + kPad + 0xfffff) & ~(size_t)0xfffff, 1u << 20);
+        HIPCHK(c, hipHostMalloc(&s.pinned, cap, hipHostMallocDefault));
+        s.pinned_cap = cap - kPad;
+    }
+    if (len > s.d_text_cap) {
+        if (s.d_text) hipFree(s.d_text);
+        s.d_text = nullptr;
+        s.d_text_cap = 0;
+        size_t cap = std::max<size_t>((len + kPad + 0xfffff) & ~(size_t)0xfffff, 1u << 20);
+        HIPCHK(c, hipMalloc((void **)&s.d_text, cap));
+        s.d_text_cap = cap - kPad;
+    }
+    // tiles at the smallest tile size any variant uses
+    size_t tiles = len / gscan::scan_tile_bytes(2) + 2;
+    if (tiles > s.tiles_cap) {
+        if (s.d_desc) hipFree(s.d_desc);
+        if (s.d_tile_seg) hipFree(s.d_tile_seg);
+        if (s.h_desc) hipHostFree(s.h_desc);
+        s.d_desc = nullptr;
+        s.d_tile_seg = nullptr;
+        s.h_desc = nullptr;
+        s.tiles_cap = 0;
+        size_t cap = tiles + tiles / 4;
+        HIPCHK(c, hipMalloc((void **)&s.d_desc, cap * 8));
+        HIPCHK(c, hipMalloc((void **)&s.d_tile_seg, cap * 4));
+        HIPCHK(c, hipMemset(s.d_tile_seg, 0, cap * 4));
+        HIPCHK(c, hipHostMalloc((void **)&s.h_desc, cap * 8, hipHostMallocDefault));
+        s.tiles_cap = cap;
+    }
+    size_t want = std::max<size_t>(len / 64, kSpecRecs);
+    if (want > s.rec_cap) {
+        if (s.d_recs) hipFree(s.d_recs);
+        s.d_recs = nullptr;
+        s.rec_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&s.d_recs, want * 4));
+        s.rec_cap = want;
+    }
+    return 0;
+}
+
+int slot_launch(gscan_ctx *c, Slot &s)
+{
+    const Database &db = s.db->db;
+    const uint32_t tile_bytes = gscan::scan_tile_bytes(c->variant);
+    s.n_tiles = (uint32_t)((s.len + tile_bytes - 1) / tile_bytes);
+    s.h_meta->seg.offset = 0;
+    s.h_meta->seg.len = (uint32_t)s.len;
+    s.h_meta->seg._pad = 0;
+    s.h_meta->tile_first[0] = 0;
+    s.h_meta->tile_first[1] = s.n_tiles;
+    HIPCHK(c, hipMemcpyAsync(s.d_meta, s.h_meta, sizeof(Meta), hipMemcpyHostToDevice, c->compute));
+    HIPCHK(c, hipMemsetAsync(s.d_counter, 0, 8, c->compute));
+    ScanArgs a;
+    a.base = s.d_text;
+    a.segs = &s.d_meta->seg;
+    a.tile_first = s.d_meta->tile_first;
+    a.tile_seg = s.d_tile_seg;
+    a.n_tiles = s.n_tiles;
+    a.cap = (uint32_t)std::min<size_t>(s.rec_cap, 0xffffffffu);
+    a.recs = s.d_recs;
+    a.desc = s.d_desc;
+    a.counter = s.d_counter;
+    a.prog = c->d_prog;
+    if (s.n_tiles) HIPCHK(c, gscan::launch_scan(db.tier, c->variant, db.prog.m, a, grid_for(c, s.n_tiles), c->compute));
+    HIPCHK(c, hipMemcpyAsync(s.h_counter, s.d_counter, 8, hipMemcpyDeviceToHost, c->compute));
+    if (s.n_tiles)
+        HIPCHK(c, hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)s.n_tiles * 8, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(c, hipMemcpyAsync(s.h_spec, s.d_recs, kSpecRecs * 4, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(c, hipEventRecord(s.done, c->compute));
+    return 0;
+}
+
+void free_slot(Slot &s)
+{
+    if (s.pinned) hipHostFree(s.pinned);
+    if (s.d_text) hipFree(s.d_text);
+    if (s.d_recs) hipFree(s.d_recs);
+    if (s.d_desc) hipFree(s.d_desc);
+    if (s.d_tile_seg) hipFree(s.d_tile_seg);
+    if (s.d_counter) hipFree(s.d_counter);
+    if (s.d_meta) hipFree(s.d_meta);
+    if (s.h_meta) hipHostFree(s.h_meta);
+    if (s.h_counter) hipHostFree(s.h_counter);
+    if (s.h_desc) hipHostFree(s.h_desc);
+    if (s.h_spec) hipHostFree(s.h_spec);
+    if (s.copied) hipEventDestroy(s.copied);
+    if (s.done) hipEventDestroy(s.done);
+    s = Slot();
+}
+
+} // namespace
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" {
+
+int gscan_compile(const char *pat, size_t len, unsigned flags, gscan_db **out, int *minlen, char *err,
+                  size_t errcap)
+{
+    if (!pat || !out) return GSCAN_EINVAL;
+    gscan_db *d = new (std::nothrow) gscan_db();
+    if (!d) return GSCAN_ENOMEM;
+    std::string why;
+    int rc = gscan::compile_pattern(pat, len, flags, d->db, why);
+    if (rc != 0) {
+        if (err && errcap) snprintf(err, errcap, "%s", why.c_str());
+        delete d;
+        *out = nullptr;
+        return rc < 0 ? GSCAN_EINVAL : GSCAN_UNSUPPORTED;
+    }
+    if (minlen) *minlen = d->db.minlen;
+    *out = d;
+    return GSCAN_OK;
+}
+
+void gscan_free(gscan_db *db) { delete db; }
+
+int gscan_db_info(const gscan_db *db, gscan_info *info)
+{
+    if (!db || !info) return GSCAN_EINVAL;
+    const Database &d = db->db;
+    info->tier = d.tier;
+    info->minlen = d.minlen;
+    info->n_classes = (int)d.classes.size();
+    info->has_tail = d.has_tail;
+    info->tail_extra = d.tail_extra;
+    info->anchor_off = (int)d.prog.anchor_off;
+    info->anchor_len = (int)d.prog.anchor_len;
+    info->is_literal = (int)d.prog.is_literal;
+    return GSCAN_OK;
+}
+
+int gscan_db_class(const gscan_db *db, int pos, uint8_t table[256])
+{
+    if (!db || !table) return GSCAN_EINVAL;
+    const Database &d = db->db;
+    const gscan::ByteSet *s = nullptr;
+    if (pos == -1) {
+        if (!d.has_tail) return GSCAN_EINVAL;
+        s = &d.tail;
+    } else {
+        if (pos < 0 || (size_t)pos >= d.window.size()) return GSCAN_EINVAL;
+        s = &d.classes[d.window[(size_t)pos]];
+    }
+    for (int b = 0; b < 256; b++) table[b] = s->test((unsigned)b);
+    return GSCAN_OK;
+}
+
+uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, uint32_t start)
+{
+    const Database &d = db->db;
+    size_t e = (size_t)start + (size_t)(d.minlen > 0 ? d.minlen : 0);
+    if (d.has_tail) {
+        const uint8_t *t = (const uint8_t *)content;
+        uint64_t extra = 0;
+        while (e < clen && extra < (uint64_t)d.tail_extra && d.tail.test(t[e])) {
+            e++;
+            extra++;
+        }
+    }
+    return (uint32_t)e;
+}
+
+int gscan_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
+{
+    if (!out) return GSCAN_EINVAL;
+    *out = nullptr;
+    if (max_chunk == 0 || max_chunk > kMaxChunk) return GSCAN_ETOOBIG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GSCAN_EHIP; // no device: there is no CPU path
+    if (hip_device < 0 || hip_device >= n) return GSCAN_EINVAL;
+    gscan_ctx *c = new (std::nothrow) gscan_ctx();
+    if (!c) return GSCAN_ENOMEM;
+    c->device = hip_device;
+    c->max_chunk = max_chunk;
+    auto bail = [&](int rc) {
+        gscan_close(c);
+        return rc;
+    };
+    if (hipSetDevice(hip_device) != hipSuccess) return bail(GSCAN_EHIP);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess) c->cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
+    if (hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
+    if (hipMalloc((void **)&c->d_prog, sizeof(DevProgram)) != hipSuccess) return bail(GSCAN_EHIP);
+    if (hipHostMalloc((void **)&c->h_prog, sizeof(DevProgram), hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
+    for (Slot &s : c->slot) {
+        if (hipMalloc((void **)&s.d_counter, 8) != hipSuccess) return bail(GSCAN_EHIP);
+        if (hipMalloc((void **)&s.d_meta, sizeof(Meta)) != hipSuccess) return bail(GSCAN_EHIP);
+        if (hipHostMalloc((void **)&s.h_meta, sizeof(Meta), hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
+        if (hipHostMalloc((void **)&s.h_counter, 8, hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
+        if (hipHostMalloc((void **)&s.h_spec, kSpecRecs * 4, hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
+        if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
+        if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
+    }
+    if (hipMalloc((void **)&c->dv_counter, 8) != hipSuccess) return bail(GSCAN_EHIP);
+    *out = c;
+    return GSCAN_OK;
+}
+
+void gscan_close(gscan_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (Slot &s : c->slot) free_slot(s);
+    if (c->d_prog) hipFree(c->d_prog);
+    if (c->h_prog) hipHostFree(c->h_prog);
+    if (c->dv_recs) hipFree(c->dv_recs);
+    if (c->dv_desc) hipFree(c->dv_desc);
+    if (c->dv_tile_seg) hipFree(c->dv_tile_seg);
+    if (c->dv_tile_first) hipFree(c->dv_tile_first);
+    if (c->dv_segs) hipFree(c->dv_segs);
+    if (c->dv_counter) hipFree(c->dv_counter);
+    for (auto &e : c->ev_pool) {
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    if (c->copy) hipStreamDestroy(c->copy);
+    if (c->compute) hipStreamDestroy(c->compute);
+    delete c;
+}
+
+const char *gscan_strerror(const gscan_ctx *c) { return c ? c->err.c_str() : "no context"; }
+
+int gscan_acquire(gscan_ctx *c, size_t len, void **pinned)
+{
+    if (!c || !pinned) return GSCAN_EINVAL;
+    if (len > c->max_chunk) return fail(c, GSCAN_ETOOBIG, "chunk of %zu bytes exceeds max_chunk %zu", len, c->max_chunk);
+    HIPCHK(c, hipSetDevice(c->device));
+    for (Slot &s : c->slot)
+        if (s.state == ACQUIRED) { // re-acquire: same slot
+            int rc = slot_reserve(c, s, len);
+            if (rc) return rc;
+            *pinned = s.pinned;
+            return GSCAN_OK;
+        }
+    for (Slot &s : c->slot)
+        if (s.state == FREE) {
+            int rc = slot_reserve(c, s, len);
+            if (rc) return rc;
+            s.state = ACQUIRED;
+            *pinned = s.pinned;
+            return GSCAN_OK;
+        }
+    return fail(c, GSCAN_EBUSY, "all %d slots in flight", GSCAN_SLOTS);
+}
+
+int gscan_submit(gscan_ctx *c, const gscan_db *db, const void *host_bytes, size_t len, uint64_t tag)
+{
+    if (!c || !db || (!host_bytes && len)) return GSCAN_EINVAL;
+    if (db->db.tier == GSCAN_TIER_NULL) return fail(c, GSCAN_EINVAL, "a pattern that can match the empty string scans nothing");
+    if (len > c->max_chunk) return fail(c, GSCAN_ETOOBIG, "chunk of %zu bytes exceeds max_chunk %zu", len, c->max_chunk);
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot *s = nullptr;
+    for (Slot &x : c->slot)
+        if (x.state == ACQUIRED) s = &x;
+    if (!s) {
+        void *p;
+        int rc = gscan_acquire(c, len, &p);
+        if (rc) return rc;
+        for (Slot &x : c->slot)
+            if (x.state == ACQUIRED) s = &x;
+    } else if (len > s->pinned_cap) {
+        return fail(c, GSCAN_EINVAL, "submitted %zu bytes into a slot acquired for %zu", len, s->pinned_cap);
+    }
+    int rc = ensure_prog(c, db, c->compute);
+    if (rc) return rc;
+    if (host_bytes == s->pinned) {
+        if (len) HIPCHK(c, hipMemcpyAsync(s->d_text, s->pinned, len, hipMemcpyHostToDevice, c->copy));
+    } else {
+        rc = slot_reserve(c, *s, len);
+        if (rc) return rc;
+        for (size_t o = 0; o < len; o += kCopyPiece) { // memcpy of piece i+1 overlaps the DMA of piece i
+            size_t n = std::min(kCopyPiece, len - o);
+            memcpy((char *)s->pinned + o, (const char *)host_bytes + o, n);
+            HIPCHK(c, hipMemcpyAsync(s->d_text + o, (char *)s->pinned + o, n, hipMemcpyHostToDevice, c->copy));
+        }
+    }
+    HIPCHK(c, hipEventRecord(s->copied, c->copy));
+    HIPCHK(c, hipStreamWaitEvent(c->compute, s->copied, 0));
+    s->db = db;
+    s->len = len;
+    s->tag = tag;
+    s->seq = c->next_seq++;
+    rc = slot_launch(c, *s);
+    if (rc) return rc;
+    s->state = INFLIGHT;
+    return GSCAN_OK;
+}
+
+int gscan_wait(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, size_t *n, const void **content)
+{
+    if (!c || !starts || !n) return GSCAN_EINVAL;
+    Slot *s = nullptr;
+    for (Slot &x : c->slot)
+        if (x.state == INFLIGHT && (!s || x.seq < s->seq)) s = &x;
+    if (!s) return fail(c, GSCAN_EEMPTY, "nothing in flight");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(s->done));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        uint32_t total = s->h_counter[0];
+        bool overflow = s->h_counter[1] != 0;
+        if (!overflow) break;
+        if (attempt == 1) return fail(c, GSCAN_EHIP, "record buffer overflow persisted after regrow");
+        // the text is still in HBM: grow the record buffer to what the kernel asked for and rescan
+        size_t want = (size_t)total + (size_t)total / 8 + 1024;
+        HIPCHK(c, hipStreamSynchronize(c->compute));
+        if (s->d_recs) hipFree(s->d_recs);
+        s->d_recs = nullptr;
+        s->rec_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&s->d_recs, want * 4));
+        s->rec_cap = want;
+        int rc = slot_launch(c, *s);
+        if (rc) return rc;
+        HIPCHK(c, hipEventSynchronize(s->done));
+    }
+    const uint32_t total = s->h_counter[0];
+    const uint32_t *recs = s->h_spec;
+    if (total > kSpecRecs) {
+        s->raw.resize(total);
+        HIPCHK(c, hipMemcpy(s->raw.data(), s->d_recs, (size_t)total * 4, hipMemcpyDeviceToHost));
+        recs = s->raw.data();
+    }
+    s->sorted.clear();
+    s->sorted.reserve(total);
+    for (uint32_t t = 0; t < s->n_tiles; t++) { // tiles are in text order: concatenating their runs sorts the list
+        unsigned long long d = s->h_desc[t];
+        uint32_t cnt = (uint32_t)d, base = (uint32_t)(d >> 32);
+        if (cnt) s->sorted.insert(s->sorted.end(), recs + base, recs + base + cnt);
+    }
+    if (s->sorted.size() != total) return fail(c, GSCAN_EHIP, "descriptor total %zu != counter %u", s->sorted.size(), total);
+    if (tag) *tag = s->tag;
+    *starts = s->sorted.data();
+    *n = s->sorted.size();
+    if (content) *content = s->pinned;
+    s->state = FREE;
+    return GSCAN_OK;
+}
+
+int gscan_set_capacity(gscan_ctx *c, size_t n_records)
+{
+    if (!c) return GSCAN_EINVAL;
+    c->dev_cap_req = n_records;
+    return GSCAN_OK;
+}
+
+int gscan_set_option(gscan_ctx *c, const char *name, long value)
+{
+    if (!c || !name) return GSCAN_EINVAL;
+    if (!strcmp(name, "variant")) {
+        if (value < 0 || value > 7 || (value & 3) == 3) return GSCAN_EINVAL;
+        c->variant = (int)value;
+        return GSCAN_OK;
+    }
+    if (!strcmp(name, "blocks_per_cu")) {
+        if (value < 0 || value > 64) return GSCAN_EINVAL;
+        c->blocks_per_cu = (int)value;
+        return GSCAN_OK;
+    }
+    return GSCAN_EINVAL;
+}
+
+int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, const gscan_seg *segs, size_t nseg,
+                      void *stream, gscan_dev_result *res)
+{
+    if (!c || !db || !res || (!segs && nseg)) return GSCAN_EINVAL;
+    if (db->db.tier == GSCAN_TIER_NULL) return fail(c, GSCAN_EINVAL, "a pattern that can match the empty string scans nothing");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->compute;
+    c->dv_stream = st;
+    int rc = ensure_prog(c, db, st);
+    if (rc) return rc;
+    const uint32_t tile_bytes = gscan::scan_tile_bytes(c->variant);
+
+    // tile map: rebuilt only when the segment table or the tile size changed
+    bool same = c->dv_last_tile_bytes == tile_bytes && c->dv_last_segs.size() == nseg &&
+                (nseg == 0 || !memcmp(c->dv_last_segs.data(), segs, nseg * sizeof(gscan_seg)));
+    if (!same) {
+        std::vector<uint32_t> &tf = c->dv_tile_first_h;
+        tf.assign(nseg + 1, 0);
+        uint64_t total_bytes = 0, nt = 0;
+        for (size_t i = 0; i < nseg; i++) {
+            if (segs[i].len > kMaxChunk) return fail(c, GSCAN_ETOOBIG, "segment %zu longer than a chunk", i);
+            if (segs[i].offset & 15) return fail(c, GSCAN_EINVAL, "segment %zu is not 16-byte aligned", i);
+            tf[i] = (uint32_t)nt;
+            nt += (segs[i].len + tile_bytes - 1) / tile_bytes;
+            total_bytes += segs[i].len;
+        }
+        if (nt >= 0xffffffffull) return fail(c, GSCAN_ETOOBIG, "too many tiles");
+        tf[nseg] = (uint32_t)nt;
+        std::vector<uint32_t> ts((size_t)nt);
+        for (size_t i = 0; i < nseg; i++) std::fill(ts.begin() + tf[i], ts.begin() + tf[i + 1], (uint32_t)i);
+        HIPCHK(c, hipStreamSynchronize(st)); // earlier scans may still read the old tables
+        if (nt + 1 > c->dv_tiles_cap) {
+            if (c->dv_desc) hipFree(c->dv_desc);
+            if (c->dv_tile_seg) hipFree(c->dv_tile_seg);
+            c->dv_desc = nullptr;
+            c->dv_tile_seg = nullptr;
+            c->dv_tiles_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->dv_desc, (size_t)(nt + 1) * 8));
+            HIPCHK(c, hipMalloc((void **)&c->dv_tile_seg, (size_t)(nt + 1) * 4));
+            c->dv_tiles_cap = (size_t)nt + 1;
+        }
+        if (nseg + 1 > c->dv_segs_cap) {
+            if (c->dv_segs) hipFree(c->dv_segs);
+            if (c->dv_tile_first) hipFree(c->dv_tile_first);
+            c->dv_segs = nullptr;
+            c->dv_tile_first = nullptr;
+            c->dv_segs_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->dv_segs, (nseg + 1) * sizeof(gscan_seg)));
+            HIPCHK(c, hipMalloc((void **)&c->dv_tile_first, (nseg + 1) * 4));
+            c->dv_segs_cap = nseg + 1;
+        }
+        if (nseg) HIPCHK(c, hipMemcpy(c->dv_segs, segs, nseg * sizeof(gscan_seg), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->dv_tile_first, tf.data(), (nseg + 1) * 4, hipMemcpyHostToDevice));
+        if (nt) HIPCHK(c, hipMemcpy(c->dv_tile_seg, ts.data(), (size_t)nt * 4, hipMemcpyHostToDevice));
+        c->dv_last_segs.assign(segs, segs + nseg);
+        c->dv_last_tile_bytes = tile_bytes;
+        size_t want = c->dev_cap_req ? c->dev_cap_req : std::max<size_t>((size_t)(total_bytes / 16), 1u << 16);
+        want = std::min<size_t>(want, 0xffffffffu);
+        if (want > c->dv_rec_cap || (c->dev_cap_req && want != c->dv_rec_cap)) {
+            if (c->dv_recs) hipFree(c->dv_recs);
+            c->dv_recs = nullptr;
+            c->dv_rec_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->dv_recs, want * 4));
+            c->dv_rec_cap = want;
+        }
+    }
+    const uint32_t n_tiles = c->dv_tile_first_h.empty() ? 0 : c->dv_tile_first_h.back();
+
+    HIPCHK(c, hipMemsetAsync(c->dv_counter, 0, 8, st));
+    ScanArgs a;
+    a.base = (const uint8_t *)dev_base;
+    a.segs = c->dv_segs;
+    a.tile_first = c->dv_tile_first;
+    a.tile_seg = c->dv_tile_seg;
+    a.n_tiles = n_tiles;
+    a.cap = (uint32_t)c->dv_rec_cap;
+    a.recs = c->dv_recs;
+    a.desc = c->dv_desc;
+    a.counter = c->dv_counter;
+    a.prog = c->d_prog;
+    if (c->ev_used == c->ev_pool.size() && c->ev_pool.size() < 4096) {
+        EvPair e;
+        HIPCHK(c, hipEventCreate(&e.a));
+        HIPCHK(c, hipEventCreate(&e.b));
+        c->ev_pool.push_back(e);
+    }
+    bool timed = c->ev_used < c->ev_pool.size();
+    if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used].a, st));
+    if (n_tiles) HIPCHK(c, gscan::launch_scan(db->db.tier, c->variant, db->db.prog.m, a, grid_for(c, n_tiles), st));
+    if (timed) {
+        HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used].b, st));
+        c->ev_used++;
+    }
+    res->recs = c->dv_recs;
+    res->desc = (const uint64_t *)c->dv_desc;
+    res->tile_seg = c->dv_tile_seg;
+    res->n_tiles = n_tiles;
+    res->tile_bytes = tile_bytes;
+    res->total = 0;
+    res->overflow = 0;
+    return GSCAN_OK;
+}
+
+int gscan_dev_sync(gscan_ctx *c, gscan_dev_result *res)
+{
+    if (!c || !res) return GSCAN_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->dv_stream ? c->dv_stream : c->compute;
+    uint32_t h[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(h, c->dv_counter, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    res->total = h[0];
+    res->overflow = h[1] != 0;
+    return GSCAN_OK;
+}
+
+long gscan_dev_fetch(gscan_ctx *c, const gscan_dev_result *res, size_t seg, uint32_t *out, size_t cap)
+{
+    if (!c || !res) return GSCAN_EINVAL;
+    if (seg + 1 >= c->dv_tile_first_h.size()) return fail(c, GSCAN_EINVAL, "segment index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->dv_stream ? c->dv_stream : c->compute;
+    HIPCHK(c, hipStreamSynchronize(st));
+    uint32_t t0 = c->dv_tile_first_h[seg], t1 = c->dv_tile_first_h[seg + 1];
+    std::vector<unsigned long long> d(t1 - t0);
+    if (t1 > t0) HIPCHK(c, hipMemcpy(d.data(), c->dv_desc + t0, (size_t)(t1 - t0) * 8, hipMemcpyDeviceToHost));
+    size_t n = 0;
+    for (unsigned long long v : d) {
+        uint32_t cnt = (uint32_t)v, base = (uint32_t)(v >> 32);
+        if (!cnt) continue;
+        if ((size_t)base + cnt > c->dv_rec_cap) return fail(c, GSCAN_EHIP, "record buffer overflowed; raise gscan_set_capacity");
+        if (out && n + cnt <= cap) HIPCHK(c, hipMemcpy(out + n, c->dv_recs + base, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        n += cnt;
+    }
+    return (long)n;
+}
+
+int gscan_kernel_time(gscan_ctx *c, double *sum_ms, uint64_t *launches, int reset)
+{
+    if (!c) return GSCAN_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    double sum = 0;
+    for (size_t i = 0; i < c->ev_used; i++) {
+        float ms = 0;
+        HIPCHK(c, hipEventSynchronize(c->ev_pool[i].b));
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b));
+        sum += ms;
+    }
+    if (sum_ms) *sum_ms = sum;
+    if (launches) *launches = c->ev_used;
+    if (reset) c->ev_used = 0;
+    return GSCAN_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,74 @@
+// filegrep.h -- host-side drop-in for the reference's FileGrep class.
+//
+// Public interface = the one /root/reference/src/grab.h:55-85 declares (what the CLI,
+// the nftw callback and the worker threads call): why / recurse / show_path / prepare /
+// config / find(path) / find(path, st, typeflag) / find_recursive, all returning 0 or
+// -1 with the reason in why().  Behind it the libpcre match loop is gone: prepare()
+// compiles the pattern for the gfx950 scan engine and opens a device context, find()
+// streams the file's chunks through HBM and prints from the engine's candidate list.
+// There is no CPU scanning path: prepare() fails if the pattern is outside the engine's
+// subset or no HIP device can be opened.
+#pragma once
+
+#include <sys/stat.h>
+#include <sys/types.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <string>
+
+#include "../../include/gscan.h"
+
+// Output switches of one scan, in the bit layout grab_report_chunk() takes.
+enum : unsigned {
+    GRAB_OFFSETS = 1u, // -O  "Match at offset N"
+    GRAB_NOLINE = 2u,  // -l  do not print the line
+    GRAB_SINGLE = 4u,  // -s  stop after the first match
+    GRAB_PREFIX = 8u,  // "path:" in front of every record (-r, or several paths)
+    GRAB_COLOR = 16u,  // -I  inverse video around the match
+};
+
+class FileGrep {
+public:
+    FileGrep();
+    ~FileGrep();
+    FileGrep(const FileGrep &) = delete;
+    FileGrep &operator=(const FileGrep &) = delete;
+
+    const char *why() { return err_.c_str(); }
+    void recurse() { recursive_ = true; }
+    void show_path(bool on) { show_path_ = on; }
+
+    // keys the reference understands (grab.cc:83-98): color noline offsets single low_mem
+    // chunk_size; extensions: literal (-S), device (HIP device index), out_fd
+    void config(const std::map<std::string, size_t> &kv);
+    int prepare(const std::string &regex);
+    int find(const std::string &path);
+    int find(const char *path, const struct stat *st, int typeflag);
+    int find_recursive(const std::string &path);
+
+    // engine knob pass-through (gscan_set_option) for A/B runs
+    int engine_option(const char *name, long value);
+
+private:
+    unsigned report_flags() const;
+    int read_chunk(int fd, void *dst, size_t len, off_t at);
+    void emit(std::string &text);
+
+    std::string err_;
+    int minlen_ = 1;               // PCRE_INFO_MINLENGTH of the pattern (grab.h:44)
+    size_t chunk_size_ = 1u << 30; // grab.h:48
+    bool offsets_ = false, noline_ = false, single_ = false, color_ = false, low_mem_ = false;
+    bool recursive_ = false, show_path_ = false, literal_ = false;
+    uid_t uid_;
+    int device_ = 0, out_fd_ = 1;
+    gscan_db *db_ = nullptr;   // replaces pcre *d_pcreh
+    gscan_ctx *ctx_ = nullptr; // replaces pcre_extra *d_extra (+ owns streams and buffers)
+};
+
+// What the reference prints for ONE chunk (grab.cc:171-213), driven by the engine's
+// ascending candidate list instead of repeated pcre_exec calls.  Pure host function.
+void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const char *path,
+                       const char *content, size_t clen, long long off, const uint32_t *starts,
+                       size_t nstarts, std::string &out);

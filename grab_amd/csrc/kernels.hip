@@ -1,0 +1,454 @@
+// kernels.hip -- gfx950 (MI355X / CDNA4) scan kernels.  Hand-written HIP, wave64.
+//
+// What they replace: the byte-stream work of pcre_exec over one chunk
+// (/root/reference/src/grab.cc:178), restated as "emit every offset p whose
+// minlen-byte window satisfies the pattern" (SURVEY.md Appendix C).
+//
+// Both kernels are HBM-bound byte-stream scans (no MFMA).  Shared structure:
+//   * work unit = TILE of WAVES*ITER KiB of one segment; a 256-thread workgroup
+//     (4 waves) takes a tile, each wave a contiguous ITER-KiB sub-tile;
+//   * every lane issues all its ITER+1 16-byte loads up front (global_load_dwordx4,
+//     lane i -> bytes [16i,16i+16) of each KiB: fully coalesced, each input byte is
+//     fetched from HBM exactly once; the +1 is a <=64-byte halo for windows that
+//     straddle the sub-tile end);
+//   * per KiB step each lane produces a 16-bit candidate mask for its 16 positions;
+//     masks stay in registers until the tile is done (2 steps per VGPR);
+//   * compaction: per-lane popcount -> wave reduce -> one LDS slot per wave -> ONE
+//     global atomicAdd per tile that has any candidate reserves a contiguous run in
+//     the record buffer; lanes then expand their masks in text order using a wave
+//     prefix sum, and the tile's descriptor {count, base} is written at desc[tile].
+//     Tiles are in text order, so walking desc[] yields ascending offsets with no
+//     sort and no second pass over the text.
+//
+// K1 (literal / anchored class sequence): SWAR compare of the 4-byte anchor at all
+//   16 byte alignments of the lane's data (v_alignbyte + xor + min3), ~2.3 VALU
+//   ops/byte; the rare anchor hit is verified against the whole window in a cold
+//   path.  No LDS in the hot loop.
+// K2 (class runs, <=4 classes, window <=49): LDS-staged byte->class-bits table,
+//   replicated once per LDS bank (32 KiB) so the 64 random lookups of a wave never
+//   conflict; 16 lookups/lane/step accumulate into two registers; neighbouring
+//   lanes' masks come in by DPP/bpermute; runs of n consecutive class bits are
+//   found by shift-AND doubling (log2 n steps) on 32- or 64-bit words.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scan_args.h"
+
+namespace gscan {
+
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWG = 256;
+constexpr int kWaves = kWG / kWave;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte load through a buffer descriptor: the hardware bounds check (offset >=
+// num_records -> zeros) replaces per-load exec-mask branches, so the ITER+1 loads of a
+// sub-tile issue back to back and the compiler can wait on them one by one (vmcnt(N)).
+// NT sets the nontemporal bit for the read-once text stream.
+template <bool NT>
+__device__ __forceinline__ u32x4 load16(__amdgpu_buffer_rsrc_t rsrc, int voff)
+{
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, NT ? 2 : 0));
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// x of lane+1; lane 63 gets `fill` (a wave-uniform value).  One v_mov_b32_dpp
+// wave_shl:1 (gfx9-generation wavefront shift): lane 63 has no source lane and, with
+// bound_ctrl off, keeps the `old` operand.
+__device__ __forceinline__ uint32_t down1(uint32_t x, uint32_t fill)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x130, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+
+// inclusive prefix sum over the wave
+__device__ __forceinline__ uint32_t wave_scan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = (uint32_t)__shfl_up((int)v, o, 64);
+        if (lane >= (uint32_t)o) v += t;
+    }
+    return v;
+}
+
+// 16-bit mask of the positions pos0..pos0+15 that lie in [lo, hi] (signed).
+__device__ __forceinline__ uint32_t valid16(int pos0, int lo, int hi)
+{
+    int jlo = lo - pos0, jhi = hi - pos0;
+    if (jlo < 0) jlo = 0;
+    if (jhi > 15) jhi = 15;
+    if (jlo > 15 || jhi < 0 || jlo > jhi) return 0u;
+    return (0xffffu << jlo) & (0xffffu >> (15 - jhi)) & 0xffffu;
+}
+
+// Cold path of K1: does the whole window match at p?  (segment-relative p, in bounds)
+__device__ __noinline__ bool verify_window(const uint8_t *seg, const DevProgram *pg, uint32_t p)
+{
+    const uint32_t m = pg->m;
+    if (pg->is_literal) {
+        for (uint32_t i = 0; i < m; i++)
+            if (seg[p + i] != pg->window[i]) return false;
+        return true;
+    }
+    for (uint32_t i = 0; i < m; i++) {
+        uint32_t b = seg[p + i];
+        uint32_t c = pg->window[i];
+        if (!((pg->cls_bits[c][b >> 5] >> (b & 31)) & 1u)) return false;
+    }
+    return true;
+}
+
+struct TileCtx {
+    const uint8_t *seg; // segment base
+    __amdgpu_buffer_rsrc_t rsrc; // descriptor over [seg, seg + slen rounded up to 16)
+    int slen;           // segment length
+    int tile_off;       // first byte of the tile inside the segment
+    bool live;          // segment long enough to hold a window at all
+};
+
+__device__ __forceinline__ TileCtx tile_ctx(const ScanArgs &a, uint32_t t, uint32_t tile_bytes, uint32_t m)
+{
+    TileCtx c;
+    uint32_t s = a.tile_seg[t];
+    uint32_t local = t - a.tile_first[s];
+    gscan_seg sg = a.segs[s];
+    // t is blockIdx-derived, so all of this is wave-uniform; readfirstlane makes that
+    // provable and keeps the descriptor in SGPRs (otherwise hipcc wraps every buffer
+    // load in a waterfall loop).
+    const uint64_t addr = (uint64_t)(a.base + sg.offset);
+    const uint32_t alo = __builtin_amdgcn_readfirstlane((uint32_t)addr);
+    const uint32_t ahi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+    const uint32_t len = __builtin_amdgcn_readfirstlane(sg.len);
+    c.seg = (const uint8_t *)(((uint64_t)ahi << 32) | alo);
+    c.slen = (int)len;
+    c.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)c.seg, 0, (int)((len + 15u) & ~15u), 0x00020000);
+    c.tile_off = (int)__builtin_amdgcn_readfirstlane(local * tile_bytes);
+    c.live = len >= m;
+    return c;
+}
+
+// Load the wave's sub-tile: ITER full steps + the halo step (only the first
+// HALO_LANES lanes carry data there).  16-byte blocks that start at or beyond the
+// segment end come back as zeros (descriptor bounds check); the last partial block is
+// read whole (segment bases are 16-byte aligned, so this stays inside the allocation)
+// and its garbage bytes can only reach windows that valid16() removes.
+template <int ITER, bool NT, int HALO_LANES>
+__device__ __forceinline__ void load_subtile(u32x4 (&buf)[ITER + 1], const TileCtx &c, int sub_off, uint32_t lane)
+{
+    const int v0 = sub_off + (int)lane * 16;
+#pragma unroll
+    for (int k = 0; k < ITER; k++) buf[k] = load16<NT>(c.rsrc, v0 + k * 1024);
+    // lanes >= HALO_LANES point far out of range -> zeros, no branch
+    buf[ITER] = load16<false>(c.rsrc, lane < (uint32_t)HALO_LANES ? v0 + ITER * 1024 : 0x7ffffff0);
+}
+
+// Tile epilogue shared by both kernels: hits[] holds the per-step 16-bit masks of
+// this lane (two per register), cnt its popcount.  `bias` is subtracted from every
+// position (K1 records window starts, its masks mark anchor positions).
+template <int ITER>
+__device__ __forceinline__ void emit_tile(const ScanArgs &a, uint32_t t, const uint32_t (&hits)[(ITER + 1) / 2],
+                                          uint32_t cnt, int sub_off, uint32_t bias, uint32_t lane, uint32_t wave,
+                                          uint32_t *s_cnt, uint32_t *s_base)
+{
+    uint32_t wtot = wave_sum(cnt);
+    if (lane == 0) s_cnt[wave] = wtot;
+    __syncthreads();
+    uint32_t total = 0, before = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) {
+        uint32_t c = s_cnt[w];
+        total += c;
+        if ((uint32_t)w < wave) before += c;
+    }
+    if (total == 0) {
+        if (threadIdx.x == 0) a.desc[t] = 0ull;
+        __syncthreads(); // s_cnt is rewritten by the next tile
+        return;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t b = atomicAdd(a.counter, total);
+        *s_base = b;
+        a.desc[t] = (unsigned long long)total | ((unsigned long long)b << 32);
+        if ((unsigned long long)b + total > (unsigned long long)a.cap) atomicOr(a.counter + 1, 1u);
+    }
+    __syncthreads();
+    uint32_t base = *s_base;
+    __syncthreads(); // s_base / s_cnt free for the next tile
+    if ((unsigned long long)base + total > (unsigned long long)a.cap) return; // overflow: host re-runs bigger
+    if (wtot == 0) return;
+    uint32_t run = base + before;
+#pragma unroll
+    for (int k = 0; k < ITER; k++) {
+        uint32_t bits = (hits[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+        if (__ballot(bits != 0) == 0ull) continue; // wave-uniform
+        uint32_t c = (uint32_t)__popc(bits);
+        uint32_t inc = wave_scan(c, lane);
+        uint32_t idx = run + inc - c;
+        uint32_t pos0 = (uint32_t)(sub_off + k * 1024) + lane * 16u - bias;
+        while (bits) {
+            uint32_t j = (uint32_t)__ffs((int)bits) - 1u;
+            bits &= bits - 1u;
+            a.recs[idx++] = pos0 + j;
+        }
+        run += (uint32_t)__shfl((int)inc, 63, 64);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K1: literal / anchored window.
+// ------------------------------------------------------------------------------------
+template <int ITER, bool NT>
+__global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a)
+{
+    __shared__ uint32_t s_cnt[kWaves];
+    __shared__ uint32_t s_base;
+    constexpr uint32_t kTile = kWaves * ITER * 1024;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x / kWave;
+    const DevProgram *pg = a.prog;
+    const uint32_t anchor = pg->anchor, amask = pg->anchor_mask;
+    const uint32_t aoff = pg->anchor_off, m = pg->m;
+
+    for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        TileCtx c = tile_ctx(a, t, kTile, m);
+        const int sub_off = c.tile_off + (int)(wave * ITER * 1024);
+        uint32_t hits[(ITER + 1) / 2];
+#pragma unroll
+        for (int i = 0; i < (ITER + 1) / 2; i++) hits[i] = 0;
+        uint32_t cnt = 0;
+
+        if (c.live && sub_off < c.slen) {
+            u32x4 buf[ITER + 1];
+            load_subtile<ITER, NT, 1>(buf, c, sub_off, lane);
+            // anchor positions that correspond to an in-bounds window
+            const int lo = (int)aoff, hi = c.slen - (int)m + (int)aoff;
+#pragma unroll
+            for (int k = 0; k < ITER; k++) {
+                const uint32_t d0 = buf[k].x, d1 = buf[k].y, d2 = buf[k].z, d3 = buf[k].w;
+                const uint32_t nx = __builtin_amdgcn_readfirstlane(buf[k + 1].x);
+                const uint32_t d4 = down1(d0, nx);
+                // x_j == 0  <=>  the anchor sits at byte j of this lane's 16
+                uint32_t acc = 0xffffffffu;
+#define GS_X(lo_, hi_, sh_) ((__builtin_amdgcn_alignbyte(hi_, lo_, sh_) ^ anchor) & amask)
+#define GS_MIN3(p_, q_, r_) min(min(p_, q_), r_)
+                acc = GS_MIN3(acc, (d0 ^ anchor) & amask, GS_X(d0, d1, 1));
+                acc = GS_MIN3(acc, GS_X(d0, d1, 2), GS_X(d0, d1, 3));
+                acc = GS_MIN3(acc, (d1 ^ anchor) & amask, GS_X(d1, d2, 1));
+                acc = GS_MIN3(acc, GS_X(d1, d2, 2), GS_X(d1, d2, 3));
+                acc = GS_MIN3(acc, (d2 ^ anchor) & amask, GS_X(d2, d3, 1));
+                acc = GS_MIN3(acc, GS_X(d2, d3, 2), GS_X(d2, d3, 3));
+                acc = GS_MIN3(acc, (d3 ^ anchor) & amask, GS_X(d3, d4, 1));
+                acc = GS_MIN3(acc, GS_X(d3, d4, 2), GS_X(d3, d4, 3));
+                if (acc == 0) { // cold: find which alignments hit, bounds-check, verify the window
+                    const int pos0 = sub_off + k * 1024 + (int)lane * 16;
+                    const uint32_t vm = valid16(pos0, lo, hi);
+                    const uint32_t dd[5] = {d0, d1, d2, d3, d4};
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        uint32_t u = (j & 3) ? __builtin_amdgcn_alignbyte(dd[j / 4 + 1], dd[j / 4], j & 3) : dd[j / 4];
+                        if (((u ^ anchor) & amask) == 0) bits |= 1u << j;
+                    }
+                    bits &= vm;
+                    if (m > pg->anchor_len) {
+                        uint32_t keep = 0, b2 = bits;
+                        while (b2) {
+                            uint32_t j = (uint32_t)__ffs((int)b2) - 1u;
+                            b2 &= b2 - 1u;
+                            if (verify_window(c.seg, pg, (uint32_t)pos0 + j - aoff)) keep |= 1u << j;
+                        }
+                        bits = keep;
+                    }
+                    hits[k >> 1] |= bits << (16 * (k & 1));
+                    cnt += (uint32_t)__popc(bits);
+                }
+#undef GS_X
+#undef GS_MIN3
+            }
+        }
+        emit_tile<ITER>(a, t, hits, cnt, sub_off, aoff, lane, wave, s_cnt, &s_base);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K2: class runs.
+// ------------------------------------------------------------------------------------
+// One lookup: byte -> dword of class bits (bit 8c = member of class c); the table copy
+// in LDS bank (lane&31) is used, so lanes never collide (ds_read_b32 services lanes
+// 0-31 and 32-63 separately).
+#define GS_LUT(w_, sh_) tbl[((((w_) >> (sh_)) & 0xffu) << 5) | bank]
+
+template <int ITER, bool NT, bool WIDE>
+__global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a)
+{
+    __shared__ uint32_t tbl[256 * 32];
+    __shared__ uint32_t s_cnt[kWaves];
+    __shared__ uint32_t s_base;
+    constexpr uint32_t kTile = kWaves * ITER * 1024;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x / kWave;
+    const uint32_t bank = lane & 31u;
+    const DevProgram *pg = a.prog;
+    const uint32_t m = pg->m, ncls = pg->n_classes, nruns = pg->nruns;
+
+    { // stage the class table: entry b replicated into all 32 banks
+        uint32_t b = threadIdx.x; // kWG == 256 entries
+        uint32_t v = pg->k2_table[b];
+#pragma unroll 8
+        for (uint32_t r = 0; r < 32; r++) tbl[(b << 5) | ((r + lane) & 31u)] = v;
+    }
+    __syncthreads();
+
+    for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        TileCtx c = tile_ctx(a, t, kTile, m);
+        const int sub_off = c.tile_off + (int)(wave * ITER * 1024);
+        uint32_t hits[(ITER + 1) / 2];
+#pragma unroll
+        for (int i = 0; i < (ITER + 1) / 2; i++) hits[i] = 0;
+        uint32_t cnt = 0;
+
+        if (c.live && sub_off < c.slen) {
+            u32x4 buf[ITER + 1];
+            load_subtile<ITER, NT, 4>(buf, c, sub_off, lane);
+            const int hi = c.slen - (int)m;
+            const bool interior = sub_off + ITER * 1024 + 64 <= hi;
+
+            // class masks of one 16-byte piece: P01 = cls0 | cls1<<16, P23 = cls2 | cls3<<16
+            uint32_t p01n, p23n;
+            auto masks = [&](const u32x4 &d, uint32_t &p01, uint32_t &p23) {
+                uint32_t lo = 0, hi8 = 0;
+                lo = (lo << 1) | GS_LUT(d.y, 24); lo = (lo << 1) | GS_LUT(d.y, 16);
+                lo = (lo << 1) | GS_LUT(d.y, 8);  lo = (lo << 1) | GS_LUT(d.y, 0);
+                lo = (lo << 1) | GS_LUT(d.x, 24); lo = (lo << 1) | GS_LUT(d.x, 16);
+                lo = (lo << 1) | GS_LUT(d.x, 8);  lo = (lo << 1) | GS_LUT(d.x, 0);
+                hi8 = (hi8 << 1) | GS_LUT(d.w, 24); hi8 = (hi8 << 1) | GS_LUT(d.w, 16);
+                hi8 = (hi8 << 1) | GS_LUT(d.w, 8);  hi8 = (hi8 << 1) | GS_LUT(d.w, 0);
+                hi8 = (hi8 << 1) | GS_LUT(d.z, 24); hi8 = (hi8 << 1) | GS_LUT(d.z, 16);
+                hi8 = (hi8 << 1) | GS_LUT(d.z, 8);  hi8 = (hi8 << 1) | GS_LUT(d.z, 0);
+                // byte c of lo = positions 0-7 of class c, byte c of hi8 = positions 8-15
+                p01 = (lo & 0xffu) | ((hi8 & 0xffu) << 8) | ((lo & 0xff00u) << 8) | ((hi8 & 0xff00u) << 16);
+                p23 = ((lo >> 16) & 0xffu) | (((hi8 >> 16) & 0xffu) << 8) | ((lo >> 8) & 0xff0000u) | (hi8 & 0xff000000u);
+            };
+            masks(buf[0], p01n, p23n);
+#pragma unroll
+            for (int k = 0; k < ITER; k++) {
+                const uint32_t p01 = p01n, p23 = p23n;
+                masks(buf[k + 1], p01n, p23n); // next step's masks: lanes 61-63 look into them
+                uint32_t bits;
+                if (!WIDE) { // look-ahead <= 16 positions: one neighbour
+                    const uint32_t a01 = down1(p01, __builtin_amdgcn_readfirstlane(p01n));
+                    const uint32_t a23 = ncls > 2 ? down1(p23, __builtin_amdgcn_readfirstlane(p23n)) : 0u;
+                    uint32_t W[4];
+                    W[0] = (p01 & 0xffffu) | (a01 << 16);
+                    W[1] = (p01 >> 16) | (a01 & 0xffff0000u);
+                    W[2] = (p23 & 0xffffu) | (a23 << 16);
+                    W[3] = (p23 >> 16) | (a23 & 0xffff0000u);
+                    uint32_t cand = 0xffffffffu;
+                    for (uint32_t r = 0; r < nruns; r++) {
+                        const uint32_t cls = pg->run_cls[r], n = pg->run_len[r], off = pg->run_off[r];
+                        uint32_t x = cls == 0 ? W[0] : cls == 1 ? W[1] : cls == 2 ? W[2] : W[3];
+                        uint32_t len = 1;
+                        while (2 * len <= n) {
+                            x &= x >> len;
+                            len *= 2;
+                        }
+                        if (len < n) x &= x >> (n - len);
+                        cand &= x >> off;
+                    }
+                    bits = cand & 0xffffu;
+                } else { // look-ahead <= 48 positions: three neighbours
+                    const uint32_t s01_0 = __builtin_amdgcn_readlane(p01n, 0), s01_1 = __builtin_amdgcn_readlane(p01n, 1),
+                                   s01_2 = __builtin_amdgcn_readlane(p01n, 2);
+                    const uint32_t a01 = down1(p01, s01_0);
+                    const uint32_t b01 = down1(a01, s01_1);
+                    const uint32_t c01 = down1(b01, s01_2);
+                    uint32_t a23 = 0, b23 = 0, c23 = 0;
+                    if (ncls > 2) {
+                        const uint32_t s0 = __builtin_amdgcn_readlane(p23n, 0), s1 = __builtin_amdgcn_readlane(p23n, 1),
+                                       s2 = __builtin_amdgcn_readlane(p23n, 2);
+                        a23 = down1(p23, s0);
+                        b23 = down1(a23, s1);
+                        c23 = down1(b23, s2);
+                    }
+                    uint64_t W[4];
+                    W[0] = (uint64_t)((p01 & 0xffffu) | (a01 << 16)) | ((uint64_t)((b01 & 0xffffu) | (c01 << 16)) << 32);
+                    W[1] = (uint64_t)((p01 >> 16) | (a01 & 0xffff0000u)) | ((uint64_t)((b01 >> 16) | (c01 & 0xffff0000u)) << 32);
+                    W[2] = (uint64_t)((p23 & 0xffffu) | (a23 << 16)) | ((uint64_t)((b23 & 0xffffu) | (c23 << 16)) << 32);
+                    W[3] = (uint64_t)((p23 >> 16) | (a23 & 0xffff0000u)) | ((uint64_t)((b23 >> 16) | (c23 & 0xffff0000u)) << 32);
+                    uint64_t cand = ~0ull;
+                    for (uint32_t r = 0; r < nruns; r++) {
+                        const uint32_t cls = pg->run_cls[r], n = pg->run_len[r], off = pg->run_off[r];
+                        uint64_t x = cls == 0 ? W[0] : cls == 1 ? W[1] : cls == 2 ? W[2] : W[3];
+                        uint32_t len = 1;
+                        while (2 * len <= n) {
+                            x &= x >> len;
+                            len *= 2;
+                        }
+                        if (len < n) x &= x >> (n - len);
+                        cand &= x >> off;
+                    }
+                    bits = (uint32_t)cand & 0xffffu;
+                }
+                if (!interior) bits &= valid16(sub_off + k * 1024 + (int)lane * 16, 0, hi);
+                hits[k >> 1] |= bits << (16 * (k & 1));
+                cnt += (uint32_t)__popc(bits);
+            }
+        }
+        emit_tile<ITER>(a, t, hits, cnt, sub_off, 0u, lane, wave, s_cnt, &s_base);
+    }
+}
+#undef GS_LUT
+
+} // namespace
+
+// ---- host-callable launchers (engine.hip) ----
+// variant: bits 0-1 ITER index {0:16, 1:8, 2:4}, bit 2 = nontemporal loads
+uint32_t scan_tile_bytes(int variant)
+{
+    static const int iters[4] = {16, 8, 4, 16};
+    return (uint32_t)(kWaves * iters[variant & 3] * 1024);
+}
+
+template <int ITER>
+static hipError_t launch_iter(int tier, bool nt, bool wide, const ScanArgs &a, uint32_t grid, hipStream_t st)
+{
+    dim3 g(grid), b(kWG);
+    if (tier == GSCAN_TIER_LITERAL) {
+        if (nt) hipLaunchKernelGGL((k1_anchor_scan<ITER, true>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k1_anchor_scan<ITER, false>), g, b, 0, st, a);
+    } else {
+        if (wide) {
+            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, true>), g, b, 0, st, a);
+            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, true>), g, b, 0, st, a);
+        } else {
+            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, false>), g, b, 0, st, a);
+            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, false>), g, b, 0, st, a);
+        }
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(int tier, int variant, uint32_t window, const ScanArgs &a, uint32_t grid, hipStream_t st)
+{
+    const bool nt = (variant >> 2) & 1;
+    const bool wide = window > 17; // K2: look-ahead beyond one neighbouring lane
+    switch (variant & 3) {
+    case 1: return launch_iter<8>(tier, nt, wide, a, grid, st);
+    case 2: return launch_iter<4>(tier, nt, wide, a, grid, st);
+    default: return launch_iter<16>(tier, nt, wide, a, grid, st);
+    }
+}
+
+} // namespace gscan

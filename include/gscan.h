@@ -1,0 +1,149 @@
+/*
+ * gscan.h -- C ABI of the MI355X (gfx950) scan engine that replaces the regex
+ * engine calls inside stealth/grab's per-file match loop.
+ *
+ * The reference has no plugin/FFI layer; its seam is the four libpcre calls made by
+ * FileGrep (citations relative to /root/reference):
+ *
+ *   pcre_compile + pcre_study + pcre_fullinfo(PCRE_INFO_MINLENGTH)   src/grab.cc:106,115,120
+ *       -> gscan_compile()      (pattern -> database, minlen with PCRE's meaning)
+ *   pcre_exec(h, extra, start, end-start, 0, 0, ovector, 3)          src/grab.cc:178
+ *       -> gscan_submit()/gscan_wait()   (one call per CHUNK instead of one per match:
+ *          the engine returns every offset p of the chunk at which pcre_exec would
+ *          report a match if asked to start at p -- the "candidate superset"; the
+ *          restart orbit of src/grab.cc:175-213 is then a host walk over that list,
+ *          see grab_host.h / DESIGN.md)
+ *       -> gscan_match_end()    (ovector[1] for one selected start, computed lazily)
+ *   pcre_free_study                                                   src/grab.cc:79
+ *       -> gscan_free()
+ *
+ * Plain C: pointers and sizes only, no exceptions, no global state.  A gscan_db is
+ * immutable and may be shared between threads; a gscan_ctx belongs to one thread
+ * (the reference builds one FileGrep per pthread, src/main.cc:195-199).
+ *
+ * All functions return 0 on success, GSCAN_UNSUPPORTED (1) from gscan_compile when
+ * the pattern is valid but outside the GPU engine's subset, and a negative
+ * GSCAN_E* code on error.  There is NO CPU scanning path behind this interface: if
+ * no HIP device can be opened, gscan_open fails.
+ */
+#ifndef GSCAN_H
+#define GSCAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSCAN_ABI_VERSION 1
+
+/* return codes */
+#define GSCAN_OK 0
+#define GSCAN_UNSUPPORTED 1 /* gscan_compile: valid pattern, not in the engine's subset */
+#define GSCAN_EINVAL (-1)   /* bad argument / malformed pattern */
+#define GSCAN_ENOMEM (-2)
+#define GSCAN_EHIP (-3)     /* a HIP call failed; text via gscan_strerror(ctx) */
+#define GSCAN_EBUSY (-4)    /* all in-flight slots used: call gscan_wait first */
+#define GSCAN_EEMPTY (-5)   /* gscan_wait with nothing in flight */
+#define GSCAN_ETOOBIG (-6)  /* chunk larger than the context was opened for */
+
+/* gscan_compile flags */
+#define GSCAN_LITERAL 1u /* treat the pattern as a literal byte string (grab's documented -S) */
+
+/* engine tiers (gscan_info.tier) */
+#define GSCAN_TIER_NULL 0    /* pattern can match the empty string: PCRE minlen -1, grab skips every file (Q2) */
+#define GSCAN_TIER_LITERAL 1 /* K1: 4-byte anchor compare + class-sequence verify */
+#define GSCAN_TIER_CLASSRUN 2 /* K2: LDS class table -> per-class bitmaps -> run detection */
+
+typedef struct gscan_db gscan_db;
+typedef struct gscan_ctx gscan_ctx;
+
+typedef struct gscan_info {
+    int tier;            /* GSCAN_TIER_* */
+    int minlen;          /* == PCRE_INFO_MINLENGTH for the pattern (window length), -1 for TIER_NULL */
+    int n_classes;       /* distinct byte classes in the window */
+    int has_tail;        /* 1 if the last atom is a greedy variable repeat */
+    uint32_t tail_extra; /* max bytes the tail may take beyond the window (UINT32_MAX = unbounded) */
+    int anchor_off;      /* K1: offset of the anchor inside the window */
+    int anchor_len;      /* K1: 1..4 bytes */
+    int is_literal;      /* 1 if every window position is a single byte value */
+} gscan_info;
+
+/* one scan unit inside a device-resident arena (gscan_scan_device) */
+typedef struct gscan_seg {
+    uint64_t offset; /* byte offset of the segment from dev_base; must be 16-byte aligned */
+    uint32_t len;    /* bytes; <= 2^30 like a grab chunk (src/grab.h:48) */
+    uint32_t _pad;
+} gscan_seg;
+
+/* result of a device-resident scan: everything stays in HBM */
+typedef struct gscan_dev_result {
+    const uint32_t *recs;  /* device: candidate starts, segment-relative; runs of ascending offsets */
+    const uint64_t *desc;  /* device: per tile {count:u32 | base:u32<<32}; tile order == text order */
+    const uint32_t *tile_seg; /* device: per tile, index of its segment */
+    uint64_t n_tiles;
+    uint32_t tile_bytes;
+    uint64_t total;        /* number of records the scan produced (valid after gscan_dev_sync) */
+    int overflow;          /* 1 if the record buffer was too small: total says how many are needed */
+} gscan_dev_result;
+
+/* ---- pattern database (host only; no device needed) ---- */
+int gscan_compile(const char *pat, size_t len, unsigned flags, gscan_db **out, int *minlen,
+                  char *err, size_t errcap);
+void gscan_free(gscan_db *db);
+int gscan_db_info(const gscan_db *db, gscan_info *info);
+/* 256-entry membership table (1 byte each) of window position `pos`; pos == -1: the tail class */
+int gscan_db_class(const gscan_db *db, int pos, uint8_t table[256]);
+/* ovector[1] for a match starting at `start` of content[0..clen): src/grab.cc:178 semantics */
+uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, uint32_t start);
+
+/* ---- device context: one per worker thread ---- */
+int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out);
+void gscan_close(gscan_ctx *ctx);
+const char *gscan_strerror(const gscan_ctx *ctx);
+int gscan_device_count(void);
+
+/*
+ * Host-chunk path (what FileGrep::find uses).  gscan_acquire hands out the pinned
+ * staging buffer of a free slot so the caller can read(2) a chunk straight into it;
+ * gscan_submit then starts H2D (copy stream) + scan (compute stream) and returns at
+ * once.  Passing any other host pointer to gscan_submit makes the engine copy it
+ * into a pinned slot first.  Up to GSCAN_SLOTS chunks may be in flight; gscan_wait
+ * returns them in submission order.
+ */
+#define GSCAN_SLOTS 2
+int gscan_acquire(gscan_ctx *ctx, size_t len, void **pinned);
+int gscan_submit(gscan_ctx *ctx, const gscan_db *db, const void *host_bytes, size_t len,
+                 uint64_t tag);
+/* starts[0..n): every candidate start of the chunk, ascending.  *content is the
+ * pinned copy of the chunk; both stay valid until the second gscan_acquire/
+ * gscan_submit after this call reuses the slot. */
+int gscan_wait(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, size_t *n,
+               const void **content);
+
+/*
+ * Device-resident path (bench, batching): scan nseg segments of an arena that is
+ * already in HBM, one launch, on `stream` (a hipStream_t, NULL = the context's
+ * compute stream).  Asynchronous; results stay on the device.
+ */
+int gscan_scan_device(gscan_ctx *ctx, const gscan_db *db, const void *dev_base,
+                      const gscan_seg *segs, size_t nseg, void *stream,
+                      gscan_dev_result *res);
+/* wait for the scan, fill res->total / res->overflow */
+int gscan_dev_sync(gscan_ctx *ctx, gscan_dev_result *res);
+/* copy the records of segment `seg` to the host, ascending; returns count or <0 */
+long gscan_dev_fetch(gscan_ctx *ctx, const gscan_dev_result *res, size_t seg, uint32_t *out,
+                     size_t cap);
+/* record-buffer capacity (records) for device scans; default = arena bytes / 16 */
+int gscan_set_capacity(gscan_ctx *ctx, size_t n_records);
+/* kernel tuning knobs for A/B runs: name in {"variant","blocks_per_cu"}; see DESIGN.md */
+int gscan_set_option(gscan_ctx *ctx, const char *name, long value);
+/* scan-kernel time of the gscan_scan_device launches since the last reset: HIP events recorded
+ * around each launch on the launch's own stream.  Waits for the launches to finish. */
+int gscan_kernel_time(gscan_ctx *ctx, double *sum_ms, uint64_t *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSCAN_H */
