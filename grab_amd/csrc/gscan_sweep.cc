@@ -1,0 +1,110 @@
+// gscan_sweep.cc -- native A/B harness for the scan kernels (no Python, no torch).
+//
+//   gscan_sweep [--gib G] [--seg-mib M] [--pattern P] [--iters N] [--variants 0,1,2,4,5,6] [--bpc 0,4,8,16]
+//
+// Fills a G GiB arena in HBM with synthetic text (57-symbol alphabet, SURVEY.md 8d
+// distribution, xorshift stream), splits it into M MiB segments, and for every
+// (variant, blocks_per_cu) pair runs N timed launches of gscan_scan_device, interleaved
+// round-robin over the pairs so clock/thermal drift hits all of them alike.  Prints one
+// line per pair: mean/min kernel time (HIP events on the launch stream) and GB/s.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gscan.h"
+
+extern "C" int gscan_kernel_time(gscan_ctx *, double *, uint64_t *, int);
+
+static std::vector<long> parse_list(const char *s)
+{
+    std::vector<long> v;
+    for (const char *p = s; *p;) {
+        v.push_back(strtol(p, (char **)&p, 10));
+        if (*p == ',') p++;
+    }
+    return v;
+}
+
+int main(int argc, char **argv)
+{
+    double gib = 8;
+    int seg_mib = 64, iters = 10;
+    std::string pattern = "foobardoesnotexist";
+    std::vector<long> variants = {0, 1, 2, 4, 5, 6}, bpcs = {0, 8};
+    int plant_every_mib = 1;
+    for (int i = 1; i < argc; i++) {
+        auto is = [&](const char *f) { return !strcmp(argv[i], f) && i + 1 < argc; };
+        if (is("--gib")) gib = atof(argv[++i]);
+        else if (is("--seg-mib")) seg_mib = atoi(argv[++i]);
+        else if (is("--pattern")) pattern = argv[++i];
+        else if (is("--iters")) iters = atoi(argv[++i]);
+        else if (is("--variants")) variants = parse_list(argv[++i]);
+        else if (is("--bpc")) bpcs = parse_list(argv[++i]);
+        else if (is("--plant-mib")) plant_every_mib = atoi(argv[++i]);
+        else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+    const size_t seg_bytes = (size_t)seg_mib << 20;
+    const size_t nseg = (size_t)(gib * 1024 / seg_mib);
+    const size_t total = nseg * seg_bytes;
+
+    static const char alphabet[] = "abcdefghijklmnopqrstuvwxyz     _0123456789ABCDEF(){};=.,\n";
+    std::vector<uint8_t> block(seg_bytes);
+    uint64_t x = 0x67726162u;
+    for (size_t i = 0; i < seg_bytes; i++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        block[i] = (uint8_t)alphabet[(x >> 11) % 57];
+    }
+    if (plant_every_mib > 0)
+        for (size_t at = 300000; at + 64 < seg_bytes; at += (size_t)plant_every_mib << 20) memcpy(&block[at], "foobardoesnotexist", 18);
+
+    uint8_t *arena = nullptr;
+    if (hipMalloc((void **)&arena, total + 4096) != hipSuccess) { fprintf(stderr, "hipMalloc %zu failed\n", total); return 1; }
+    hipMemcpy(arena, block.data(), seg_bytes, hipMemcpyHostToDevice);
+    for (size_t s = 1; s < nseg; s++) hipMemcpy(arena + s * seg_bytes, arena, seg_bytes, hipMemcpyDeviceToDevice);
+    hipDeviceSynchronize();
+
+    gscan_ctx *ctx = nullptr;
+    if (gscan_open(0, 1u << 30, &ctx) != GSCAN_OK) { fprintf(stderr, "gscan_open failed\n"); return 1; }
+    gscan_db *db = nullptr;
+    char err[128];
+    int minlen = 0;
+    if (gscan_compile(pattern.data(), pattern.size(), 0, &db, &minlen, err, sizeof err) != GSCAN_OK) { fprintf(stderr, "compile: %s\n", err); return 1; }
+    gscan_info info;
+    gscan_db_info(db, &info);
+    std::vector<gscan_seg> segs(nseg);
+    for (size_t s = 0; s < nseg; s++) segs[s] = {s * seg_bytes, (uint32_t)seg_bytes, 0};
+    gscan_set_capacity(ctx, 1u << 28);
+
+    struct Cell { long variant, bpc; double sum = 0, best = 1e30; int n = 0; uint64_t matches = 0; };
+    std::vector<Cell> cells;
+    for (long v : variants) for (long b : bpcs) { Cell c; c.variant = v; c.bpc = b; cells.push_back(c); }
+    printf("# arena %.2f GiB in %zu x %d MiB segments, pattern '%s' (tier %d, minlen %d), %d iters\n", total / 1073741824.0, nseg, seg_mib, pattern.c_str(), info.tier, minlen, iters);
+    for (int it = -1; it < iters; it++) { // it == -1: warm-up round
+        for (Cell &c : cells) {
+            gscan_set_option(ctx, "variant", c.variant);
+            gscan_set_option(ctx, "blocks_per_cu", c.bpc);
+            gscan_dev_result res;
+            int rc = gscan_scan_device(ctx, db, arena, segs.data(), nseg, nullptr, &res);
+            if (rc != GSCAN_OK) { fprintf(stderr, "scan failed: %s\n", gscan_strerror(ctx)); return 1; }
+            gscan_dev_sync(ctx, &res);
+            double ms = 0; uint64_t n = 0;
+            gscan_kernel_time(ctx, &ms, &n, 1);
+            if (it >= 0) { c.sum += ms; c.best = ms < c.best ? ms : c.best; c.n++; }
+            c.matches = res.total;
+            if (res.overflow) fprintf(stderr, "overflow (total %llu)\n", (unsigned long long)res.total);
+        }
+    }
+    for (const Cell &c : cells) {
+        const double bytes = (double)total + 4.0 * c.matches;
+        printf("variant %ld bpc %2ld : mean %8.3f ms  min %8.3f ms  -> %8.1f GB/s mean, %8.1f GB/s best   matches %llu\n", c.variant, c.bpc,
+               c.sum / c.n, c.best, bytes / (c.sum / c.n) / 1e6, bytes / c.best / 1e6, (unsigned long long)c.matches);
+    }
+    gscan_free(db);
+    gscan_close(ctx);
+    hipFree(arena);
+    return 0;
+}

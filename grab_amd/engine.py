@@ -1,0 +1,233 @@
+"""ctypes binding of include/gscan.h -- the C ABI of the gfx950 scan engine.
+
+Mirrors the header one to one; see the header for what each entry point replaces in
+the reference (/root/reference/src/grab.cc:106-178).  No scanning happens in Python and
+there is no fallback: if libgscan.so is missing or no HIP device opens, this raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import lib_path
+
+OK, UNSUPPORTED = 0, 1
+EINVAL, ENOMEM, EHIP, EBUSY, EEMPTY, ETOOBIG = -1, -2, -3, -4, -5, -6
+LITERAL = 1
+TIER_NULL, TIER_LITERAL, TIER_CLASSRUN = 0, 1, 2
+SLOTS = 2
+
+# every symbol include/gscan.h declares
+SYMBOLS = [
+    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_match_end",
+    "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
+    "gscan_acquire", "gscan_submit", "gscan_wait",
+    "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
+    "gscan_set_option", "gscan_kernel_time",
+]
+
+
+class Info(C.Structure):
+    _fields_ = [("tier", C.c_int), ("minlen", C.c_int), ("n_classes", C.c_int), ("has_tail", C.c_int),
+                ("tail_extra", C.c_uint32), ("anchor_off", C.c_int), ("anchor_len", C.c_int),
+                ("is_literal", C.c_int)]
+
+
+class Seg(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("len", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class DevResult(C.Structure):
+    _fields_ = [("recs", C.c_void_p), ("desc", C.c_void_p), ("tile_seg", C.c_void_p),
+                ("n_tiles", C.c_uint64), ("tile_bytes", C.c_uint32), ("total", C.c_uint64),
+                ("overflow", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = lib_path("libgscan.so")
+        try:
+            # torch bundles a HIP runtime with the same SONAME (libamdhip64.so.7); loading torch first
+            # makes libgscan.so bind to that one copy, so device pointers and streams are shared.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        if not os.path.exists(path):
+            raise RuntimeError("libgscan.so is not built (%s): run __graft_entry__.build()" % path)
+        L = C.CDLL(path)
+        L.gscan_compile.argtypes = [C.c_char_p, C.c_size_t, C.c_uint, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                    C.c_char_p, C.c_size_t]
+        L.gscan_compile.restype = C.c_int
+        L.gscan_free.argtypes = [C.c_void_p]
+        L.gscan_free.restype = None
+        L.gscan_db_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+        L.gscan_db_class.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gscan_match_end.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
+        L.gscan_match_end.restype = C.c_uint32
+        L.gscan_open.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.gscan_close.argtypes = [C.c_void_p]
+        L.gscan_close.restype = None
+        L.gscan_strerror.argtypes = [C.c_void_p]
+        L.gscan_strerror.restype = C.c_char_p
+        L.gscan_device_count.restype = C.c_int
+        L.gscan_acquire.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.gscan_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
+        L.gscan_wait.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint32)),
+                                 C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+        L.gscan_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Seg), C.c_size_t, C.c_void_p,
+                                        C.POINTER(DevResult)]
+        L.gscan_dev_sync.argtypes = [C.c_void_p, C.POINTER(DevResult)]
+        L.gscan_dev_fetch.argtypes = [C.c_void_p, C.POINTER(DevResult), C.c_size_t, C.c_void_p, C.c_size_t]
+        L.gscan_dev_fetch.restype = C.c_long
+        L.gscan_set_capacity.argtypes = [C.c_void_p, C.c_size_t]
+        L.gscan_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+        L.gscan_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        _lib = L
+    return _lib
+
+
+class Unsupported(ValueError):
+    """The pattern is valid but outside the GPU engine's subset (GSCAN_UNSUPPORTED)."""
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Database:
+    """A compiled pattern (gscan_db). Host only; needs no device."""
+
+    def __init__(self, pattern, literal=False):
+        if isinstance(pattern, str):
+            pattern = pattern.encode("latin-1")
+        self.pattern = pattern
+        self._h = C.c_void_p()
+        ml = C.c_int(0)
+        err = C.create_string_buffer(200)
+        rc = lib().gscan_compile(pattern, len(pattern), LITERAL if literal else 0, C.byref(self._h), C.byref(ml), err, 200)
+        if rc == UNSUPPORTED:
+            raise Unsupported(err.value.decode())
+        if rc != OK:
+            raise ValueError("malformed pattern: " + err.value.decode())
+        self.minlen = ml.value
+        info = Info()
+        lib().gscan_db_info(self._h, C.byref(info))
+        self.info = info
+
+    def class_table(self, pos):
+        t = np.zeros(256, np.uint8)
+        rc = lib().gscan_db_class(self._h, pos, t.ctypes.data)
+        if rc != OK:
+            raise ValueError("no class at position %d" % pos)
+        return t.astype(bool)
+
+    def match_end(self, content, start):
+        buf = np.frombuffer(content, np.uint8)
+        return int(lib().gscan_match_end(self._h, buf.ctypes.data, buf.size, start))
+
+    def close(self):
+        if self._h:
+            lib().gscan_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """A device context (gscan_ctx): one per worker thread."""
+
+    def __init__(self, device=0, max_chunk=1 << 30):
+        self._h = C.c_void_p()
+        rc = lib().gscan_open(device, max_chunk, C.byref(self._h))
+        if rc != OK:
+            raise EngineError("gscan_open(device=%d) failed with %d: no usable HIP device" % (device, rc))
+        self._keep = None
+
+    def _chk(self, rc, what):
+        if rc != OK:
+            raise EngineError("%s failed (%d): %s" % (what, rc, lib().gscan_strerror(self._h).decode()))
+
+    def set_option(self, name, value):
+        self._chk(lib().gscan_set_option(self._h, name.encode(), value), "gscan_set_option(%s)" % name)
+
+    def set_capacity(self, n):
+        self._chk(lib().gscan_set_capacity(self._h, n), "gscan_set_capacity")
+
+    # ---- host-chunk path ----
+    def submit(self, db, data, tag=0):
+        buf = np.ascontiguousarray(np.frombuffer(data, np.uint8))
+        self._keep = buf
+        self._chk(lib().gscan_submit(self._h, db._h, buf.ctypes.data if buf.size else None, buf.size, tag), "gscan_submit")
+
+    def wait(self):
+        tag = C.c_uint64()
+        ptr = C.POINTER(C.c_uint32)()
+        n = C.c_size_t()
+        content = C.c_void_p()
+        self._chk(lib().gscan_wait(self._h, C.byref(tag), C.byref(ptr), C.byref(n), C.byref(content)), "gscan_wait")
+        starts = np.ctypeslib.as_array(ptr, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint32)
+        return tag.value, starts
+
+    def scan(self, db, data):
+        """All candidate starts of one chunk (ascending uint32)."""
+        self.submit(db, data)
+        return self.wait()[1]
+
+    # ---- device-resident path ----
+    @staticmethod
+    def make_segs(segs):
+        arr = (Seg * len(segs))()
+        for i, (off, ln) in enumerate(segs):
+            arr[i].offset, arr[i].len = off, ln
+        return arr
+
+    def scan_device(self, db, dev_ptr, segs, stream=None):
+        """segs: list of (offset, len) or an array from make_segs (reuse it across steps)."""
+        arr = segs if isinstance(segs, C.Array) else self.make_segs(segs)
+        res = DevResult()
+        self._chk(lib().gscan_scan_device(self._h, db._h, dev_ptr, arr, len(segs), stream, C.byref(res)), "gscan_scan_device")
+        self._segarr = arr
+        return res
+
+    def dev_sync(self, res):
+        self._chk(lib().gscan_dev_sync(self._h, C.byref(res)), "gscan_dev_sync")
+        return int(res.total), bool(res.overflow)
+
+    def dev_fetch(self, res, seg):
+        n = lib().gscan_dev_fetch(self._h, C.byref(res), seg, None, 0)
+        if n < 0:
+            self._chk(int(n), "gscan_dev_fetch")
+        out = np.zeros(max(n, 1), np.uint32)
+        n2 = lib().gscan_dev_fetch(self._h, C.byref(res), seg, out.ctypes.data, out.size)
+        if n2 < 0:
+            self._chk(int(n2), "gscan_dev_fetch")
+        return out[:n2]
+
+    def kernel_time(self, reset=True):
+        s = C.c_double()
+        n = C.c_uint64()
+        self._chk(lib().gscan_kernel_time(self._h, C.byref(s), C.byref(n), 1 if reset else 0), "gscan_kernel_time")
+        return s.value, n.value
+
+    def close(self):
+        if self._h:
+            lib().gscan_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_count():
+    return int(lib().gscan_device_count())

@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/golden.json by running the REAL reference (oracle/_ref/grab_jit, built
+from /root/reference/src by `make -C oracle ref`) on inputs described by small recipes.
+
+Run in the build container only (the GPU box has no /root/reference and only consumes the
+committed JSON).  Every case stores the recipe of its input, the command-line flags and either
+the full stdout (small) or its md5 + line count + head (large).  The non-JIT build
+(oracle/_ref/grab, PCRE 8.45) is run on every case too and must agree byte for byte.
+
+    python tests/golden/make_golden.py
+"""
+import base64
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from inputs import materialize  # noqa: E402
+
+REF_JIT = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
+REF_NOJIT = os.path.join(ROOT, "oracle", "_ref", "grab")
+NEEDLE = "foobardoesnotexist"
+IDENT = "[A-Za-z_][A-Za-z0-9_]{15,}"
+T1 = "hello foo world\nno match here\nfoo at start and foo again\ntail foo"
+L5 = ["-L"] * 5  # 32 MiB chunks
+
+
+def lit(s):
+    return {"kind": "bytes", "b64": base64.b64encode(s.encode("latin-1") if isinstance(s, str) else s).decode()}
+
+
+CASES = [
+    # ---- output formats ----
+    dict(name="t1_default", inputs={"t1.txt": lit(T1)}, args=["foo", "t1.txt"]),
+    dict(name="t1_O", inputs={"t1.txt": lit(T1)}, args=["-O", "foo", "t1.txt"]),
+    dict(name="t1_Ol", inputs={"t1.txt": lit(T1)}, args=["-O", "-l", "foo", "t1.txt"]),
+    dict(name="t1_l", inputs={"t1.txt": lit(T1)}, args=["-l", "foo", "t1.txt"]),
+    dict(name="t1_s", inputs={"t1.txt": lit(T1)}, args=["-s", "foo", "t1.txt"]),
+    dict(name="t1_sOl", inputs={"t1.txt": lit(T1)}, args=["-s", "-O", "-l", "foo", "t1.txt"]),
+    dict(name="t1_two_paths", inputs={"t1.txt": lit(T1), "t2.txt": lit("a foo b\n")}, args=["-O", "foo", "t1.txt", "t2.txt"]),
+    dict(name="tree_rO", inputs={"d/t1.txt": lit(T1), "d/sub/t2.txt": lit("x foo y\nfoo\n"), "d/sub/none.txt": lit("nothing\n")},
+         args=["-r", "-O", "foo", "d"], sort=True),
+    dict(name="tree_n2", inputs={"d/t1.txt": lit(T1), "d/sub/t2.txt": lit("x foo y\nfoo\n"), "d/a/b/c.txt": lit("foofoo foo\n")},
+         args=["-n", "2", "-r", "-O", "-l", "foo", "d"], sort=True),
+    dict(name="nomatch", inputs={"t1.txt": lit(T1)}, args=["zzz", "t1.txt"]),
+    dict(name="dir_without_r", inputs={"d/t1.txt": lit(T1)}, args=["foo", "d"]),
+    dict(name="missing_file", inputs={}, args=["foo", "nope.txt"]),
+    dict(name="bad_regex", inputs={"t1.txt": lit(T1)}, args=["a(", "t1.txt"]),
+    dict(name="n2_without_r", inputs={"t1.txt": lit(T1)}, args=["-n", "2", "foo", "t1.txt"]),
+    # ---- A.2 quirks ----
+    dict(name="q2_empty_matchable", inputs={"t1.txt": lit(T1)}, args=["-O", "q*", "t1.txt"], jit_only=True),  # Q12: the non-JIT lib fails pcre_study here
+    dict(name="q3_exact_len", inputs={"f": lit("foo")}, args=["-O", "-l", "foo", "f"]),
+    dict(name="q3_xfoofoo", inputs={"f": lit("xfoofoo")}, args=["-O", "-l", "foo", "f"]),
+    dict(name="q3_foox", inputs={"f": lit("foox")}, args=["-O", "-l", "foo", "f"]),
+    dict(name="q4_wordb", inputs={"f": lit("foofoo")}, args=["-O", "-l", "\\bfoo", "f"]),
+    dict(name="q4_caret", inputs={"f": lit("ab\nfoo\nfoo\n")}, args=["-O", "-l", "^foo", "f"]),
+    dict(name="q4_caret_m", inputs={"f": lit("ab\nfoo\nfoo\n")}, args=["-O", "-l", "(?m)^foo", "f"]),
+    dict(name="q4_dollar", inputs={"f": lit("ab\nfoo\nfoo\n")}, args=["-O", "-l", "foo$", "f"]),
+    dict(name="q5_capture", inputs={"t1.txt": lit(T1)}, args=["-O", "(foo)", "t1.txt"]),
+    dict(name="q5_noncapture", inputs={"t1.txt": lit(T1)}, args=["-O", "(?:foo)", "t1.txt"]),
+    dict(name="q7_context_cap", inputs={"f": lit("A" * 600 + "NEEDLE" + "B" * 600)}, args=["NEEDLE", "f"]),
+    dict(name="q7_cap_restart", inputs={"f": lit("A" * 600 + "NEEDLE" + "B" * 520 + "NEEDLE" + "C" * 30 + "\nNEEDLE tail\n")}, args=["-O", "NEEDLE", "f"]),
+    dict(name="q21_alt_priority", inputs={"f": lit("xabab_")}, args=["-O", "-l", "a|ab", "f"]),
+    # ---- class / tail patterns inside the engine's subset ----
+    dict(name="cls_digits_tail", inputs={"f": lit("abc123 abc abc9x\nabc00000000000000000000\nxabc")}, args=["-O", "abc[0-9]*", "f"]),
+    dict(name="cls_bounded_tail", inputs={"f": lit("abcdefghijklmnop qr s tuv\n" * 3)}, args=["-O", "-l", "[a-z]{2,5}", "f"]),
+    dict(name="cls_phone", inputs={"f": lit("call 555-1234 or 5555-12345, not 55-1234\n555-12345678\n")}, args=["-O", "\\d{3}-\\d{4}", "f"]),
+    dict(name="cls_linus", inputs={"f": lit("Linus and linus and LINUS\nxlinusx Linu s\n")}, args=["-O", "[Ll]inus", "f"]),
+    dict(name="cls_dot", inputs={"f": lit("a.c abc a\nc axc\n")}, args=["-O", "-l", "a.c", "f"]),
+    dict(name="cls_negated_nl", inputs={"f": lit("ab\ncd xxxxx\nefghijk\nx\n")}, args=["-O", "[^x]{5,}", "f"]),
+    dict(name="cls_posix", inputs={"f": lit("ab1 abc ABC9 a_c\n")}, args=["-O", "-l", "[[:alpha:]]{3}", "f"]),
+    dict(name="cls_escape_meta", inputs={"f": lit("foo.bar fooxbar foo.bar\n")}, args=["-O", "-l", "foo\\.bar", "f"]),
+    dict(name="cls_hex", inputs={"f": lit("A\nB A\n\nA\n")}, args=["-O", "-l", "\\x41\\n", "f"]),
+    dict(name="cls_quote", inputs={"f": lit("a.b a+b axb\n")}, args=["-O", "-l", "\\Qa.b\\E", "f"]),
+    # ---- synthetic text (SURVEY section 8d generator) ----
+    dict(name="syn8_ident_Ol", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 0}}, args=["-O", "-l", IDENT, "syn"]),
+    dict(name="syn8_ident_O", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 0}}, args=["-O", IDENT, "syn"]),
+    dict(name="syn8_ident_lines", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 0}}, args=[IDENT, "syn"]),
+    dict(name="syn8_needle_absent", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 0}}, args=["-O", NEEDLE, "syn"]),
+    dict(name="syn8_needle_planted", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 3, "plant": [NEEDLE, 64]}}, args=["-O", "-l", NEEDLE, "syn"]),
+    dict(name="syn8_needle_planted_lines", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 3, "plant": [NEEDLE, 64]}}, args=["-O", NEEDLE, "syn"]),
+    dict(name="syn8_hex4", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 1}}, args=["-O", "-l", "[0-9A-F]{6}[a-z]", "syn"]),
+    dict(name="syn8_e_run", inputs={"syn": {"kind": "synth", "nbytes": 1 << 20, "k": 2}}, args=["-O", "-l", "e+", "syn"]),
+    # SURVEY A.4 known answers (256 MiB, seed k=0)
+    dict(name="syn256_needle", inputs={"syn": {"kind": "synth", "nbytes": 256 << 20, "k": 0}}, args=[NEEDLE, "syn"], big=True),
+    dict(name="syn256_ident_Ol", inputs={"syn": {"kind": "synth", "nbytes": 256 << 20, "k": 0}}, args=["-O", "-l", IDENT, "syn"], big=True),
+    dict(name="syn256_ident_Ol_L5", inputs={"syn": {"kind": "synth", "nbytes": 256 << 20, "k": 0}}, args=L5 + ["-O", "-l", IDENT, "syn"], big=True),
+    dict(name="syn256_ident_O", inputs={"syn": {"kind": "synth", "nbytes": 256 << 20, "k": 0}}, args=["-O", IDENT, "syn"], big=True),
+    # ---- A.5 chunk-boundary fixtures, 32 MiB chunks ----
+    dict(name="big_Ol_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "NEEDLE", "big.txt"], big=True),
+    dict(name="big_O_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "NEEDLE", "big.txt"], big=True),
+    dict(name="big_Ol_1g", inputs={"big.txt": {"kind": "big"}}, args=["-O", "-l", "NEEDLE", "big.txt"], big=True),
+    dict(name="big2_needle_L5", inputs={"big2.txt": {"kind": "big2"}}, args=L5 + ["-O", "-l", "NEEDLE", "big2.txt"], big=True),
+    dict(name="big2_arun_L5", inputs={"big2.txt": {"kind": "big2"}}, args=L5 + ["-O", "-l", "a{30,}", "big2.txt"], big=True),
+    dict(name="big2_arun_1g", inputs={"big2.txt": {"kind": "big2"}}, args=["-O", "-l", "a{30,}", "big2.txt"], big=True),
+    dict(name="big_s_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-s", "-O", "-l", "NEEDLE", "big.txt"], big=True),
+    dict(name="big_l_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-l", "NEEDLE", "big.txt"], big=True),
+]
+
+
+def run(binary, args, cwd):
+    r = subprocess.run([binary] + args, cwd=cwd, capture_output=True)
+    return r.returncode, r.stdout, r.stderr
+
+
+def main():
+    if not os.path.exists(REF_JIT):
+        sys.exit("oracle/_ref/grab_jit missing: run `make -C oracle ref` (needs /root/reference)")
+    out = {"_about": "outputs of the reference binary (oracle/_ref/grab_jit, PCRE 8.39 JIT) -- generated by tests/golden/make_golden.py; do not edit",
+           "cases": []}
+    cache = {}
+    for case in CASES:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            for rel, recipe in case["inputs"].items():
+                materialize(recipe, os.path.join(td, rel), cache)
+            rc, so, se = run(REF_JIT, case["args"], td)
+            rc2, so2, se2 = run(REF_NOJIT, case["args"], td)
+            if case.get("sort"):
+                so = b"".join(sorted(so.splitlines(True)))
+                so2 = b"".join(sorted(so2.splitlines(True)))
+            if not case.get("jit_only"):
+                assert (rc, so) == (rc2, so2), "JIT and non-JIT reference builds disagree on " + case["name"]
+        rec = {"name": case["name"], "inputs": case["inputs"], "args": case["args"], "rc": rc,
+               "sorted": bool(case.get("sort")), "big": bool(case.get("big")),
+               "stderr": se.decode("latin-1"),
+               "stdout_md5": hashlib.md5(so).hexdigest(), "stdout_len": len(so), "stdout_lines": so.count(b"\n")}
+        if len(so) <= 16384:
+            rec["stdout_b64"] = base64.b64encode(so).decode()
+        else:
+            rec["stdout_head_b64"] = base64.b64encode(so[:512]).decode()
+        out["cases"].append(rec)
+        print("%-28s rc=%d lines=%d md5=%s" % (case["name"], rc, rec["stdout_lines"], rec["stdout_md5"]))
+    with open(os.path.join(ROOT, "tests", "golden", "golden.json"), "w") as f:
+        json.dump(out, f, indent=1)
+        f.write("\n")
+
+
+if __name__ == "__main__":
+    main()

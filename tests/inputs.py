@@ -1,0 +1,64 @@
+"""Input recipes shared by tests/golden/make_golden.py and the tests: small JSON-able
+descriptions that are turned into byte strings / files deterministically."""
+import base64
+import os
+
+import numpy as np
+
+from grab_amd import synth
+
+
+def big_txt():
+    """SURVEY Appendix A.5 `big.txt`: chunk-boundary fixture for 32 MiB chunks."""
+    C = 1 << 25
+    stride = C - 4096
+    size = 2 * stride + 5_000_000
+    buf = np.full(size, ord("."), np.uint8)
+    buf[79::80] = 10
+    nd = np.frombuffer(b"NEEDLE", np.uint8)
+    buf[C:C + 3] = np.frombuffer(b"DLE", np.uint8)
+    for at in (100, stride + 1000, C - 6, stride, 2 * stride + 2000, size - 6):
+        buf[at:at + 6] = nd
+    return buf
+
+
+def big2_txt():
+    """SURVEY Appendix A.5 `big2.txt`: a literal straddling a chunk end, a run straddling a chunk start."""
+    C = 1 << 25
+    stride = C - 4096
+    size = stride + 1_000_000
+    buf = np.full(size, ord("."), np.uint8)
+    buf[79::80] = 10
+    buf[C - 3:C + 3] = np.frombuffer(b"NEEDLE", np.uint8)
+    buf[stride - 10:stride + 30] = ord("a")
+    return buf
+
+
+def build(recipe, cache=None):
+    """recipe -> uint8 numpy array."""
+    key = repr(sorted(recipe.items()))
+    if cache is not None and key in cache:
+        return cache[key]
+    kind = recipe["kind"]
+    if kind == "bytes":
+        buf = np.frombuffer(base64.b64decode(recipe["b64"]), np.uint8).copy()
+    elif kind == "synth":
+        buf = synth.text(recipe["nbytes"], recipe.get("k", 0))
+        if "plant" in recipe:
+            needle, count = recipe["plant"]
+            synth.plant(buf, needle.encode(), count, recipe.get("k", 0))
+    elif kind == "big":
+        buf = big_txt()
+    elif kind == "big2":
+        buf = big2_txt()
+    else:
+        raise ValueError(kind)
+    if cache is not None:
+        cache.clear()  # keep at most one big buffer alive
+        cache[key] = buf
+    return buf
+
+
+def materialize(recipe, path, cache=None):
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    build(recipe, cache).tofile(path)

@@ -1,0 +1,69 @@
+"""The C-ABI libraries load and export every symbol the headers declare; without a HIP
+device the product refuses to run (no CPU scanning path)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT, has_gpu
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(g(?:scan|rab)_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_gscan_exports(built):
+    from grab_amd import engine
+
+    names = _declared("gscan.h")
+    assert sorted(engine.SYMBOLS) == names, "engine.py binds exactly what gscan.h declares"
+    L = C.CDLL(built.lib_path("libgscan.so"))
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_grab_host_exports(built):
+    from grab_amd import filegrep
+
+    names = _declared("grab_host.h")
+    assert sorted(filegrep.SYMBOLS) == names
+    C.CDLL(built.lib_path("libgscan.so"), mode=C.RTLD_GLOBAL)
+    L = C.CDLL(built.lib_path("libgrabhost.so"))
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_engine_has_no_pcre_dependency(built):
+    out = subprocess.run(["ldd", built.lib_path("libgscan.so")], capture_output=True, text=True).stdout
+    assert "pcre" not in out
+
+
+def test_product_does_not_touch_oracle():
+    """Nothing under grab_amd/ may import, link or execute oracle/ (the checker is not the product)."""
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "grab_amd")):
+        for f in files:
+            if f.endswith((".py", ".cc", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dp, f), errors="replace").read()
+                if re.search(r"scan_oracle|liboracle|grab_oracle|oracle/", text):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a HIP device")
+def test_fails_loudly_without_device(built, tmp_path):
+    from grab_amd import engine, filegrep
+
+    with pytest.raises(engine.EngineError):
+        engine.Context()
+    g = filegrep.FileGrep()
+    assert g.prepare("foo") == -1
+    assert "HIP device" in g.why()
+    f = tmp_path / "t.txt"
+    f.write_text("foo\n")
+    r = subprocess.run([built.bin_path(), "foo", str(f)], capture_output=True, text=True)
+    assert r.returncode == 255 and r.stdout == "" and "HIP device" in r.stderr

@@ -1,0 +1,189 @@
+"""GPU parity, engine level: candidate starts produced by the HIP kernels (through the C ABI,
+include/gscan.h) must equal the oracle's on the same seeded inputs -- bit-exact, every kernel
+variant, ragged sizes, tile/wave boundaries, dense outputs, multi-segment arenas."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from grab_amd import engine, synth
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import scan_oracle as so  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [0, 1, 2, 4, 5, 6]  # KiB per wave {16, 8, 4} x nontemporal loads {off, on}
+PATTERNS = ["foobardoesnotexist", "foo", "e", "xy", "[A-Za-z_][A-Za-z0-9_]{15,}", "[a-z]{2,5}", "abc[0-9]*", r"\d{3}-\d{4}",
+            "[Ll]inus", "a.c", "[^x]{5,}", "[0-9a-f]{32}", "[0-9A-F]{6}[a-z]", "e+", r"\w\s\w\s\w", "[a-z][0-9][A-Z][.,][;:]q",
+            "[ab][cd][ef][gh]{20}", "[0-9]{17}", "[0-9]{18}", "[a-z_]{49}"]
+
+
+@pytest.fixture(scope="module")
+def ctx(built):
+    c = engine.Context(0, 1 << 30)
+    yield c
+    c.close()
+
+
+def oracle_starts(db, data):
+    tables = [db.class_table(i) for i in range(db.minlen)]
+    return so.window_starts(data, tables)
+
+
+def sample(n, seed):
+    """Text with every test pattern planted a few times, also across 1 KiB / 16 KiB / 64 KiB boundaries."""
+    rng = np.random.default_rng(seed)
+    buf = synth.text(n, seed % 1000)
+    plants = [b"foobardoesnotexist", b"foo", b"Linus", b"linus", b"555-1234", b"abc0123456789", b"a\nc", b"axc",
+              b"0123456789abcdef0123456789abcdef", b"ABCDEF012x", b"a 1 b 2 c", b"k7Q,;q", b"acegggggggggggggggggggggggg",
+              b"12345678901234567890", b"abcdefghijklmnopqrstuvwxyz_abcdefghijklmnopqrstuvwxyz", b"eeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeee"]
+    if n > 400:
+        spots = list(rng.integers(0, n - 64, 40)) + [b - d for b in (1024, 4096, 16384, 32768, 65536, 131072) for d in (1, 3, 9, 17, 30) if b < n - 64]
+        for i, at in enumerate(spots):
+            p = plants[i % len(plants)]
+            at = int(max(0, min(at, n - len(p))))
+            buf[at:at + len(p)] = np.frombuffer(p, np.uint8)
+    return buf
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_parity_patterns(ctx, variant):
+    ctx.set_option("variant", variant)
+    data = sample(300_007, 1)
+    for pattern in PATTERNS:
+        db = engine.Database(pattern)
+        got = ctx.scan(db, data)
+        want = oracle_starts(db, data)
+        assert got.dtype == np.uint32
+        assert np.array_equal(got.astype(np.int64), want), (pattern, variant, len(got), len(want))
+    ctx.set_option("variant", 0)
+
+
+SIZES = [0, 1, 2, 3, 4, 5, 15, 16, 17, 18, 19, 31, 32, 33, 63, 64, 65, 1023, 1024, 1025, 1039, 1040, 4095, 4096, 4097,
+         16383, 16384, 16385, 16400, 32767, 32768, 32769, 65535, 65536, 65537, 65553, 131071, 131072, 131073, 200000]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_ragged_sizes(ctx, variant):
+    """Every length around lane / wave-step / sub-tile / tile boundaries; matches planted at the very end."""
+    ctx.set_option("variant", variant)
+    pats = ["foo", "foobardoesnotexist", "[a-z]{2,5}", "[A-Za-z_][A-Za-z0-9_]{15,}", "[0-9a-f]{32}", "e+"]
+    dbs = [engine.Database(p) for p in pats]
+    base = sample(200_000, 2)
+    for n in SIZES:
+        data = base[:n].copy()
+        if n >= 40:
+            data[n - 3:] = np.frombuffer(b"foo", np.uint8)
+            data[n - 40:n - 22] = np.frombuffer(b"foobardoesnotexist", np.uint8)
+        for db, p in zip(dbs, pats):
+            if db.minlen > n and n > 0:
+                # shorter than the window: the host never submits it; the engine must still answer "nothing"
+                pass
+            got = ctx.scan(db, data)
+            want = oracle_starts(db, data)
+            assert np.array_equal(got.astype(np.int64), want), (p, n, variant)
+    ctx.set_option("variant", 0)
+
+
+def test_dense_output_and_regrow(ctx):
+    """Every position matches: 4 bytes of output per input byte, record buffer overflow -> regrow -> rescan."""
+    n = 3_000_001
+    data = np.full(n, ord("a"), np.uint8)
+    for pattern in ["a", "aa", "[a-z]{3}", "a+"]:
+        db = engine.Database(pattern)
+        got = ctx.scan(db, data)
+        assert np.array_equal(got, np.arange(n - db.minlen + 1, dtype=np.uint32)), pattern
+    data[::7] = ord("\n")
+    db = engine.Database("[^\\n]{3}")
+    assert np.array_equal(ctx.scan(db, data).astype(np.int64), oracle_starts(db, data))
+
+
+def test_adversarial_anchor(ctx):
+    """The anchor hits everywhere but the window rarely matches (K1 verify path on every lane)."""
+    n = 500_000
+    data = np.frombuffer(b"abcd", np.uint8)[np.arange(n) % 4].copy()
+    data[123456:123464] = np.frombuffer(b"abcdabcX", np.uint8)
+    for pattern in ["abcdabcX", "bcdabcX", "[ab]bcdabcX"]:
+        db = engine.Database(pattern)
+        assert np.array_equal(ctx.scan(db, data).astype(np.int64), oracle_starts(db, data)), pattern
+
+
+def test_binary_data(ctx):
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 256, 1_000_003, dtype=np.uint8)
+    data[5000:5004] = [0, 255, 0, 255]
+    for pattern in [r"\x00\xff\x00\xff", r"[\x80-\xff]{6}", r"\x00[^\x00]{3}\x00", r"[\x00-\x1f][\x7f-\xff]{2,}"]:
+        db = engine.Database(pattern)
+        assert np.array_equal(ctx.scan(db, data).astype(np.int64), oracle_starts(db, data)), pattern
+
+
+def test_pipelined_submits(ctx):
+    """Two chunks in flight come back in submission order with their own results."""
+    a, b = sample(1 << 20, 3), sample((1 << 20) + 77, 4)
+    db = engine.Database("[a-z]{2,5}")
+    ctx.submit(db, a, tag=11)
+    ctx.submit(db, b, tag=22)
+    with pytest.raises(engine.EngineError):
+        ctx.submit(db, a, tag=33)  # GSCAN_EBUSY: both slots in flight
+    t1, s1 = ctx.wait()
+    t2, s2 = ctx.wait()
+    assert (t1, t2) == (11, 22)
+    assert np.array_equal(s1.astype(np.int64), oracle_starts(db, a))
+    assert np.array_equal(s2.astype(np.int64), oracle_starts(db, b))
+    with pytest.raises(engine.EngineError):
+        ctx.wait()  # GSCAN_EEMPTY
+
+
+def test_pattern_switch(ctx):
+    """Alternating databases on one context re-uploads the program each time."""
+    data = sample(100_000, 6)
+    dbs = [engine.Database(p) for p in ("foo", "[a-z]{2,5}", "foobardoesnotexist", "e+")]
+    for _ in range(3):
+        for db in dbs:
+            assert np.array_equal(ctx.scan(db, data).astype(np.int64), oracle_starts(db, data))
+
+
+def test_device_resident_segments(ctx):
+    """gscan_scan_device over an arena of ragged, 16-byte aligned segments == per-segment oracle."""
+    import torch
+
+    lens = [0, 5, 17, 1000, 65536, 65537, 70001, 300000, 16, 131072, 1]
+    offs, pos = [], 0
+    for ln in lens:
+        offs.append(pos)
+        pos += (ln + 15) // 16 * 16 + 16 * (len(offs) % 3)
+    host = sample(pos + 64, 9)
+    host[offs[5] + 65536 - 2: offs[5] + 65536 + 1] = np.frombuffer(b"foo", np.uint8)
+    arena = torch.from_numpy(host).cuda()
+    segs = list(zip(offs, lens))
+    for pattern in ["foo", "[a-z]{2,5}", "[A-Za-z_][A-Za-z0-9_]{15,}"]:
+        db = engine.Database(pattern)
+        for variant in (0, 1, 2):
+            ctx.set_option("variant", variant)
+            res = ctx.scan_device(db, arena.data_ptr(), segs)
+            total, overflow = ctx.dev_sync(res)
+            assert not overflow
+            n = 0
+            for i, (o, ln) in enumerate(segs):
+                got = ctx.dev_fetch(res, i)
+                want = oracle_starts(db, host[o:o + ln])
+                assert np.array_equal(got.astype(np.int64), want), (pattern, variant, i)
+                n += len(want)
+            assert n == total
+    ctx.set_option("variant", 0)
+    ms, launches = ctx.kernel_time()
+    assert launches > 0 and ms > 0
+
+
+def test_grid_shapes(ctx):
+    """One workgroup per tile vs. persistent grid-stride give identical results."""
+    data = sample(5_000_000, 8)
+    db = engine.Database("[a-z]{2,5}")
+    want = oracle_starts(db, data)
+    for bpc in (0, 1, 2, 8, 16):
+        ctx.set_option("blocks_per_cu", bpc)
+        assert np.array_equal(ctx.scan(db, data).astype(np.int64), want), bpc
+    ctx.set_option("blocks_per_cu", 8)

@@ -1,0 +1,134 @@
+"""GPU parity, drop-in level: the `grab` binary and the FileGrep mirror must print exactly what
+the reference prints -- checked against the golden outputs of the reference binary
+(tests/golden/golden.json) and, on fresh random trees, against the oracle run side by side."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, golden_ids, split_args
+from grab_amd import engine, filegrep, synth
+from inputs import materialize
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_pattern(case):
+    _, pattern, _ = split_args(case["args"])
+    try:
+        engine.Database(pattern)
+        return True
+    except ValueError:
+        return False
+
+
+def _run(binary, args, cwd):
+    r = subprocess.run([binary] + args, cwd=cwd, capture_output=True)
+    return r.returncode, r.stdout, r.stderr
+
+
+@pytest.mark.parametrize("case", GOLDEN, ids=golden_ids(GOLDEN))
+def test_cli_matches_reference(case, built, tmp_path):
+    cache = {}
+    for rel, recipe in case["inputs"].items():
+        materialize(recipe, str(tmp_path / rel), cache)
+    rc, out, err = _run(built.bin_path(), case["args"], str(tmp_path))
+    if case["name"] in ("bad_regex", "missing_file", "n2_without_r", "dir_without_r"):
+        assert (rc, out) == (case["rc"], b"")
+        assert err.decode("latin-1") == case["stderr"]
+        return
+    if not _engine_pattern(case):
+        # valid PCRE outside the engine's subset: refuse loudly, never scan on the CPU
+        assert rc == 255 and out == b"" and b"outside the GPU engine's subset" in err
+        return
+    if case["sorted"]:
+        out = b"".join(sorted(out.splitlines(True)))
+    assert rc == case["rc"], err
+    assert len(out) == case["stdout_len"]
+    assert hashlib.md5(out).hexdigest() == case["stdout_md5"]
+    if "stdout" in case:
+        assert out == case["stdout"]
+
+
+def test_filegrep_interface(built, tmp_path):
+    """The ctypes mirror of FileGrep: same calls the reference's main() makes (main.cc:231-252)."""
+    f = tmp_path / "t1.txt"
+    f.write_bytes(b"hello foo world\nno match here\nfoo at start and foo again\ntail foo")
+    outp = tmp_path / "out"
+    fd = os.open(str(outp), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    g = filegrep.FileGrep()
+    g.config({"offsets": 1, "noline": 1, "chunk_size": 1 << 30, "out_fd": fd})
+    assert g.prepare("foo") == 0, g.why()
+    assert g.find(str(f)) == 0
+    assert g.find(str(tmp_path / "missing")) == -1 and g.why().startswith("FileGrep::find::stat: ")
+    os.close(fd)
+    assert outp.read_bytes() == b"Match at offset 6\nMatch at offset 30\nMatch at offset 47\nMatch at offset 62\n"
+    g2 = filegrep.FileGrep()
+    assert g2.prepare("foo|bar") == -1 and "outside the GPU engine's subset" in g2.why()
+    g3 = filegrep.FileGrep()
+    assert g3.prepare("a(") == -1 and g3.why() == "FileGrep::prepare::pcre_compile error"
+
+
+def _tree(root, rng, nfiles):
+    names = []
+    for i in range(nfiles):
+        d = root / ("d%d" % (i % 5)) / ("s%d" % (i % 3))
+        d.mkdir(parents=True, exist_ok=True)
+        n = int(rng.choice([0, 1, 7, 100, 5000, 70000, 300000]))
+        buf = synth.text(n, 100 + i)
+        if n >= 5000:
+            synth.plant(buf, b"foobardoesnotexist", 3, i, gap=200)
+        p = d / ("f%03d.txt" % i)
+        buf.tofile(str(p))
+        names.append(p)
+    os.symlink(str(names[0]), str(root / "link.txt"))
+    return names
+
+
+@pytest.mark.parametrize("args", [["-r", "-O"], ["-r", "-O", "-l"], ["-r"], ["-r", "-l"], ["-r", "-s"], ["-n", "2", "-r", "-O", "-l"], ["-n", "3", "-r"]])
+@pytest.mark.parametrize("pattern", ["foobardoesnotexist", "[A-Za-z_][A-Za-z0-9_]{15,}", "[0-9A-F]{6}[a-z]"])
+def test_tree_differential(args, pattern, built, oracle_built, tmp_path):
+    """Random tree, recursive + threaded modes: sorted output == the oracle's (the reference's own
+    criterion for -n, README.md:206-216); the real reference binary is compared too when present."""
+    rng = np.random.default_rng(42)
+    root = tmp_path / "tree"
+    root.mkdir()
+    _tree(root, rng, 24)
+    argv = args + [pattern, "tree"]
+    rc, out, err = _run(built.bin_path(), argv, str(tmp_path))
+    orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), argv, str(tmp_path))
+    assert rc == orc == 0, err
+    assert sorted(out.splitlines(True)) == sorted(oout.splitlines(True))
+    if "-n" not in args:
+        assert out == oout  # serial walk: same nftw order, byte-identical
+    ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
+    if os.path.exists(ref):
+        rrc, rout, _ = _run(ref, argv, str(tmp_path))
+        assert rrc == 0 and sorted(out.splitlines(True)) == sorted(rout.splitlines(True))
+
+
+def test_multichunk_pipeline(built, oracle_built, tmp_path):
+    """A 100 MiB file at 32 MiB chunks: 4 chunks through the 2-slot pipeline, dense output, -O with lines."""
+    buf = synth.text(100 << 20, 7)
+    p = tmp_path / "f"
+    buf.tofile(str(p))
+    for flags in (["-O", "-l"], ["-O"], []):
+        argv = ["-L"] * 5 + flags + ["[A-Za-z_][A-Za-z0-9_]{15,}", "f"]
+        rc, out, err = _run(built.bin_path(), argv, str(tmp_path))
+        orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), argv, str(tmp_path))
+        assert rc == orc == 0, err
+        assert hashlib.md5(out).hexdigest() == hashlib.md5(oout).hexdigest() and len(out) == len(oout)
+
+
+def test_literal_flag_S(built, tmp_path):
+    p = tmp_path / "f"
+    p.write_bytes(b"a.c abc a.c|x\n(a.c)\n")
+    rc, out, _ = _run(built.bin_path(), ["-S", "-O", "-l", "a.c", "f"], str(tmp_path))
+    assert rc == 0 and out == b"Match at offset 0\nMatch at offset 8\nMatch at offset 15\n"
+    rc, out, _ = _run(built.bin_path(), ["-H", "-2", "-S", "-O", "-l", "(a.c)", "f"], str(tmp_path))
+    assert rc == 0 and out == b"Match at offset 14\n"

@@ -1,0 +1,142 @@
+"""Pattern compiler (grab_amd/csrc/pattern.cc through the C ABI): tiering, PCRE-equal minlen,
+class tables and greedy match ends, checked against libpcre (liboracle) and Python's re."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+from grab_amd import engine
+
+SUPPORTED = [
+    # pattern, tier, minlen
+    ("foo", engine.TIER_LITERAL, 3),
+    ("foobardoesnotexist", engine.TIER_LITERAL, 18),
+    ("[A-Za-z_][A-Za-z0-9_]{15,}", engine.TIER_CLASSRUN, 16),
+    ("abc[0-9]*", engine.TIER_LITERAL, 3),
+    ("[a-z]{2,5}", engine.TIER_CLASSRUN, 2),
+    ("[a-z]+", engine.TIER_CLASSRUN, 1),
+    (r"\d{3}-\d{4}", engine.TIER_CLASSRUN, 8),
+    ("[Ll]inus", engine.TIER_LITERAL, 5),
+    ("a.c", engine.TIER_CLASSRUN, 3),
+    (r"\w+", engine.TIER_CLASSRUN, 1),
+    (r"foo\.bar", engine.TIER_LITERAL, 7),
+    (r"\x41\n", engine.TIER_LITERAL, 2),
+    ("ab{2}c", engine.TIER_LITERAL, 4),
+    ("[^x]{5,}", engine.TIER_CLASSRUN, 5),
+    ("[[:alpha:]]{3}", engine.TIER_CLASSRUN, 3),
+    (r"\Qa.b\E", engine.TIER_LITERAL, 3),
+    ("[0-9a-f]{32}", engine.TIER_CLASSRUN, 32),
+    (r"[a-z][0-9][A-Z][_]x", engine.TIER_CLASSRUN, 5),     # 5 positions, 'x' and '_' singletons, 5 classes > 4 -> K1 on "_x"
+    (r"[a-z][0-9][A-Z][.,][;:]q", engine.TIER_LITERAL, 6),  # >4 classes, weak 1-byte anchor
+    ("a{3}", engine.TIER_LITERAL, 3),
+    ("x{0}abc", engine.TIER_LITERAL, 3),
+    ("a{2}[b-c]{2}d?", engine.TIER_CLASSRUN, 4),
+    (r"[\d\-x]{4}", engine.TIER_CLASSRUN, 4),
+    (r"[]a]{2}", engine.TIER_CLASSRUN, 2),
+    (r"\t\e\f\a\cA\0\07\x7", engine.TIER_LITERAL, 8),
+    ("{,3}", engine.TIER_LITERAL, 4),  # not a quantifier: literal text
+    ("a{1,2}", engine.TIER_LITERAL, 1),
+]
+
+NULL_TIER = ["a?", "x*", "", "a{0}", "[a-z]{0,3}", "x{0}"]
+
+UNSUPPORTED = ["foo|bar", "(foo)", "(?:foo)", "^foo", "foo$", r"\bfoo", "a+b", "a?b", "ab*c", "a{2,}?", "a++", r"\1", r"\pL",
+               "(?i)foo", r"\Rfoo", "a{2}{3}", "[a-z][0-9][A-Z][.,][;:]", "x" * 300, r"\Afoo", r"foo\z"]
+
+# "a(" is reported as unsupported (groups) by the engine alone; FileGrep::prepare asks libpcre first and
+# gives the reference's "pcre_compile error" for it (tests/test_gpu_filegrep.py, golden case bad_regex)
+MALFORMED = ["[abc", "*a", "+", "?x", "a{3,2}", "[z-a]", "\\", "a)", "[[:nope:]]"]
+
+
+def _fix5(p):
+    return p
+
+
+@pytest.mark.parametrize("pattern,tier,minlen", SUPPORTED)
+def test_supported(pattern, tier, minlen, built, liboracle):
+    db = engine.Database(pattern)
+    if pattern == r"[a-z][0-9][A-Z][_]x":
+        assert db.info.tier == engine.TIER_LITERAL
+    else:
+        assert db.info.tier == tier, pattern
+    assert db.minlen == minlen
+    ml = C.c_int()
+    assert liboracle.oracle_minlen(pattern.encode(), C.byref(ml)) == 0
+    assert ml.value == minlen, "engine minlen must equal PCRE_INFO_MINLENGTH"
+
+
+@pytest.mark.parametrize("pattern", NULL_TIER)
+def test_empty_matchable(pattern, built, liboracle):
+    db = engine.Database(pattern)
+    assert db.info.tier == engine.TIER_NULL and db.minlen == -1
+    ml = C.c_int()
+    assert liboracle.oracle_minlen(pattern.encode(), C.byref(ml)) == 0 and ml.value == -1
+
+
+@pytest.mark.parametrize("pattern", UNSUPPORTED)
+def test_unsupported(pattern, built):
+    with pytest.raises(engine.Unsupported):
+        engine.Database(pattern)
+
+
+@pytest.mark.parametrize("pattern", MALFORMED)
+def test_malformed(pattern, built, liboracle):
+    with pytest.raises(ValueError) as ei:
+        engine.Database(pattern)
+    assert not isinstance(ei.value, engine.Unsupported)
+    ml = C.c_int()
+    assert liboracle.oracle_minlen(pattern.encode(), C.byref(ml)) != 0, "PCRE rejects it too"
+
+
+def test_literal_flag(built):
+    db = engine.Database("a.c|(x", literal=True)
+    assert db.info.tier == engine.TIER_LITERAL and db.minlen == 6 and db.info.is_literal
+    assert db.class_table(1)[ord(".")] and db.class_table(1).sum() == 1
+
+
+ATOMS = [("a", "a"), (".", "."), (r"\d", r"\d"), (r"\D", r"\D"), (r"\w", r"\w"), (r"\W", r"\W"), (r"\s", r"\s"),
+         (r"\S", r"\S"), ("[a-fA-F0-9]", "[a-fA-F0-9]"), ("[^a-z\\n]", "[^a-z\\n]"), (r"[\w.-]", r"[\w.-]"),
+         (r"[\x00-\x1f]", r"[\x00-\x1f]"), (r"[]x]", r"[]x]"), (r"[a\-z]", r"[a\-z]"), (r"\x80", r"\x80"),
+         (r"[\x80-\xff]", r"[\x80-\xff]"), (r"\.", r"\."), (r"[a-]", r"[a-]"), (r"[\d-x]", r"[\d\-x]"),
+         (r"\h", "[\\t \\xa0]"), (r"\v", "[\\n\\x0b\\f\\r\\x85]"), (r"\N", "[^\\n]"), ("[[:digit:][:upper:]]", "[0-9A-Z]"),
+         ("[[:^space:]]", r"\S"), ("[[:punct:]]", "[!-/:-@\\[-`{-~]"), ("[[:xdigit:]]", "[0-9a-fA-F]")]
+
+
+@pytest.mark.parametrize("atom,pyatom", ATOMS)
+def test_class_tables(atom, pyatom, built, liboracle):
+    """byte membership == Python re == libpcre, for all 256 byte values."""
+    db = engine.Database(atom + "q")  # 'q' keeps a literal in the pattern; position 0 is the atom
+    tbl = db.class_table(0)
+    rx = re.compile(pyatom.encode("latin-1"))
+    want = np.array([rx.fullmatch(bytes([b])) is not None for b in range(256)])
+    assert np.array_equal(tbl, want)
+    buf = bytes(range(256))
+    starts = np.zeros(256, np.uint32)
+    n = liboracle.oracle_all_starts(atom.encode("latin-1"), buf, 256, starts.ctypes.data, None, 256)
+    got = np.zeros(256, bool)
+    got[starts[:n]] = True
+    assert np.array_equal(tbl, got)
+
+
+TAILS = ["abc[0-9]*", "[a-z]{2,5}", "[A-Za-z_][A-Za-z0-9_]{15,}", "e+", "x[^y]{0,7}", "foo", r"\d{3}-\d{4}", "ab?"]
+
+
+@pytest.mark.parametrize("pattern", TAILS)
+def test_match_end(pattern, built, liboracle):
+    rng = np.random.default_rng(7)
+    data = np.frombuffer(b"abcexy0123456789_Z \n", np.uint8)[rng.integers(0, 20, 5000)]
+    data[200:260] = ord("e")
+    data[4990:] = ord("e")
+    data[300:312] = np.frombuffer(b"abc01234567x", np.uint8)
+    data[400:404] = np.frombuffer(b"abcx", np.uint8)
+    data[500:512] = np.frombuffer(b"x555-1234567", np.uint8)
+    data[600:606] = np.frombuffer(b"foofoo", np.uint8)
+    buf = data.tobytes()
+    starts = np.zeros(len(buf), np.uint32)
+    ends = np.zeros(len(buf), np.uint32)
+    n = liboracle.oracle_all_starts(pattern.encode(), buf, len(buf), starts.ctypes.data, ends.ctypes.data, len(buf))
+    assert n > 0
+    db = engine.Database(pattern)
+    for p, e in zip(starts[:n].tolist(), ends[:n].tolist()):
+        assert db.match_end(buf, p) == e

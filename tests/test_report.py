@@ -1,0 +1,84 @@
+"""Host-side printing rule (grab_report_chunk, grab_amd/csrc/filegrep.cc) on the CPU: with the
+candidate list supplied by the oracle instead of the GPU, the product's chunk walk must
+reproduce the reference binary's output byte for byte (golden.json), including chunk-overlap
+duplicates, the strict loop bound, the 511-byte context caps and -s / -l rules."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, golden_ids, split_args
+from grab_amd import engine, filegrep
+from inputs import build
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import scan_oracle as so  # noqa: E402
+
+
+def _supported(case):
+    flags, pattern, paths = split_args(case["args"])
+    if len(paths) != 1 or paths[0] not in case["inputs"] or "-r" in flags or "-n" in flags or case["rc"] != 0 or not case["inputs"]:
+        return False
+    try:
+        engine.Database(pattern)
+    except ValueError:
+        return False
+    return True
+
+
+def host_find(db, data, flags, chunk, path=b""):
+    """FileGrep::find's control flow with oracle-made candidates in place of gscan_wait."""
+    minlen = db.minlen
+    if minlen < 0 or minlen > len(data):
+        return b""
+    tables = [db.class_table(i) for i in range(minlen)]
+    out = []
+    for off, clen in so.chunks(len(data), chunk):
+        part = data[off:off + clen]
+        starts = so.window_starts(part, tables)
+        text = filegrep.report_chunk(db, flags, path, part, off, starts.astype(np.uint32))
+        if text:
+            out.append(text)
+            if flags & filegrep.SINGLE:
+                break
+    return b"".join(out)
+
+
+_CASES = [c for c in GOLDEN if not c["name"].startswith("syn256")]
+
+
+@pytest.mark.parametrize("case", _CASES, ids=golden_ids(_CASES))
+def test_report_matches_reference(case, built):
+    if not _supported(case):
+        pytest.skip("pattern or mode outside this test (unsupported pattern cases are covered by test_pattern)")
+    flags, pattern, paths = split_args(case["args"])
+    f = (filegrep.OFFSETS if "-O" in flags else 0) | (filegrep.NOLINE if "-l" in flags else 0) | (filegrep.SINGLE if "-s" in flags else 0)
+    db = engine.Database(pattern)
+    data = build(case["inputs"][paths[0]])
+    out = host_find(db, data, f, so.chunk_size(flags.count("-L")))
+    assert len(out) == case["stdout_len"]
+    assert hashlib.md5(out).hexdigest() == case["stdout_md5"]
+
+
+def test_report_prefix_and_colour(built):
+    db = engine.Database("foo")
+    data = np.frombuffer(b"a foo b\nfoo\n", np.uint8)
+    starts = np.array([2, 8], np.uint32)
+    out = filegrep.report_chunk(db, filegrep.OFFSETS | filegrep.PREFIX | filegrep.COLOR, "dir/f", data, 1000, starts)
+    assert out == b"dir/f:Match at offset 1002\na \x1b[7mfoo\x1b[27m b\ndir/f:Match at offset 1008\n\x1b[7mfoo\x1b[27m\n"
+
+
+def test_report_matches_python_oracle_random(built):
+    """Random texts x patterns x flags: product walk == scan_oracle.grab_file."""
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"abcdeffoo0123456789_AZ \n\n", np.uint8)
+    for pattern in ["foo", "[a-z]{2,5}", "abc[0-9]*", "e+", "[A-Za-z_][A-Za-z0-9_]{3,}", r"\d\d", "[^\\n]{4}"]:
+        db = engine.Database(pattern)
+        for trial in range(6):
+            n = int(rng.integers(0, 3000))
+            data = alphabet[rng.integers(0, alphabet.size, n)]
+            for f in (0, 1, 3, 2, 4, 5, 7):
+                want = so.grab_file(pattern, data.tobytes(), f, 1 << 30)
+                assert host_find(db, data, f, 1 << 30) == want, (pattern, n, f)
