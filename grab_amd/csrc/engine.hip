@@ -34,16 +34,13 @@ struct gscan_db {
 namespace {
 
 constexpr size_t kPad = 4096;          // slack behind every text buffer
-constexpr size_t kSpecRecs = 16384;    // records fetched speculatively with the header
+constexpr size_t kSpecPer = 2048;       // records of EACH shard region fetched speculatively with the header
+constexpr size_t kSpecRecs = kSpecPer * gscan::kShards;
+constexpr size_t kCounterWords = gscan::kShards + 1; // per-shard counts + overflow flag
 constexpr size_t kCopyPiece = 32u << 20; // memcpy/H2D pipelining granule for foreign host buffers
 constexpr size_t kMaxChunk = (1ull << 30) + 4096;
 
 enum SlotState { FREE = 0, ACQUIRED, INFLIGHT };
-
-struct Meta { // per-slot launch metadata, lives in pinned memory, copied as one block
-    gscan_seg seg;
-    uint32_t tile_first[2];
-};
 
 struct Slot {
     SlotState state = FREE;
@@ -54,15 +51,12 @@ struct Slot {
     uint32_t *d_recs = nullptr;
     size_t rec_cap = 0;
     unsigned long long *d_desc = nullptr;
-    uint32_t *d_tile_seg = nullptr; // all zero: one segment
     size_t tiles_cap = 0;
-    uint32_t *d_counter = nullptr;
-    Meta *h_meta = nullptr; // pinned
-    Meta *d_meta = nullptr;
-    uint32_t *h_counter = nullptr;        // pinned, 2 words
+    uint32_t *d_counter = nullptr;        // kCounterWords
+    uint32_t *h_counter = nullptr;        // pinned, kCounterWords
     unsigned long long *h_desc = nullptr; // pinned
     size_t h_desc_cap = 0;
-    uint32_t *h_spec = nullptr; // pinned, kSpecRecs
+    uint32_t *h_spec = nullptr; // pinned, kShards rows of kSpecPer
     std::vector<uint32_t> raw, sorted;
     hipEvent_t copied = nullptr, done = nullptr;
     uint64_t tag = 0;
@@ -98,9 +92,8 @@ struct gscan_ctx {
     uint32_t *dv_recs = nullptr;
     size_t dv_rec_cap = 0;
     unsigned long long *dv_desc = nullptr;
-    uint32_t *dv_tile_seg = nullptr, *dv_tile_first = nullptr;
-    gscan_seg *dv_segs = nullptr;
-    size_t dv_tiles_cap = 0, dv_segs_cap = 0;
+    gscan::TileDesc *dv_tiles = nullptr;
+    size_t dv_tiles_cap = 0;
     uint32_t *dv_counter = nullptr;
     std::vector<gscan_seg> dv_last_segs;
     std::vector<uint32_t> dv_tile_first_h;
@@ -170,23 +163,19 @@ int slot_reserve(gscan_ctx *c, Slot &s, size_t len)
         s.d_text_cap = cap - kPad;
     }
     // tiles at the smallest tile size any variant uses
-    size_t tiles = len / gscan::scan_tile_bytes(2) + 2;
+    size_t tiles = len / gscan::scan_tile_bytes(1) + 2;
     if (tiles > s.tiles_cap) {
         if (s.d_desc) hipFree(s.d_desc);
-        if (s.d_tile_seg) hipFree(s.d_tile_seg);
         if (s.h_desc) hipHostFree(s.h_desc);
         s.d_desc = nullptr;
-        s.d_tile_seg = nullptr;
         s.h_desc = nullptr;
         s.tiles_cap = 0;
         size_t cap = tiles + tiles / 4;
         HIPCHK(c, hipMalloc((void **)&s.d_desc, cap * 8));
-        HIPCHK(c, hipMalloc((void **)&s.d_tile_seg, cap * 4));
-        HIPCHK(c, hipMemset(s.d_tile_seg, 0, cap * 4));
         HIPCHK(c, hipHostMalloc((void **)&s.h_desc, cap * 8, hipHostMallocDefault));
         s.tiles_cap = cap;
     }
-    size_t want = std::max<size_t>(len / 64, kSpecRecs);
+    size_t want = std::max<size_t>((len / 64 + gscan::kShards - 1) / gscan::kShards * gscan::kShards, kSpecRecs);
     if (want > s.rec_cap) {
         if (s.d_recs) hipFree(s.d_recs);
         s.d_recs = nullptr;
@@ -202,29 +191,27 @@ int slot_launch(gscan_ctx *c, Slot &s)
     const Database &db = s.db->db;
     const uint32_t tile_bytes = gscan::scan_tile_bytes(c->variant);
     s.n_tiles = (uint32_t)((s.len + tile_bytes - 1) / tile_bytes);
-    s.h_meta->seg.offset = 0;
-    s.h_meta->seg.len = (uint32_t)s.len;
-    s.h_meta->seg._pad = 0;
-    s.h_meta->tile_first[0] = 0;
-    s.h_meta->tile_first[1] = s.n_tiles;
-    HIPCHK(c, hipMemcpyAsync(s.d_meta, s.h_meta, sizeof(Meta), hipMemcpyHostToDevice, c->compute));
-    HIPCHK(c, hipMemsetAsync(s.d_counter, 0, 8, c->compute));
+    HIPCHK(c, hipMemsetAsync(s.d_counter, 0, kCounterWords * 4, c->compute));
     ScanArgs a;
+    memset(&a, 0, sizeof a);
     a.base = s.d_text;
-    a.segs = &s.d_meta->seg;
-    a.tile_first = s.d_meta->tile_first;
-    a.tile_seg = s.d_tile_seg;
+    a.tiles = nullptr; // one segment, tiled in order
+    a.seg0_off = 0;
+    a.seg0_len = (uint32_t)s.len;
     a.n_tiles = s.n_tiles;
-    a.cap = (uint32_t)std::min<size_t>(s.rec_cap, 0xffffffffu);
+    a.cap_shard = (uint32_t)(s.rec_cap / gscan::kShards);
     a.recs = s.d_recs;
     a.desc = s.d_desc;
     a.counter = s.d_counter;
     a.prog = c->d_prog;
-    if (s.n_tiles) HIPCHK(c, gscan::launch_scan(db.tier, c->variant, db.prog.m, a, grid_for(c, s.n_tiles), c->compute));
-    HIPCHK(c, hipMemcpyAsync(s.h_counter, s.d_counter, 8, hipMemcpyDeviceToHost, c->compute));
+    gscan::fill_program(a, db.prog);
+    if (s.n_tiles) HIPCHK(c, gscan::launch_scan(db.tier, c->variant, a, grid_for(c, s.n_tiles), c->compute));
+    HIPCHK(c, hipMemcpyAsync(s.h_counter, s.d_counter, kCounterWords * 4, hipMemcpyDeviceToHost, c->compute));
     if (s.n_tiles)
         HIPCHK(c, hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)s.n_tiles * 8, hipMemcpyDeviceToHost, c->compute));
-    HIPCHK(c, hipMemcpyAsync(s.h_spec, s.d_recs, kSpecRecs * 4, hipMemcpyDeviceToHost, c->compute));
+    // the head of every shard region in one strided copy: enough for any sparse result
+    HIPCHK(c, hipMemcpy2DAsync(s.h_spec, kSpecPer * 4, s.d_recs, (size_t)a.cap_shard * 4, kSpecPer * 4, gscan::kShards,
+                               hipMemcpyDeviceToHost, c->compute));
     HIPCHK(c, hipEventRecord(s.done, c->compute));
     return 0;
 }
@@ -235,10 +222,7 @@ void free_slot(Slot &s)
     if (s.d_text) hipFree(s.d_text);
     if (s.d_recs) hipFree(s.d_recs);
     if (s.d_desc) hipFree(s.d_desc);
-    if (s.d_tile_seg) hipFree(s.d_tile_seg);
     if (s.d_counter) hipFree(s.d_counter);
-    if (s.d_meta) hipFree(s.d_meta);
-    if (s.h_meta) hipHostFree(s.h_meta);
     if (s.h_counter) hipHostFree(s.h_counter);
     if (s.h_desc) hipHostFree(s.h_desc);
     if (s.h_spec) hipHostFree(s.h_spec);
@@ -352,15 +336,13 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     if (hipMalloc((void **)&c->d_prog, sizeof(DevProgram)) != hipSuccess) return bail(GSCAN_EHIP);
     if (hipHostMalloc((void **)&c->h_prog, sizeof(DevProgram), hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
     for (Slot &s : c->slot) {
-        if (hipMalloc((void **)&s.d_counter, 8) != hipSuccess) return bail(GSCAN_EHIP);
-        if (hipMalloc((void **)&s.d_meta, sizeof(Meta)) != hipSuccess) return bail(GSCAN_EHIP);
-        if (hipHostMalloc((void **)&s.h_meta, sizeof(Meta), hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
-        if (hipHostMalloc((void **)&s.h_counter, 8, hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
+        if (hipMalloc((void **)&s.d_counter, 64) != hipSuccess) return bail(GSCAN_EHIP);
+        if (hipHostMalloc((void **)&s.h_counter, 64, hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
         if (hipHostMalloc((void **)&s.h_spec, kSpecRecs * 4, hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
         if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
         if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
     }
-    if (hipMalloc((void **)&c->dv_counter, 8) != hipSuccess) return bail(GSCAN_EHIP);
+    if (hipMalloc((void **)&c->dv_counter, 64) != hipSuccess) return bail(GSCAN_EHIP);
     *out = c;
     return GSCAN_OK;
 }
@@ -375,9 +357,7 @@ void gscan_close(gscan_ctx *c)
     if (c->h_prog) hipHostFree(c->h_prog);
     if (c->dv_recs) hipFree(c->dv_recs);
     if (c->dv_desc) hipFree(c->dv_desc);
-    if (c->dv_tile_seg) hipFree(c->dv_tile_seg);
-    if (c->dv_tile_first) hipFree(c->dv_tile_first);
-    if (c->dv_segs) hipFree(c->dv_segs);
+    if (c->dv_tiles) hipFree(c->dv_tiles);
     if (c->dv_counter) hipFree(c->dv_counter);
     for (auto &e : c->ev_pool) {
         hipEventDestroy(e.a);
@@ -465,13 +445,14 @@ int gscan_wait(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, size_t *n, 
     if (!s) return fail(c, GSCAN_EEMPTY, "nothing in flight");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventSynchronize(s->done));
+    const size_t K = gscan::kShards;
     for (int attempt = 0; attempt < 2; attempt++) {
-        uint32_t total = s->h_counter[0];
-        bool overflow = s->h_counter[1] != 0;
-        if (!overflow) break;
+        if (s->h_counter[K] == 0) break; // no shard overflowed
         if (attempt == 1) return fail(c, GSCAN_EHIP, "record buffer overflow persisted after regrow");
-        // the text is still in HBM: grow the record buffer to what the kernel asked for and rescan
-        size_t want = (size_t)total + (size_t)total / 8 + 1024;
+        // the text is still in HBM: size every shard for the fullest one (+25%) and rescan
+        uint32_t worst = 0;
+        for (size_t k = 0; k < K; k++) worst = std::max(worst, s->h_counter[k]);
+        size_t want = ((size_t)worst + (size_t)worst / 4 + kSpecPer) * K;
         HIPCHK(c, hipStreamSynchronize(c->compute));
         if (s->d_recs) hipFree(s->d_recs);
         s->d_recs = nullptr;
@@ -482,21 +463,31 @@ int gscan_wait(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, size_t *n, 
         if (rc) return rc;
         HIPCHK(c, hipEventSynchronize(s->done));
     }
-    const uint32_t total = s->h_counter[0];
-    const uint32_t *recs = s->h_spec;
-    if (total > kSpecRecs) {
-        s->raw.resize(total);
-        HIPCHK(c, hipMemcpy(s->raw.data(), s->d_recs, (size_t)total * 4, hipMemcpyDeviceToHost));
-        recs = s->raw.data();
+    const size_t cap_shard = s->rec_cap / K;
+    size_t total = 0;
+    bool spec_ok = true;
+    for (size_t k = 0; k < K; k++) {
+        total += s->h_counter[k];
+        if (s->h_counter[k] > kSpecPer) spec_ok = false;
+    }
+    if (!spec_ok) { // dense result: fetch each shard region's used part
+        s->raw.resize(s->rec_cap);
+        for (size_t k = 0; k < K; k++)
+            if (s->h_counter[k])
+                HIPCHK(c, hipMemcpy(s->raw.data() + k * cap_shard, s->d_recs + k * cap_shard, (size_t)s->h_counter[k] * 4,
+                                    hipMemcpyDeviceToHost));
     }
     s->sorted.clear();
     s->sorted.reserve(total);
     for (uint32_t t = 0; t < s->n_tiles; t++) { // tiles are in text order: concatenating their runs sorts the list
         unsigned long long d = s->h_desc[t];
-        uint32_t cnt = (uint32_t)d, base = (uint32_t)(d >> 32);
-        if (cnt) s->sorted.insert(s->sorted.end(), recs + base, recs + base + cnt);
+        uint32_t cnt = (uint32_t)d;
+        size_t base = (size_t)(d >> 32);
+        if (!cnt) continue;
+        const uint32_t *src = spec_ok ? s->h_spec + (base / cap_shard) * kSpecPer + base % cap_shard : s->raw.data() + base;
+        s->sorted.insert(s->sorted.end(), src, src + cnt);
     }
-    if (s->sorted.size() != total) return fail(c, GSCAN_EHIP, "descriptor total %zu != counter %u", s->sorted.size(), total);
+    if (s->sorted.size() != total) return fail(c, GSCAN_EHIP, "descriptor total %zu != counter %zu", s->sorted.size(), total);
     if (tag) *tag = s->tag;
     *starts = s->sorted.data();
     *n = s->sorted.size();
@@ -516,7 +507,7 @@ int gscan_set_option(gscan_ctx *c, const char *name, long value)
 {
     if (!c || !name) return GSCAN_EINVAL;
     if (!strcmp(name, "variant")) {
-        if (value < 0 || value > 7 || (value & 3) == 3) return GSCAN_EINVAL;
+        if (value < 0 || value > 7 || (value & 3) == 3) return GSCAN_EINVAL; // KiB per wave {16,8,12} | nontemporal<<2
         c->variant = (int)value;
         return GSCAN_OK;
     }
@@ -539,75 +530,69 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
     int rc = ensure_prog(c, db, st);
     if (rc) return rc;
     const uint32_t tile_bytes = gscan::scan_tile_bytes(c->variant);
+    const size_t K = gscan::kShards;
 
-    // tile map: rebuilt only when the segment table or the tile size changed
+    // tile table: rebuilt only when the segment table or the tile size changed
     bool same = c->dv_last_tile_bytes == tile_bytes && c->dv_last_segs.size() == nseg &&
                 (nseg == 0 || !memcmp(c->dv_last_segs.data(), segs, nseg * sizeof(gscan_seg)));
     if (!same) {
         std::vector<uint32_t> &tf = c->dv_tile_first_h;
         tf.assign(nseg + 1, 0);
-        uint64_t total_bytes = 0, nt = 0;
+        uint64_t nt = 0;
         for (size_t i = 0; i < nseg; i++) {
             if (segs[i].len > kMaxChunk) return fail(c, GSCAN_ETOOBIG, "segment %zu longer than a chunk", i);
             if (segs[i].offset & 15) return fail(c, GSCAN_EINVAL, "segment %zu is not 16-byte aligned", i);
             tf[i] = (uint32_t)nt;
             nt += (segs[i].len + tile_bytes - 1) / tile_bytes;
-            total_bytes += segs[i].len;
         }
         if (nt >= 0xffffffffull) return fail(c, GSCAN_ETOOBIG, "too many tiles");
         tf[nseg] = (uint32_t)nt;
-        std::vector<uint32_t> ts((size_t)nt);
-        for (size_t i = 0; i < nseg; i++) std::fill(ts.begin() + tf[i], ts.begin() + tf[i + 1], (uint32_t)i);
-        HIPCHK(c, hipStreamSynchronize(st)); // earlier scans may still read the old tables
+        std::vector<gscan::TileDesc> td((size_t)nt);
+        for (size_t i = 0; i < nseg; i++)
+            for (uint32_t t = tf[i]; t < tf[i + 1]; t++) td[t] = {segs[i].offset, segs[i].len, (t - tf[i]) * tile_bytes};
+        HIPCHK(c, hipStreamSynchronize(st)); // earlier scans may still read the old table
         if (nt + 1 > c->dv_tiles_cap) {
             if (c->dv_desc) hipFree(c->dv_desc);
-            if (c->dv_tile_seg) hipFree(c->dv_tile_seg);
+            if (c->dv_tiles) hipFree(c->dv_tiles);
             c->dv_desc = nullptr;
-            c->dv_tile_seg = nullptr;
+            c->dv_tiles = nullptr;
             c->dv_tiles_cap = 0;
             HIPCHK(c, hipMalloc((void **)&c->dv_desc, (size_t)(nt + 1) * 8));
-            HIPCHK(c, hipMalloc((void **)&c->dv_tile_seg, (size_t)(nt + 1) * 4));
+            HIPCHK(c, hipMalloc((void **)&c->dv_tiles, (size_t)(nt + 1) * sizeof(gscan::TileDesc)));
             c->dv_tiles_cap = (size_t)nt + 1;
         }
-        if (nseg + 1 > c->dv_segs_cap) {
-            if (c->dv_segs) hipFree(c->dv_segs);
-            if (c->dv_tile_first) hipFree(c->dv_tile_first);
-            c->dv_segs = nullptr;
-            c->dv_tile_first = nullptr;
-            c->dv_segs_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->dv_segs, (nseg + 1) * sizeof(gscan_seg)));
-            HIPCHK(c, hipMalloc((void **)&c->dv_tile_first, (nseg + 1) * 4));
-            c->dv_segs_cap = nseg + 1;
-        }
-        if (nseg) HIPCHK(c, hipMemcpy(c->dv_segs, segs, nseg * sizeof(gscan_seg), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->dv_tile_first, tf.data(), (nseg + 1) * 4, hipMemcpyHostToDevice));
-        if (nt) HIPCHK(c, hipMemcpy(c->dv_tile_seg, ts.data(), (size_t)nt * 4, hipMemcpyHostToDevice));
+        if (nt) HIPCHK(c, hipMemcpy(c->dv_tiles, td.data(), (size_t)nt * sizeof(gscan::TileDesc), hipMemcpyHostToDevice));
         c->dv_last_segs.assign(segs, segs + nseg);
         c->dv_last_tile_bytes = tile_bytes;
-        size_t want = c->dev_cap_req ? c->dev_cap_req : std::max<size_t>((size_t)(total_bytes / 16), 1u << 16);
-        want = std::min<size_t>(want, 0xffffffffu);
-        if (want > c->dv_rec_cap || (c->dev_cap_req && want != c->dv_rec_cap)) {
-            if (c->dv_recs) hipFree(c->dv_recs);
-            c->dv_recs = nullptr;
-            c->dv_rec_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->dv_recs, want * 4));
-            c->dv_rec_cap = want;
-        }
     }
     const uint32_t n_tiles = c->dv_tile_first_h.empty() ? 0 : c->dv_tile_first_h.back();
 
-    HIPCHK(c, hipMemsetAsync(c->dv_counter, 0, 8, st));
+    // record buffer: the caller's capacity if set, else arena bytes / 16; kShards equal regions
+    uint64_t total_bytes = 0;
+    for (size_t i = 0; i < nseg; i++) total_bytes += segs[i].len;
+    size_t want = c->dev_cap_req ? c->dev_cap_req : std::max<size_t>((size_t)(total_bytes / 16), 1u << 16);
+    want = std::min<size_t>((want + K - 1) / K * K, 0xfffffff8u);
+    if (want != c->dv_rec_cap && (c->dev_cap_req || want > c->dv_rec_cap)) {
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (c->dv_recs) hipFree(c->dv_recs);
+        c->dv_recs = nullptr;
+        c->dv_rec_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->dv_recs, want * 4));
+        c->dv_rec_cap = want;
+    }
+
+    HIPCHK(c, hipMemsetAsync(c->dv_counter, 0, kCounterWords * 4, st));
     ScanArgs a;
+    memset(&a, 0, sizeof a);
     a.base = (const uint8_t *)dev_base;
-    a.segs = c->dv_segs;
-    a.tile_first = c->dv_tile_first;
-    a.tile_seg = c->dv_tile_seg;
+    a.tiles = c->dv_tiles;
     a.n_tiles = n_tiles;
-    a.cap = (uint32_t)c->dv_rec_cap;
+    a.cap_shard = (uint32_t)(c->dv_rec_cap / K);
     a.recs = c->dv_recs;
     a.desc = c->dv_desc;
     a.counter = c->dv_counter;
     a.prog = c->d_prog;
+    gscan::fill_program(a, db->db.prog);
     if (c->ev_used == c->ev_pool.size() && c->ev_pool.size() < 4096) {
         EvPair e;
         HIPCHK(c, hipEventCreate(&e.a));
@@ -616,14 +601,13 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
     }
     bool timed = c->ev_used < c->ev_pool.size();
     if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used].a, st));
-    if (n_tiles) HIPCHK(c, gscan::launch_scan(db->db.tier, c->variant, db->db.prog.m, a, grid_for(c, n_tiles), st));
+    if (n_tiles) HIPCHK(c, gscan::launch_scan(db->db.tier, c->variant, a, grid_for(c, n_tiles), st));
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used].b, st));
         c->ev_used++;
     }
     res->recs = c->dv_recs;
     res->desc = (const uint64_t *)c->dv_desc;
-    res->tile_seg = c->dv_tile_seg;
     res->n_tiles = n_tiles;
     res->tile_bytes = tile_bytes;
     res->total = 0;
@@ -636,11 +620,12 @@ int gscan_dev_sync(gscan_ctx *c, gscan_dev_result *res)
     if (!c || !res) return GSCAN_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->dv_stream ? c->dv_stream : c->compute;
-    uint32_t h[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(h, c->dv_counter, 8, hipMemcpyDeviceToHost, st));
+    uint32_t h[kCounterWords] = {0};
+    HIPCHK(c, hipMemcpyAsync(h, c->dv_counter, sizeof h, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    res->total = h[0];
-    res->overflow = h[1] != 0;
+    res->total = 0;
+    for (size_t k = 0; k < (size_t)gscan::kShards; k++) res->total += h[k];
+    res->overflow = h[gscan::kShards] != 0;
     return GSCAN_OK;
 }
 
@@ -654,11 +639,13 @@ long gscan_dev_fetch(gscan_ctx *c, const gscan_dev_result *res, size_t seg, uint
     uint32_t t0 = c->dv_tile_first_h[seg], t1 = c->dv_tile_first_h[seg + 1];
     std::vector<unsigned long long> d(t1 - t0);
     if (t1 > t0) HIPCHK(c, hipMemcpy(d.data(), c->dv_desc + t0, (size_t)(t1 - t0) * 8, hipMemcpyDeviceToHost));
+    const size_t cap_shard = c->dv_rec_cap / gscan::kShards;
     size_t n = 0;
     for (unsigned long long v : d) {
-        uint32_t cnt = (uint32_t)v, base = (uint32_t)(v >> 32);
+        uint32_t cnt = (uint32_t)v;
+        size_t base = (size_t)(v >> 32);
         if (!cnt) continue;
-        if ((size_t)base + cnt > c->dv_rec_cap) return fail(c, GSCAN_EHIP, "record buffer overflowed; raise gscan_set_capacity");
+        if (base % cap_shard + cnt > cap_shard) return fail(c, GSCAN_EHIP, "record buffer overflowed; raise gscan_set_capacity");
         if (out && n + cnt <= cap) HIPCHK(c, hipMemcpy(out + n, c->dv_recs + base, (size_t)cnt * 4, hipMemcpyDeviceToHost));
         n += cnt;
     }

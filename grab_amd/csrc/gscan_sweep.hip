@@ -1,4 +1,4 @@
-// gscan_sweep.cc -- native A/B harness for the scan kernels (no Python, no torch).
+// gscan_sweep.hip -- native A/B harness for the scan kernels (no Python, no torch).
 //
 //   gscan_sweep [--gib G] [--seg-mib M] [--pattern P] [--iters N] [--variants 0,1,2,4,5,6] [--bpc 0,4,8,16]
 //
@@ -9,6 +9,7 @@
 // line per pair: mean/min kernel time (HIP events on the launch stream) and GB/s.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,51 @@
 #include "../../include/gscan.h"
 
 extern "C" int gscan_kernel_time(gscan_ctx *, double *, uint64_t *, int);
+
+// ---- read-ceiling probe: the scan kernels' exact load pattern (256-thread workgroup, each wave
+// ITER x 1 KiB via buffer_load_dwordx4 issued up front) with a trivial reduction instead of the
+// scan.  What this reaches is the practical ceiling for "read every byte once" on this box.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int ITER, bool NT>
+__global__ __launch_bounds__(256) void k0_read_probe(const uint8_t *base, uint32_t n_tiles, uint32_t *sink)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr uint32_t kTile = 4 * ITER * 1024;
+    uint32_t acc = 0;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t addr = (uint64_t)base + (uint64_t)t * kTile;
+        const uint32_t alo = __builtin_amdgcn_readfirstlane((uint32_t)addr), ahi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)ahi << 32) | alo), 0, (int)kTile, 0x00020000);
+        u32x4 buf[ITER];
+        const int v0 = (int)(wave * ITER * 1024 + lane * 16);
+#pragma unroll
+        for (int k = 0; k < ITER; k++) buf[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + k * 1024, 0, NT ? 2 : 0));
+#pragma unroll
+        for (int k = 0; k < ITER; k++) acc ^= buf[k].x ^ buf[k].y ^ buf[k].z ^ buf[k].w;
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc; // never true on text; keeps the loads alive
+}
+
+template <int ITER, bool NT>
+static float probe(const uint8_t *arena, size_t total, uint32_t *sink, int bpc, int iters)
+{
+    const uint32_t n_tiles = (uint32_t)(total / (4 * ITER * 1024));
+    const uint32_t grid = bpc > 0 ? std::min<uint32_t>(n_tiles, 256u * bpc) : n_tiles;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    float best = 1e30f;
+    for (int i = 0; i < iters + 1; i++) {
+        (void)hipEventRecord(a, 0);
+        hipLaunchKernelGGL((k0_read_probe<ITER, NT>), dim3(grid), dim3(256), 0, 0, arena, n_tiles, sink);
+        (void)hipEventRecord(b, 0);
+        (void)hipEventSynchronize(b);
+        float ms;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (i > 0 && ms < best) best = ms;
+    }
+    return best;
+}
 
 static std::vector<long> parse_list(const char *s)
 {
@@ -36,6 +82,7 @@ int main(int argc, char **argv)
     std::string pattern = "foobardoesnotexist";
     std::vector<long> variants = {0, 1, 2, 4, 5, 6}, bpcs = {0, 8};
     int plant_every_mib = 1;
+    bool ceiling = false;
     for (int i = 1; i < argc; i++) {
         auto is = [&](const char *f) { return !strcmp(argv[i], f) && i + 1 < argc; };
         if (is("--gib")) gib = atof(argv[++i]);
@@ -45,6 +92,7 @@ int main(int argc, char **argv)
         else if (is("--variants")) variants = parse_list(argv[++i]);
         else if (is("--bpc")) bpcs = parse_list(argv[++i]);
         else if (is("--plant-mib")) plant_every_mib = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--ceiling")) ceiling = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     const size_t seg_bytes = (size_t)seg_mib << 20;
@@ -63,9 +111,23 @@ int main(int argc, char **argv)
 
     uint8_t *arena = nullptr;
     if (hipMalloc((void **)&arena, total + 4096) != hipSuccess) { fprintf(stderr, "hipMalloc %zu failed\n", total); return 1; }
-    hipMemcpy(arena, block.data(), seg_bytes, hipMemcpyHostToDevice);
-    for (size_t s = 1; s < nseg; s++) hipMemcpy(arena + s * seg_bytes, arena, seg_bytes, hipMemcpyDeviceToDevice);
-    hipDeviceSynchronize();
+    (void)hipMemcpy(arena, block.data(), seg_bytes, hipMemcpyHostToDevice);
+    for (size_t s = 1; s < nseg; s++) (void)hipMemcpy(arena + s * seg_bytes, arena, seg_bytes, hipMemcpyDeviceToDevice);
+    (void)hipDeviceSynchronize();
+
+    if (ceiling) {
+        uint32_t *sink = nullptr;
+        (void)hipMalloc((void **)&sink, 64);
+        printf("# read-ceiling probe, %.2f GiB, best of %d\n", total / 1073741824.0, iters);
+        for (int bpc : {0, 8, 16}) {
+            printf("probe ITER16      bpc %2d : %8.1f GB/s\n", bpc, total / probe<16, false>(arena, total, sink, bpc, iters) / 1e6);
+            printf("probe ITER16 nt   bpc %2d : %8.1f GB/s\n", bpc, total / probe<16, true>(arena, total, sink, bpc, iters) / 1e6);
+            printf("probe ITER8       bpc %2d : %8.1f GB/s\n", bpc, total / probe<8, false>(arena, total, sink, bpc, iters) / 1e6);
+            printf("probe ITER8  nt   bpc %2d : %8.1f GB/s\n", bpc, total / probe<8, true>(arena, total, sink, bpc, iters) / 1e6);
+            printf("probe ITER32 nt   bpc %2d : %8.1f GB/s\n", bpc, total / probe<32, true>(arena, total, sink, bpc, iters) / 1e6);
+        }
+        (void)hipFree(sink);
+    }
 
     gscan_ctx *ctx = nullptr;
     if (gscan_open(0, 1u << 30, &ctx) != GSCAN_OK) { fprintf(stderr, "gscan_open failed\n"); return 1; }
@@ -105,6 +167,6 @@ int main(int argc, char **argv)
     }
     gscan_free(db);
     gscan_close(ctx);
-    hipFree(arena);
+    (void)hipFree(arena);
     return 0;
 }

@@ -6,36 +6,39 @@
 //
 // Both kernels are HBM-bound byte-stream scans (no MFMA).  Shared structure:
 //   * work unit = TILE of WAVES*ITER KiB of one segment; a 256-thread workgroup
-//     (4 waves) takes a tile, each wave a contiguous ITER-KiB sub-tile;
-//   * every lane issues all its ITER+1 16-byte loads up front (global_load_dwordx4,
+//     (4 waves) takes a tile, each wave a contiguous ITER-KiB sub-tile; the tile's
+//     16-byte descriptor comes in with one scalar load;
+//   * every lane issues all its ITER+1 16-byte loads up front (buffer_load_dwordx4,
 //     lane i -> bytes [16i,16i+16) of each KiB: fully coalesced, each input byte is
 //     fetched from HBM exactly once; the +1 is a <=64-byte halo for windows that
-//     straddle the sub-tile end);
+//     straddle the sub-tile end; the buffer descriptor's bounds check zero-fills past
+//     the segment end, so there are no per-load branches);
 //   * per KiB step each lane produces a 16-bit candidate mask for its 16 positions;
 //     masks stay in registers until the tile is done (2 steps per VGPR);
 //   * compaction: per-lane popcount -> wave reduce -> one LDS slot per wave -> ONE
 //     global atomicAdd per tile that has any candidate reserves a contiguous run in
-//     the record buffer; lanes then expand their masks in text order using a wave
-//     prefix sum, and the tile's descriptor {count, base} is written at desc[tile].
-//     Tiles are in text order, so walking desc[] yields ascending offsets with no
-//     sort and no second pass over the text.
+//     the record buffer (8 counters, one per record-buffer shard, tile t uses shard
+//     t&7, so dense outputs do not serialise on one address); lanes then expand their
+//     masks in text order using a wave prefix sum, and the tile's descriptor
+//     {count, base} is written at desc[tile].  Tiles are in text order, so walking
+//     desc[] yields ascending offsets with no sort and no second pass over the text.
 //
 // K1 (literal / anchored class sequence): SWAR compare of the 4-byte anchor at all
-//   16 byte alignments of the lane's data (v_alignbyte + xor + min3), ~2.3 VALU
+//   16 byte alignments of the lane's data (v_alignbyte + v_bitop3 + v_min3), ~2.6 VALU
 //   ops/byte; the rare anchor hit is verified against the whole window in a cold
 //   path.  No LDS in the hot loop.
 // K2 (class runs, <=4 classes, window <=49): LDS-staged byte->class-bits table,
 //   replicated once per LDS bank (32 KiB) so the 64 random lookups of a wave never
 //   conflict; 16 lookups/lane/step accumulate into two registers; neighbouring
-//   lanes' masks come in by DPP/bpermute; runs of n consecutive class bits are
-//   found by shift-AND doubling (log2 n steps) on 32- or 64-bit words.
+//   lanes' masks come in by DPP wave shifts; runs of n consecutive class bits are
+//   found by shift-AND doubling (log2 n steps) on 32- or 64-bit words.  The run
+//   program sits in the lanes of one VGPR (v_readlane), not in memory.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "scan_args.h"
 
 namespace gscan {
-
 
 namespace {
 
@@ -111,31 +114,41 @@ __device__ __noinline__ bool verify_window(const uint8_t *seg, const DevProgram 
 }
 
 struct TileCtx {
-    const uint8_t *seg; // segment base
+    const uint8_t *seg;          // segment base
     __amdgpu_buffer_rsrc_t rsrc; // descriptor over [seg, seg + slen rounded up to 16)
-    int slen;           // segment length
-    int tile_off;       // first byte of the tile inside the segment
-    bool live;          // segment long enough to hold a window at all
+    int slen;                    // segment length
+    int tile_off;                // first byte of the tile inside the segment
+    bool live;                   // segment long enough to hold a window at all
 };
 
-__device__ __forceinline__ TileCtx tile_ctx(const ScanArgs &a, uint32_t t, uint32_t tile_bytes, uint32_t m)
+// t is blockIdx-derived, so everything here is wave-uniform; the descriptor is read with
+// a scalar load and readfirstlane makes the uniformity provable, which keeps the buffer
+// descriptor in SGPRs (otherwise hipcc wraps every buffer load in a waterfall loop).
+__device__ __forceinline__ TileCtx tile_ctx(const ScanArgs &a, const TileDesc *__restrict__ tiles, uint32_t t,
+                                            uint32_t tile_bytes)
 {
-    TileCtx c;
-    uint32_t s = a.tile_seg[t];
-    uint32_t local = t - a.tile_first[s];
-    gscan_seg sg = a.segs[s];
-    // t is blockIdx-derived, so all of this is wave-uniform; readfirstlane makes that
-    // provable and keeps the descriptor in SGPRs (otherwise hipcc wraps every buffer
-    // load in a waterfall loop).
-    const uint64_t addr = (uint64_t)(a.base + sg.offset);
+    uint64_t seg_off;
+    uint32_t len, toff;
+    if (tiles) {
+        const TileDesc d = tiles[t];
+        seg_off = d.seg_off;
+        len = d.seg_len;
+        toff = d.tile_off;
+    } else {
+        seg_off = a.seg0_off;
+        len = a.seg0_len;
+        toff = t * tile_bytes;
+    }
+    const uint64_t addr = (uint64_t)a.base + seg_off;
     const uint32_t alo = __builtin_amdgcn_readfirstlane((uint32_t)addr);
     const uint32_t ahi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
-    const uint32_t len = __builtin_amdgcn_readfirstlane(sg.len);
+    len = __builtin_amdgcn_readfirstlane(len);
+    TileCtx c;
     c.seg = (const uint8_t *)(((uint64_t)ahi << 32) | alo);
     c.slen = (int)len;
     c.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)c.seg, 0, (int)((len + 15u) & ~15u), 0x00020000);
-    c.tile_off = (int)__builtin_amdgcn_readfirstlane(local * tile_bytes);
-    c.live = len >= m;
+    c.tile_off = (int)__builtin_amdgcn_readfirstlane(toff);
+    c.live = len >= a.m;
     return c;
 }
 
@@ -177,18 +190,19 @@ __device__ __forceinline__ void emit_tile(const ScanArgs &a, uint32_t t, const u
         __syncthreads(); // s_cnt is rewritten by the next tile
         return;
     }
+    const uint32_t shard = t & (kShards - 1);
     if (threadIdx.x == 0) {
-        uint32_t b = atomicAdd(a.counter, total);
+        uint32_t b = atomicAdd(a.counter + shard, total); // index inside the shard's region
         *s_base = b;
-        a.desc[t] = (unsigned long long)total | ((unsigned long long)b << 32);
-        if ((unsigned long long)b + total > (unsigned long long)a.cap) atomicOr(a.counter + 1, 1u);
+        a.desc[t] = (unsigned long long)total | ((unsigned long long)(shard * a.cap_shard + b) << 32);
+        if ((unsigned long long)b + total > (unsigned long long)a.cap_shard) atomicOr(a.counter + kShards, 1u);
     }
     __syncthreads();
     uint32_t base = *s_base;
     __syncthreads(); // s_base / s_cnt free for the next tile
-    if ((unsigned long long)base + total > (unsigned long long)a.cap) return; // overflow: host re-runs bigger
+    if ((unsigned long long)base + total > (unsigned long long)a.cap_shard) return; // overflow: host re-runs bigger
     if (wtot == 0) return;
-    uint32_t run = base + before;
+    uint32_t run = shard * a.cap_shard + base + before;
 #pragma unroll
     for (int k = 0; k < ITER; k++) {
         uint32_t bits = (hits[k >> 1] >> (16 * (k & 1))) & 0xffffu;
@@ -210,19 +224,18 @@ __device__ __forceinline__ void emit_tile(const ScanArgs &a, uint32_t t, const u
 // K1: literal / anchored window.
 // ------------------------------------------------------------------------------------
 template <int ITER, bool NT>
-__global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a)
+__global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     __shared__ uint32_t s_cnt[kWaves];
     __shared__ uint32_t s_base;
     constexpr uint32_t kTile = kWaves * ITER * 1024;
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x / kWave;
-    const DevProgram *pg = a.prog;
-    const uint32_t anchor = pg->anchor, amask = pg->anchor_mask;
-    const uint32_t aoff = pg->anchor_off, m = pg->m;
+    const uint32_t anchor = a.anchor, amask = a.anchor_mask;
+    const uint32_t aoff = a.anchor_off, m = a.m;
 
     for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-        TileCtx c = tile_ctx(a, t, kTile, m);
+        TileCtx c = tile_ctx(a, tiles, t, kTile);
         const int sub_off = c.tile_off + (int)(wave * ITER * 1024);
         uint32_t hits[(ITER + 1) / 2];
 #pragma unroll
@@ -262,12 +275,12 @@ __global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a)
                         if (((u ^ anchor) & amask) == 0) bits |= 1u << j;
                     }
                     bits &= vm;
-                    if (m > pg->anchor_len) {
+                    if (m > a.anchor_len) {
                         uint32_t keep = 0, b2 = bits;
                         while (b2) {
                             uint32_t j = (uint32_t)__ffs((int)b2) - 1u;
                             b2 &= b2 - 1u;
-                            if (verify_window(c.seg, pg, (uint32_t)pos0 + j - aoff)) keep |= 1u << j;
+                            if (verify_window(c.seg, a.prog, (uint32_t)pos0 + j - aoff)) keep |= 1u << j;
                         }
                         bits = keep;
                     }
@@ -290,8 +303,30 @@ __global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a)
 // 0-31 and 32-63 separately).
 #define GS_LUT(w_, sh_) tbl[((((w_) >> (sh_)) & 0xffu) << 5) | bank]
 
+// cand(p) = AND over runs r of "class cls_r holds at p+off_r .. p+off_r+len_r-1".  A run of
+// n set bits starting at bit p of x: double the verified length (x &= x >> len) while it
+// fits, then one overlapping step for the remainder.  Everything but x is in SGPRs.
+template <typename W>
+__device__ __forceinline__ W run_and(uint32_t nruns, uint32_t vrd, const W (&cls)[4])
+{
+    W cand = ~(W)0;
+    for (uint32_t r = 0; r < nruns; r++) {
+        const uint32_t d = __builtin_amdgcn_readlane(vrd, r); // descriptor r: one v_readlane, no memory, no wait
+        const uint32_t c = d & 0xffu, n = (d >> 8) & 0xffu, off = d >> 16;
+        W x = c == 0 ? cls[0] : c == 1 ? cls[1] : c == 2 ? cls[2] : cls[3];
+        uint32_t len = 1;
+        while (2 * len <= n) {
+            x &= x >> len;
+            len *= 2;
+        }
+        if (len < n) x &= x >> (n - len);
+        cand &= x >> off;
+    }
+    return cand;
+}
+
 template <int ITER, bool NT, bool WIDE>
-__global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a)
+__global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     __shared__ uint32_t tbl[256 * 32];
     __shared__ uint32_t s_cnt[kWaves];
@@ -300,19 +335,23 @@ __global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a)
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t bank = lane & 31u;
-    const DevProgram *pg = a.prog;
-    const uint32_t m = pg->m, ncls = pg->n_classes, nruns = pg->nruns;
+    const uint32_t m = a.m, ncls = a.n_classes, nruns = a.nruns;
+    // The run program lives in the lanes of one VGPR (lane r = descriptor r) and is read back
+    // with v_readlane inside the run loop.  Fetching it from the kernel-argument segment there
+    // would put a scalar load + s_waitcnt lgkmcnt(0) into every step, and that wait also drains
+    // the LDS lookups already in flight for the next step.
+    const uint32_t vrd = a.run_desc[lane & (kK2MaxRuns - 1)];
 
     { // stage the class table: entry b replicated into all 32 banks
         uint32_t b = threadIdx.x; // kWG == 256 entries
-        uint32_t v = pg->k2_table[b];
+        uint32_t v = a.prog->k2_table[b];
 #pragma unroll 8
         for (uint32_t r = 0; r < 32; r++) tbl[(b << 5) | ((r + lane) & 31u)] = v;
     }
     __syncthreads();
 
     for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-        TileCtx c = tile_ctx(a, t, kTile, m);
+        TileCtx c = tile_ctx(a, tiles, t, kTile);
         const int sub_off = c.tile_off + (int)(wave * ITER * 1024);
         uint32_t hits[(ITER + 1) / 2];
 #pragma unroll
@@ -350,24 +389,9 @@ __global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a)
                 if (!WIDE) { // look-ahead <= 16 positions: one neighbour
                     const uint32_t a01 = down1(p01, __builtin_amdgcn_readfirstlane(p01n));
                     const uint32_t a23 = ncls > 2 ? down1(p23, __builtin_amdgcn_readfirstlane(p23n)) : 0u;
-                    uint32_t W[4];
-                    W[0] = (p01 & 0xffffu) | (a01 << 16);
-                    W[1] = (p01 >> 16) | (a01 & 0xffff0000u);
-                    W[2] = (p23 & 0xffffu) | (a23 << 16);
-                    W[3] = (p23 >> 16) | (a23 & 0xffff0000u);
-                    uint32_t cand = 0xffffffffu;
-                    for (uint32_t r = 0; r < nruns; r++) {
-                        const uint32_t cls = pg->run_cls[r], n = pg->run_len[r], off = pg->run_off[r];
-                        uint32_t x = cls == 0 ? W[0] : cls == 1 ? W[1] : cls == 2 ? W[2] : W[3];
-                        uint32_t len = 1;
-                        while (2 * len <= n) {
-                            x &= x >> len;
-                            len *= 2;
-                        }
-                        if (len < n) x &= x >> (n - len);
-                        cand &= x >> off;
-                    }
-                    bits = cand & 0xffffu;
+                    const uint32_t W[4] = {(p01 & 0xffffu) | (a01 << 16), (p01 >> 16) | (a01 & 0xffff0000u),
+                                           (p23 & 0xffffu) | (a23 << 16), (p23 >> 16) | (a23 & 0xffff0000u)};
+                    bits = run_and<uint32_t>(nruns, vrd, W) & 0xffffu;
                 } else { // look-ahead <= 48 positions: three neighbours
                     const uint32_t s01_0 = __builtin_amdgcn_readlane(p01n, 0), s01_1 = __builtin_amdgcn_readlane(p01n, 1),
                                    s01_2 = __builtin_amdgcn_readlane(p01n, 2);
@@ -382,24 +406,12 @@ __global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a)
                         b23 = down1(a23, s1);
                         c23 = down1(b23, s2);
                     }
-                    uint64_t W[4];
-                    W[0] = (uint64_t)((p01 & 0xffffu) | (a01 << 16)) | ((uint64_t)((b01 & 0xffffu) | (c01 << 16)) << 32);
-                    W[1] = (uint64_t)((p01 >> 16) | (a01 & 0xffff0000u)) | ((uint64_t)((b01 >> 16) | (c01 & 0xffff0000u)) << 32);
-                    W[2] = (uint64_t)((p23 & 0xffffu) | (a23 << 16)) | ((uint64_t)((b23 & 0xffffu) | (c23 << 16)) << 32);
-                    W[3] = (uint64_t)((p23 >> 16) | (a23 & 0xffff0000u)) | ((uint64_t)((b23 >> 16) | (c23 & 0xffff0000u)) << 32);
-                    uint64_t cand = ~0ull;
-                    for (uint32_t r = 0; r < nruns; r++) {
-                        const uint32_t cls = pg->run_cls[r], n = pg->run_len[r], off = pg->run_off[r];
-                        uint64_t x = cls == 0 ? W[0] : cls == 1 ? W[1] : cls == 2 ? W[2] : W[3];
-                        uint32_t len = 1;
-                        while (2 * len <= n) {
-                            x &= x >> len;
-                            len *= 2;
-                        }
-                        if (len < n) x &= x >> (n - len);
-                        cand &= x >> off;
-                    }
-                    bits = (uint32_t)cand & 0xffffu;
+                    const uint64_t W[4] = {
+                        (uint64_t)((p01 & 0xffffu) | (a01 << 16)) | ((uint64_t)((b01 & 0xffffu) | (c01 << 16)) << 32),
+                        (uint64_t)((p01 >> 16) | (a01 & 0xffff0000u)) | ((uint64_t)((b01 >> 16) | (c01 & 0xffff0000u)) << 32),
+                        (uint64_t)((p23 & 0xffffu) | (a23 << 16)) | ((uint64_t)((b23 & 0xffffu) | (c23 << 16)) << 32),
+                        (uint64_t)((p23 >> 16) | (a23 & 0xffff0000u)) | ((uint64_t)((b23 >> 16) | (c23 & 0xffff0000u)) << 32)};
+                    bits = (uint32_t)run_and<uint64_t>(nruns, vrd, W) & 0xffffu;
                 }
                 if (!interior) bits &= valid16(sub_off + k * 1024 + (int)lane * 16, 0, hi);
                 hits[k >> 1] |= bits << (16 * (k & 1));
@@ -414,39 +426,51 @@ __global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a)
 } // namespace
 
 // ---- host-callable launchers (engine.hip) ----
-// variant: bits 0-1 ITER index {0:16, 1:8, 2:4}, bit 2 = nontemporal loads
-uint32_t scan_tile_bytes(int variant)
-{
-    static const int iters[4] = {16, 8, 4, 16};
-    return (uint32_t)(kWaves * iters[variant & 3] * 1024);
-}
+static const int kIters[4] = {16, 8, 12, 16};
+
+uint32_t scan_tile_bytes(int variant) { return (uint32_t)(kWaves * kIters[variant & 3] * 1024); }
 
 template <int ITER>
 static hipError_t launch_iter(int tier, bool nt, bool wide, const ScanArgs &a, uint32_t grid, hipStream_t st)
 {
     dim3 g(grid), b(kWG);
+    const TileDesc *tiles = a.tiles;
     if (tier == GSCAN_TIER_LITERAL) {
-        if (nt) hipLaunchKernelGGL((k1_anchor_scan<ITER, true>), g, b, 0, st, a);
-        else hipLaunchKernelGGL((k1_anchor_scan<ITER, false>), g, b, 0, st, a);
+        if (nt) hipLaunchKernelGGL((k1_anchor_scan<ITER, true>), g, b, 0, st, a, tiles);
+        else hipLaunchKernelGGL((k1_anchor_scan<ITER, false>), g, b, 0, st, a, tiles);
     } else {
         if (wide) {
-            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, true>), g, b, 0, st, a);
-            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, true>), g, b, 0, st, a);
+            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, true>), g, b, 0, st, a, tiles);
+            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, true>), g, b, 0, st, a, tiles);
         } else {
-            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, false>), g, b, 0, st, a);
-            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, false>), g, b, 0, st, a);
+            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, false>), g, b, 0, st, a, tiles);
+            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, false>), g, b, 0, st, a, tiles);
         }
     }
     return hipGetLastError();
 }
 
-hipError_t launch_scan(int tier, int variant, uint32_t window, const ScanArgs &a, uint32_t grid, hipStream_t st)
+// Fills the pattern-program part of the argument block from a compiled database.
+void fill_program(ScanArgs &a, const DevProgram &pg)
+{
+    a.m = pg.m;
+    a.anchor = pg.anchor;
+    a.anchor_mask = pg.anchor_mask;
+    a.anchor_off = pg.anchor_off;
+    a.anchor_len = pg.anchor_len;
+    a.n_classes = pg.n_classes;
+    a.nruns = pg.nruns;
+    for (int r = 0; r < kK2MaxRuns; r++)
+        a.run_desc[r] = (uint32_t)pg.run_cls[r] | ((uint32_t)pg.run_len[r] << 8) | ((uint32_t)pg.run_off[r] << 16);
+}
+
+hipError_t launch_scan(int tier, int variant, const ScanArgs &a, uint32_t grid, hipStream_t st)
 {
     const bool nt = (variant >> 2) & 1;
-    const bool wide = window > 17; // K2: look-ahead beyond one neighbouring lane
+    const bool wide = a.m > 17; // K2: look-ahead beyond one neighbouring lane
     switch (variant & 3) {
     case 1: return launch_iter<8>(tier, nt, wide, a, grid, st);
-    case 2: return launch_iter<4>(tier, nt, wide, a, grid, st);
+    case 2: return launch_iter<12>(tier, nt, wide, a, grid, st);
     default: return launch_iter<16>(tier, nt, wide, a, grid, st);
     }
 }

@@ -56,7 +56,7 @@ constexpr int kMaxWindow = 256; // window positions a database may hold
 constexpr int kMaxClasses = 64; // distinct byte classes per database
 constexpr int kK2MaxClasses = 4;
 constexpr int kK2MaxWindow = 49; // 16 own positions + 48 bits of look-ahead
-constexpr int kK2MaxRuns = 16;
+constexpr int kK2MaxRuns = 16; // run descriptors live in the lanes of one VGPR for the whole kernel
 
 // POD uploaded verbatim to the device; the kernels read it from global memory /
 // kernel arguments.  Keep in sync with kernels.hip.

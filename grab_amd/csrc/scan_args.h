@@ -8,21 +8,39 @@
 
 namespace gscan {
 
-struct ScanArgs {
-    const uint8_t *base;        // arena
-    const gscan_seg *segs;      // [nseg]
-    const uint32_t *tile_first; // [nseg+1] first tile of each segment
-    const uint32_t *tile_seg;   // [n_tiles] segment of each tile
-    uint32_t n_tiles;
-    uint32_t cap;               // record capacity
-    uint32_t *recs;             // candidate starts, segment-relative
-    unsigned long long *desc;   // [n_tiles] count | base<<32
-    uint32_t *counter;          // [0] records reserved, [1] overflow flag
-    const DevProgram *prog;
+constexpr int kShards = 8; // record-buffer regions, each with its own reservation counter
+
+// One scan unit of the launch: a tile of one segment.  16 bytes so a workgroup fetches it
+// with a single scalar load.
+struct TileDesc {
+    uint64_t seg_off;  // segment start, bytes from ScanArgs::base (16-byte aligned)
+    uint32_t seg_len;  // segment length
+    uint32_t tile_off; // first byte of this tile inside the segment
 };
 
-// variant: bits 0-1 select KiB per wave {0:16, 1:8, 2:4}; bit 2 = nontemporal loads
+// Everything a kernel needs, passed by value (kernarg segment -> SGPRs; nothing the hot
+// loop uses is fetched from global memory).
+struct ScanArgs {
+    const uint8_t *base;     // arena
+    const TileDesc *tiles;   // [n_tiles]; nullptr = one segment {seg0_off, seg0_len} tiled in order
+    uint64_t seg0_off;
+    uint32_t seg0_len;
+    uint32_t n_tiles;
+    uint32_t cap_shard;      // record capacity of ONE shard region (regions are back to back)
+    uint32_t *recs;          // candidate starts, segment-relative
+    unsigned long long *desc; // [n_tiles] count | base<<32 (base = absolute record index)
+    uint32_t *counter;       // [0..kShards) records reserved per shard, [kShards] overflow flag
+    const DevProgram *prog;  // cold paths only (K1 verify, K2 table staging)
+    // pattern program, hot-loop copy
+    uint32_t m;              // window length
+    uint32_t anchor, anchor_mask, anchor_off, anchor_len; // K1
+    uint32_t n_classes, nruns;                            // K2
+    uint32_t run_desc[kK2MaxRuns];                        // K2: cls | len<<8 | off<<16
+};
+
+// variant: bits 0-1 select KiB per wave {0:16, 1:8, 2:12}; bit 2 = nontemporal loads
 uint32_t scan_tile_bytes(int variant);
-hipError_t launch_scan(int tier, int variant, uint32_t window, const ScanArgs &a, uint32_t grid, hipStream_t st);
+void fill_program(ScanArgs &a, const DevProgram &pg);
+hipError_t launch_scan(int tier, int variant, const ScanArgs &a, uint32_t grid, hipStream_t st);
 
 } // namespace gscan

@@ -38,7 +38,7 @@ class Seg(C.Structure):
 
 
 class DevResult(C.Structure):
-    _fields_ = [("recs", C.c_void_p), ("desc", C.c_void_p), ("tile_seg", C.c_void_p),
+    _fields_ = [("recs", C.c_void_p), ("desc", C.c_void_p),
                 ("n_tiles", C.c_uint64), ("tile_bytes", C.c_uint32), ("total", C.c_uint64),
                 ("overflow", C.c_int)]
 

@@ -80,8 +80,8 @@ typedef struct gscan_seg {
 /* result of a device-resident scan: everything stays in HBM */
 typedef struct gscan_dev_result {
     const uint32_t *recs;  /* device: candidate starts, segment-relative; runs of ascending offsets */
-    const uint64_t *desc;  /* device: per tile {count:u32 | base:u32<<32}; tile order == text order */
-    const uint32_t *tile_seg; /* device: per tile, index of its segment */
+    const uint64_t *desc;  /* device: per tile {count:u32 | base:u32<<32}, base = index into recs;
+                              tiles are in (segment, text) order, so walking desc yields ascending offsets */
     uint64_t n_tiles;
     uint32_t tile_bytes;
     uint64_t total;        /* number of records the scan produced (valid after gscan_dev_sync) */
@@ -135,7 +135,8 @@ int gscan_dev_sync(gscan_ctx *ctx, gscan_dev_result *res);
 /* copy the records of segment `seg` to the host, ascending; returns count or <0 */
 long gscan_dev_fetch(gscan_ctx *ctx, const gscan_dev_result *res, size_t seg, uint32_t *out,
                      size_t cap);
-/* record-buffer capacity (records) for device scans; default = arena bytes / 16 */
+/* record-buffer capacity (records, split into 8 equal shard regions) for device scans;
+ * default = arena bytes / 16 */
 int gscan_set_capacity(gscan_ctx *ctx, size_t n_records);
 /* kernel tuning knobs for A/B runs: name in {"variant","blocks_per_cu"}; see DESIGN.md */
 int gscan_set_option(gscan_ctx *ctx, const char *name, long value);

@@ -15,7 +15,7 @@ import scan_oracle as so  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [0, 1, 2, 4, 5, 6]  # KiB per wave {16, 8, 4} x nontemporal loads {off, on}
+VARIANTS = [0, 1, 2, 4, 5, 6]  # KiB per wave {16, 8, 12} x nontemporal loads {off, on}
 PATTERNS = ["foobardoesnotexist", "foo", "e", "xy", "[A-Za-z_][A-Za-z0-9_]{15,}", "[a-z]{2,5}", "abc[0-9]*", r"\d{3}-\d{4}",
             "[Ll]inus", "a.c", "[^x]{5,}", "[0-9a-f]{32}", "[0-9A-F]{6}[a-z]", "e+", r"\w\s\w\s\w", "[a-z][0-9][A-Z][.,][;:]q",
             "[ab][cd][ef][gh]{20}", "[0-9]{17}", "[0-9]{18}", "[a-z_]{49}"]
@@ -159,6 +159,7 @@ def test_device_resident_segments(ctx):
     host[offs[5] + 65536 - 2: offs[5] + 65536 + 1] = np.frombuffer(b"foo", np.uint8)
     arena = torch.from_numpy(host).cuda()
     segs = list(zip(offs, lens))
+    ctx.set_capacity(1 << 20)
     for pattern in ["foo", "[a-z]{2,5}", "[A-Za-z_][A-Za-z0-9_]{15,}"]:
         db = engine.Database(pattern)
         for variant in (0, 1, 2):
@@ -176,6 +177,16 @@ def test_device_resident_segments(ctx):
     ctx.set_option("variant", 0)
     ms, launches = ctx.kernel_time()
     assert launches > 0 and ms > 0
+    # a deliberately small record buffer reports overflow instead of writing out of bounds
+    ctx.set_capacity(64)
+    db = engine.Database("[a-z]{2,5}")
+    res = ctx.scan_device(db, arena.data_ptr(), segs)
+    total, overflow = ctx.dev_sync(res)
+    assert overflow and total > 64
+    ctx.set_capacity(1 << 20)
+    res = ctx.scan_device(db, arena.data_ptr(), segs)
+    total2, overflow = ctx.dev_sync(res)
+    assert not overflow and total2 == total
 
 
 def test_grid_shapes(ctx):
