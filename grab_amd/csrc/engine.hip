@@ -85,8 +85,10 @@ struct gscan_ctx {
     DevProgram *h_prog = nullptr; // pinned staging
     uint64_t prog_id = 0;
     // options
-    int variant = 0;
-    int blocks_per_cu = 8;
+    // defaults from the sweeps under profiles/: 12 KiB per wave (110 VGPRs -> 4 waves/SIMD) with
+    // nontemporal loads, one workgroup per tile
+    int variant = 6;
+    int blocks_per_cu = 0;
     // device-resident path
     size_t dev_cap_req = 0;
     uint32_t *dv_recs = nullptr;
