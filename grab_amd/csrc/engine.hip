@@ -139,10 +139,13 @@ int ensure_prog(gscan_ctx *c, const gscan_db *db, hipStream_t st)
     return 0;
 }
 
-uint32_t grid_for(const gscan_ctx *c, uint32_t n_tiles)
+uint32_t grid_for(const gscan_ctx *c, const Database &db, uint32_t n_tiles)
 {
-    if (c->blocks_per_cu <= 0) return n_tiles;
-    uint64_t g = (uint64_t)c->cus * (uint64_t)c->blocks_per_cu;
+    // kernels that stage a big LDS table once per workgroup always run as a persistent grid
+    const uint32_t fixed = gscan::scan_persistent_blocks(db.tier, db.prog.n_classes);
+    const uint32_t bpc = fixed ? fixed : (uint32_t)std::max(c->blocks_per_cu, 0);
+    if (bpc == 0) return n_tiles;
+    uint64_t g = (uint64_t)c->cus * (uint64_t)bpc;
     return (uint32_t)std::min<uint64_t>(g, n_tiles);
 }
 
@@ -165,7 +168,7 @@ int slot_reserve(gscan_ctx *c, Slot &s, size_t len)
         s.d_text_cap = cap - kPad;
     }
     // tiles at the smallest tile size any variant uses
-    size_t tiles = len / gscan::scan_tile_bytes(1) + 2;
+    size_t tiles = len / gscan::scan_min_tile_bytes() + 2;
     if (tiles > s.tiles_cap) {
         if (s.d_desc) hipFree(s.d_desc);
         if (s.h_desc) hipHostFree(s.h_desc);
@@ -191,7 +194,7 @@ int slot_reserve(gscan_ctx *c, Slot &s, size_t len)
 int slot_launch(gscan_ctx *c, Slot &s)
 {
     const Database &db = s.db->db;
-    const uint32_t tile_bytes = gscan::scan_tile_bytes(c->variant);
+    const uint32_t tile_bytes = gscan::scan_tile_bytes(db.tier, c->variant, db.prog.n_classes);
     s.n_tiles = (uint32_t)((s.len + tile_bytes - 1) / tile_bytes);
     HIPCHK(c, hipMemsetAsync(s.d_counter, 0, kCounterWords * 4, c->compute));
     ScanArgs a;
@@ -207,7 +210,7 @@ int slot_launch(gscan_ctx *c, Slot &s)
     a.counter = s.d_counter;
     a.prog = c->d_prog;
     gscan::fill_program(a, db.prog);
-    if (s.n_tiles) HIPCHK(c, gscan::launch_scan(db.tier, c->variant, a, grid_for(c, s.n_tiles), c->compute));
+    if (s.n_tiles) HIPCHK(c, gscan::launch_scan(db.tier, c->variant, a, grid_for(c, db, s.n_tiles), c->compute));
     HIPCHK(c, hipMemcpyAsync(s.h_counter, s.d_counter, kCounterWords * 4, hipMemcpyDeviceToHost, c->compute));
     if (s.n_tiles)
         HIPCHK(c, hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)s.n_tiles * 8, hipMemcpyDeviceToHost, c->compute));
@@ -531,7 +534,7 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
     c->dv_stream = st;
     int rc = ensure_prog(c, db, st);
     if (rc) return rc;
-    const uint32_t tile_bytes = gscan::scan_tile_bytes(c->variant);
+    const uint32_t tile_bytes = gscan::scan_tile_bytes(db->db.tier, c->variant, db->db.prog.n_classes);
     const size_t K = gscan::kShards;
 
     // tile table: rebuilt only when the segment table or the tile size changed
@@ -603,7 +606,7 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
     }
     bool timed = c->ev_used < c->ev_pool.size();
     if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used].a, st));
-    if (n_tiles) HIPCHK(c, gscan::launch_scan(db->db.tier, c->variant, a, grid_for(c, n_tiles), st));
+    if (n_tiles) HIPCHK(c, gscan::launch_scan(db->db.tier, c->variant, a, grid_for(c, db->db, n_tiles), st));
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used].b, st));
         c->ev_used++;

@@ -68,23 +68,24 @@ __device__ __forceinline__ uint32_t down1(uint32_t x, uint32_t fill)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x130, 0xf, 0xf, false);
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+// Inclusive prefix sum over the 64 lanes, all in the VALU: four row_shr DPP adds scan each row
+// of 16, row_bcast:15 / row_bcast:31 carry the row totals across (the sequence the gfx9 backend
+// itself uses for wave scans).  No LDS round trips: a ds_bpermute chain here costs ~6 x 100+
+// cycles of dependent latency per step that has candidates.
+#define GS_DPP_ADD(v_, ctrl_, rows_) v_ += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v_, ctrl_, rows_, 0xf, false)
+__device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    GS_DPP_ADD(v, 0x111, 0xf); // row_shr:1
+    GS_DPP_ADD(v, 0x112, 0xf); // row_shr:2
+    GS_DPP_ADD(v, 0x114, 0xf); // row_shr:4
+    GS_DPP_ADD(v, 0x118, 0xf); // row_shr:8
+    GS_DPP_ADD(v, 0x142, 0xa); // row_bcast:15 -> rows 1,3
+    GS_DPP_ADD(v, 0x143, 0xc); // row_bcast:31 -> rows 2,3
     return v;
 }
+#undef GS_DPP_ADD
 
-// inclusive prefix sum over the wave
-__device__ __forceinline__ uint32_t wave_scan(uint32_t v, uint32_t lane)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = (uint32_t)__shfl_up((int)v, o, 64);
-        if (lane >= (uint32_t)o) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return __builtin_amdgcn_readlane(wave_scan(v), 63); }
 
 // 16-bit mask of the positions pos0..pos0+15 that lie in [lo, hi] (signed).
 __device__ __forceinline__ uint32_t valid16(int pos0, int lo, int hi)
@@ -170,7 +171,7 @@ __device__ __forceinline__ void load_subtile(u32x4 (&buf)[ITER + 1], const TileC
 // Tile epilogue shared by both kernels: hits[] holds the per-step 16-bit masks of
 // this lane (two per register), cnt its popcount.  `bias` is subtracted from every
 // position (K1 records window starts, its masks mark anchor positions).
-template <int ITER>
+template <int ITER, int NWAVES>
 __device__ __forceinline__ void emit_tile(const ScanArgs &a, uint32_t t, const uint32_t (&hits)[(ITER + 1) / 2],
                                           uint32_t cnt, int sub_off, uint32_t bias, uint32_t lane, uint32_t wave,
                                           uint32_t *s_cnt, uint32_t *s_base)
@@ -180,7 +181,7 @@ __device__ __forceinline__ void emit_tile(const ScanArgs &a, uint32_t t, const u
     __syncthreads();
     uint32_t total = 0, before = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; w++) {
+    for (int w = 0; w < NWAVES; w++) {
         uint32_t c = s_cnt[w];
         total += c;
         if ((uint32_t)w < wave) before += c;
@@ -208,7 +209,7 @@ __device__ __forceinline__ void emit_tile(const ScanArgs &a, uint32_t t, const u
         uint32_t bits = (hits[k >> 1] >> (16 * (k & 1))) & 0xffffu;
         if (__ballot(bits != 0) == 0ull) continue; // wave-uniform
         uint32_t c = (uint32_t)__popc(bits);
-        uint32_t inc = wave_scan(c, lane);
+        uint32_t inc = wave_scan(c);
         uint32_t idx = run + inc - c;
         uint32_t pos0 = (uint32_t)(sub_off + k * 1024) + lane * 16u - bias;
         while (bits) {
@@ -216,7 +217,7 @@ __device__ __forceinline__ void emit_tile(const ScanArgs &a, uint32_t t, const u
             bits &= bits - 1u;
             a.recs[idx++] = pos0 + j;
         }
-        run += (uint32_t)__shfl((int)inc, 63, 64);
+        run += __builtin_amdgcn_readlane(inc, 63);
     }
 }
 
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a, const TileDesc
 #undef GS_MIN3
             }
         }
-        emit_tile<ITER>(a, t, hits, cnt, sub_off, aoff, lane, wave, s_cnt, &s_base);
+        emit_tile<ITER, kWaves>(a, t, hits, cnt, sub_off, aoff, lane, wave, s_cnt, &s_base);
     }
 }
 
@@ -325,13 +326,23 @@ __device__ __forceinline__ W run_and(uint32_t nruns, uint32_t vrd, const W (&cls
     return cand;
 }
 
-template <int ITER, bool NT, bool WIDE>
-__global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
+// PAIR = false: the general form (<= 4 classes): 256-thread workgroup, 32 KiB bank-replicated
+//   table of per-byte class bits, 16 lookups per lane per step.
+// PAIR = true: <= 2 classes: 512-thread workgroup sharing a 64 KiB table indexed by TWO text
+//   bytes at once (entry = class bits of both bytes: class 0 in bits 0-1, class 1 in bits 4-5).
+//   8 lookups per lane per step and about a third of the VALU work of the general form, which is
+//   what the kernel is bound by (integer VALU issues one wave64 instruction per 4 cycles: PMC
+//   runs under profiles/).  Bank conflicts are possible here (random 16-bit indices) but the LDS
+//   has the cycles to spare; the table is built once per workgroup, so this form runs as a
+//   persistent grid.
+template <int ITER, bool NT, bool WIDE, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
-    __shared__ uint32_t tbl[256 * 32];
-    __shared__ uint32_t s_cnt[kWaves];
+    constexpr int kNW = PAIR ? 8 : 4; // waves per workgroup
+    __shared__ uint32_t tbl[PAIR ? 65536 / 4 : 256 * 32];
+    __shared__ uint32_t s_cnt[kNW];
     __shared__ uint32_t s_base;
-    constexpr uint32_t kTile = kWaves * ITER * 1024;
+    constexpr uint32_t kTile = kNW * ITER * 1024;
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t bank = lane & 31u;
@@ -341,12 +352,27 @@ __global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a, const TileDe
     // would put a scalar load + s_waitcnt lgkmcnt(0) into every step, and that wait also drains
     // the LDS lookups already in flight for the next step.
     const uint32_t vrd = a.run_desc[lane & (kK2MaxRuns - 1)];
+    const uint8_t *tbl8 = reinterpret_cast<const uint8_t *>(tbl);
 
-    { // stage the class table: entry b replicated into all 32 banks
-        uint32_t b = threadIdx.x; // kWG == 256 entries
+    if (!PAIR) { // stage the class table: entry b replicated into all 32 banks
+        uint32_t b = threadIdx.x; // 256 threads == 256 entries
         uint32_t v = a.prog->k2_table[b];
 #pragma unroll 8
         for (uint32_t r = 0; r < 32; r++) tbl[(b << 5) | ((r + lane) & 31u)] = v;
+    } else { // build the pair table from the 256-entry one: index = first byte | second byte << 8
+        const uint32_t *base = a.prog->k2_table;
+        for (uint32_t q = threadIdx.x; q < 65536 / 4; q += 512) { // one dword = 4 consecutive first bytes
+            const uint32_t b1 = q >> 6, b0 = (q & 63u) << 2;
+            const uint32_t t1 = base[b1];
+            const uint32_t hi = (((t1 & 1u) << 1) | ((t1 >> 8 & 1u) << 5)) * 0x01010101u; // second byte's bits, all 4 entries
+            uint32_t lo = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t t0 = base[b0 + j];
+                lo |= ((t0 & 1u) | ((t0 >> 8 & 1u) << 4)) << (8 * j);
+            }
+            tbl[q] = lo | hi;
+        }
     }
     __syncthreads();
 
@@ -365,30 +391,43 @@ __global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a, const TileDe
             const bool interior = sub_off + ITER * 1024 + 64 <= hi;
 
             // class masks of one 16-byte piece: P01 = cls0 | cls1<<16, P23 = cls2 | cls3<<16
-            uint32_t p01n, p23n;
+            uint32_t p01n, p23n = 0;
             auto masks = [&](const u32x4 &d, uint32_t &p01, uint32_t &p23) {
-                uint32_t lo = 0, hi8 = 0;
-                lo = (lo << 1) | GS_LUT(d.y, 24); lo = (lo << 1) | GS_LUT(d.y, 16);
-                lo = (lo << 1) | GS_LUT(d.y, 8);  lo = (lo << 1) | GS_LUT(d.y, 0);
-                lo = (lo << 1) | GS_LUT(d.x, 24); lo = (lo << 1) | GS_LUT(d.x, 16);
-                lo = (lo << 1) | GS_LUT(d.x, 8);  lo = (lo << 1) | GS_LUT(d.x, 0);
-                hi8 = (hi8 << 1) | GS_LUT(d.w, 24); hi8 = (hi8 << 1) | GS_LUT(d.w, 16);
-                hi8 = (hi8 << 1) | GS_LUT(d.w, 8);  hi8 = (hi8 << 1) | GS_LUT(d.w, 0);
-                hi8 = (hi8 << 1) | GS_LUT(d.z, 24); hi8 = (hi8 << 1) | GS_LUT(d.z, 16);
-                hi8 = (hi8 << 1) | GS_LUT(d.z, 8);  hi8 = (hi8 << 1) | GS_LUT(d.z, 0);
-                // byte c of lo = positions 0-7 of class c, byte c of hi8 = positions 8-15
-                p01 = (lo & 0xffu) | ((hi8 & 0xffu) << 8) | ((lo & 0xff00u) << 8) | ((hi8 & 0xff00u) << 16);
-                p23 = ((lo >> 16) & 0xffu) | (((hi8 >> 16) & 0xffu) << 8) | ((lo >> 8) & 0xff0000u) | (hi8 & 0xff000000u);
+                if (PAIR) {
+                    // 8 two-byte lookups; e_k has class 0 of its two positions in bits 0-1, class 1 in bits 4-5
+                    const uint32_t e0 = tbl8[d.x & 0xffffu], e1 = tbl8[d.x >> 16], e2 = tbl8[d.y & 0xffffu], e3 = tbl8[d.y >> 16];
+                    const uint32_t e4 = tbl8[d.z & 0xffffu], e5 = tbl8[d.z >> 16], e6 = tbl8[d.w & 0xffffu], e7 = tbl8[d.w >> 16];
+                    // byte q of g: low nibble = class 0 of positions 4q..4q+3, high nibble = class 1
+                    const uint32_t g = (e0 | (e1 << 2)) | ((e2 | (e3 << 2)) << 8) | ((e4 | (e5 << 2)) << 16) | ((e6 | (e7 << 2)) << 24);
+                    const uint32_t x = g & 0x0f0f0f0fu, y = (g >> 4) & 0x0f0f0f0fu;
+                    const uint32_t tx = x | (x >> 4), ty = y | (y >> 4); // bytes 0 and 2 now hold 8 positions each
+                    p01 = (tx & 0xffu) | ((tx >> 8) & 0xff00u) | ((ty & 0xffu) << 16) | ((ty << 8) & 0xff000000u);
+                    p23 = 0;
+                } else {
+                    uint32_t lo = 0, hi8 = 0;
+                    lo = (lo << 1) | GS_LUT(d.y, 24); lo = (lo << 1) | GS_LUT(d.y, 16);
+                    lo = (lo << 1) | GS_LUT(d.y, 8);  lo = (lo << 1) | GS_LUT(d.y, 0);
+                    lo = (lo << 1) | GS_LUT(d.x, 24); lo = (lo << 1) | GS_LUT(d.x, 16);
+                    lo = (lo << 1) | GS_LUT(d.x, 8);  lo = (lo << 1) | GS_LUT(d.x, 0);
+                    hi8 = (hi8 << 1) | GS_LUT(d.w, 24); hi8 = (hi8 << 1) | GS_LUT(d.w, 16);
+                    hi8 = (hi8 << 1) | GS_LUT(d.w, 8);  hi8 = (hi8 << 1) | GS_LUT(d.w, 0);
+                    hi8 = (hi8 << 1) | GS_LUT(d.z, 24); hi8 = (hi8 << 1) | GS_LUT(d.z, 16);
+                    hi8 = (hi8 << 1) | GS_LUT(d.z, 8);  hi8 = (hi8 << 1) | GS_LUT(d.z, 0);
+                    // byte c of lo = positions 0-7 of class c, byte c of hi8 = positions 8-15
+                    p01 = (lo & 0xffu) | ((hi8 & 0xffu) << 8) | ((lo & 0xff00u) << 8) | ((hi8 & 0xff00u) << 16);
+                    p23 = ((lo >> 16) & 0xffu) | (((hi8 >> 16) & 0xffu) << 8) | ((lo >> 8) & 0xff0000u) | (hi8 & 0xff000000u);
+                }
             };
             masks(buf[0], p01n, p23n);
 #pragma unroll
             for (int k = 0; k < ITER; k++) {
                 const uint32_t p01 = p01n, p23 = p23n;
                 masks(buf[k + 1], p01n, p23n); // next step's masks: lanes 61-63 look into them
+                const bool more = !PAIR && ncls > 2;
                 uint32_t bits;
                 if (!WIDE) { // look-ahead <= 16 positions: one neighbour
                     const uint32_t a01 = down1(p01, __builtin_amdgcn_readfirstlane(p01n));
-                    const uint32_t a23 = ncls > 2 ? down1(p23, __builtin_amdgcn_readfirstlane(p23n)) : 0u;
+                    const uint32_t a23 = more ? down1(p23, __builtin_amdgcn_readfirstlane(p23n)) : 0u;
                     const uint32_t W[4] = {(p01 & 0xffffu) | (a01 << 16), (p01 >> 16) | (a01 & 0xffff0000u),
                                            (p23 & 0xffffu) | (a23 << 16), (p23 >> 16) | (a23 & 0xffff0000u)};
                     bits = run_and<uint32_t>(nruns, vrd, W) & 0xffffu;
@@ -399,7 +438,7 @@ __global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a, const TileDe
                     const uint32_t b01 = down1(a01, s01_1);
                     const uint32_t c01 = down1(b01, s01_2);
                     uint32_t a23 = 0, b23 = 0, c23 = 0;
-                    if (ncls > 2) {
+                    if (more) {
                         const uint32_t s0 = __builtin_amdgcn_readlane(p23n, 0), s1 = __builtin_amdgcn_readlane(p23n, 1),
                                        s2 = __builtin_amdgcn_readlane(p23n, 2);
                         a23 = down1(p23, s0);
@@ -418,7 +457,7 @@ __global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a, const TileDe
                 cnt += (uint32_t)__popc(bits);
             }
         }
-        emit_tile<ITER>(a, t, hits, cnt, sub_off, 0u, lane, wave, s_cnt, &s_base);
+        emit_tile<ITER, kNW>(a, t, hits, cnt, sub_off, 0u, lane, wave, s_cnt, &s_base);
     }
 }
 #undef GS_LUT
@@ -428,23 +467,43 @@ __global__ __launch_bounds__(kWG) void k2_classrun_scan(ScanArgs a, const TileDe
 // ---- host-callable launchers (engine.hip) ----
 static const int kIters[4] = {16, 8, 12, 16};
 
-uint32_t scan_tile_bytes(int variant) { return (uint32_t)(kWaves * kIters[variant & 3] * 1024); }
+// K2 runs its pair-table form whenever the pattern has at most two classes
+static bool k2_pair(const ScanArgs &a) { return a.n_classes <= 2; }
+
+uint32_t scan_tile_bytes(int tier, int variant, uint32_t n_classes)
+{
+    const int waves = (tier == GSCAN_TIER_CLASSRUN && n_classes <= 2) ? 8 : kWaves;
+    return (uint32_t)(waves * kIters[variant & 3] * 1024);
+}
+
+uint32_t scan_min_tile_bytes() { return (uint32_t)(kWaves * 8 * 1024); }
+
+// resident workgroups per CU the kernel is designed for when it runs as a persistent grid (0 = no preference)
+uint32_t scan_persistent_blocks(int tier, uint32_t n_classes) { return (tier == GSCAN_TIER_CLASSRUN && n_classes <= 2) ? 2u : 0u; }
 
 template <int ITER>
 static hipError_t launch_iter(int tier, bool nt, bool wide, const ScanArgs &a, uint32_t grid, hipStream_t st)
 {
-    dim3 g(grid), b(kWG);
+    dim3 g(grid);
     const TileDesc *tiles = a.tiles;
     if (tier == GSCAN_TIER_LITERAL) {
-        if (nt) hipLaunchKernelGGL((k1_anchor_scan<ITER, true>), g, b, 0, st, a, tiles);
-        else hipLaunchKernelGGL((k1_anchor_scan<ITER, false>), g, b, 0, st, a, tiles);
+        if (nt) hipLaunchKernelGGL((k1_anchor_scan<ITER, true>), g, dim3(kWG), 0, st, a, tiles);
+        else hipLaunchKernelGGL((k1_anchor_scan<ITER, false>), g, dim3(kWG), 0, st, a, tiles);
+    } else if (k2_pair(a)) {
+        if (wide) {
+            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, true, true>), g, dim3(512), 0, st, a, tiles);
+            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, true, true>), g, dim3(512), 0, st, a, tiles);
+        } else {
+            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, false, true>), g, dim3(512), 0, st, a, tiles);
+            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, false, true>), g, dim3(512), 0, st, a, tiles);
+        }
     } else {
         if (wide) {
-            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, true>), g, b, 0, st, a, tiles);
-            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, true>), g, b, 0, st, a, tiles);
+            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, true, false>), g, dim3(kWG), 0, st, a, tiles);
+            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, true, false>), g, dim3(kWG), 0, st, a, tiles);
         } else {
-            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, false>), g, b, 0, st, a, tiles);
-            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, false>), g, b, 0, st, a, tiles);
+            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, false, false>), g, dim3(kWG), 0, st, a, tiles);
+            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, false, false>), g, dim3(kWG), 0, st, a, tiles);
         }
     }
     return hipGetLastError();

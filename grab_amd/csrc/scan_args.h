@@ -39,7 +39,9 @@ struct ScanArgs {
 };
 
 // variant: bits 0-1 select KiB per wave {0:16, 1:8, 2:12}; bit 2 = nontemporal loads
-uint32_t scan_tile_bytes(int variant);
+uint32_t scan_tile_bytes(int tier, int variant, uint32_t n_classes);
+uint32_t scan_min_tile_bytes();
+uint32_t scan_persistent_blocks(int tier, uint32_t n_classes);
 void fill_program(ScanArgs &a, const DevProgram &pg);
 hipError_t launch_scan(int tier, int variant, const ScanArgs &a, uint32_t grid, hipStream_t st);
 
