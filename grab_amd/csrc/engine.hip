@@ -295,6 +295,16 @@ int gscan_db_class(const gscan_db *db, int pos, uint8_t table[256])
     return GSCAN_OK;
 }
 
+int gscan_match_at(const gscan_db *db, const void *content, size_t clen, uint32_t p)
+{
+    const Database &d = db->db;
+    if (d.minlen <= 0 || (size_t)p + (size_t)d.minlen > clen) return 0;
+    const uint8_t *t = (const uint8_t *)content + p;
+    for (int i = 0; i < d.minlen; i++)
+        if (!d.classes[d.window[(size_t)i]].test(t[i])) return 0;
+    return 1;
+}
+
 uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, uint32_t start)
 {
     const Database &d = db->db;

@@ -46,9 +46,12 @@ const char kInvOn[] = "\33[7m", kInvOff[] = "\33[27m"; // grab.cc:66-67
 // One chunk's output.
 //
 // The reference repeats: m = leftmost match in [s, clen); print; s = m.end (+ rest of the
-// printed line).  For the engine's pattern subset "a match starts at p" depends only on
-// the minlen bytes at p, so the leftmost match from s is the first candidate >= s and its
-// end is the greedy tail extension.  Rules kept from grab.cc:
+// printed line).  For the engine's pattern subset "a match starts at p" (p is a candidate)
+// depends only on the minlen bytes at p.  The engine reports the start of every group of
+// consecutive candidates, so the leftmost match from s is s itself when the window matches
+// there, else the first reported start after s (a candidate that follows a non-candidate
+// begins a group, so it is in the list); its end is the greedy tail extension.
+// Rules kept from grab.cc:
 //   :175      the loop runs while s + minlen < clen (strict)
 //   :186      printed offset = file offset of the chunk + match start
 //   :190-196  line context: back to a newline, to s, or 511 bytes; forward to a newline,
@@ -65,9 +68,12 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
     char line[64];
     size_t s = 0;
     while (s + (size_t)minlen < clen) {
-        cur = std::lower_bound(cur, last, s, [](uint32_t v, size_t key) { return (size_t)v < key; });
-        if (cur == last) break;
-        const size_t m0 = *cur;
+        size_t m0 = s;
+        if (!gscan_match_at(db, content, clen, (uint32_t)s)) {
+            cur = std::upper_bound(cur, last, s, [](size_t key, uint32_t v) { return key < (size_t)v; });
+            if (cur == last) break;
+            m0 = *cur;
+        }
         const size_t m1 = gscan_match_end(db, content, clen, (uint32_t)m0);
 
         if (flags & GRAB_PREFIX) {

@@ -14,7 +14,10 @@
 //     straddle the sub-tile end; the buffer descriptor's bounds check zero-fills past
 //     the segment end, so there are no per-load branches);
 //   * per KiB step each lane produces a 16-bit candidate mask for its 16 positions;
-//     masks stay in registers until the tile is done (2 steps per VGPR);
+//     a candidate whose predecessor position is known to be a candidate too is dropped
+//     (only the START of each group of consecutive candidates has to be reported: the
+//     host re-tests the window at its restart position, see gscan.h); masks stay in
+//     registers until the tile is done (2 steps per VGPR);
 //   * compaction: per-lane popcount -> wave reduce -> one LDS slot per wave -> ONE
 //     global atomicAdd per tile that has any candidate reserves a contiguous run in
 //     the record buffer (8 counters, one per record-buffer shard, tile t uses shard
@@ -73,6 +76,12 @@ __device__ __forceinline__ uint32_t down1(uint32_t x, uint32_t fill)
 // itself uses for wave scans).  No LDS round trips: a ds_bpermute chain here costs ~6 x 100+
 // cycles of dependent latency per step that has candidates.
 #define GS_DPP_ADD(v_, ctrl_, rows_) v_ += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v_, ctrl_, rows_, 0xf, false)
+// x of lane-1; lane 0 gets `fill` (wave_shr:1).
+__device__ __forceinline__ uint32_t up1(uint32_t x, uint32_t fill)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x138, 0xf, 0xf, false);
+}
+
 __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 {
     GS_DPP_ADD(v, 0x111, 0xf); // row_shr:1
@@ -285,6 +294,7 @@ __global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a, const TileDesc
                         }
                         bits = keep;
                     }
+                    bits &= ~(bits << 1); // keep group starts (within the lane; a superset of them is fine)
                     hits[k >> 1] |= bits << (16 * (k & 1));
                     cnt += (uint32_t)__popc(bits);
                 }
@@ -419,6 +429,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
                 }
             };
             masks(buf[0], p01n, p23n);
+            uint32_t last63 = 0; // candidate mask of lane 63 in the previous step (0: unknown at the sub-tile start)
 #pragma unroll
             for (int k = 0; k < ITER; k++) {
                 const uint32_t p01 = p01n, p23 = p23n;
@@ -453,6 +464,11 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
                     bits = (uint32_t)run_and<uint64_t>(nruns, vrd, W) & 0xffffu;
                 }
                 if (!interior) bits &= valid16(sub_off + k * 1024 + (int)lane * 16, 0, hi);
+                // drop candidates whose predecessor position is a candidate: bit j-1 of this lane, or bit 15
+                // of the previous lane (previous step's lane 63 for lane 0)
+                const uint32_t prev = up1(bits, last63);
+                last63 = __builtin_amdgcn_readlane(bits, 63);
+                bits &= ~((bits << 1) | (prev >> 15));
                 hits[k >> 1] |= bits << (16 * (k & 1));
                 cnt += (uint32_t)__popc(bits);
             }

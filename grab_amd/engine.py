@@ -19,7 +19,7 @@ SLOTS = 2
 
 # every symbol include/gscan.h declares
 SYMBOLS = [
-    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_match_end",
+    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_match_at", "gscan_match_end",
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
     "gscan_acquire", "gscan_submit", "gscan_wait",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
@@ -66,6 +66,8 @@ def lib():
         L.gscan_free.restype = None
         L.gscan_db_info.argtypes = [C.c_void_p, C.POINTER(Info)]
         L.gscan_db_class.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gscan_match_at.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
+        L.gscan_match_at.restype = C.c_int
         L.gscan_match_end.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
         L.gscan_match_end.restype = C.c_uint32
         L.gscan_open.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -125,6 +127,10 @@ class Database:
             raise ValueError("no class at position %d" % pos)
         return t.astype(bool)
 
+    def match_at(self, content, p):
+        buf = np.frombuffer(content, np.uint8)
+        return bool(lib().gscan_match_at(self._h, buf.ctypes.data, buf.size, p))
+
     def match_end(self, content, start):
         buf = np.frombuffer(content, np.uint8)
         return int(lib().gscan_match_end(self._h, buf.ctypes.data, buf.size, start))
@@ -177,7 +183,7 @@ class Context:
         return tag.value, starts
 
     def scan(self, db, data):
-        """All candidate starts of one chunk (ascending uint32)."""
+        """Candidate group starts of one chunk (ascending uint32; see gscan_wait in include/gscan.h)."""
         self.submit(db, data)
         return self.wait()[1]
 

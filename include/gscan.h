@@ -9,10 +9,12 @@
  *       -> gscan_compile()      (pattern -> database, minlen with PCRE's meaning)
  *   pcre_exec(h, extra, start, end-start, 0, 0, ovector, 3)          src/grab.cc:178
  *       -> gscan_submit()/gscan_wait()   (one call per CHUNK instead of one per match:
- *          the engine returns every offset p of the chunk at which pcre_exec would
- *          report a match if asked to start at p -- the "candidate superset"; the
- *          restart orbit of src/grab.cc:175-213 is then a host walk over that list,
- *          see grab_host.h / DESIGN.md)
+ *          the engine scans for every offset p of the chunk at which pcre_exec would
+ *          report a match if asked to start at p -- the "candidates" -- and returns the
+ *          start of every group of consecutive candidates; the restart orbit of
+ *          src/grab.cc:175-213 is then a host walk over that list, see grab_host.h /
+ *          DESIGN.md)
+ *       -> gscan_match_at()     (is offset p a candidate: the window test, on the host)
  *       -> gscan_match_end()    (ovector[1] for one selected start, computed lazily)
  *   pcre_free_study                                                   src/grab.cc:79
  *       -> gscan_free()
@@ -79,7 +81,7 @@ typedef struct gscan_seg {
 
 /* result of a device-resident scan: everything stays in HBM */
 typedef struct gscan_dev_result {
-    const uint32_t *recs;  /* device: candidate starts, segment-relative; runs of ascending offsets */
+    const uint32_t *recs;  /* device: candidate group starts (see gscan_wait), segment-relative; runs of ascending offsets */
     const uint64_t *desc;  /* device: per tile {count:u32 | base:u32<<32}, base = index into recs;
                               tiles are in (segment, text) order, so walking desc yields ascending offsets */
     uint64_t n_tiles;
@@ -95,6 +97,8 @@ void gscan_free(gscan_db *db);
 int gscan_db_info(const gscan_db *db, gscan_info *info);
 /* 256-entry membership table (1 byte each) of window position `pos`; pos == -1: the tail class */
 int gscan_db_class(const gscan_db *db, int pos, uint8_t table[256]);
+/* 1 if the pattern matches AT offset p of content[0..clen) (window test on the host), else 0 */
+int gscan_match_at(const gscan_db *db, const void *content, size_t clen, uint32_t p);
 /* ovector[1] for a match starting at `start` of content[0..clen): src/grab.cc:178 semantics */
 uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, uint32_t start);
 
@@ -116,8 +120,12 @@ int gscan_device_count(void);
 int gscan_acquire(gscan_ctx *ctx, size_t len, void **pinned);
 int gscan_submit(gscan_ctx *ctx, const gscan_db *db, const void *host_bytes, size_t len,
                  uint64_t tag);
-/* starts[0..n): every candidate start of the chunk, ascending.  *content is the
- * pinned copy of the chunk; both stay valid until the second gscan_acquire/
+/* starts[0..n), ascending: the START of every group of consecutive candidate offsets of the
+ * chunk (offsets p at which the pattern matches), possibly with further candidates of the
+ * same groups in between.  That is all pcre_exec's "leftmost match at or after s" needs:
+ *     gscan_match_at(db, content, clen, s) ? s : first starts[i] > s
+ * (if s is a candidate it is the answer; if not, the next candidate after s begins a group).
+ * *content is the pinned copy of the chunk; both stay valid until the second gscan_acquire/
  * gscan_submit after this call reuses the slot. */
 int gscan_wait(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, size_t *n,
                const void **content);

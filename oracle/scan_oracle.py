@@ -85,6 +85,25 @@ def window_starts(data, tables):
     return np.flatnonzero(ok).astype(np.int64)
 
 
+def group_starts(cands):
+    """Candidates whose predecessor offset is not a candidate (what the engine must at least report)."""
+    c = np.asarray(cands, np.int64)
+    if c.size == 0:
+        return c
+    keep = np.ones(c.size, bool)
+    keep[1:] = c[1:] != c[:-1] + 1
+    return c[keep]
+
+
+def check_reported(got, cands):
+    """The engine's contract: every group start is reported, and nothing but candidates."""
+    got = np.asarray(got, np.int64)
+    cands = np.asarray(cands, np.int64)
+    if got.size and (np.any(np.diff(got) <= 0) or not np.all(np.isin(got, cands))):
+        return False
+    return bool(np.all(np.isin(group_starts(cands), got)))
+
+
 def scan_chunk(rx, minlen, flags, path, content, off):
     """grab.cc:171-213 for one chunk; returns the bytes the reference appends to its ostringstream."""
     out = []

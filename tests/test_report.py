@@ -28,8 +28,10 @@ def _supported(case):
     return True
 
 
-def host_find(db, data, flags, chunk, path=b""):
-    """FileGrep::find's control flow with oracle-made candidates in place of gscan_wait."""
+def host_find(db, data, flags, chunk, path=b"", minimal=True):
+    """FileGrep::find's control flow with oracle-made candidates in place of gscan_wait.
+    minimal=True hands over only what the engine must report (group starts); False hands over every
+    candidate (the engine may report any superset of the group starts)."""
     minlen = db.minlen
     if minlen < 0 or minlen > len(data):
         return b""
@@ -38,6 +40,8 @@ def host_find(db, data, flags, chunk, path=b""):
     for off, clen in so.chunks(len(data), chunk):
         part = data[off:off + clen]
         starts = so.window_starts(part, tables)
+        if minimal:
+            starts = so.group_starts(starts)
         text = filegrep.report_chunk(db, flags, path, part, off, starts.astype(np.uint32))
         if text:
             out.append(text)
@@ -57,9 +61,10 @@ def test_report_matches_reference(case, built):
     f = (filegrep.OFFSETS if "-O" in flags else 0) | (filegrep.NOLINE if "-l" in flags else 0) | (filegrep.SINGLE if "-s" in flags else 0)
     db = engine.Database(pattern)
     data = build(case["inputs"][paths[0]])
-    out = host_find(db, data, f, so.chunk_size(flags.count("-L")))
-    assert len(out) == case["stdout_len"]
-    assert hashlib.md5(out).hexdigest() == case["stdout_md5"]
+    for minimal in (True, False):
+        out = host_find(db, data, f, so.chunk_size(flags.count("-L")), minimal=minimal)
+        assert len(out) == case["stdout_len"]
+        assert hashlib.md5(out).hexdigest() == case["stdout_md5"]
 
 
 def test_report_prefix_and_colour(built):
@@ -74,7 +79,7 @@ def test_report_matches_python_oracle_random(built):
     """Random texts x patterns x flags: product walk == scan_oracle.grab_file."""
     rng = np.random.default_rng(11)
     alphabet = np.frombuffer(b"abcdeffoo0123456789_AZ \n\n", np.uint8)
-    for pattern in ["foo", "[a-z]{2,5}", "abc[0-9]*", "e+", "[A-Za-z_][A-Za-z0-9_]{3,}", r"\d\d", "[^\\n]{4}"]:
+    for pattern in ["foo", "ff", "f", "[a-z]{2,5}", "abc[0-9]*", "e+", "[A-Za-z_][A-Za-z0-9_]{3,}", r"\d\d", "[^\\n]{4}", "[a-f]{3}"]:
         db = engine.Database(pattern)
         for trial in range(6):
             n = int(rng.integers(0, 3000))
@@ -82,3 +87,4 @@ def test_report_matches_python_oracle_random(built):
             for f in (0, 1, 3, 2, 4, 5, 7):
                 want = so.grab_file(pattern, data.tobytes(), f, 1 << 30)
                 assert host_find(db, data, f, 1 << 30) == want, (pattern, n, f)
+                assert host_find(db, data, f, 1 << 30, minimal=False) == want, (pattern, n, f)
