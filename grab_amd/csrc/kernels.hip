@@ -216,11 +216,19 @@ __device__ __forceinline__ void emit_tile(const ScanArgs &a, uint32_t t, const u
 #pragma unroll
     for (int k = 0; k < ITER; k++) {
         uint32_t bits = (hits[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-        if (__ballot(bits != 0) == 0ull) continue; // wave-uniform
+        const unsigned long long any = __ballot(bits != 0);
+        if (any == 0ull) continue; // wave-uniform
+        const uint32_t pos0 = (uint32_t)(sub_off + k * 1024) + lane * 16u - bias;
+        if (__ballot((bits & (bits - 1u)) != 0) == 0ull) {
+            // common case: no lane holds two records in this step -> rank = lanes below me that hold one
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+            if (bits) a.recs[run + rank] = pos0 + (uint32_t)__ffs((int)bits) - 1u;
+            run += (uint32_t)__popcll(any);
+            continue;
+        }
         uint32_t c = (uint32_t)__popc(bits);
         uint32_t inc = wave_scan(c);
         uint32_t idx = run + inc - c;
-        uint32_t pos0 = (uint32_t)(sub_off + k * 1024) + lane * 16u - bias;
         while (bits) {
             uint32_t j = (uint32_t)__ffs((int)bits) - 1u;
             bits &= bits - 1u;
