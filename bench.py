@@ -116,6 +116,22 @@ def build_corpus(files, file_bytes, needles, rank, device):
     return arena, plants
 
 
+def measured_traffic(config, nbytes):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/*pmc_traffic.json; PMC cannot be collected from inside the run).  None if the workload
+    differs from the profiled one."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        if name.endswith("pmc_traffic.json"):
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", name))).get(config)
+            except (OSError, ValueError):
+                continue
+            if rec and rec.get("workload_bytes") == nbytes:
+                best = int(rec["traffic_bytes"])
+    return best
+
+
 def cpu_baseline(arena, files, file_bytes, pattern, flags, want_gib=8):
     """Time the reference (or the oracle port) on this box's host cores over a bounded sample."""
     ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
@@ -246,7 +262,7 @@ def main():
             "matches_per_s": round(matches_all / (elapsed / a.steps), 1),
             "check": check,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(a.config, nbytes),
                          "kernel_ms": round(kern_avg_ms, 4), "launches": int(launches),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
