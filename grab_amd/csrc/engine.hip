@@ -271,48 +271,70 @@ int gscan_db_info(const gscan_db *db, gscan_info *info)
     info->tier = d.tier;
     info->minlen = d.minlen;
     info->n_classes = (int)d.classes.size();
-    info->has_tail = d.has_tail;
-    info->tail_extra = d.tail_extra;
+    info->has_tail = !d.alts.empty() && d.alts[0].has_tail;
+    info->tail_extra = d.alts.empty() ? 0 : d.alts[0].tail_extra;
     info->anchor_off = (int)d.prog.anchor_off;
     info->anchor_len = (int)d.prog.anchor_len;
     info->is_literal = (int)d.prog.is_literal;
+    info->n_alts = (int)d.alts.size();
     return GSCAN_OK;
 }
 
-int gscan_db_class(const gscan_db *db, int pos, uint8_t table[256])
+int gscan_db_alt_class(const gscan_db *db, int alt, int pos, uint8_t table[256], int *len)
 {
     if (!db || !table) return GSCAN_EINVAL;
     const Database &d = db->db;
+    if (alt < 0 || (size_t)alt >= d.alts.size()) return GSCAN_EINVAL;
+    const gscan::AltSeq &a = d.alts[(size_t)alt];
     const gscan::ByteSet *s = nullptr;
     if (pos == -1) {
-        if (!d.has_tail) return GSCAN_EINVAL;
-        s = &d.tail;
+        if (!a.has_tail) return GSCAN_EINVAL;
+        s = &a.tail;
     } else {
-        if (pos < 0 || (size_t)pos >= d.window.size()) return GSCAN_EINVAL;
-        s = &d.classes[d.window[(size_t)pos]];
+        if (pos < 0 || (size_t)pos >= a.window.size()) return GSCAN_EINVAL;
+        s = &d.classes[a.window[(size_t)pos]];
     }
     for (int b = 0; b < 256; b++) table[b] = s->test((unsigned)b);
+    if (len) *len = (int)a.window.size();
     return GSCAN_OK;
 }
+
+int gscan_db_class(const gscan_db *db, int pos, uint8_t table[256]) { return gscan_db_alt_class(db, 0, pos, table, nullptr); }
+
+namespace {
+// The alternative pcre_exec's match at p goes through: the first one, in priority order, whose
+// window fits into the chunk and matches there (pattern.h).  nullptr: no match starts at p.
+const gscan::AltSeq *alt_at(const Database &d, const uint8_t *content, size_t clen, size_t p)
+{
+    for (const gscan::AltSeq &a : d.alts) {
+        const size_t m = a.window.size();
+        if (p + m > clen) continue;
+        const uint8_t *t = content + p;
+        size_t i = 0;
+        while (i < m && d.classes[a.window[i]].test(t[i])) i++;
+        if (i == m) return &a;
+    }
+    return nullptr;
+}
+} // namespace
 
 int gscan_match_at(const gscan_db *db, const void *content, size_t clen, uint32_t p)
 {
     const Database &d = db->db;
-    if (d.minlen <= 0 || (size_t)p + (size_t)d.minlen > clen) return 0;
-    const uint8_t *t = (const uint8_t *)content + p;
-    for (int i = 0; i < d.minlen; i++)
-        if (!d.classes[d.window[(size_t)i]].test(t[i])) return 0;
-    return 1;
+    if (d.minlen <= 0) return 0;
+    return alt_at(d, (const uint8_t *)content, clen, p) != nullptr;
 }
 
 uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, uint32_t start)
 {
     const Database &d = db->db;
-    size_t e = (size_t)start + (size_t)(d.minlen > 0 ? d.minlen : 0);
-    if (d.has_tail) {
-        const uint8_t *t = (const uint8_t *)content;
+    const uint8_t *t = (const uint8_t *)content;
+    const gscan::AltSeq *a = d.minlen > 0 ? alt_at(d, t, clen, start) : nullptr;
+    if (!a) return start; // not a match start
+    size_t e = (size_t)start + a->window.size();
+    if (a->has_tail) {
         uint64_t extra = 0;
-        while (e < clen && extra < (uint64_t)d.tail_extra && d.tail.test(t[e])) {
+        while (e < clen && extra < (uint64_t)a->tail_extra && a->tail.test(t[e])) {
             e++;
             extra++;
         }

@@ -36,6 +36,13 @@
 //   lanes' masks come in by DPP wave shifts; runs of n consecutive class bits are
 //   found by shift-AND doubling (log2 n steps) on 32- or 64-bit words.  The run
 //   program sits in the lanes of one VGPR (v_readlane), not in memory.
+// K3 (several alternatives, or one class sequence with > 4 classes): the multi-pattern
+//   filter.  The alternatives share 8 buckets; one LDS lookup per text byte (same
+//   bank-replicated 32 KiB table layout as K2) returns, for each of 4 window positions,
+//   the set of buckets that accept the byte there; position q is a hit when some bucket
+//   accepts bytes q..q+3 at positions 0..3 (2 VALU ops per byte to align and AND the four
+//   bucket sets).  Hits are verified against the full windows of their buckets'
+//   alternatives in a cold path, unless the filter is already exact.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -121,6 +128,25 @@ __device__ __noinline__ bool verify_window(const uint8_t *seg, const DevProgram 
         if (!((pg->cls_bits[c][b >> 5] >> (b & 31)) & 1u)) return false;
     }
     return true;
+}
+
+// Cold path of K3: does some alternative of the buckets in `buckets` match at p, inside the segment?
+__device__ __forceinline__ bool verify_alts(const uint8_t *seg, uint32_t slen, const DevProgram *pg, uint32_t p, uint32_t buckets)
+{
+    const uint32_t n = pg->n_alts;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!((buckets >> pg->alt_bucket[i]) & 1u)) continue;
+        const uint32_t m = pg->alt_len[i];
+        if (p + m > slen) continue;
+        const uint8_t *w = pg->alt_window + pg->alt_off[i];
+        uint32_t k = 0;
+        for (; k < m; k++) {
+            const uint32_t b = seg[p + k];
+            if (!((pg->cls_bits[w[k]][b >> 5] >> (b & 31)) & 1u)) break;
+        }
+        if (k == m) return true;
+    }
+    return false;
 }
 
 struct TileCtx {
@@ -486,6 +512,136 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
 }
 #undef GS_LUT
 
+// ------------------------------------------------------------------------------------
+// K3: bucket filter over 4 window positions (alternations; class sequences with > 4 classes).
+// ------------------------------------------------------------------------------------
+// Table entry of byte b: byte k = buckets that accept b at window position k3_off + k.
+// With e_j the entry of text byte j:   hit(j) = e_j.b0 & e_{j+1}.b1 & e_{j+2}.b2 & e_{j+3}.b3 != 0.
+//   g_j = e_j & rotr(e_{j+1}, 8)        byte 0: positions 0,1 at j     byte 2: positions 2,3 at j-2... i.e. at j: e_j.b2 & e_{j+1}.b3
+//   h_j = g_j & (g_{j+2} >> 16)         byte 0 = the four-way AND
+template <int ITER, bool NT>
+__global__ __launch_bounds__(kWG) void k3_bucket_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
+{
+    __shared__ uint32_t tbl[256 * 32];
+    __shared__ __attribute__((aligned(16))) uint8_t s_pos[kK3Confirm * 256];
+    __shared__ uint8_t s_blen[kK3Buckets];
+    __shared__ uint32_t s_cnt[kWaves];
+    __shared__ uint32_t s_base;
+    constexpr uint32_t kTile = kWaves * ITER * 1024;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x / kWave;
+    const uint32_t bank = lane & 31u;
+    const uint32_t koff = a.k3_off, m = a.m;
+    const bool exact = a.k3_exact != 0;
+    const bool confirm_exact = a.prog->k3_confirm_exact != 0; // wave-uniform (scalar load)
+    {
+        const uint32_t b = threadIdx.x; // 256 threads == 256 entries, each replicated into all 32 banks
+        const uint32_t v = a.prog->k3_table[b];
+#pragma unroll 8
+        for (uint32_t r = 0; r < 32; r++) tbl[(b << 5) | ((r + lane) & 31u)] = v;
+        // confirm tables (cold path only): kK3Confirm window positions x 256 bytes, one copy
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(&a.prog->k3_pos[0][0]);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(s_pos);
+        for (uint32_t q = b; q < (uint32_t)(kK3Confirm * 256 / 16); q += kWG) dst[q] = src[q];
+        if (b < (uint32_t)kK3Buckets) s_blen[b] = a.prog->k3_blen[b];
+    }
+    __syncthreads();
+
+    for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        TileCtx c = tile_ctx(a, tiles, t, kTile);
+        const int sub_off = c.tile_off + (int)(wave * ITER * 1024);
+        uint32_t hits[(ITER + 1) / 2];
+#pragma unroll
+        for (int i = 0; i < (ITER + 1) / 2; i++) hits[i] = 0;
+        uint32_t cnt = 0;
+
+        if (c.live && sub_off < c.slen) {
+            u32x4 buf[ITER + 1];
+            load_subtile<ITER, NT, 1>(buf, c, sub_off, lane);
+            // filter positions q = p + koff of window starts p with 0 <= p and p + m <= slen
+            const int lo = (int)koff, hi = c.slen - (int)m + (int)koff;
+#pragma unroll
+            for (int k = 0; k < ITER; k++) {
+                const u32x4 d = buf[k];
+                const uint32_t nx = __builtin_amdgcn_readfirstlane(buf[k + 1].x);
+                uint32_t e[19];
+#define GS_E(i_, w_, sh_) e[i_] = tbl[((((w_) >> (sh_)) & 0xffu) << 5) | bank]
+                GS_E(0, d.x, 0);  GS_E(1, d.x, 8);  GS_E(2, d.x, 16);  GS_E(3, d.x, 24);
+                GS_E(4, d.y, 0);  GS_E(5, d.y, 8);  GS_E(6, d.y, 16);  GS_E(7, d.y, 24);
+                GS_E(8, d.z, 0);  GS_E(9, d.z, 8);  GS_E(10, d.z, 16); GS_E(11, d.z, 24);
+                GS_E(12, d.w, 0); GS_E(13, d.w, 8); GS_E(14, d.w, 16); GS_E(15, d.w, 24);
+                uint32_t n0, n1, n2; // entries of the first three bytes of the NEXT step (lane 63 looks into them)
+                n0 = tbl[(((nx >> 0) & 0xffu) << 5) | bank];
+                n1 = tbl[(((nx >> 8) & 0xffu) << 5) | bank];
+                n2 = tbl[(((nx >> 16) & 0xffu) << 5) | bank];
+#undef GS_E
+                e[16] = down1(e[0], n0);
+                e[17] = down1(e[1], n1);
+                e[18] = down1(e[2], n2);
+                uint32_t g[18];
+#pragma unroll
+                for (int j = 0; j < 18; j++) g[j] = e[j] & __builtin_amdgcn_alignbit(e[j + 1], e[j + 1], 8);
+                uint32_t h[16], any = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    h[j] = g[j] & (g[j + 2] >> 16);
+                    any |= h[j];
+                }
+                if (any & 0xffu) { // cold: which positions, bounds, full windows
+                    const int pos0 = sub_off + k * 1024 + (int)lane * 16;
+                    const uint32_t vm = valid16(pos0, lo, hi);
+                    const bool direct = exact && pos0 + 16 + kK3Depth <= c.slen; // filter == pattern, windows in bounds
+                    uint32_t hm = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) hm |= (h[j] & 0xffu) ? 1u << j : 0u;
+                    hm &= vm;
+                    uint32_t bits = hm;
+                    if (!direct) {
+                        // confirm every hit against the first kK3Confirm (24) window positions: the window's bytes are
+                        // re-read (beyond the segment the descriptor returns zeros), then one LDS byte per position
+                        // gives the buckets that accept the byte there
+                        bits = 0;
+                        while (hm) {
+                            const uint32_t j = (uint32_t)__ffs((int)hm) - 1u;
+                            hm &= hm - 1u;
+                            const uint32_t p = (uint32_t)pos0 + j - koff;
+                            // aligned dword loads (each one bounds-checked on its own: an unaligned 16-byte load that
+                            // straddles the segment end comes back as zeros altogether), shifted into place
+                            const int pa = (int)(p & ~3u);
+                            uint32_t dw[kK3Confirm / 4 + 1];
+#pragma unroll
+                            for (int q = 0; q <= kK3Confirm / 4; q++) dw[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(c.rsrc, pa + 4 * q, 0, 0);
+                            uint32_t w[kK3Confirm / 4];
+#pragma unroll
+                            for (int q = 0; q < kK3Confirm / 4; q++) w[q] = __builtin_amdgcn_alignbyte(dw[q + 1], dw[q], p & 3u);
+                            uint32_t mk = 0xffu;
+#pragma unroll
+                            for (int q = 0; q < kK3Confirm; q++) mk &= s_pos[q * 256 + ((w[q >> 2] >> (8 * (q & 3))) & 0xffu)];
+                            bool ok = false;
+                            if (mk) {
+                                if (confirm_exact) { // the tables are the pattern: only the segment end is left to check
+                                    while (mk) {
+                                        const uint32_t b = (uint32_t)__ffs((int)mk) - 1u;
+                                        mk &= mk - 1u;
+                                        if (p + s_blen[b] <= (uint32_t)c.slen) ok = true;
+                                    }
+                                } else {
+                                    ok = verify_alts(c.seg, (uint32_t)c.slen, a.prog, p, 0xffu);
+                                }
+                            }
+                            if (ok) bits |= 1u << j;
+                        }
+                    }
+                    bits &= ~(bits << 1); // keep group starts (within the lane; a superset of them is fine)
+                    hits[k >> 1] |= bits << (16 * (k & 1));
+                    cnt += (uint32_t)__popc(bits);
+                }
+            }
+        }
+        emit_tile<ITER, kWaves>(a, t, hits, cnt, sub_off, koff, lane, wave, s_cnt, &s_base);
+    }
+}
+
 } // namespace
 
 // ---- host-callable launchers (engine.hip) ----
@@ -510,7 +666,10 @@ static hipError_t launch_iter(int tier, bool nt, bool wide, const ScanArgs &a, u
 {
     dim3 g(grid);
     const TileDesc *tiles = a.tiles;
-    if (tier == GSCAN_TIER_LITERAL) {
+    if (tier == GSCAN_TIER_BUCKET) {
+        if (nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true>), g, dim3(kWG), 0, st, a, tiles);
+        else hipLaunchKernelGGL((k3_bucket_scan<ITER, false>), g, dim3(kWG), 0, st, a, tiles);
+    } else if (tier == GSCAN_TIER_LITERAL) {
         if (nt) hipLaunchKernelGGL((k1_anchor_scan<ITER, true>), g, dim3(kWG), 0, st, a, tiles);
         else hipLaunchKernelGGL((k1_anchor_scan<ITER, false>), g, dim3(kWG), 0, st, a, tiles);
     } else if (k2_pair(a)) {
@@ -543,6 +702,11 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
     a.anchor_len = pg.anchor_len;
     a.n_classes = pg.n_classes;
     a.nruns = pg.nruns;
+    a.k3_off = pg.k3_off;
+    // the filter IS the pattern when every alternative has its own bucket and lies inside the filtered positions
+    a.k3_exact = pg.n_alts <= (uint32_t)kK3Buckets && pg.k3_off == 0;
+    for (uint32_t i = 0; i < pg.n_alts; i++)
+        if (pg.alt_len[i] > (uint32_t)kK3Depth) a.k3_exact = 0;
     for (int r = 0; r < kK2MaxRuns; r++)
         a.run_desc[r] = (uint32_t)pg.run_cls[r] | ((uint32_t)pg.run_len[r] << 8) | ((uint32_t)pg.run_off[r] << 16);
 }

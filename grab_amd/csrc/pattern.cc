@@ -1,6 +1,7 @@
 // pattern.cc -- see pattern.h.  Host only; no HIP.
 #include "pattern.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cctype>
 #include <cstring>
@@ -10,12 +11,26 @@
 namespace gscan {
 namespace {
 
-struct Atom {
+constexpr uint32_t kInf = UINT32_MAX;
+
+// Parse tree.  SET = one byte drawn from a class; REP repeats its single child.
+struct Node {
+    enum Kind { SET, CAT, ALT, REP } kind = SET;
     ByteSet set;
-    uint32_t min = 1, max = 1; // max == UINT32_MAX: unbounded
+    std::vector<Node> kids;
+    uint32_t min = 1, max = 1; // REP; max == kInf: unbounded
+    int mode = 0;              // REP: 0 greedy, 1 lazy, 2 possessive
 };
 
-constexpr uint32_t kInf = UINT32_MAX;
+// One path through the pattern: window classes + optional variable repeat at the end.
+struct Seq {
+    std::vector<ByteSet> win;
+    bool has_tail = false;
+    ByteSet tail;
+    uint32_t tail_extra = 0;
+    int tail_mode = 0;
+    bool empty() const { return win.empty() && !has_tail; }
+};
 
 // C-locale character tables, as pcre_maketables() builds them without setlocale()
 // (/root/reference/src/grab.cc:106).
@@ -100,6 +115,11 @@ struct Parser {
     size_t n, i = 0;
     std::string why;
     int rc = 0; // 0 ok, 1 unsupported, -1 malformed
+    // inline options in force (PCRE: a change made inside a group lasts to the end of that
+    // group, and carries into the alternatives that follow it there)
+    bool caseless = false, dotall = false;
+    bool quoting = false; // inside \Q...\E
+    int depth = 0;
 
     bool fail(int code, const char *msg)
     {
@@ -117,6 +137,18 @@ struct Parser {
         if (c >= 'a' && c <= 'f') return c - 'a' + 10;
         if (c >= 'A' && c <= 'F') return c - 'A' + 10;
         return -1;
+    }
+
+    // (?i): every member of the set also matches in its other case (C locale: ASCII letters only)
+    static void fold_case(ByteSet &s)
+    {
+        for (unsigned c = 'a'; c <= 'z'; c++) {
+            const unsigned u = c - 32;
+            if (s.test(c) || s.test(u)) {
+                s.set(c);
+                s.set(u);
+            }
+        }
     }
 
     // After a backslash (i points at the escape letter).  Yields a set.  in_class
@@ -255,6 +287,7 @@ struct Parser {
                     }
                     ByteSet ps;
                     if (!posix_class(name, ps)) return fail(-1, "unknown POSIX class name");
+                    if (pneg && caseless) return fail(1, "negated POSIX class under (?i)");
                     if (pneg) ps.negate();
                     s.merge(ps);
                     i = j + 2;
@@ -303,6 +336,7 @@ struct Parser {
             }
             s.merge(lo);
         }
+        if (caseless) fold_case(s); // before negation: (?i)[^a] excludes 'A' too
         if (neg) s.negate();
         out = s;
         return true;
@@ -341,12 +375,86 @@ struct Parser {
         return true;
     }
 
-    bool parse(std::vector<Atom> &atoms)
+    // "(?" just consumed.  Either an option setting "(?i)" (returns with is_group = false), or the
+    // opening of a non-capturing group "(?:" / "(?i:" (is_group = true; options already applied,
+    // the caller restores them at the closing parenthesis).
+    bool group_head(bool &is_group)
     {
-        bool quoting = false;
+        is_group = false;
+        if (eof()) return fail(-1, "unrecognized character after (?");
+        int c = p[i];
+        if (c == '#') { // comment
+            while (!eof() && p[i] != ')') i++;
+            if (eof()) return fail(-1, "missing ) after comment");
+            i++;
+            return true;
+        }
+        if (c == ':') {
+            i++;
+            is_group = true;
+            return true;
+        }
+        if (c == '=' || c == '!' || c == '<') return fail(1, "look-around / named group");
+        if (c == '>') return fail(1, "atomic group");
+        if (c == '|') return fail(1, "branch-reset group");
+        if (c == 'P' || c == '\'' || c == 'R' || c == '&' || c == '(' || c == 'C' || c == '+' || (c >= '0' && c <= '9'))
+            return fail(1, "named group / recursion / conditional / callout");
+        bool on = true, ci = caseless, da = dotall;
+        for (;; i++) {
+            if (eof()) return fail(-1, "missing ) after option setting");
+            c = p[i];
+            if (c == '-') {
+                if (!on) return fail(-1, "unrecognized character after (?");
+                on = false;
+            } else if (c == 'i') {
+                ci = on;
+            } else if (c == 's') {
+                da = on;
+            } else if (c == 'm') {
+                // multiline only changes ^ and $, which the engine does not take anyway
+            } else if (c == 'x' || c == 'J' || c == 'U' || c == 'X') {
+                return fail(1, "inline option outside the engine's subset");
+            } else if (c == ')' || c == ':') {
+                break;
+            } else {
+                return fail(-1, "unrecognized character after (?");
+            }
+        }
+        caseless = ci;
+        dotall = da;
+        is_group = (p[i] == ':');
+        i++;
+        return true;
+    }
+
+    // alternation := cat ('|' cat)*
+    bool parse_alt(Node &out)
+    {
+        Node alt;
+        alt.kind = Node::ALT;
+        for (;;) {
+            Node cat;
+            if (!parse_cat(cat)) return false;
+            alt.kids.push_back(std::move(cat));
+            if (!eof() && !quoting && p[i] == '|') {
+                i++;
+                continue;
+            }
+            break;
+        }
+        if (alt.kids.size() == 1) out = std::move(alt.kids[0]);
+        else out = std::move(alt);
+        return true;
+    }
+
+    // cat := piece*   (stops at '|', ')' or the end)
+    bool parse_cat(Node &out)
+    {
+        out = Node();
+        out.kind = Node::CAT;
         while (!eof()) {
             int c = p[i];
-            Atom a;
+            Node a;
             if (quoting) {
                 if (c == '\\' && i + 1 < n && p[i + 1] == 'E') {
                     quoting = false;
@@ -354,8 +462,18 @@ struct Parser {
                     continue;
                 }
                 a.set.set((unsigned)c);
+                if (caseless) fold_case(a.set);
                 i++;
+                if (i + 1 < n && p[i] == '\\' && p[i + 1] == 'E') { // the quote ends here: a quantifier after \E applies to this char
+                    quoting = false;
+                    i += 2;
+                }
             } else {
+                if (c == '|') break;
+                if (c == ')') {
+                    if (depth == 0) return fail(-1, "unmatched parentheses");
+                    break;
+                }
                 switch (c) {
                 case '\\':
                     if (i + 1 < n && p[i + 1] == 'Q') {
@@ -371,21 +489,42 @@ struct Parser {
                     {
                         bool is_set;
                         if (!escape(a.set, false, is_set)) return false;
+                        if (caseless) fold_case(a.set);
                     }
                     break;
                 case '.':
                     a.set = set_dot();
+                    if (dotall) a.set.set('\n');
                     i++;
                     break;
                 case '[':
                     i++;
                     if (!bracket(a.set)) return false;
                     break;
+                case '(': {
+                    i++;
+                    if (eof()) return fail(-1, "missing )");
+                    if (p[i] == '*') return fail(1, "backtracking control verb");
+                    if (p[i] != '?') return fail(1, "capturing group (the reference prints nothing for a pattern with one: ovector[3])");
+                    i++;
+                    const bool ci = caseless, da = dotall;
+                    bool is_group;
+                    if (!group_head(is_group)) return false;
+                    if (!is_group) { // "(?i)": stays in force to the end of the enclosing group
+                        if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?')) return fail(-1, "nothing to repeat");
+                        continue;
+                    }
+                    depth++;
+                    if (!parse_alt(a)) return false;
+                    depth--;
+                    if (eof() || p[i] != ')') return fail(-1, "missing )");
+                    i++;
+                    caseless = ci;
+                    dotall = da;
+                    break;
+                }
                 case '^': return fail(1, "anchor ^");
                 case '$': return fail(1, "anchor $");
-                case '|': return fail(1, "alternation");
-                case '(': return fail(1, "group");
-                case ')': return fail(-1, "unmatched parentheses");
                 case '*':
                 case '+':
                 case '?': return fail(-1, "nothing to repeat");
@@ -399,6 +538,7 @@ struct Parser {
                 }
                 default:
                     a.set.set((unsigned)c);
+                    if (caseless) fold_case(a.set);
                     i++;
                 }
             }
@@ -407,33 +547,188 @@ struct Parser {
             if (!quoting && !eof()) {
                 int q = p[i];
                 bool have = false;
-                if (q == '*') { a.min = 0; a.max = kInf; i++; have = true; }
-                else if (q == '+') { a.min = 1; a.max = kInf; i++; have = true; }
-                else if (q == '?') { a.min = 0; a.max = 1; i++; have = true; }
+                uint32_t qmin = 1, qmax = 1;
+                if (q == '*') { qmin = 0; qmax = kInf; i++; have = true; }
+                else if (q == '+') { qmin = 1; qmax = kInf; i++; have = true; }
+                else if (q == '?') { qmin = 0; qmax = 1; i++; have = true; }
                 else if (q == '{') {
                     uint32_t mn, mx;
                     size_t end;
                     if (counted(mn, mx, end)) {
                         if (mx != kInf && mx < mn) return fail(-1, "numbers out of order in {} quantifier");
                         if (mn > 65535 || (mx != kInf && mx > 65535)) return fail(-1, "number too big in {} quantifier");
-                        a.min = mn;
-                        a.max = mx;
+                        qmin = mn;
+                        qmax = mx;
                         i = end;
                         have = true;
                     }
                 }
-                if (have && !eof()) {
-                    int r = p[i];
-                    if (r == '?') return fail(1, "lazy quantifier");
-                    if (r == '+') return fail(1, "possessive quantifier");
-                    uint32_t mn, mx;
-                    size_t end;
-                    if (r == '*' || (r == '{' && counted(mn, mx, end))) return fail(1, "stacked quantifiers");
+                if (have) {
+                    int mode = 0;
+                    if (!eof() && p[i] == '?') { mode = 1; i++; }
+                    else if (!eof() && p[i] == '+') { mode = 2; i++; }
+                    if (!eof()) {
+                        int r = p[i];
+                        uint32_t mn, mx;
+                        size_t end;
+                        if (r == '*' || r == '+' || r == '?' || (r == '{' && counted(mn, mx, end))) return fail(1, "stacked quantifiers");
+                    }
+                    Node rep;
+                    rep.kind = Node::REP;
+                    rep.min = qmin;
+                    rep.max = qmax;
+                    rep.mode = mode;
+                    rep.kids.push_back(std::move(a));
+                    a = std::move(rep);
                 }
             }
-            atoms.push_back(a);
+            out.kids.push_back(std::move(a));
         }
         return true;
+    }
+
+    bool parse(Node &root)
+    {
+        if (!parse_alt(root)) return false;
+        if (!eof()) return fail(-1, "unmatched parentheses"); // a ')' at depth 0
+        return true;
+    }
+};
+
+// ---- unfolding the tree into priority-ordered alternatives ----
+struct Unfold {
+    std::string why;
+    int rc = 0;
+    bool fail(const char *msg)
+    {
+        if (rc == 0) {
+            rc = 1;
+            why = msg;
+        }
+        return false;
+    }
+    bool room(size_t count) { return count <= (size_t)kMaxAlts * 4 ? true : fail("pattern unfolds into too many alternatives"); }
+
+    // every path of `a` followed by every path of `b`.  PCRE backtracks the most recent choice
+    // first, so the order is: a's choices major (a variable repeat at the end of `a` counts as one:
+    // longest first when greedy, shortest first when lazy), b's choices minor.
+    bool concat(const std::vector<Seq> &A, const std::vector<Seq> &B, std::vector<Seq> &out)
+    {
+        out.clear();
+        if (B.size() == 1 && B[0].empty()) {
+            out = A;
+            return true;
+        }
+        for (const Seq &a : A) {
+            std::vector<Seq> heads;
+            if (!a.has_tail) {
+                heads.push_back(a);
+            } else { // the repeat is no longer at the end: unfold it into explicit counts
+                if (a.tail_mode == 2) return fail("possessive repeat before the end of the pattern");
+                if (a.tail_extra == kInf || a.tail_extra > kMaxMidRepeat) return fail("variable repeat before the end of the pattern");
+                for (uint32_t k = 0; k <= a.tail_extra; k++) {
+                    const uint32_t t = a.tail_mode == 1 ? k : a.tail_extra - k;
+                    Seq h;
+                    h.win = a.win;
+                    h.win.insert(h.win.end(), t, a.tail);
+                    heads.push_back(std::move(h));
+                }
+            }
+            for (const Seq &h : heads)
+                for (const Seq &b : B) {
+                    Seq s = h;
+                    s.win.insert(s.win.end(), b.win.begin(), b.win.end());
+                    s.has_tail = b.has_tail;
+                    s.tail = b.tail;
+                    s.tail_extra = b.tail_extra;
+                    s.tail_mode = b.tail_mode;
+                    if (s.win.size() > (size_t)kMaxWindow) return fail("window longer than the engine supports");
+                    out.push_back(std::move(s));
+                    if (!room(out.size())) return false;
+                }
+        }
+        return true;
+    }
+
+    // (?:E){lo,hi}: after each iteration the choice is "one more" (tried first when greedy) or "stop"
+    bool repeat_paths(const std::vector<Seq> &E, uint32_t lo, uint32_t hi, bool lazy, std::vector<Seq> &out)
+    {
+        out.clear();
+        if (hi == 0) {
+            out.push_back(Seq());
+            return true;
+        }
+        std::vector<Seq> rest, more;
+        if (!repeat_paths(E, lo > 0 ? lo - 1 : 0, hi - 1, lazy, rest)) return false;
+        if (!concat(E, rest, more)) return false;
+        if (lo > 0) {
+            out = std::move(more);
+            return true;
+        }
+        if (lazy) out.push_back(Seq());
+        out.insert(out.end(), more.begin(), more.end());
+        if (!lazy) out.push_back(Seq());
+        return room(out.size());
+    }
+
+    bool run(const Node &nd, std::vector<Seq> &out)
+    {
+        out.clear();
+        switch (nd.kind) {
+        case Node::SET: {
+            Seq s;
+            s.win.push_back(nd.set);
+            out.push_back(std::move(s));
+            return true;
+        }
+        case Node::CAT: {
+            out.push_back(Seq());
+            for (const Node &k : nd.kids) {
+                std::vector<Seq> kid, joined;
+                if (!run(k, kid)) return false;
+                if (!concat(out, kid, joined)) return false;
+                out.swap(joined);
+            }
+            return true;
+        }
+        case Node::ALT:
+            for (const Node &k : nd.kids) {
+                std::vector<Seq> kid;
+                if (!run(k, kid)) return false;
+                out.insert(out.end(), kid.begin(), kid.end());
+                if (!room(out.size())) return false;
+            }
+            return true;
+        case Node::REP: {
+            const Node &k = nd.kids[0];
+            if (nd.max == 0) { // {0}: matches nothing, consumes nothing
+                out.push_back(Seq());
+                return true;
+            }
+            if (k.kind == Node::SET) {
+                if (nd.min > (uint32_t)kMaxWindow) return fail("window longer than the engine supports");
+                Seq s;
+                s.win.assign(nd.min, k.set);
+                if (nd.max > nd.min) {
+                    s.has_tail = true;
+                    s.tail = k.set;
+                    s.tail_extra = nd.max == kInf ? kInf : nd.max - nd.min;
+                    s.tail_mode = nd.mode;
+                }
+                out.push_back(std::move(s));
+                return true;
+            }
+            std::vector<Seq> E;
+            if (!run(k, E)) return false;
+            for (const Seq &e : E)
+                if (e.win.empty()) return fail("repeated group that can match the empty string");
+            if (nd.mode == 2) return fail("possessive repeat of a group");
+            if (nd.max == kInf) return fail("unbounded repeat of a group");
+            if (nd.max > 2 * kMaxMidRepeat) return fail("pattern unfolds into too many alternatives");
+            return repeat_paths(E, nd.min, nd.max, nd.mode == 1, out);
+        }
+        }
+        return fail("internal: unknown node");
     }
 };
 
@@ -463,90 +758,188 @@ std::atomic<uint64_t> g_next_id{1};
 
 int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, std::string &why)
 {
-    std::vector<Atom> atoms;
+    std::vector<Seq> seqs;
     if (flags & GSCAN_LITERAL) {
+        Seq s;
         for (size_t k = 0; k < len; k++) {
-            Atom a;
-            a.set.set((unsigned char)pat[k]);
-            atoms.push_back(a);
+            ByteSet b;
+            b.set((unsigned char)pat[k]);
+            s.win.push_back(b);
         }
+        if (s.win.size() > (size_t)kMaxWindow) {
+            why = "window longer than the engine supports";
+            return 1;
+        }
+        seqs.push_back(std::move(s));
     } else {
         Parser ps{(const unsigned char *)pat, len};
-        if (!ps.parse(atoms)) {
+        Node root;
+        if (!ps.parse(root)) {
             why = ps.why;
             return ps.rc;
         }
+        Unfold uf;
+        if (!uf.run(root, seqs)) {
+            why = uf.why;
+            return uf.rc;
+        }
     }
 
-    // drop {0} atoms; an atom that can match no byte at all makes the pattern unmatchable
-    std::vector<Atom> kept;
-    for (auto &a : atoms) {
-        if (a.max == 0) continue;
-        if (a.set.count() == 0) {
+    // a lazy repeat at the very end takes its minimum, a possessive one behaves like a greedy one
+    for (Seq &s : seqs)
+        if (s.has_tail && s.tail_mode == 1) s.has_tail = false;
+    // an atom that can match no byte at all makes its alternative unmatchable
+    for (const Seq &s : seqs) {
+        for (const ByteSet &b : s.win)
+            if (b.count() == 0) {
+                why = "empty character class";
+                return 1;
+            }
+        if (s.has_tail && s.tail.count() == 0) {
             why = "empty character class";
             return 1;
         }
-        kept.push_back(a);
     }
-    atoms.swap(kept);
-
-    for (size_t k = 0; k + 1 < atoms.size(); k++)
-        if (atoms[k].min != atoms[k].max) {
-            why = "variable repeat before the last atom";
-            return 1;
+    // a later duplicate of an alternative can never be the first one to match
+    {
+        std::vector<Seq> uniq;
+        for (Seq &s : seqs) {
+            bool dup = false;
+            for (const Seq &u : uniq)
+                if (u.win.size() == s.win.size() && u.has_tail == s.has_tail &&
+                    (!u.has_tail || (u.tail == s.tail && u.tail_extra == s.tail_extra)) &&
+                    std::equal(u.win.begin(), u.win.end(), s.win.begin()))
+                    dup = true;
+            if (!dup) uniq.push_back(std::move(s));
         }
+        seqs.swap(uniq);
+    }
 
     db = Database();
     db.id = g_next_id.fetch_add(1);
     memset(&db.prog, 0, sizeof db.prog);
 
-    uint64_t m = 0;
-    for (auto &a : atoms) m += a.min;
-    if (m == 0) { // can match the empty string: PCRE_INFO_MINLENGTH == -1
+    size_t minm = SIZE_MAX, total = 0;
+    for (const Seq &s : seqs) {
+        minm = std::min(minm, s.win.size());
+        total += s.win.size();
+    }
+    if (seqs.empty() || minm == 0) { // can match the empty string: PCRE_INFO_MINLENGTH == -1
         db.tier = GSCAN_TIER_NULL;
         db.minlen = -1;
         return 0;
     }
-    if (m > (uint64_t)kMaxWindow) {
-        why = "window longer than the engine supports";
+    if (seqs.size() > (size_t)kMaxAlts || total > (size_t)kAltWindowBytes) {
+        why = "pattern unfolds into too many alternatives";
         return 1;
     }
 
-    // window + class table
-    for (auto &a : atoms) {
-        int id = -1;
-        for (size_t c = 0; c < db.classes.size(); c++)
-            if (db.classes[c] == a.set) id = (int)c;
-        if (id < 0 && a.min > 0) {
-            if ((int)db.classes.size() >= kMaxClasses) {
-                why = "too many distinct classes";
-                return 1;
+    // class table + alternatives
+    for (const Seq &s : seqs) {
+        AltSeq a;
+        for (const ByteSet &b : s.win) {
+            int id = -1;
+            for (size_t c = 0; c < db.classes.size(); c++)
+                if (db.classes[c] == b) id = (int)c;
+            if (id < 0) {
+                if ((int)db.classes.size() >= kMaxClasses) {
+                    why = "too many distinct classes";
+                    return 1;
+                }
+                db.classes.push_back(b);
+                id = (int)db.classes.size() - 1;
             }
-            db.classes.push_back(a.set);
-            id = (int)db.classes.size() - 1;
+            a.window.push_back((uint8_t)id);
         }
-        for (uint32_t r = 0; r < a.min; r++) db.window.push_back((uint8_t)id);
+        a.has_tail = s.has_tail;
+        a.tail = s.tail;
+        a.tail_extra = s.has_tail ? s.tail_extra : 0;
+        db.alts.push_back(std::move(a));
     }
-    if (!atoms.empty() && atoms.back().max > atoms.back().min) {
-        db.has_tail = true;
-        db.tail = atoms.back().set;
-        db.tail_extra = atoms.back().max == kInf ? kInf : atoms.back().max - atoms.back().min;
-    }
-    db.minlen = (int)m;
+    db.minlen = (int)minm;
 
     DevProgram &pg = db.prog;
-    pg.m = (uint32_t)m;
+    const std::vector<uint8_t> &w0 = db.alts[0].window;
+    const size_t m = w0.size();
+    pg.m = (uint32_t)minm;
     pg.n_classes = (uint32_t)db.classes.size();
     for (size_t c = 0; c < db.classes.size(); c++) memcpy(pg.cls_bits[c], db.classes[c].w, 32);
+    pg.n_alts = (uint32_t)db.alts.size();
+    {
+        size_t at = 0;
+        for (size_t i = 0; i < db.alts.size(); i++) {
+            pg.alt_off[i] = (uint16_t)at;
+            pg.alt_len[i] = (uint16_t)db.alts[i].window.size();
+            pg.alt_bucket[i] = (uint8_t)(i % kK3Buckets);
+            memcpy(pg.alt_window + at, db.alts[i].window.data(), db.alts[i].window.size());
+            at += db.alts[i].window.size();
+        }
+    }
+
+    // K3 filter: the kK3Depth window positions from k3_off on, per bucket.  The offset is common to
+    // all alternatives (a hit at text position q means a window start at q - k3_off); it is chosen
+    // to make the filter as selective as possible.  Positions beyond an alternative's end accept
+    // any byte.
+    {
+        const size_t max_off = minm > (size_t)kK3Depth ? minm - kK3Depth : 0;
+        double best = -1;
+        size_t best_off = 0;
+        for (size_t off = 0; off <= max_off; off++) {
+            double score = 0;
+            for (const AltSeq &a : db.alts) {
+                double prod = 1;
+                for (int k = 0; k < kK3Depth; k++)
+                    prod *= off + k < a.window.size() ? db.classes[a.window[off + k]].count() / 256.0 : 1.0;
+                score += prod;
+            }
+            if (best < 0 || score < best) {
+                best = score;
+                best_off = off;
+            }
+        }
+        pg.k3_off = (uint32_t)best_off;
+        for (int b = 0; b < 256; b++) {
+            uint32_t e = 0;
+            for (size_t i = 0; i < db.alts.size(); i++) {
+                const AltSeq &a = db.alts[i];
+                for (int k = 0; k < kK3Depth; k++) {
+                    const size_t pos = best_off + k;
+                    if (pos >= a.window.size() || db.classes[a.window[pos]].test((unsigned)b))
+                        e |= 1u << (8 * k + pg.alt_bucket[i]);
+                }
+            }
+            pg.k3_table[b] = e;
+        }
+        // confirm tables: the same bucket sets for the first kK3Confirm window positions
+        for (int k = 0; k < kK3Confirm; k++)
+            for (int b = 0; b < 256; b++) {
+                uint32_t e = 0;
+                for (size_t i = 0; i < db.alts.size(); i++) {
+                    const AltSeq &a = db.alts[i];
+                    if ((size_t)k >= a.window.size() || db.classes[a.window[(size_t)k]].test((unsigned)b)) e |= 1u << pg.alt_bucket[i];
+                }
+                pg.k3_pos[k][b] = (uint8_t)e;
+            }
+        pg.k3_confirm_exact = db.alts.size() <= (size_t)kK3Buckets;
+        for (size_t i = 0; i < db.alts.size(); i++) {
+            if (db.alts[i].window.size() > (size_t)kK3Confirm) pg.k3_confirm_exact = 0;
+            if (i < (size_t)kK3Buckets) pg.k3_blen[i] = (uint8_t)std::min<size_t>(db.alts[i].window.size(), 255);
+        }
+    }
+
+    if (db.alts.size() > 1) { // several alternatives: the bucket filter is the one kernel that takes them
+        db.tier = GSCAN_TIER_BUCKET;
+        return 0;
+    }
 
     bool literal = true;
     std::vector<int> lit(m, -1);
     for (size_t k = 0; k < m; k++) {
-        lit[k] = db.classes[db.window[k]].single();
+        lit[k] = db.classes[w0[k]].single();
         if (lit[k] < 0) literal = false;
     }
     pg.is_literal = literal;
-    for (size_t k = 0; k < m; k++) pg.window[k] = literal ? (uint8_t)lit[k] : db.window[k];
+    for (size_t k = 0; k < m; k++) pg.window[k] = literal ? (uint8_t)lit[k] : w0[k];
 
     // K1 anchor: longest (<=4) run of single-byte positions, rarest bytes first
     int best_len = 0, best_off = 0, best_score = 1 << 30;
@@ -573,17 +966,17 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     }
 
     // K2 program: runs of equal class ids
-    bool k2 = db.classes.size() <= (size_t)kK2MaxClasses && m <= (uint64_t)kK2MaxWindow;
+    bool k2 = db.classes.size() <= (size_t)kK2MaxClasses && m <= (size_t)kK2MaxWindow;
     if (k2) {
         uint32_t nr = 0;
         for (size_t k = 0; k < m;) {
             size_t e = k;
-            while (e < m && db.window[e] == db.window[k]) e++;
+            while (e < m && w0[e] == w0[k]) e++;
             if (nr >= (uint32_t)kK2MaxRuns) {
                 k2 = false;
                 break;
             }
-            pg.run_cls[nr] = db.window[k];
+            pg.run_cls[nr] = w0[k];
             pg.run_len[nr] = (uint8_t)(e - k);
             pg.run_off[nr] = (uint8_t)k;
             nr++;
@@ -599,19 +992,15 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             }
     }
 
-    // tier choice: a >=3-byte literal anchor makes K1 the cheapest kernel (no LDS
-    // lookups); otherwise the class-run kernel if the window fits it; a weak anchor
-    // (1-2 bytes) still scans correctly, just with a busier verify path.
+    // tier choice: a >=3-byte literal anchor makes K1 the cheapest kernel (no LDS lookups);
+    // otherwise the class-run kernel if the window fits it; otherwise the bucket filter on the
+    // window's most selective 4 positions (any class sequence fits it).
     if (literal || best_len >= 3)
         db.tier = GSCAN_TIER_LITERAL;
     else if (k2)
         db.tier = GSCAN_TIER_CLASSRUN;
-    else if (best_len >= 1)
-        db.tier = GSCAN_TIER_LITERAL;
-    else {
-        why = "class sequence with more than 4 classes and no literal byte to anchor on";
-        return 1;
-    }
+    else
+        db.tier = GSCAN_TIER_BUCKET;
     return 0;
 }
 

@@ -1,13 +1,22 @@
 // pattern.h -- PCRE-subset pattern compiler for the gfx950 scan engine.
 //
 // Replaces the reference's pcre_compile/pcre_study/pcre_fullinfo(MINLENGTH) step
-// (/root/reference/src/grab.cc:101-123) for the patterns the GPU engine can scan:
-// a concatenation of single-byte atoms (literal, '.', escape class, [...] class),
-// each with a FIXED repeat count, optionally ending in ONE greedy variable repeat
-// (*, +, ?, {n,}, {n,m}).  For that shape "pcre_exec reports a match starting at p"
-// is a pure function of the minlen-byte window at p, which is what makes the
-// "GPU emits all candidate starts, host walks the restart orbit" split exact
-// (SURVEY.md Appendix C).  Everything else is reported as GSCAN_UNSUPPORTED.
+// (/root/reference/src/grab.cc:101-123) for the patterns the GPU engine can scan.
+// Accepted: single-byte atoms (literal, '.', escape class, [...] class), repeats,
+// alternation, non-capturing groups and the inline options i / s / m -- as long as the
+// pattern unfolds into a short, PRIORITY-ORDERED list of alternatives, each of which is
+// a fixed class window optionally ending in ONE variable repeat of a single class
+// ("tail": * + ? {n,} {n,m}, greedy/lazy/possessive).  Optional and bounded repeats
+// in the middle of the pattern (colou?r, [ab]{1,3}c, (?:foo|bar)?baz) unfold into
+// alternatives in the order PCRE's backtracking tries them, so "the first alternative
+// whose window matches at p" is exactly pcre_exec's match at p, and its end is the
+// window end plus the tail's extension.  For that shape "pcre_exec reports a match
+// starting at p" is a pure function of the bytes at p (and of the chunk end), which
+// is what makes the "GPU emits all candidate starts, host walks the restart orbit"
+// split exact.  Everything else -- capturing groups (for which
+// the reference prints nothing), anchors, \b, look-around, back
+// references, an unbounded repeat before the end of an alternative -- is reported as
+// GSCAN_UNSUPPORTED.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -57,6 +66,12 @@ constexpr int kMaxClasses = 64; // distinct byte classes per database
 constexpr int kK2MaxClasses = 4;
 constexpr int kK2MaxWindow = 49; // 16 own positions + 48 bits of look-ahead
 constexpr int kK2MaxRuns = 16; // run descriptors live in the lanes of one VGPR for the whole kernel
+constexpr int kMaxAlts = 64;          // alternatives a pattern may unfold into
+constexpr int kAltWindowBytes = 4096; // sum of their window lengths
+constexpr int kK3Buckets = 8;         // K3: alternatives share 8 filter buckets
+constexpr int kK3Depth = 4;           // K3: window positions the filter looks at
+constexpr int kK3Confirm = 24;        // K3: window positions the LDS confirm tables cover
+constexpr uint32_t kMaxMidRepeat = 16; // a bounded repeat {n,m} before the end unfolds if m-n <= this
 
 // POD uploaded verbatim to the device; the kernels read it from global memory /
 // kernel arguments.  Keep in sync with kernels.hip.
@@ -74,17 +89,33 @@ struct DevProgram {
     uint8_t run_off[kK2MaxRuns];
     uint32_t k2_table[256];              // K2: byte -> class bits at bit 0/8/16/24
     uint32_t cls_bits[kMaxClasses][8];   // 256-bit membership bitmap per class
-    uint8_t window[kMaxWindow];          // class id per window position (or the literal byte)
+    uint8_t window[kMaxWindow];          // alternative 0: class id per window position (or the literal byte)
+    // all alternatives, in priority order (K3 verify path)
+    uint32_t n_alts;
+    uint32_t k3_off;                     // K3: window offset of the 4 filtered positions
+    uint16_t alt_off[kMaxAlts];          // start of alternative i inside alt_window
+    uint16_t alt_len[kMaxAlts];          // its window length
+    uint8_t alt_bucket[kMaxAlts];        // its K3 bucket
+    uint8_t alt_window[kAltWindowBytes]; // class ids
+    uint32_t k3_table[256];              // K3: byte -> 4 x 8 bucket bits (byte k: buckets that accept it at position k3_off+k)
+    uint8_t k3_pos[kK3Confirm][256];     // K3 confirm: [window position][byte] -> buckets that accept it there (all, past an alternative's end)
+    uint8_t k3_blen[kK3Buckets];         // K3 confirm: window length of the bucket's alternative when k3_confirm_exact
+    uint32_t k3_confirm_exact;           // every alternative has its own bucket and fits kK3Confirm positions: the tables ARE the pattern
+};
+
+// One alternative: a fixed class window + an optional variable repeat of one class at its end.
+struct AltSeq {
+    std::vector<uint8_t> window; // class id per position
+    bool has_tail = false;
+    uint32_t tail_extra = 0;     // max bytes beyond the window (UINT32_MAX = unbounded)
+    ByteSet tail;
 };
 
 struct Database {
     int tier = 0;
-    int minlen = -1;
-    bool has_tail = false;
-    uint32_t tail_extra = 0;
-    ByteSet tail;
+    int minlen = -1;             // shortest alternative == PCRE_INFO_MINLENGTH; -1 if "" can match
     std::vector<ByteSet> classes;
-    std::vector<uint8_t> window; // class id per position
+    std::vector<AltSeq> alts;    // priority order: the first one whose window matches at p is PCRE's match at p
     DevProgram prog;
     uint64_t id = 0; // unique per compile; contexts key their device copy on it
 };

@@ -35,6 +35,7 @@ struct ScanArgs {
     uint32_t m;              // window length
     uint32_t anchor, anchor_mask, anchor_off, anchor_len; // K1
     uint32_t n_classes, nruns;                            // K2
+    uint32_t k3_off, k3_exact;                            // K3
     uint32_t run_desc[kK2MaxRuns];                        // K2: cls | len<<8 | off<<16
 };
 

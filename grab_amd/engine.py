@@ -14,12 +14,12 @@ from .build import lib_path
 OK, UNSUPPORTED = 0, 1
 EINVAL, ENOMEM, EHIP, EBUSY, EEMPTY, ETOOBIG = -1, -2, -3, -4, -5, -6
 LITERAL = 1
-TIER_NULL, TIER_LITERAL, TIER_CLASSRUN = 0, 1, 2
+TIER_NULL, TIER_LITERAL, TIER_CLASSRUN, TIER_BUCKET = 0, 1, 2, 3
 SLOTS = 2
 
 # every symbol include/gscan.h declares
 SYMBOLS = [
-    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_match_at", "gscan_match_end",
+    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end",
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
     "gscan_acquire", "gscan_submit", "gscan_wait",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
@@ -30,7 +30,7 @@ SYMBOLS = [
 class Info(C.Structure):
     _fields_ = [("tier", C.c_int), ("minlen", C.c_int), ("n_classes", C.c_int), ("has_tail", C.c_int),
                 ("tail_extra", C.c_uint32), ("anchor_off", C.c_int), ("anchor_len", C.c_int),
-                ("is_literal", C.c_int)]
+                ("is_literal", C.c_int), ("n_alts", C.c_int)]
 
 
 class Seg(C.Structure):
@@ -66,6 +66,7 @@ def lib():
         L.gscan_free.restype = None
         L.gscan_db_info.argtypes = [C.c_void_p, C.POINTER(Info)]
         L.gscan_db_class.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gscan_db_alt_class.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         L.gscan_match_at.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
         L.gscan_match_at.restype = C.c_int
         L.gscan_match_end.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
@@ -120,12 +121,20 @@ class Database:
         lib().gscan_db_info(self._h, C.byref(info))
         self.info = info
 
-    def class_table(self, pos):
+    def class_table(self, pos, alt=0):
         t = np.zeros(256, np.uint8)
-        rc = lib().gscan_db_class(self._h, pos, t.ctypes.data)
+        rc = lib().gscan_db_alt_class(self._h, alt, pos, t.ctypes.data, None)
         if rc != OK:
-            raise ValueError("no class at position %d" % pos)
+            raise ValueError("no class at position %d of alternative %d" % (pos, alt))
         return t.astype(bool)
+
+    def alt_len(self, alt):
+        """Window length of alternative `alt` (alternatives are in PCRE's priority order)."""
+        t = np.zeros(256, np.uint8)
+        n = C.c_int()
+        if lib().gscan_db_alt_class(self._h, alt, 0, t.ctypes.data, C.byref(n)) != OK:
+            raise ValueError("no alternative %d" % alt)
+        return n.value
 
     def match_at(self, content, p):
         buf = np.frombuffer(content, np.uint8)

@@ -57,6 +57,7 @@ extern "C" {
 #define GSCAN_TIER_NULL 0    /* pattern can match the empty string: PCRE minlen -1, grab skips every file (Q2) */
 #define GSCAN_TIER_LITERAL 1 /* K1: 4-byte anchor compare + class-sequence verify */
 #define GSCAN_TIER_CLASSRUN 2 /* K2: LDS class table -> per-class bitmaps -> run detection */
+#define GSCAN_TIER_BUCKET 3  /* K3: several alternatives (or > 4 classes): LDS bucket filter on 4 window positions + verify */
 
 typedef struct gscan_db gscan_db;
 typedef struct gscan_ctx gscan_ctx;
@@ -70,6 +71,7 @@ typedef struct gscan_info {
     int anchor_off;      /* K1: offset of the anchor inside the window */
     int anchor_len;      /* K1: 1..4 bytes */
     int is_literal;      /* 1 if every window position is a single byte value */
+    int n_alts;          /* alternatives the pattern unfolds into (priority order); the fields above describe alternative 0 */
 } gscan_info;
 
 /* one scan unit inside a device-resident arena (gscan_scan_device) */
@@ -95,8 +97,10 @@ int gscan_compile(const char *pat, size_t len, unsigned flags, gscan_db **out, i
                   char *err, size_t errcap);
 void gscan_free(gscan_db *db);
 int gscan_db_info(const gscan_db *db, gscan_info *info);
-/* 256-entry membership table (1 byte each) of window position `pos`; pos == -1: the tail class */
+/* 256-entry membership table (1 byte each) of window position `pos`; pos == -1: the tail class (alternative 0) */
 int gscan_db_class(const gscan_db *db, int pos, uint8_t table[256]);
+/* the same for alternative `alt`; *len (optional) receives that alternative's window length */
+int gscan_db_alt_class(const gscan_db *db, int alt, int pos, uint8_t table[256], int *len);
 /* 1 if the pattern matches AT offset p of content[0..clen) (window test on the host), else 0 */
 int gscan_match_at(const gscan_db *db, const void *content, size_t clen, uint32_t p);
 /* ovector[1] for a match starting at `start` of content[0..clen): src/grab.cc:178 semantics */

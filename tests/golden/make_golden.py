@@ -77,6 +77,30 @@ CASES = [
     dict(name="cls_escape_meta", inputs={"f": lit("foo.bar fooxbar foo.bar\n")}, args=["-O", "-l", "foo\\.bar", "f"]),
     dict(name="cls_hex", inputs={"f": lit("A\nB A\n\nA\n")}, args=["-O", "-l", "\\x41\\n", "f"]),
     dict(name="cls_quote", inputs={"f": lit("a.b a+b axb\n")}, args=["-O", "-l", "\\Qa.b\\E", "f"]),
+    # ---- alternation / optional / bounded repeats / inline options (unfolded into priority-ordered alternatives) ----
+    dict(name="alt_foo_tail", inputs={"t1.txt": lit(T1)}, args=["-O", "foo|tail|here", "t1.txt"]),
+    dict(name="alt_foo_tail_Ol", inputs={"t1.txt": lit(T1)}, args=["-O", "-l", "foo|tail|here", "t1.txt"]),
+    dict(name="alt_prefix_order", inputs={"f": lit("foo fo f foofo ffoo\n")}, args=["-O", "-l", "f|fo|foo", "f"]),
+    dict(name="alt_prefix_order2", inputs={"f": lit("foo fo f foofo ffoo\n")}, args=["-O", "-l", "foo|fo|f", "f"]),
+    dict(name="alt_optional", inputs={"f": lit("color colour colouur\ncolr colouR\n")}, args=["-O", "colou?r", "f"]),
+    dict(name="alt_optional_lazy", inputs={"f": lit("abbbc abc ac abbbbbc\n")}, args=["-O", "-l", "ab{1,3}?c|ab", "f"]),
+    dict(name="alt_caseless", inputs={"f": lit("Linus and linus and LINUS\nxlInUsx Linu s\n")}, args=["-O", "(?i)linus", "f"]),
+    dict(name="alt_caseless_scoped", inputs={"f": lit("FOO foo Bar bar BAR\n")}, args=["-O", "-l", "(?i:foo)|bar", "f"]),
+    dict(name="alt_bounded_mid", inputs={"f": lit("ababc abc c bbbbc aac\n")}, args=["-O", "-l", "[ab]{1,3}c", "f"]),
+    dict(name="alt_group_tail", inputs={"f": lit("foobaz barba foobazzzz barbaz\nfooba\n")}, args=["-O", "(?:foo|bar)baz*", "f"]),
+    dict(name="alt_group_repeat", inputs={"f": lit("abab abcd cdcdcd ab cdab\n")}, args=["-O", "-l", "(?:ab|cd){2,3}", "f"]),
+    dict(name="alt_dfs_order", inputs={"f": lit("aba abab aab\n")}, args=["-O", "-l", "(?:a|ab){1,2}", "f"]),
+    dict(name="alt_dotall", inputs={"f": lit("a\nc abc a\n\nc\n")}, args=["-O", "-l", "(?s)a.c", "f"]),
+    dict(name="alt_empty_branch", inputs={"t1.txt": lit(T1)}, args=["-O", "foo|", "t1.txt"], jit_only=True),  # can match "": every file skipped (Q2)
+    dict(name="alt_end_of_file", inputs={"f": lit("xx foobar")}, args=["-O", "-l", "foobar|foo|bar", "f"]),  # strict loop bound (Q3) with alternatives of different lengths
+    dict(name="alt_end_of_file2", inputs={"f": lit("xx foobarx")}, args=["-O", "-l", "foobar|foo|bar", "f"]),
+    dict(name="syn8_alt_Ol", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 3, "plant": [NEEDLE, 64]}},
+         args=["-O", "-l", "foobardoes(?:not)?exist|[0-9A-F]{7}[a-z]?|(?i:xyzzy)", "syn"]),
+    dict(name="syn8_alt_O", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 3, "plant": [NEEDLE, 64]}},
+         args=["-O", "foobardoes(?:not)?exist|[0-9A-F]{7}[a-z]?|(?i:xyzzy)", "syn"]),
+    dict(name="syn8_alt_lines", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 3, "plant": [NEEDLE, 64]}},
+         args=["foobardoes(?:not)?exist|[0-9A-F]{7}[a-z]?|(?i:xyzzy)", "syn"]),
+    dict(name="syn8_caseless_hex", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 1}}, args=["-O", "-l", "(?i)[a-f]{5}[g-z]_", "syn"]),
     # ---- synthetic text (SURVEY section 8d generator) ----
     dict(name="syn8_ident_Ol", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 0}}, args=["-O", "-l", IDENT, "syn"]),
     dict(name="syn8_ident_O", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 0}}, args=["-O", IDENT, "syn"]),
@@ -98,6 +122,9 @@ CASES = [
     dict(name="big2_needle_L5", inputs={"big2.txt": {"kind": "big2"}}, args=L5 + ["-O", "-l", "NEEDLE", "big2.txt"], big=True),
     dict(name="big2_arun_L5", inputs={"big2.txt": {"kind": "big2"}}, args=L5 + ["-O", "-l", "a{30,}", "big2.txt"], big=True),
     dict(name="big2_arun_1g", inputs={"big2.txt": {"kind": "big2"}}, args=["-O", "-l", "a{30,}", "big2.txt"], big=True),
+    dict(name="big_alt_Ol_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "NEE?DLE|DLE|\\n\\.{79}\\n\\.{3}N", "big.txt"], big=True),
+    dict(name="big_alt_O_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "NEE?DLE|DLE", "big.txt"], big=True),
+    dict(name="big2_alt_L5", inputs={"big2.txt": {"kind": "big2"}}, args=L5 + ["-O", "-l", "a{30,}|NEEDLE|a{5}\\.", "big2.txt"], big=True),
     dict(name="big_s_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-s", "-O", "-l", "NEEDLE", "big.txt"], big=True),
     dict(name="big_l_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-l", "NEEDLE", "big.txt"], big=True),
 ]

@@ -62,3 +62,22 @@ def build(recipe, cache=None):
 def materialize(recipe, path, cache=None):
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
     build(recipe, cache).tofile(path)
+
+
+def db_candidates(db, data):
+    """Every offset at which the compiled pattern matches (the candidate set), from the database's own class
+    tables: the union over its alternatives of the offsets where that alternative's window fits and matches.
+    (The tables themselves are pinned against libpcre and Python's re in tests/test_pattern.py.)"""
+    import os
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import scan_oracle as so
+
+    out = [np.zeros(0, np.int64)]
+    for a in range(db.info.n_alts):
+        tables = [db.class_table(i, a) for i in range(db.alt_len(a))]
+        out.append(so.window_starts(data, tables))
+    return np.unique(np.concatenate(out))

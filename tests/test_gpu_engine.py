@@ -9,6 +9,7 @@ import pytest
 
 from conftest import ROOT
 from grab_amd import engine, synth
+from inputs import db_candidates
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import scan_oracle as so  # noqa: E402
@@ -18,7 +19,11 @@ pytestmark = pytest.mark.gpu
 VARIANTS = [0, 1, 2, 4, 5, 6]  # KiB per wave {16, 8, 12} x nontemporal loads {off, on}
 PATTERNS = ["foobardoesnotexist", "foo", "e", "xy", "[A-Za-z_][A-Za-z0-9_]{15,}", "[a-z]{2,5}", "abc[0-9]*", r"\d{3}-\d{4}",
             "[Ll]inus", "a.c", "[^x]{5,}", "[0-9a-f]{32}", "[0-9A-F]{6}[a-z]", "e+", r"\w\s\w\s\w", "[a-z][0-9][A-Z][.,][;:]q",
-            "[ab][cd][ef][gh]{20}", "[0-9]{17}", "[0-9]{18}", "[a-z_]{49}"]
+            "[ab][cd][ef][gh]{20}", "[0-9]{17}", "[0-9]{18}", "[a-z_]{49}",
+            # K3 (bucket filter): alternations, optional / bounded repeats in the middle, (?i), > 4 classes
+            "foo|bar", "foobardoesnotexist|Linus|555-1234", "colou?r|axc", "(?i)linus", "[ab]{1,3}c", "(?:foo|bar)baz?",
+            "a|ab", "(?:a|b|c|d|e|f|x|y|0|1)x", "[a-z][0-9][A-Z][.,][;:]", "(?i)foobar|k7Q,;q|[0-9]{12}x?", "e|ee|eee",
+            "(?:ab|cd|ef|gh|ij|kl|mn|op){2}", "a 1 b|ABCDEF012x|acegg+", "[0-9a-f]{30}(?:ab|cd)"]
 
 
 @pytest.fixture(scope="module")
@@ -30,8 +35,7 @@ def ctx(built):
 
 def oracle_starts(db, data):
     """Every candidate offset (the oracle's definition)."""
-    tables = [db.class_table(i) for i in range(db.minlen)]
-    return so.window_starts(data, tables)
+    return db_candidates(db, data)
 
 
 def same(got, want):

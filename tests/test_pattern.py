@@ -27,8 +27,25 @@ SUPPORTED = [
     ("[[:alpha:]]{3}", engine.TIER_CLASSRUN, 3),
     (r"\Qa.b\E", engine.TIER_LITERAL, 3),
     ("[0-9a-f]{32}", engine.TIER_CLASSRUN, 32),
-    (r"[a-z][0-9][A-Z][_]x", engine.TIER_CLASSRUN, 5),     # 5 positions, 'x' and '_' singletons, 5 classes > 4 -> K1 on "_x"
-    (r"[a-z][0-9][A-Z][.,][;:]q", engine.TIER_LITERAL, 6),  # >4 classes, weak 1-byte anchor
+    (r"[a-z][0-9][A-Z][_]x", engine.TIER_BUCKET, 5),       # 5 classes > 4 and only a 2-byte literal run -> bucket filter
+    (r"[a-z][0-9][A-Z][.,][;:]q", engine.TIER_BUCKET, 6),  # >4 classes, 1-byte literal
+    (r"[a-z][0-9][A-Z][.,][;:]", engine.TIER_BUCKET, 5),   # >4 classes, no literal at all
+    # several alternatives (priority order) -> bucket filter
+    ("foo|bar", engine.TIER_BUCKET, 3),
+    ("a|ab", engine.TIER_BUCKET, 1),
+    ("(?:foo)", engine.TIER_LITERAL, 3),
+    ("colou?r", engine.TIER_BUCKET, 5),
+    ("a?b", engine.TIER_BUCKET, 1),
+    ("[ab]{1,3}c", engine.TIER_BUCKET, 2),
+    ("(?:foo|bar)baz", engine.TIER_BUCKET, 6),
+    ("(?:ab|cde){2}", engine.TIER_BUCKET, 4),
+    ("(?i)foo", engine.TIER_CLASSRUN, 3),
+    ("(?i:foo)|bar", engine.TIER_BUCKET, 3),
+    ("(?s)a.c", engine.TIER_CLASSRUN, 3),
+    ("a{2,}?", engine.TIER_LITERAL, 2),
+    ("a++", engine.TIER_LITERAL, 1),
+    ("ab{2,5}?c|x", engine.TIER_BUCKET, 1),
+    (r"(?i)\Qab\E+", engine.TIER_CLASSRUN, 2),
     ("a{3}", engine.TIER_LITERAL, 3),
     ("x{0}abc", engine.TIER_LITERAL, 3),
     ("a{2}[b-c]{2}d?", engine.TIER_CLASSRUN, 4),
@@ -39,14 +56,15 @@ SUPPORTED = [
     ("a{1,2}", engine.TIER_LITERAL, 1),
 ]
 
-NULL_TIER = ["a?", "x*", "", "a{0}", "[a-z]{0,3}", "x{0}"]
+NULL_TIER = ["a?", "x*", "", "a{0}", "[a-z]{0,3}", "x{0}", "a|", "(?:foo|b?)", "a??", "(?:ab)?", "x*?y{0}"]
 
-UNSUPPORTED = ["foo|bar", "(foo)", "(?:foo)", "^foo", "foo$", r"\bfoo", "a+b", "a?b", "ab*c", "a{2,}?", "a++", r"\1", r"\pL",
-               "(?i)foo", r"\Rfoo", "a{2}{3}", "[a-z][0-9][A-Z][.,][;:]", "x" * 300, r"\Afoo", r"foo\z"]
+UNSUPPORTED = ["(foo)", "(foo|bar)", "^foo", "foo$", r"\bfoo", "a+b", "ab*c", "a{2,}b", "a{1,40}b", "a++b", r"\1", r"\pL",
+               r"\Rfoo", "a{2}{3}", "x" * 300, r"\Afoo", r"foo\z", "(?=foo)", "(?<!a)b", "(?>ab)c", "(?x)a b", "(?:ab)+", "(?:a|b)*c",
+               "(?:ab)?+c", "(?:a|)+b", "(?P<n>a)", "(?|a|b)", "(?:a|b|c|d){4}", "(*UTF8)a", "(?i)[[:^upper:]]a", "a(?R)?b"]
 
 # "a(" is reported as unsupported (groups) by the engine alone; FileGrep::prepare asks libpcre first and
 # gives the reference's "pcre_compile error" for it (tests/test_gpu_filegrep.py, golden case bad_regex)
-MALFORMED = ["[abc", "*a", "+", "?x", "a{3,2}", "[z-a]", "\\", "a)", "[[:nope:]]"]
+MALFORMED = ["[abc", "*a", "+", "?x", "a{3,2}", "[z-a]", "\\", "a)", "[[:nope:]]", "(?:a", "(?i", "(?:a|*b)", "a|+", "(?z)a", "(?i)+a"]
 
 
 def _fix5(p):
@@ -56,10 +74,7 @@ def _fix5(p):
 @pytest.mark.parametrize("pattern,tier,minlen", SUPPORTED)
 def test_supported(pattern, tier, minlen, built, liboracle):
     db = engine.Database(pattern)
-    if pattern == r"[a-z][0-9][A-Z][_]x":
-        assert db.info.tier == engine.TIER_LITERAL
-    else:
-        assert db.info.tier == tier, pattern
+    assert db.info.tier == tier, pattern
     assert db.minlen == minlen
     ml = C.c_int()
     assert liboracle.oracle_minlen(pattern.encode(), C.byref(ml)) == 0
@@ -140,3 +155,54 @@ def test_match_end(pattern, built, liboracle):
     db = engine.Database(pattern)
     for p, e in zip(starts[:n].tolist(), ends[:n].tolist()):
         assert db.match_end(buf, p) == e
+
+
+ALT_PATTERNS = ["foo|bar", "colou?r", "(?i)linus", "[ab]{1,3}c", "(?:foo|bar)baz", "a{2,5}b?", "(?:a|ab){1,2}", "x(?:a|b|)y", "(?:ab)?c",
+                "fo{1,}|bar+", "(?i:foo)|bar", "a(?i)b|c", "a{2,5}?b", "(?:ab|cde){2}", "(?s)a.c", "(?i)[^a]b", "(?i)[a-c]x", "ab+?", "ab++",
+                "a??b", "(?m)foo", "a|ab", "ab|a", "(?:a|b)(?:c|d)e*", "(?:ab){1,3}?c", "a(?:b|c){0,2}a", "foo|fo|f", "f|fo|foo",
+                "(?:a?b){2}", "(?i)a[b-d]+|X{2}", "(?-i)ab|(?i)cd", r"(?i)\x41b", "(?#c)ab", "a(?#x)b|c", "(?:foo|bar){0}ab", "ab{0}|c",
+                "[[:upper:]]b|(?i)[[:upper:]]c", r"\Qa|b\E|c", r"(?i)\Qab\E+", "a{0,3}b{0,2}c", "(?:a|b|c|d|e|f|x|y|0|1)x",
+                "(?:ab|ba){2,3}x", "(?i)(?:li|LI)nus|(?-i:Foo)", "a(?:b(?:c|d)|e)f", "(?:a|b){2}(?:c|d){2}"]
+
+
+@pytest.mark.parametrize("pattern", ALT_PATTERNS)
+def test_alternatives_match_pcre(pattern, built, liboracle):
+    """Unfolded alternatives in priority order: for EVERY offset p of a random text, "a match starts at p" and
+    its end (ovector[1]) are exactly what pcre_exec(ANCHORED) gives with the subject starting at p; minlen ==
+    PCRE_INFO_MINLENGTH.  (pcre_exec is libpcre's, called by the oracle exactly as the reference calls it.)"""
+    rng = np.random.default_rng(11)
+    alpha = np.frombuffer(b"abcdefoxyABFOLINUSlinusrz01 \n.", np.uint8)
+    data = alpha[rng.integers(0, alpha.size, 12000)]
+    for w in [b"foobar", b"colour", b"color", b"LiNuS", b"barbaz", b"ababc", b"aaaaab", b"abcde", b"xay", b"xy", b"abab", b"abababc",
+              b"cdCD", b"aaabbc", b"abbaabx", b"abdf", b"aef", b"abcd"]:
+        for _ in range(12):
+            o = int(rng.integers(0, data.size - 10))
+            data[o:o + len(w)] = np.frombuffer(w, np.uint8)
+    buf = data.tobytes()
+    ml = C.c_int()
+    assert liboracle.oracle_minlen(pattern.encode("latin-1"), C.byref(ml)) == 0
+    db = engine.Database(pattern)
+    assert db.minlen == ml.value
+    s = np.zeros(len(buf) + 1, np.uint32)
+    e = np.zeros(len(buf) + 1, np.uint32)
+    n = liboracle.oracle_all_starts(pattern.encode("latin-1"), buf, len(buf), s.ctypes.data, e.ctypes.data, len(buf) + 1)
+    want = dict(zip(s[:n].tolist(), e[:n].tolist()))
+    got = {p: db.match_end(buf, p) for p in range(len(buf)) if db.match_at(buf, p)}
+    assert got == want
+    # the device-side view of the same thing: the union of the alternatives' windows is the candidate set
+    from inputs import db_candidates
+    assert db_candidates(db, data).tolist() == sorted(want)
+
+
+def test_alternative_order_and_limits(built):
+    db = engine.Database("colou?r")  # greedy ?: the longer path is tried first
+    assert db.info.n_alts == 2 and [db.alt_len(0), db.alt_len(1)] == [6, 5]
+    db = engine.Database("colou??r")  # lazy: the shorter one first
+    assert [db.alt_len(0), db.alt_len(1)] == [5, 6]
+    db = engine.Database("(?:a|ab){1,2}")  # depth-first: a.a, a.ab, a, ab.a, ab.ab, ab
+    assert [db.alt_len(i) for i in range(db.info.n_alts)] == [2, 3, 1, 3, 4, 2]
+    db = engine.Database("foo|foo|bar|foo")  # a later duplicate can never be the first to match
+    assert db.info.n_alts == 2
+    with pytest.raises(engine.Unsupported):
+        engine.Database("|".join("w%03d" % i for i in range(65)))  # > 64 alternatives
+    assert engine.Database("|".join("w%03d" % i for i in range(64))).info.n_alts == 64

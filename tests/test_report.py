@@ -11,7 +11,7 @@ import pytest
 
 from conftest import GOLDEN, ROOT, golden_ids, split_args
 from grab_amd import engine, filegrep
-from inputs import build
+from inputs import build, db_candidates
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import scan_oracle as so  # noqa: E402
@@ -35,11 +35,10 @@ def host_find(db, data, flags, chunk, path=b"", minimal=True):
     minlen = db.minlen
     if minlen < 0 or minlen > len(data):
         return b""
-    tables = [db.class_table(i) for i in range(minlen)]
     out = []
     for off, clen in so.chunks(len(data), chunk):
         part = data[off:off + clen]
-        starts = so.window_starts(part, tables)
+        starts = db_candidates(db, part)
         if minimal:
             starts = so.group_starts(starts)
         text = filegrep.report_chunk(db, flags, path, part, off, starts.astype(np.uint32))
@@ -79,7 +78,8 @@ def test_report_matches_python_oracle_random(built):
     """Random texts x patterns x flags: product walk == scan_oracle.grab_file."""
     rng = np.random.default_rng(11)
     alphabet = np.frombuffer(b"abcdeffoo0123456789_AZ \n\n", np.uint8)
-    for pattern in ["foo", "ff", "f", "[a-z]{2,5}", "abc[0-9]*", "e+", "[A-Za-z_][A-Za-z0-9_]{3,}", r"\d\d", "[^\\n]{4}", "[a-f]{3}"]:
+    for pattern in ["foo", "ff", "f", "[a-z]{2,5}", "abc[0-9]*", "e+", "[A-Za-z_][A-Za-z0-9_]{3,}", r"\d\d", "[^\\n]{4}", "[a-f]{3}",
+                    "foo|ab", "a|ab", "ab|a", "fo?o", "(?:f|e){1,3}0", "(?i)Az|f+", "[a-f]{1,2}[0-9]", "(?:ab|cd)?e", "f{2,4}?o", "0|1|2|[3-9]+"]:
         db = engine.Database(pattern)
         for trial in range(6):
             n = int(rng.integers(0, 3000))
