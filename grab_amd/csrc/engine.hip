@@ -10,14 +10,37 @@
 //   gscan_wait: sync `done`, fetch the rest if needed, stitch runs in tile order.
 //
 // With GSCAN_SLOTS = 2 the copy of chunk k+1 overlaps the scan and report of chunk k.
+//
+// How the bytes get to the copy stream (measured on the MI355X box, profiles/r01_g_host_probe.txt:
+// hipHostMalloc 0.22 s/GiB, page cache -> pinned 8-10 GB/s per thread and linear in threads,
+// H2D 57 GB/s, register + unregister + munmap of a mapping ~55 ms/GiB per thread and slower with
+// more threads):
+//   gscan_submit_fd   a file range: the process-wide reader threads pread(2) it piecewise into a
+//                     small pool of 8 MiB pinned blocks and DMA each piece as soon as it is read;
+//                     nothing is pinned per chunk
+//   gscan_submit_segs many small files packed by the caller into the slot's pinned block: one
+//                     H2D, one launch over a segment table
+//   gscan_submit      a caller buffer: registered and DMA'd in place (>= 1 MiB) or staged
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
+#include <sched.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "scan_args.h"
@@ -40,6 +63,231 @@ constexpr size_t kCounterWords = gscan::kShards + 1; // per-shard counts + overf
 constexpr size_t kCopyPiece = 32u << 20; // memcpy/H2D pipelining granule for foreign host buffers
 constexpr size_t kMaxChunk = (1ull << 30) + 4096;
 
+constexpr size_t kBlock = 8u << 20; // pinned pool block == read piece == batch buffer
+
+// A pinned block of the process-wide pool.  ev is recorded after the last DMA out of the block.
+struct PinBlock {
+    void *p = nullptr;
+    hipEvent_t ev = nullptr;
+};
+
+// One piece of a file range on its way to HBM.
+struct ReadGroup {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t pending = 0;
+    int err = 0; // errno of the first failed read, -1 for a short file, -2 for a HIP failure
+};
+struct ReadTask {
+    int fd;
+    off_t off;
+    size_t n;
+    uint8_t *dst;       // device
+    hipStream_t stream; // the submitting context's copy stream
+    ReadGroup *grp;
+};
+
+// Process-wide, one per device: pinned blocks + the reader threads that fill them.
+// Two block pools so that readers can never be starved by blocks parked in contexts' slots:
+//   reader blocks (at most 2 per reader thread) cycle  free -> read -> DMA in flight -> free;
+//   slot blocks back gscan_acquire and are cached here between contexts.
+class Ingest {
+public:
+    static Ingest *get(int device)
+    {
+        static std::mutex gm;
+        static std::vector<Ingest *> all;
+        std::lock_guard<std::mutex> lk(gm);
+        for (Ingest *i : all)
+            if (i->device_ == device) return i;
+        all.push_back(new Ingest(device)); // lives as long as the process: its threads are never joined
+        return all.back();
+    }
+
+    PinBlock *take_slot_block()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (!slot_free_.empty()) {
+                PinBlock *b = slot_free_.back();
+                slot_free_.pop_back();
+                return b;
+            }
+        }
+        return alloc_block();
+    }
+    void give_slot_block(PinBlock *b)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        slot_free_.push_back(b);
+    }
+
+    void read(const ReadTask &t)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!started_) {
+            started_ = true;
+            for (int i = 0; i < readers_; i++) std::thread([this] { reader_main(); }).detach();
+        }
+        tasks_.push_back(t);
+        cv_tasks_.notify_one();
+    }
+    int readers() const { return readers_; }
+
+private:
+    explicit Ingest(int device) : device_(device)
+    {
+        const char *e = getenv("GSCAN_READERS");
+        long r = e ? atol(e) : 8; // 8 threads x 8.4 GB/s of pread cover one PCIe Gen5 x16 link
+        const long hw = (long)std::thread::hardware_concurrency();
+        if (hw > 0 && r > hw) r = hw;
+        readers_ = (int)std::max<long>(1, std::min<long>(r, 64));
+        cap_ = (size_t)readers_ * 2;
+        // the readers are started later, possibly from a worker thread that is pinned to one CPU (grab -n pins
+        // worker i to CPU i like the reference): they run with the affinity of the thread that opened the first context
+        have_mask_ = sched_getaffinity(0, sizeof mask_, &mask_) == 0;
+        timing_ = getenv("GSCAN_TIMING") != nullptr;
+    }
+
+public:
+    void report_if_timing()
+    {
+        if (timing_ && n_pieces_) report();
+    }
+
+private:
+
+    PinBlock *alloc_block()
+    {
+        PinBlock *b = new (std::nothrow) PinBlock();
+        if (!b) return nullptr;
+        (void)hipSetDevice(device_);
+        if (hipHostMalloc(&b->p, kBlock + kPad, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (b->p) hipHostFree(b->p);
+            delete b;
+            return nullptr;
+        }
+        return b;
+    }
+
+    PinBlock *take_reader_block()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            if (!free_.empty()) {
+                PinBlock *b = free_.back();
+                free_.pop_back();
+                return b;
+            }
+            if (n_alloc_ < cap_) {
+                n_alloc_++;
+                lk.unlock();
+                PinBlock *b = alloc_block();
+                if (b) return b;
+                lk.lock();
+                n_alloc_--;
+                if (n_alloc_ == 0 && busy_.empty()) return nullptr; // no pinned memory at all
+                continue;
+            }
+            if (!busy_.empty()) { // the oldest DMA out of a block: wait for it outside the lock
+                PinBlock *b = busy_.front();
+                busy_.pop_front();
+                lk.unlock();
+                (void)hipEventSynchronize(b->ev);
+                return b;
+            }
+            cv_blocks_.wait(lk);
+        }
+    }
+    void give_reader_block(PinBlock *b, bool dma_pending)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (dma_pending) busy_.push_back(b);
+        else free_.push_back(b);
+        cv_blocks_.notify_one();
+    }
+
+    void reader_main()
+    {
+        if (have_mask_) (void)pthread_setaffinity_np(pthread_self(), sizeof mask_, &mask_);
+        (void)hipSetDevice(device_);
+        for (;;) {
+            ReadTask t;
+            double t0 = timing_ ? now() : 0;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_tasks_.wait(lk, [&] { return !tasks_.empty(); });
+                t = tasks_.front();
+                tasks_.pop_front();
+            }
+            double t1 = timing_ ? now() : 0;
+            int err = 0;
+            PinBlock *b = take_reader_block();
+            double t2 = timing_ ? now() : 0, t3 = t2;
+            if (!b) {
+                err = -2;
+            } else {
+                size_t got = 0;
+                while (got < t.n && !err) {
+                    const ssize_t r = pread(t.fd, (char *)b->p + got, t.n - got, t.off + (off_t)got);
+                    if (r > 0) got += (size_t)r;
+                    else if (r == 0) err = -1;
+                    else if (errno != EINTR) err = errno;
+                }
+                t3 = timing_ ? now() : 0;
+                bool dma = false;
+                if (!err) {
+                    if (hipMemcpyAsync(t.dst, b->p, t.n, hipMemcpyHostToDevice, t.stream) != hipSuccess ||
+                        hipEventRecord(b->ev, t.stream) != hipSuccess) {
+                        (void)hipGetLastError();
+                        (void)hipStreamSynchronize(t.stream);
+                        err = -2;
+                    } else {
+                        dma = true;
+                    }
+                }
+                give_reader_block(b, dma);
+            }
+            if (timing_) {
+                const double t4 = now();
+                ns_idle_ += (uint64_t)((t1 - t0) * 1e9);
+                ns_block_ += (uint64_t)((t2 - t1) * 1e9);
+                ns_read_ += (uint64_t)((t3 - t2) * 1e9);
+                ns_hip_ += (uint64_t)((t4 - t3) * 1e9);
+                n_pieces_++;
+                n_bytes_ += t.n;
+            }
+            std::lock_guard<std::mutex> lk(t.grp->m);
+            if (err && !t.grp->err) t.grp->err = err;
+            if (--t.grp->pending == 0) t.grp->cv.notify_all();
+        }
+    }
+
+    // GSCAN_TIMING=1: where the reader threads spend their time, printed when a context closes
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    bool timing_ = false;
+    std::atomic<uint64_t> ns_idle_{0}, ns_block_{0}, ns_read_{0}, ns_hip_{0}, n_pieces_{0}, n_bytes_{0};
+    void report()
+    {
+        fprintf(stderr, "[gscan timing] device %d readers %d: pieces %llu bytes %llu | per reader: idle %.3f s  wait-for-block %.3f s  pread %.3f s  hip calls %.3f s\n",
+                device_, readers_, (unsigned long long)n_pieces_.load(), (unsigned long long)n_bytes_.load(), ns_idle_ / 1e9 / readers_,
+                ns_block_ / 1e9 / readers_, ns_read_ / 1e9 / readers_, ns_hip_ / 1e9 / readers_);
+    }
+    int device_;
+    int readers_ = 8;
+    cpu_set_t mask_;
+    bool have_mask_ = false;
+    size_t cap_ = 16, n_alloc_ = 0;
+    bool started_ = false;
+    std::mutex m_;
+    std::condition_variable cv_blocks_, cv_tasks_;
+    std::vector<PinBlock *> free_, slot_free_;
+    std::deque<PinBlock *> busy_;
+    std::deque<ReadTask> tasks_;
+};
+
 enum SlotState { FREE = 0, ACQUIRED, INFLIGHT };
 
 struct Slot {
@@ -58,6 +306,16 @@ struct Slot {
     size_t h_desc_cap = 0;
     uint32_t *h_spec = nullptr; // pinned, kShards rows of kSpecPer
     std::vector<uint32_t> raw, sorted;
+    const void *ext = nullptr;  // caller's buffer this chunk was copied from (gscan_wait hands it back as *content)
+    void *ext_reg = nullptr;    // ... registered with the runtime for direct DMA until the scan is done
+    PinBlock *blk = nullptr; // pool block serving as this slot's pinned buffer (acquires of <= kBlock bytes)
+    bool no_content = false;    // gscan_submit_fd: the bytes never sat in a host buffer of ours
+    // multi-segment chunks (gscan_submit_segs)
+    std::vector<gscan_seg> segs;
+    std::vector<uint32_t> tile_first; // first tile of segment i; [nseg] = n_tiles
+    std::vector<size_t> seg_first;    // result: first record of segment i in `sorted`; [nseg] = total
+    gscan::TileDesc *d_tiles = nullptr, *h_tiles = nullptr;
+    size_t seg_tiles_cap = 0;
     hipEvent_t copied = nullptr, done = nullptr;
     uint64_t tag = 0;
     size_t len = 0;
@@ -77,10 +335,12 @@ struct gscan_ctx {
     int cus = 256;
     size_t max_chunk = 0;
     hipStream_t copy = nullptr, compute = nullptr;
+    Ingest *ingest = nullptr;
     Slot slot[GSCAN_SLOTS];
     uint64_t next_seq = 1;
     std::string err;
     // compiled program on the device
+    void *h_arena = nullptr, *d_arena = nullptr; // one pinned and one device allocation behind all the small buffers below
     DevProgram *d_prog = nullptr;
     DevProgram *h_prog = nullptr; // pinned staging
     uint64_t prog_id = 0;
@@ -89,6 +349,7 @@ struct gscan_ctx {
     // nontemporal loads, one workgroup per tile
     int variant = 6;
     int blocks_per_cu = 0;
+    size_t register_min = 1u << 20; // caller buffers of at least this many bytes are registered and DMA'd in place
     // device-resident path
     size_t dev_cap_req = 0;
     uint32_t *dv_recs = nullptr;
@@ -149,7 +410,7 @@ uint32_t grid_for(const gscan_ctx *c, const Database &db, uint32_t n_tiles)
     return (uint32_t)std::min<uint64_t>(g, n_tiles);
 }
 
-int slot_reserve(gscan_ctx *c, Slot &s, size_t len)
+int slot_reserve_pinned(gscan_ctx *c, Slot &s, size_t len)
 {
     if (len > s.pinned_cap) {
         if (s.pinned) hipHostFree(s.pinned);
@@ -159,6 +420,11 @@ int slot_reserve(gscan_ctx *c, Slot &s, size_t len)
         HIPCHK(c, hipHostMalloc(&s.pinned, cap, hipHostMallocDefault));
         s.pinned_cap = cap - kPad;
     }
+    return 0;
+}
+
+int slot_reserve_device(gscan_ctx *c, Slot &s, size_t len)
+{
     if (len > s.d_text_cap) {
         if (s.d_text) hipFree(s.d_text);
         s.d_text = nullptr;
@@ -191,16 +457,73 @@ int slot_reserve(gscan_ctx *c, Slot &s, size_t len)
     return 0;
 }
 
+int slot_reserve(gscan_ctx *c, Slot &s, size_t len)
+{
+    int rc = slot_reserve_pinned(c, s, len);
+    return rc ? rc : slot_reserve_device(c, s, len);
+}
+
+void slot_unregister(Slot &s)
+{
+    if (s.ext_reg) {
+        (void)hipHostUnregister(s.ext_reg);
+        s.ext_reg = nullptr;
+    }
+}
+
+// Tile table of a multi-segment chunk: built in pinned memory, copied on the copy stream ahead of
+// the `copied` event.  Single-segment chunks need none (the kernel tiles segment 0 in order).
+int slot_build_tiles(gscan_ctx *c, Slot &s, uint32_t tile_bytes)
+{
+    const size_t nseg = s.segs.size();
+    s.tile_first.assign(nseg + 1, 0);
+    uint64_t nt = 0;
+    for (size_t i = 0; i < nseg; i++) {
+        s.tile_first[i] = (uint32_t)nt;
+        nt += (s.segs[i].len + tile_bytes - 1) / tile_bytes;
+    }
+    s.tile_first[nseg] = (uint32_t)nt;
+    if (nt + 1 > s.seg_tiles_cap) {
+        if (s.d_tiles) hipFree(s.d_tiles);
+        if (s.h_tiles) hipHostFree(s.h_tiles);
+        s.d_tiles = nullptr;
+        s.h_tiles = nullptr;
+        s.seg_tiles_cap = 0;
+        const size_t cap = (size_t)nt + nt / 2 + 64;
+        HIPCHK(c, hipMalloc((void **)&s.d_tiles, cap * sizeof(gscan::TileDesc)));
+        HIPCHK(c, hipHostMalloc((void **)&s.h_tiles, cap * sizeof(gscan::TileDesc), hipHostMallocDefault));
+        s.seg_tiles_cap = cap;
+    }
+    for (size_t i = 0; i < nseg; i++)
+        for (uint32_t t = s.tile_first[i]; t < s.tile_first[i + 1]; t++)
+            s.h_tiles[t] = {s.segs[i].offset, s.segs[i].len, (t - s.tile_first[i]) * tile_bytes};
+    if (nt) HIPCHK(c, hipMemcpyAsync(s.d_tiles, s.h_tiles, (size_t)nt * sizeof(gscan::TileDesc), hipMemcpyHostToDevice, c->copy));
+    // descriptors: one per tile; make room (a batch of tiny files has far more tiles than len / tile size)
+    if ((size_t)nt + 2 > s.tiles_cap) {
+        if (s.d_desc) hipFree(s.d_desc);
+        if (s.h_desc) hipHostFree(s.h_desc);
+        s.d_desc = nullptr;
+        s.h_desc = nullptr;
+        s.tiles_cap = 0;
+        const size_t cap = (size_t)nt + nt / 2 + 64;
+        HIPCHK(c, hipMalloc((void **)&s.d_desc, cap * 8));
+        HIPCHK(c, hipHostMalloc((void **)&s.h_desc, cap * 8, hipHostMallocDefault));
+        s.tiles_cap = cap;
+    }
+    return 0;
+}
+
 int slot_launch(gscan_ctx *c, Slot &s)
 {
     const Database &db = s.db->db;
     const uint32_t tile_bytes = gscan::scan_tile_bytes(db.tier, c->variant, db.prog.n_classes);
-    s.n_tiles = (uint32_t)((s.len + tile_bytes - 1) / tile_bytes);
+    const bool multi = !s.segs.empty();
+    s.n_tiles = multi ? s.tile_first.back() : (uint32_t)((s.len + tile_bytes - 1) / tile_bytes);
     HIPCHK(c, hipMemsetAsync(s.d_counter, 0, kCounterWords * 4, c->compute));
     ScanArgs a;
     memset(&a, 0, sizeof a);
     a.base = s.d_text;
-    a.tiles = nullptr; // one segment, tiled in order
+    a.tiles = multi ? s.d_tiles : nullptr; // nullptr: one segment, tiled in order
     a.seg0_off = 0;
     a.seg0_len = (uint32_t)s.len;
     a.n_tiles = s.n_tiles;
@@ -221,16 +544,17 @@ int slot_launch(gscan_ctx *c, Slot &s)
     return 0;
 }
 
-void free_slot(Slot &s)
+void free_slot(gscan_ctx *c, Slot &s)
 {
+    slot_unregister(s);
+    if (s.blk && c->ingest) c->ingest->give_slot_block(s.blk); // back to the process-wide cache
+    if (s.d_tiles) hipFree(s.d_tiles);
+    if (s.h_tiles) hipHostFree(s.h_tiles);
     if (s.pinned) hipHostFree(s.pinned);
     if (s.d_text) hipFree(s.d_text);
     if (s.d_recs) hipFree(s.d_recs);
     if (s.d_desc) hipFree(s.d_desc);
-    if (s.d_counter) hipFree(s.d_counter);
-    if (s.h_counter) hipHostFree(s.h_counter);
     if (s.h_desc) hipHostFree(s.h_desc);
-    if (s.h_spec) hipHostFree(s.h_spec);
     if (s.copied) hipEventDestroy(s.copied);
     if (s.done) hipEventDestroy(s.done);
     s = Slot();
@@ -354,32 +678,65 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     if (!out) return GSCAN_EINVAL;
     *out = nullptr;
     if (max_chunk == 0 || max_chunk > kMaxChunk) return GSCAN_ETOOBIG;
+    const bool tm = getenv("GSCAN_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](const char *what) {
+        if (tm) {
+            const double t1 = now();
+            fprintf(stderr, "[gscan timing] gscan_open: %-28s %.4f s\n", what, t1 - t0);
+            t0 = t1;
+        }
+    };
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GSCAN_EHIP; // no device: there is no CPU path
+    lap("hipGetDeviceCount (runtime init)");
     if (hip_device < 0 || hip_device >= n) return GSCAN_EINVAL;
     gscan_ctx *c = new (std::nothrow) gscan_ctx();
     if (!c) return GSCAN_ENOMEM;
     c->device = hip_device;
     c->max_chunk = max_chunk;
+    c->ingest = Ingest::get(hip_device);
     auto bail = [&](int rc) {
         gscan_close(c);
         return rc;
     };
     if (hipSetDevice(hip_device) != hipSuccess) return bail(GSCAN_EHIP);
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess) c->cus = prop.multiProcessorCount;
+    lap("hipSetDevice");
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && cus > 0) c->cus = cus;
+    lap("device attribute");
     if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
     if (hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
-    if (hipMalloc((void **)&c->d_prog, sizeof(DevProgram)) != hipSuccess) return bail(GSCAN_EHIP);
-    if (hipHostMalloc((void **)&c->h_prog, sizeof(DevProgram), hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
+    lap("2 streams");
+    // one pinned allocation for every small host-side buffer of the context (each hipHostMalloc costs about a millisecond)
+    const size_t per_slot = 64 + kSpecRecs * 4;
+    const size_t host_bytes = ((sizeof(DevProgram) + 63) & ~size_t(63)) + GSCAN_SLOTS * per_slot;
+    if (hipHostMalloc((void **)&c->h_arena, host_bytes, hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
+    lap("pinned arena");
+    const size_t dev_bytes = ((sizeof(DevProgram) + 255) & ~size_t(255)) + (GSCAN_SLOTS + 1) * 256;
+    if (hipMalloc((void **)&c->d_arena, dev_bytes) != hipSuccess) return bail(GSCAN_EHIP);
+    lap("device arena");
+    {
+        char *h = (char *)c->h_arena, *d = (char *)c->d_arena;
+        c->h_prog = (DevProgram *)h;
+        h += (sizeof(DevProgram) + 63) & ~size_t(63);
+        c->d_prog = (DevProgram *)d;
+        d += (sizeof(DevProgram) + 255) & ~size_t(255);
+        for (Slot &s : c->slot) {
+            s.h_counter = (uint32_t *)h;
+            s.h_spec = (uint32_t *)(h + 64);
+            h += per_slot;
+            s.d_counter = (uint32_t *)d;
+            d += 256;
+        }
+        c->dv_counter = (uint32_t *)d;
+    }
     for (Slot &s : c->slot) {
-        if (hipMalloc((void **)&s.d_counter, 64) != hipSuccess) return bail(GSCAN_EHIP);
-        if (hipHostMalloc((void **)&s.h_counter, 64, hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
-        if (hipHostMalloc((void **)&s.h_spec, kSpecRecs * 4, hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
         if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
         if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
     }
-    if (hipMalloc((void **)&c->dv_counter, 64) != hipSuccess) return bail(GSCAN_EHIP);
+    lap("events");
     *out = c;
     return GSCAN_OK;
 }
@@ -387,15 +744,15 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
 void gscan_close(gscan_ctx *c)
 {
     if (!c) return;
+    if (c->ingest) c->ingest->report_if_timing();
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    for (Slot &s : c->slot) free_slot(s);
-    if (c->d_prog) hipFree(c->d_prog);
-    if (c->h_prog) hipHostFree(c->h_prog);
+    for (Slot &s : c->slot) free_slot(c, s);
+    if (c->d_arena) hipFree(c->d_arena);
+    if (c->h_arena) hipHostFree(c->h_arena);
     if (c->dv_recs) hipFree(c->dv_recs);
     if (c->dv_desc) hipFree(c->dv_desc);
     if (c->dv_tiles) hipFree(c->dv_tiles);
-    if (c->dv_counter) hipFree(c->dv_counter);
     for (auto &e : c->ev_pool) {
         hipEventDestroy(e.a);
         hipEventDestroy(e.b);
@@ -407,28 +764,43 @@ void gscan_close(gscan_ctx *c)
 
 const char *gscan_strerror(const gscan_ctx *c) { return c ? c->err.c_str() : "no context"; }
 
+namespace {
+// the slot's pinned buffer for `len` bytes: a block of the process-wide pool when it fits, else the slot's own allocation
+int slot_pinned_for(gscan_ctx *c, Slot &s, size_t len, void **out)
+{
+    if (len <= kBlock) {
+        if (!s.blk) s.blk = c->ingest->take_slot_block();
+        if (!s.blk) return fail(c, GSCAN_ENOMEM, "no pinned memory for a staging block");
+        *out = s.blk->p;
+        return 0;
+    }
+    int rc = slot_reserve_pinned(c, s, len);
+    if (rc) return rc;
+    *out = s.pinned;
+    return 0;
+}
+bool slot_owns(const Slot &s, const void *p) { return p && (p == s.pinned || (s.blk && p == s.blk->p)); }
+} // namespace
+
 int gscan_acquire(gscan_ctx *c, size_t len, void **pinned)
 {
     if (!c || !pinned) return GSCAN_EINVAL;
     if (len > c->max_chunk) return fail(c, GSCAN_ETOOBIG, "chunk of %zu bytes exceeds max_chunk %zu", len, c->max_chunk);
     HIPCHK(c, hipSetDevice(c->device));
-    for (Slot &s : c->slot)
-        if (s.state == ACQUIRED) { // re-acquire: same slot
-            int rc = slot_reserve(c, s, len);
-            if (rc) return rc;
-            *pinned = s.pinned;
-            return GSCAN_OK;
-        }
-    for (Slot &s : c->slot)
-        if (s.state == FREE) {
-            int rc = slot_reserve(c, s, len);
-            if (rc) return rc;
-            s.state = ACQUIRED;
-            *pinned = s.pinned;
-            return GSCAN_OK;
-        }
-    return fail(c, GSCAN_EBUSY, "all %d slots in flight", GSCAN_SLOTS);
+    Slot *s = nullptr;
+    for (Slot &x : c->slot)
+        if (x.state == ACQUIRED) s = &x; // re-acquire: same slot
+    if (!s)
+        for (Slot &x : c->slot)
+            if (x.state == FREE && !s) s = &x;
+    if (!s) return fail(c, GSCAN_EBUSY, "all %d slots in flight", GSCAN_SLOTS);
+    int rc = slot_pinned_for(c, *s, len, pinned);
+    if (rc) return rc;
+    s->state = ACQUIRED;
+    return GSCAN_OK;
 }
+
+size_t gscan_block_size(void) { return kBlock; }
 
 int gscan_submit(gscan_ctx *c, const gscan_db *db, const void *host_bytes, size_t len, uint64_t tag)
 {
@@ -439,26 +811,50 @@ int gscan_submit(gscan_ctx *c, const gscan_db *db, const void *host_bytes, size_
     Slot *s = nullptr;
     for (Slot &x : c->slot)
         if (x.state == ACQUIRED) s = &x;
+    const bool own = s && slot_owns(*s, host_bytes);
     if (!s) {
-        void *p;
-        int rc = gscan_acquire(c, len, &p);
-        if (rc) return rc;
         for (Slot &x : c->slot)
-            if (x.state == ACQUIRED) s = &x;
-    } else if (len > s->pinned_cap) {
-        return fail(c, GSCAN_EINVAL, "submitted %zu bytes into a slot acquired for %zu", len, s->pinned_cap);
+            if (x.state == FREE && !s) s = &x;
+        if (!s) return fail(c, GSCAN_EBUSY, "all %d slots in flight", GSCAN_SLOTS);
+    } else if (own && len > (host_bytes == s->pinned ? s->pinned_cap : kBlock)) {
+        return fail(c, GSCAN_EINVAL, "submitted %zu bytes into a smaller acquired buffer", len);
     }
     int rc = ensure_prog(c, db, c->compute);
     if (rc) return rc;
-    if (host_bytes == s->pinned) {
-        if (len) HIPCHK(c, hipMemcpyAsync(s->d_text, s->pinned, len, hipMemcpyHostToDevice, c->copy));
+    rc = slot_reserve_device(c, *s, len);
+    if (rc) return rc;
+    s->ext = nullptr;
+    s->no_content = false;
+    s->segs.clear();
+    if (own) {
+        s->ext = host_bytes;
+        if (len) HIPCHK(c, hipMemcpyAsync(s->d_text, host_bytes, len, hipMemcpyHostToDevice, c->copy));
     } else {
-        rc = slot_reserve(c, *s, len);
-        if (rc) return rc;
-        for (size_t o = 0; o < len; o += kCopyPiece) { // memcpy of piece i+1 overlaps the DMA of piece i
-            size_t n = std::min(kCopyPiece, len - o);
-            memcpy((char *)s->pinned + o, (const char *)host_bytes + o, n);
-            HIPCHK(c, hipMemcpyAsync(s->d_text + o, (char *)s->pinned + o, n, hipMemcpyHostToDevice, c->copy));
+        // The caller's own buffer (FileGrep hands over its mmap of the file chunk).  Big ones are registered
+        // with the runtime and DMA'd in place -- no bounce copy: 57 GB/s from the page cache on MI355X,
+        // against 8-10 GB/s per thread for memcpy into a pinned buffer (profiles/r01_g_host_probe.txt).
+        // Small ones, or memory the runtime refuses to register, are staged through the slot's pinned buffer.
+        s->ext = host_bytes;
+        bool direct = false;
+        if (len >= c->register_min) {
+            if (hipHostRegister(const_cast<void *>(host_bytes), len, hipHostRegisterDefault) == hipSuccess) {
+                s->ext_reg = const_cast<void *>(host_bytes);
+                direct = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (direct) {
+            HIPCHK(c, hipMemcpyAsync(s->d_text, host_bytes, len, hipMemcpyHostToDevice, c->copy));
+        } else {
+            void *stage = nullptr;
+            rc = slot_pinned_for(c, *s, len, &stage);
+            if (rc) return rc;
+            for (size_t o = 0; o < len; o += kCopyPiece) { // memcpy of piece i+1 overlaps the DMA of piece i
+                size_t n = std::min(kCopyPiece, len - o);
+                memcpy((char *)stage + o, (const char *)host_bytes + o, n);
+                HIPCHK(c, hipMemcpyAsync(s->d_text + o, (char *)stage + o, n, hipMemcpyHostToDevice, c->copy));
+            }
         }
     }
     HIPCHK(c, hipEventRecord(s->copied, c->copy));
@@ -473,15 +869,100 @@ int gscan_submit(gscan_ctx *c, const gscan_db *db, const void *host_bytes, size_
     return GSCAN_OK;
 }
 
-int gscan_wait(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, size_t *n, const void **content)
+int gscan_submit_segs(gscan_ctx *c, const gscan_db *db, const void *pinned, const gscan_seg *segs, size_t nseg,
+                      uint64_t tag)
 {
-    if (!c || !starts || !n) return GSCAN_EINVAL;
+    if (!c || !db || !pinned || (!segs && nseg)) return GSCAN_EINVAL;
+    if (db->db.tier == GSCAN_TIER_NULL) return fail(c, GSCAN_EINVAL, "a pattern that can match the empty string scans nothing");
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot *s = nullptr;
+    for (Slot &x : c->slot)
+        if (x.state == ACQUIRED && slot_owns(x, pinned)) s = &x;
+    if (!s) return fail(c, GSCAN_EINVAL, "gscan_submit_segs wants the buffer gscan_acquire handed out");
+    const size_t cap = pinned == s->pinned ? s->pinned_cap : kBlock;
+    size_t used = 0;
+    for (size_t i = 0; i < nseg; i++) {
+        if (segs[i].offset & 15) return fail(c, GSCAN_EINVAL, "segment %zu is not 16-byte aligned", i);
+        if (segs[i].offset + segs[i].len > cap) return fail(c, GSCAN_EINVAL, "segment %zu lies outside the acquired buffer", i);
+        used = std::max<size_t>(used, segs[i].offset + segs[i].len);
+    }
+    int rc = ensure_prog(c, db, c->compute);
+    if (rc) return rc;
+    rc = slot_reserve_device(c, *s, used);
+    if (rc) return rc;
+    s->ext = pinned;
+    s->no_content = false;
+    s->segs.assign(segs, segs + nseg);
+    if (nseg == 0) s->segs.push_back({0, 0, 0}); // keeps the chunk on the multi-segment path with one empty segment
+    rc = slot_build_tiles(c, *s, gscan::scan_tile_bytes(db->db.tier, c->variant, db->db.prog.n_classes));
+    if (rc) return rc;
+    if (used) HIPCHK(c, hipMemcpyAsync(s->d_text, pinned, used, hipMemcpyHostToDevice, c->copy));
+    HIPCHK(c, hipEventRecord(s->copied, c->copy));
+    HIPCHK(c, hipStreamWaitEvent(c->compute, s->copied, 0));
+    s->db = db;
+    s->len = used;
+    s->tag = tag;
+    s->seq = c->next_seq++;
+    rc = slot_launch(c, *s);
+    if (rc) return rc;
+    s->state = INFLIGHT;
+    return GSCAN_OK;
+}
+
+int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off, size_t len, uint64_t tag)
+{
+    if (!c || !db || fd < 0 || file_off < 0) return GSCAN_EINVAL;
+    if (db->db.tier == GSCAN_TIER_NULL) return fail(c, GSCAN_EINVAL, "a pattern that can match the empty string scans nothing");
+    if (len > c->max_chunk) return fail(c, GSCAN_ETOOBIG, "chunk of %zu bytes exceeds max_chunk %zu", len, c->max_chunk);
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot *s = nullptr;
+    for (Slot &x : c->slot)
+        if (x.state == FREE && !s) s = &x;
+    if (!s) return fail(c, GSCAN_EBUSY, "no free slot (all in flight, or one is acquired)");
+    int rc = ensure_prog(c, db, c->compute);
+    if (rc) return rc;
+    rc = slot_reserve_device(c, *s, len);
+    if (rc) return rc;
+    // fan the range out to the reader threads; every piece is DMA'd on this context's copy stream the moment it is read
+    ReadGroup grp;
+    grp.pending = (len + kBlock - 1) / kBlock;
+    for (size_t o = 0; o < len; o += kBlock)
+        c->ingest->read(ReadTask{fd, (off_t)(file_off + (long long)o), std::min(kBlock, len - o), s->d_text + o, c->copy, &grp});
+    {
+        std::unique_lock<std::mutex> lk(grp.m);
+        grp.cv.wait(lk, [&] { return grp.pending == 0; });
+    }
+    if (grp.err) {
+        HIPCHK(c, hipStreamSynchronize(c->copy)); // pieces that did make it must not land after the slot is reused
+        if (grp.err == -1) return fail(c, GSCAN_EIO, "file shrank while reading");
+        if (grp.err == -2) return fail(c, GSCAN_EHIP, "staging block or DMA failed");
+        return fail(c, GSCAN_EIO, "%s", strerror(grp.err));
+    }
+    HIPCHK(c, hipEventRecord(s->copied, c->copy));
+    HIPCHK(c, hipStreamWaitEvent(c->compute, s->copied, 0));
+    s->ext = nullptr;
+    s->no_content = true;
+    s->segs.clear();
+    s->db = db;
+    s->len = len;
+    s->tag = tag;
+    s->seq = c->next_seq++;
+    rc = slot_launch(c, *s);
+    if (rc) return rc;
+    s->state = INFLIGHT;
+    return GSCAN_OK;
+}
+
+int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const size_t **seg_first, size_t *nseg, const void **content)
+{
+    if (!c || !starts || !seg_first || !nseg) return GSCAN_EINVAL;
     Slot *s = nullptr;
     for (Slot &x : c->slot)
         if (x.state == INFLIGHT && (!s || x.seq < s->seq)) s = &x;
     if (!s) return fail(c, GSCAN_EEMPTY, "nothing in flight");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventSynchronize(s->done));
+    slot_unregister(*s); // the DMA out of the caller's buffer is over (the text stays in HBM for a possible rescan)
     const size_t K = gscan::kShards;
     for (int attempt = 0; attempt < 2; attempt++) {
         if (s->h_counter[K] == 0) break; // no shard overflowed
@@ -516,7 +997,13 @@ int gscan_wait(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, size_t *n, 
     }
     s->sorted.clear();
     s->sorted.reserve(total);
-    for (uint32_t t = 0; t < s->n_tiles; t++) { // tiles are in text order: concatenating their runs sorts the list
+    const bool multi = !s->segs.empty();
+    const size_t ns = multi ? s->segs.size() : 1;
+    s->seg_first.assign(ns + 1, 0);
+    size_t seg = 0;
+    for (uint32_t t = 0; t < s->n_tiles; t++) { // tiles are in (segment, text) order: concatenating their runs sorts the list
+        if (multi)
+            while (seg + 1 <= ns && t >= s->tile_first[seg + 1]) s->seg_first[++seg] = s->sorted.size();
         unsigned long long d = s->h_desc[t];
         uint32_t cnt = (uint32_t)d;
         size_t base = (size_t)(d >> 32);
@@ -525,12 +1012,24 @@ int gscan_wait(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, size_t *n, 
         s->sorted.insert(s->sorted.end(), src, src + cnt);
     }
     if (s->sorted.size() != total) return fail(c, GSCAN_EHIP, "descriptor total %zu != counter %zu", s->sorted.size(), total);
+    while (seg < ns) s->seg_first[++seg] = s->sorted.size(); // trailing segments without tiles / records
     if (tag) *tag = s->tag;
     *starts = s->sorted.data();
-    *n = s->sorted.size();
-    if (content) *content = s->pinned;
+    *seg_first = s->seg_first.data();
+    *nseg = ns;
+    if (content) *content = s->no_content ? nullptr : s->ext;
     s->state = FREE;
     return GSCAN_OK;
+}
+
+int gscan_wait(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, size_t *n, const void **content)
+{
+    if (!n) return GSCAN_EINVAL;
+    const size_t *first = nullptr;
+    size_t ns = 0;
+    int rc = gscan_wait_segs(c, tag, starts, &first, &ns, content);
+    if (rc == GSCAN_OK) *n = first[ns];
+    return rc;
 }
 
 int gscan_set_capacity(gscan_ctx *c, size_t n_records)
@@ -546,6 +1045,11 @@ int gscan_set_option(gscan_ctx *c, const char *name, long value)
     if (!strcmp(name, "variant")) {
         if (value < 0 || value > 7 || (value & 3) == 3) return GSCAN_EINVAL; // KiB per wave {16,8,12} | nontemporal<<2
         c->variant = (int)value;
+        return GSCAN_OK;
+    }
+    if (!strcmp(name, "register_min")) { // 0 = register everything; a huge value = always stage through pinned memory
+        if (value < 0) return GSCAN_EINVAL;
+        c->register_min = (size_t)value;
         return GSCAN_OK;
     }
     if (!strcmp(name, "blocks_per_cu")) {

@@ -11,14 +11,17 @@
 
 #include <fcntl.h>
 #include <ftw.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <deque>
 #include <iostream>
+#include <memory>
 #include <mutex>
 
 #ifdef GRAB_PCRE_VALIDATE
@@ -39,6 +42,12 @@ constexpr size_t kContext = 511; // bytes of line context kept on each side (gra
 constexpr off_t kOverlap = 0x1000; // consecutive chunks share 4 KiB (grab.cc:151)
 
 const char kInvOn[] = "\33[7m", kInvOff[] = "\33[27m"; // grab.cc:66-67
+
+// Files up to batch_max_ bytes (config key "batch", default 2 MiB, 0 = off) are read(2) into one pinned
+// block and scanned in one launch over a segment table, instead of paying one copy + launch + readback each.
+constexpr size_t kBatchMaxFiles = 4096;
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 } // namespace
 
@@ -108,10 +117,14 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
 
 // ------------------------------------------------------------------------------------
 
-FileGrep::FileGrep() : uid_(geteuid()) {}
+FileGrep::FileGrep() : uid_(geteuid()) { timing_ = getenv("GRAB_TIMING") != nullptr; }
 
 FileGrep::~FileGrep()
 {
+    flush();
+    if (timing_)
+        fprintf(stderr, "[grab timing] device %d: files %zu launches %zu bytes %zu | open %.3f s  read(batch) %.3f s  submit %.3f s  wait %.3f s  map+report %.3f s  close %.3f s\n",
+                device_, t_files_, t_chunks_, t_bytes_, t_map_, t_read_, t_submit_, t_wait_, t_report_, t_unmap_);
     if (ctx_) gscan_close(ctx_);
     if (db_) gscan_free(db_);
 }
@@ -128,6 +141,7 @@ void FileGrep::config(const std::map<std::string, size_t> &kv)
     if (has("chunk_size")) chunk_size_ = kv.at("chunk_size");
     if (has("device")) device_ = (int)kv.at("device");
     if (has("out_fd")) out_fd_ = (int)kv.at("out_fd");
+    if (has("batch")) batch_max_ = kv.at("batch");
 }
 
 unsigned FileGrep::report_flags() const
@@ -229,16 +243,153 @@ void FileGrep::emit(std::string &text)
     text.clear();
 }
 
+// ------------------------------------------------------------------------------------
+// In-flight work.  A Job is one engine chunk: a window of a big file (gscan_submit_fd), or a batch
+// of small files packed into one pinned block (gscan_submit_segs).  Jobs retire in submission
+// order, which is walk order, so the serial modes print exactly in the reference's order; they
+// stay in flight ACROSS find() calls, so the host opens and reads file k+1 while file k is on the
+// GPU.  flush() drains everything (end of a walk, explicit paths, destructor).
+// ------------------------------------------------------------------------------------
+struct FileGrep::FileRef { // what the report needs to know about a file after find() has returned
+    std::string path;
+    int fd = -1;       // big files: kept open until the last window has been printed (the report maps from it)
+    bool done = false; // -s: a chunk of this file has printed, the rest of it stays silent (grab.cc:232-233)
+    ~FileRef()
+    {
+        if (fd >= 0) close(fd);
+    }
+};
+
+struct FileGrep::Job {
+    // big-file window
+    std::shared_ptr<FileRef> file;
+    off_t off = 0;
+    size_t len = 0;
+    // batch: segment i is file i
+    std::vector<std::shared_ptr<FileRef>> files;
+    std::vector<gscan_seg> segs;
+};
+
+int FileGrep::retire_oldest(bool print)
+{
+    Job job = std::move(flight_.front());
+    flight_.pop_front();
+    const uint32_t *starts = nullptr;
+    const size_t *first = nullptr;
+    size_t nseg = 0;
+    const void *bytes = nullptr;
+    double t = timing_ ? now_s() : 0;
+    const int rc = gscan_wait_segs(ctx_, nullptr, &starts, &first, &nseg, &bytes);
+    if (timing_) t_wait_ += now_s() - t, t = now_s();
+    if (rc != GSCAN_OK) {
+        err_ = std::string("FileGrep::find::gscan_wait: ") + gscan_strerror(ctx_);
+        return -1;
+    }
+    if (!print) return 0;
+    const unsigned rflags = report_flags();
+    std::string text;
+    int status = 0;
+    if (job.files.empty()) { // one window of a big file
+        FileRef &f = *job.file;
+        // no candidate start at all -> nothing is printed (a match at s = 0 would head a group and be in the list),
+        // and the file's bytes are never touched by the host
+        if (!f.done && first[nseg] > 0) {
+            void *map = mmap(nullptr, job.len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, f.fd, job.off); // grab.cc:161
+            if (map == MAP_FAILED) {
+                err_ = std::string("FileGrep::find::mmap: ") + strerror(errno);
+                status = -1;
+            } else {
+                grab_report_chunk(db_, minlen_, rflags, f.path.c_str(), (const char *)map, job.len, (long long)job.off, starts, first[nseg], text);
+                munmap(map, job.len); // grab.cc:215
+                if (!text.empty()) {
+                    emit(text);
+                    if (single_) f.done = true;
+                }
+            }
+        }
+    } else { // a batch: every segment is a whole small file, i.e. its one and only chunk
+        for (size_t i = 0; i < job.files.size(); i++) {
+            if (first[i + 1] == first[i]) continue;
+            grab_report_chunk(db_, minlen_, rflags, job.files[i]->path.c_str(), (const char *)bytes + job.segs[i].offset, job.segs[i].len, 0,
+                              starts + first[i], first[i + 1] - first[i], text);
+        }
+        if (!text.empty()) emit(text); // one lock per batch; per-file output stays contiguous and in order
+    }
+    if (timing_) t_report_ += now_s() - t;
+    return status;
+}
+
+int FileGrep::submit_batch()
+{
+    if (batch_files_.empty()) return 0;
+    Job job;
+    job.files.swap(batch_files_);
+    job.segs.swap(batch_segs_);
+    const void *buf = batch_buf_;
+    batch_buf_ = nullptr;
+    batch_used_ = 0;
+    double t = timing_ ? now_s() : 0;
+    if (gscan_submit_segs(ctx_, db_, buf, job.segs.data(), job.segs.size(), 0) != GSCAN_OK) {
+        err_ = std::string("FileGrep::find::gscan_submit_segs: ") + gscan_strerror(ctx_);
+        return -1;
+    }
+    if (timing_) t_submit_ += now_s() - t, t_chunks_++;
+    flight_.push_back(std::move(job));
+    return 0;
+}
+
+// Everything handed over so far is scanned and printed when this returns.
+int FileGrep::flush()
+{
+    int status = 0;
+    if (!ctx_) return 0;
+    if (submit_batch() < 0) status = -1;
+    while (!flight_.empty())
+        if (retire_oldest(status == 0) < 0) status = -1;
+    return status;
+}
+
+// A small file joins the open batch: read(2) straight into the engine's pinned block.
+int FileGrep::batch_add(const char *path, int fd, size_t size)
+{
+    const size_t cap = gscan_block_size();
+    const size_t at = (batch_used_ + 15) & ~size_t(15);
+    if (batch_buf_ && (at + size > cap || batch_files_.size() >= kBatchMaxFiles) && submit_batch() < 0) return -1;
+    if (!batch_buf_) {
+        // a slot has to be free for the new batch: retire the oldest job if both are in flight
+        if (flight_.size() >= GSCAN_SLOTS && retire_oldest(true) < 0) return -1;
+        void *buf = nullptr;
+        if (gscan_acquire(ctx_, cap, &buf) != GSCAN_OK) {
+            err_ = std::string("FileGrep::find::gscan_acquire: ") + gscan_strerror(ctx_);
+            return -1;
+        }
+        batch_buf_ = buf;
+        batch_used_ = 0;
+    }
+    const size_t off = (batch_used_ + 15) & ~size_t(15);
+    double t = timing_ ? now_s() : 0;
+    if (read_chunk(fd, (char *)batch_buf_ + off, size, 0) < 0) return -1;
+    if (timing_) t_read_ += now_s() - t, t_bytes_ += size;
+    auto ref = std::make_shared<FileRef>();
+    ref->path = path;
+    batch_files_.push_back(std::move(ref));
+    batch_segs_.push_back({(uint64_t)off, (uint32_t)size, 0});
+    batch_used_ = off + size;
+    return 0;
+}
+
 // Replaces grab.cc:131-239.  Geometry is the reference's: windows of chunk_size bytes that
-// advance by chunk_size - 4 KiB, files shorter than minlen skipped unopened, per-chunk
-// output flushed atomically and in file order, -s ends the file after the first chunk that
-// printed.  Up to GSCAN_SLOTS chunks are in flight: while chunk k is on the GPU the host
-// reads chunk k+1, and while chunk k is printed chunk k+1 is being copied and scanned.
+// advance by chunk_size - 4 KiB, files shorter than minlen skipped unopened, per-chunk output
+// flushed atomically and in file order, -s ends the file after the first chunk that printed.
+// Where the reference maps a window and runs pcre_exec over it, a window goes to the engine by
+// file descriptor (reader threads -> pinned blocks -> HBM) and is mapped only if it has matches to
+// print; small files are packed into batches.  Work stays in flight when find() returns.
 int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
 {
     const off_t size = st->st_size;
     if ((size_t)minlen_ > (size_t)size) return 0;
 
+    double t0 = timing_ ? now_s() : 0;
     int oflags = O_RDONLY | O_NOCTTY;
 #ifdef __linux__
     if (st->st_uid == uid_ || uid_ == 0) oflags |= O_NOATIME; // do not dirty the inode (grab.cc:139-143)
@@ -248,61 +399,44 @@ int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
         err_ = std::string("FileGrep::find::open: ") + strerror(errno);
         return -1;
     }
-    if (size > 4 * 0x1000 && !single_) posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    if (timing_) t_map_ += now_s() - t0, t_files_++;
 
-    struct InFlight {
-        off_t off;
-        size_t len;
-    };
-    std::deque<InFlight> flight;
-    const unsigned rflags = report_flags();
-    std::string text;
-    bool printed_and_single = false;
     int status = 0;
-
-    auto retire_oldest = [&](bool print) {
-        const uint32_t *starts = nullptr;
-        size_t n = 0;
-        const void *bytes = nullptr;
-        const InFlight job = flight.front();
-        flight.pop_front();
-        if (gscan_wait(ctx_, nullptr, &starts, &n, &bytes) != GSCAN_OK) {
-            err_ = std::string("FileGrep::find::gscan_wait: ") + gscan_strerror(ctx_);
-            status = -1;
-            return;
+    bool keep_fd = false;
+    if ((size_t)size <= batch_max_ && (size_t)size <= gscan_block_size() && (size_t)size <= chunk_size_) {
+        status = batch_add(path, fd, (size_t)size);
+    } else {
+        if (submit_batch() < 0) status = -1; // keeps the submission order == walk order
+        auto ref = std::make_shared<FileRef>();
+        ref->path = path;
+        ref->fd = fd;
+        keep_fd = true;
+        const off_t stride = (off_t)chunk_size_ - kOverlap;
+        for (off_t off = 0; off < size && status == 0 && !ref->done; off += stride) {
+            const size_t len = (size_t)std::min<off_t>(size - off, (off_t)chunk_size_);
+            if (flight_.size() >= GSCAN_SLOTS && retire_oldest(true) < 0) {
+                status = -1;
+                break;
+            }
+            double t = timing_ ? now_s() : 0;
+            if (gscan_submit_fd(ctx_, db_, fd, (long long)off, len, (uint64_t)off) != GSCAN_OK) {
+                err_ = std::string("FileGrep::find::read: ") + gscan_strerror(ctx_);
+                status = -1;
+                break;
+            }
+            if (timing_) t_submit_ += now_s() - t, t_chunks_++, t_bytes_ += len;
+            Job job;
+            job.file = ref;
+            job.off = off;
+            job.len = len;
+            flight_.push_back(std::move(job));
+            // -s needs to know whether this window printed before the next one is worth reading
+            if (single_ && retire_oldest(true) < 0) status = -1;
         }
-        if (!print) return;
-        grab_report_chunk(db_, minlen_, rflags, path, (const char *)bytes, job.len, (long long)job.off, starts, n, text);
-        if (!text.empty()) {
-            emit(text);
-            if (single_) printed_and_single = true;
-        }
-    };
-
-    const off_t stride = (off_t)chunk_size_ - kOverlap;
-    for (off_t off = 0; off < size && status == 0 && !printed_and_single; off += stride) {
-        const size_t len = (size_t)std::min<off_t>(size - off, (off_t)chunk_size_);
-        void *pinned = nullptr;
-        if (gscan_acquire(ctx_, len, &pinned) != GSCAN_OK) {
-            err_ = std::string("FileGrep::find::gscan_acquire: ") + gscan_strerror(ctx_);
-            status = -1;
-            break;
-        }
-        if (read_chunk(fd, pinned, len, off) < 0) {
-            status = -1;
-            break;
-        }
-        if (gscan_submit(ctx_, db_, pinned, len, (uint64_t)off) != GSCAN_OK) {
-            err_ = std::string("FileGrep::find::gscan_submit: ") + gscan_strerror(ctx_);
-            status = -1;
-            break;
-        }
-        flight.push_back({off, len});
-        if (flight.size() == GSCAN_SLOTS) retire_oldest(true);
     }
-    while (!flight.empty()) retire_oldest(status == 0 && !printed_and_single);
-
-    close(fd);
+    t0 = timing_ ? now_s() : 0;
+    if (!keep_fd) close(fd);
+    if (timing_) t_unmap_ += now_s() - t0;
     return status;
 }
 
@@ -313,7 +447,10 @@ int FileGrep::find(const std::string &path)
         err_ = std::string("FileGrep::find::stat: ") + strerror(errno);
         return -1;
     }
-    if (S_ISREG(st.st_mode)) return find(path.c_str(), &st, FTW_F);
+    if (S_ISREG(st.st_mode)) {
+        const int rc = find(path.c_str(), &st, FTW_F);
+        return flush() < 0 ? -1 : rc; // an explicit path is done when this returns, like the reference's
+    }
     if (S_ISDIR(st.st_mode)) std::cerr << "Clever boy! Want recursion? Add -R!\n"; // grab.cc:253-254, rc stays 0
     return 0;
 }
@@ -334,5 +471,6 @@ int FileGrep::find_recursive(const std::string &path)
 {
     recursive_ = true;
     t_walker = this;
-    return nftw(path.c_str(), on_entry, 1024, FTW_PHYS); // grab.cc:278
+    const int rc = nftw(path.c_str(), on_entry, 1024, FTW_PHYS); // grab.cc:278
+    return flush() < 0 ? -1 : rc;
 }

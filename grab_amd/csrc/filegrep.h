@@ -15,8 +15,11 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <deque>
 #include <map>
+#include <memory>
 #include <string>
+#include <vector>
 
 #include "../../include/gscan.h"
 
@@ -41,17 +44,28 @@ public:
     void show_path(bool on) { show_path_ = on; }
 
     // keys the reference understands (grab.cc:83-98): color noline offsets single low_mem
-    // chunk_size; extensions: literal (-S), device (HIP device index), out_fd
+    // chunk_size; extensions: literal (-S), device (HIP device index), out_fd, batch (largest
+    // file size that is batched with others, 0 = none)
     void config(const std::map<std::string, size_t> &kv);
     int prepare(const std::string &regex);
     int find(const std::string &path);
     int find(const char *path, const struct stat *st, int typeflag);
     int find_recursive(const std::string &path);
 
+    // Work handed over by find(path, st, typeflag) stays in flight across calls (the next file is read
+    // while this one is on the GPU; small files wait for their batch to fill).  flush() scans and prints
+    // whatever is pending; find(string), find_recursive() and the destructor call it themselves.
+    int flush();
+
     // engine knob pass-through (gscan_set_option) for A/B runs
     int engine_option(const char *name, long value);
 
 private:
+    struct FileRef;
+    struct Job;
+    int retire_oldest(bool print);
+    int submit_batch();
+    int batch_add(const char *path, int fd, size_t size);
     unsigned report_flags() const;
     int read_chunk(int fd, void *dst, size_t len, off_t at);
     void emit(std::string &text);
@@ -63,6 +77,17 @@ private:
     bool recursive_ = false, show_path_ = false, literal_ = false;
     uid_t uid_;
     int device_ = 0, out_fd_ = 1;
+    // GRAB_TIMING=1 in the environment: per-instance wall-clock split, printed to stderr by the destructor
+    bool timing_ = false;
+    size_t t_files_ = 0, t_chunks_ = 0, t_bytes_ = 0;
+    double t_map_ = 0, t_read_ = 0, t_submit_ = 0, t_wait_ = 0, t_report_ = 0, t_unmap_ = 0;
+    // pipeline state
+    std::deque<Job> flight_;
+    size_t batch_max_ = size_t(2) << 20; // files up to this size are batched ("batch" config key; 0 = never)
+    void *batch_buf_ = nullptr;          // the engine's pinned block being filled
+    size_t batch_used_ = 0;
+    std::vector<std::shared_ptr<FileRef>> batch_files_;
+    std::vector<gscan_seg> batch_segs_;
     gscan_db *db_ = nullptr;   // replaces pcre *d_pcreh
     gscan_ctx *ctx_ = nullptr; // replaces pcre_extra *d_extra (+ owns streams and buffers)
 };

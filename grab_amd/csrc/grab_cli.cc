@@ -21,7 +21,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -36,6 +38,14 @@
 #include "filegrep.h"
 
 namespace {
+
+// GRAB_TIMING=1: wall-clock marks of the run on stderr (startup cost is a large part of a sub-second scan)
+const auto g_t0 = std::chrono::steady_clock::now();
+void mark(const char *what)
+{
+    static const bool on = getenv("GRAB_TIMING") != nullptr;
+    if (on) fprintf(stderr, "[grab timing] +%.3f s %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_t0).count(), what);
+}
 
 struct Options {
     std::map<std::string, size_t> cfg; // handed to FileGrep::config
@@ -79,6 +89,7 @@ Options parse(int argc, char **argv)
     while (optind < argc) o.paths.push_back(argv[optind++]);
     if (o.workers > 1) chunk >>= 2;
     o.cfg["chunk_size"] = chunk;
+    if (const char *b = getenv("GRAB_BATCH")) o.cfg["batch"] = size_t(atoll(b)); // largest file that is batched (0 = off)
     return o;
 }
 
@@ -151,12 +162,14 @@ int run_workers(const Options &o)
             return -1;
         }
     }
+    mark("contexts open, pattern compiled");
     JobQueue queue;
     g_queue = &queue;
     std::vector<std::thread> pool;
     for (int i = 0; i < o.workers; i++) {
         pool.emplace_back([&queue, g = greps[i].get()] {
             for (Job j; queue.pop(j);) g->find(j.path.c_str(), &j.st, FTW_F); // per-file errors ignored (main.cc:97)
+            g->flush(); // what is still in flight or waiting in a half-filled batch
         });
         cpu_set_t one;
         CPU_ZERO(&one);
@@ -169,7 +182,11 @@ int run_workers(const Options &o)
     }
     nftw(o.paths[0].c_str(), enqueue_entry, 1024, FTW_PHYS);
     queue.close();
+    mark("walk done");
     for (auto &t : pool) t.join();
+    mark("workers joined");
+    greps.clear();
+    mark("contexts closed");
     return 0;
 }
 
@@ -183,6 +200,7 @@ int run_serial(const Options &o)
         std::cerr << grep.why() << std::endl;
         return -1;
     }
+    mark("context open, pattern compiled");
     if (o.recursive) {
         if (grep.find_recursive(o.paths[0]) < 0) {
             std::cerr << grep.why() << std::endl;
@@ -203,8 +221,10 @@ int run_serial(const Options &o)
 
 int main(int argc, char **argv)
 {
+    mark("main");
     const Options o = parse(argc, argv);
     const int rc = o.workers > 1 ? run_workers(o) : run_serial(o);
+    mark("scan done, contexts closed");
     std::cout.flush();
     return rc; // -1 -> exit status 255, like the reference's `return -1` from main
 }

@@ -12,7 +12,7 @@ import numpy as np
 from .build import lib_path
 
 OK, UNSUPPORTED = 0, 1
-EINVAL, ENOMEM, EHIP, EBUSY, EEMPTY, ETOOBIG = -1, -2, -3, -4, -5, -6
+EINVAL, ENOMEM, EHIP, EBUSY, EEMPTY, ETOOBIG, EIO = -1, -2, -3, -4, -5, -6, -7
 LITERAL = 1
 TIER_NULL, TIER_LITERAL, TIER_CLASSRUN, TIER_BUCKET = 0, 1, 2, 3
 SLOTS = 2
@@ -21,7 +21,7 @@ SLOTS = 2
 SYMBOLS = [
     "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end",
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
-    "gscan_acquire", "gscan_submit", "gscan_wait",
+    "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
     "gscan_set_option", "gscan_kernel_time",
 ]
@@ -81,6 +81,11 @@ def lib():
         L.gscan_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
         L.gscan_wait.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint32)),
                                  C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+        L.gscan_block_size.restype = C.c_size_t
+        L.gscan_submit_segs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Seg), C.c_size_t, C.c_uint64]
+        L.gscan_submit_fd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_size_t, C.c_uint64]
+        L.gscan_wait_segs.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint32)),
+                                      C.POINTER(C.POINTER(C.c_size_t)), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         L.gscan_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Seg), C.c_size_t, C.c_void_p,
                                         C.POINTER(DevResult)]
         L.gscan_dev_sync.argtypes = [C.c_void_p, C.POINTER(DevResult)]
@@ -195,6 +200,43 @@ class Context:
         """Candidate group starts of one chunk (ascending uint32; see gscan_wait in include/gscan.h)."""
         self.submit(db, data)
         return self.wait()[1]
+
+    def submit_fd(self, db, fd, offset, length, tag=0):
+        """A range of an open file, read by the engine's reader threads straight into pinned blocks (gscan_submit_fd)."""
+        self._chk(lib().gscan_submit_fd(self._h, db._h, fd, offset, length, tag), "gscan_submit_fd")
+
+    def submit_batch(self, db, parts, tag=0):
+        """Several small inputs (bytes-like) packed into the slot's pinned block at 16-byte aligned offsets and
+        scanned in one launch (gscan_acquire + gscan_submit_segs).  Returns the (offset, len) table used."""
+        cap = lib().gscan_block_size()
+        buf = C.c_void_p()
+        self._chk(lib().gscan_acquire(self._h, cap, C.byref(buf)), "gscan_acquire")
+        segs, at = [], 0
+        for part in parts:
+            arr = np.frombuffer(part, np.uint8)
+            at = (at + 15) & ~15
+            if at + arr.size > cap:
+                raise ValueError("batch does not fit one %d-byte block" % cap)
+            C.memmove(buf.value + at, arr.ctypes.data, arr.size)
+            segs.append((at, arr.size))
+            at += arr.size
+        arr = self.make_segs(segs)
+        self._chk(lib().gscan_submit_segs(self._h, db._h, buf, arr, len(segs), tag), "gscan_submit_segs")
+        return segs
+
+    def wait_segs(self):
+        """(tag, [starts of segment 0, starts of segment 1, ...], has_content) of the oldest chunk in flight."""
+        tag = C.c_uint64()
+        ptr = C.POINTER(C.c_uint32)()
+        first = C.POINTER(C.c_size_t)()
+        nseg = C.c_size_t()
+        content = C.c_void_p()
+        self._chk(lib().gscan_wait_segs(self._h, C.byref(tag), C.byref(ptr), C.byref(first), C.byref(nseg), C.byref(content)), "gscan_wait_segs")
+        out = []
+        for i in range(nseg.value):
+            a, b = first[i], first[i + 1]
+            out.append(np.ctypeslib.as_array(ptr, shape=(b,))[a:b].copy() if b > a else np.zeros(0, np.uint32))
+        return tag.value, out, bool(content.value)
 
     # ---- device-resident path ----
     @staticmethod

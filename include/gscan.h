@@ -49,6 +49,7 @@ extern "C" {
 #define GSCAN_EBUSY (-4)    /* all in-flight slots used: call gscan_wait first */
 #define GSCAN_EEMPTY (-5)   /* gscan_wait with nothing in flight */
 #define GSCAN_ETOOBIG (-6)  /* chunk larger than the context was opened for */
+#define GSCAN_EIO (-7)      /* gscan_submit_fd: reading the file failed; text via gscan_strerror(ctx) */
 
 /* gscan_compile flags */
 #define GSCAN_LITERAL 1u /* treat the pattern as a literal byte string (grab's documented -S) */
@@ -113,26 +114,50 @@ const char *gscan_strerror(const gscan_ctx *ctx);
 int gscan_device_count(void);
 
 /*
- * Host-chunk path (what FileGrep::find uses).  gscan_acquire hands out the pinned
- * staging buffer of a free slot so the caller can read(2) a chunk straight into it;
- * gscan_submit then starts H2D (copy stream) + scan (compute stream) and returns at
- * once.  Passing any other host pointer to gscan_submit makes the engine copy it
- * into a pinned slot first.  Up to GSCAN_SLOTS chunks may be in flight; gscan_wait
- * returns them in submission order.
+ * Host-chunk path (what FileGrep::find uses): three ways to hand over the bytes that the
+ * reference mmap()s and gives to pcre_exec (src/grab.cc:161,178).  Each starts H2D (copy stream)
+ * + scan (compute stream) of one chunk; up to GSCAN_SLOTS chunks may be in flight and
+ * gscan_wait[_segs] returns them in submission order.
+ *
+ *   gscan_submit_fd    a range of an open file.  The engine's process-wide reader threads
+ *                      (GSCAN_READERS, default 8) pread(2) it in 8 MiB pieces into a small pool of
+ *                      pinned blocks and DMA every piece as soon as it is read; returns when the
+ *                      whole range is on its way (fd may be closed then).  No host copy is kept:
+ *                      gscan_wait gives *content = NULL and the caller maps the file itself if it
+ *                      has matches to print.
+ *   gscan_acquire +    the caller fills the slot's pinned buffer (gscan_block_size() bytes come
+ *   gscan_submit[_segs] from the pinned pool; more is allocated for the slot): one chunk, or MANY
+ *                      small files packed at 16-byte aligned offsets and described by a segment
+ *                      table -- one H2D and one launch for the lot (segments behave exactly like
+ *                      separate chunks).
+ *   gscan_submit       any other caller buffer: >= 1 MiB is registered with the runtime and DMA'd
+ *                      in place, less is staged through the slot's pinned buffer.  The buffer must
+ *                      stay valid and unchanged until gscan_wait has returned the chunk.
  */
 #define GSCAN_SLOTS 2
 int gscan_acquire(gscan_ctx *ctx, size_t len, void **pinned);
+size_t gscan_block_size(void);
 int gscan_submit(gscan_ctx *ctx, const gscan_db *db, const void *host_bytes, size_t len,
                  uint64_t tag);
+int gscan_submit_segs(gscan_ctx *ctx, const gscan_db *db, const void *pinned, const gscan_seg *segs,
+                      size_t nseg, uint64_t tag);
+int gscan_submit_fd(gscan_ctx *ctx, const gscan_db *db, int fd, long long file_off, size_t len,
+                    uint64_t tag);
 /* starts[0..n), ascending: the START of every group of consecutive candidate offsets of the
  * chunk (offsets p at which the pattern matches), possibly with further candidates of the
  * same groups in between.  That is all pcre_exec's "leftmost match at or after s" needs:
  *     gscan_match_at(db, content, clen, s) ? s : first starts[i] > s
  * (if s is a candidate it is the answer; if not, the next candidate after s begins a group).
- * *content is the pinned copy of the chunk; both stay valid until the second gscan_acquire/
- * gscan_submit after this call reuses the slot. */
+ * *content is the chunk's bytes on the host: the buffer the chunk was submitted from, NULL after
+ * gscan_submit_fd.  starts (and a pinned *content) stay valid until the second gscan_acquire /
+ * gscan_submit* after this call reuses the slot. */
 int gscan_wait(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, size_t *n,
                const void **content);
+/* the same for a chunk of several segments: the records of segment i are
+ * starts[seg_first[i] .. seg_first[i+1]), segment-relative; seg_first has *nseg + 1 entries
+ * (a single-segment chunk reports *nseg = 1). */
+int gscan_wait_segs(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, const size_t **seg_first,
+                    size_t *nseg, const void **content);
 
 /*
  * Device-resident path (bench, batching): scan nseg segments of an arena that is
@@ -150,7 +175,7 @@ long gscan_dev_fetch(gscan_ctx *ctx, const gscan_dev_result *res, size_t seg, ui
 /* record-buffer capacity (records, split into 8 equal shard regions) for device scans;
  * default = arena bytes / 16 */
 int gscan_set_capacity(gscan_ctx *ctx, size_t n_records);
-/* kernel tuning knobs for A/B runs: name in {"variant","blocks_per_cu"}; see DESIGN.md */
+/* tuning knobs for A/B runs: name in {"variant","blocks_per_cu","register_min"}; see DESIGN.md */
 int gscan_set_option(gscan_ctx *ctx, const char *name, long value);
 /* scan-kernel time of the gscan_scan_device launches since the last reset: HIP events recorded
  * around each launch on the launch's own stream.  Waits for the launches to finish. */

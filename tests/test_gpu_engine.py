@@ -215,3 +215,80 @@ def test_grid_shapes(ctx):
         ctx.set_option("blocks_per_cu", bpc)
         assert same(ctx.scan(db, data), want), bpc
     ctx.set_option("blocks_per_cu", 0)
+
+
+def test_submit_fd_ranges(ctx, tmp_path):
+    """gscan_submit_fd: file ranges read by the engine's reader threads in 8 MiB pieces -- sizes around the piece
+    boundary, ranges that start inside the file, two ranges in flight, and a range beyond the end of the file."""
+    blk = engine.lib().gscan_block_size()
+    assert blk == 8 << 20
+    data = sample(2 * blk + 4097 + 77, 21)
+    for at in (blk - 9, blk - 2, 2 * blk - 5):  # matches straddling piece boundaries
+        data[at:at + 18] = np.frombuffer(b"foobardoesnotexist", np.uint8)
+    path = tmp_path / "f.bin"
+    data.tofile(str(path))
+    fd = os.open(str(path), os.O_RDONLY)
+    try:
+        for pattern in ["foobardoesnotexist", "[a-z]{2,5}", "foo|bar"]:
+            db = engine.Database(pattern)
+            for off, ln in [(0, data.size), (0, blk), (0, blk + 1), (0, blk - 1), (4096, blk + 5000), (blk - 4096, blk + 4096 + 77),
+                            (data.size - 1, 1), (12288, 0), (0, 1), (0, 100)]:
+                ctx.submit_fd(db, fd, off, ln, tag=off)
+                tag, per_seg, has_content = ctx.wait_segs()
+                assert tag == off and len(per_seg) == 1 and not has_content
+                assert same(per_seg[0], oracle_starts(db, data[off:off + ln])), (pattern, off, ln)
+        db = engine.Database("[a-z]{2,5}")
+        ctx.submit_fd(db, fd, 0, blk + 123, tag=1)
+        ctx.submit_fd(db, fd, 4096, 3 * 4096, tag=2)
+        t1, s1, _ = ctx.wait_segs()
+        t2, s2, _ = ctx.wait_segs()
+        assert (t1, t2) == (1, 2)
+        assert same(s1[0], oracle_starts(db, data[:blk + 123])) and same(s2[0], oracle_starts(db, data[4096:4 * 4096]))
+        with pytest.raises(engine.EngineError, match="shrank"):
+            ctx.submit_fd(db, fd, data.size - 10, 4096)
+        ctx.submit_fd(db, fd, 0, 1000)  # the context is still usable
+        assert same(ctx.wait_segs()[1][0], oracle_starts(db, data[:1000]))
+    finally:
+        os.close(fd)
+
+
+def test_submit_batch_segments(ctx):
+    """gscan_acquire + gscan_submit_segs: many small inputs in one pinned block, one launch; every segment behaves
+    like a chunk of its own (matches never cross a segment boundary, ragged and empty segments)."""
+    rng = np.random.default_rng(33)
+    base = sample(1_200_000, 22)
+    lens = [0, 1, 2, 15, 16, 17, 18, 31, 33, 1000, 4095, 4096, 4097, 70001, 0, 300000, 5, 49151, 49152, 49153, 98304, 3]
+    parts, pos = [], 0
+    for ln in lens:
+        parts.append(base[pos:pos + ln].copy())
+        pos += ln
+    parts[9][-3:] = np.frombuffer(b"foo", np.uint8)   # ends a segment ...
+    parts[10][:3] = np.frombuffer(b"bar", np.uint8)   # ... and the next one starts with another word
+    parts[12][-2:] = np.frombuffer(b"fo", np.uint8)   # "fo" + "o...": must NOT match across the boundary
+    parts[13][0] = ord("o")
+    for pattern in ["foo", "foobardoesnotexist", "[a-z]{2,5}", "[A-Za-z_][A-Za-z0-9_]{15,}", "foo|bar", "e+"]:
+        db = engine.Database(pattern)
+        for variant in (1, 6):
+            ctx.set_option("variant", variant)
+            segs = ctx.submit_batch(db, parts, tag=7)
+            assert all(o % 16 == 0 for o, _ in segs)
+            tag, per_seg, has_content = ctx.wait_segs()
+            assert tag == 7 and has_content and len(per_seg) == len(parts)
+            for i, (part, got) in enumerate(zip(parts, per_seg)):
+                assert same(got, oracle_starts(db, part)), (pattern, variant, i, len(part))
+    ctx.set_option("variant", 6)
+    # thousands of tiny segments (more tiles than len / tile size), and an empty batch
+    tiny = [base[i * 37:i * 37 + int(rng.integers(0, 37))].copy() for i in range(3000)]
+    db = engine.Database("[a-z]{2,5}")
+    ctx.submit_batch(db, tiny)
+    _, per_seg, _ = ctx.wait_segs()
+    assert len(per_seg) == 3000
+    for part, got in zip(tiny, per_seg):
+        assert same(got, oracle_starts(db, part))
+    ctx.submit_batch(db, [])
+    _, per_seg, _ = ctx.wait_segs()
+    assert len(per_seg) == 1 and per_seg[0].size == 0
+    # a batch and a file range in flight together come back in submission order
+    ctx.submit_batch(db, parts[:5], tag=1)
+    ctx.submit(db, base[:5000], tag=2)
+    assert ctx.wait_segs()[0] == 1 and ctx.wait()[0] == 2
