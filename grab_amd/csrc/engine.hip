@@ -649,6 +649,16 @@ int gscan_match_at(const gscan_db *db, const void *content, size_t clen, uint32_
     return alt_at(d, (const uint8_t *)content, clen, p) != nullptr;
 }
 
+int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint32_t start, uint32_t *end)
+{
+    const Database &d = db->db;
+    const uint8_t *t = (const uint8_t *)content;
+    const gscan::AltSeq *a = d.minlen > 0 ? alt_at(d, t, clen, start) : nullptr;
+    if (!a) return 0;
+    if (end) *end = gscan_match_end(db, content, clen, start);
+    return a->captures ? 2 : 1;
+}
+
 uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, uint32_t start)
 {
     const Database &d = db->db;

@@ -62,6 +62,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // begins a group, so it is in the list); its end is the greedy tail extension.
 // Rules kept from grab.cc:
 //   :175      the loop runs while s + minlen < clen (strict)
+//   :171,179  ovector holds ONE pair, so a match that sets a capturing group returns 0: the chunk ends there
 //   :186      printed offset = file offset of the chunk + match start
 //   :190-196  line context: back to a newline, to s, or 511 bytes; forward to a newline,
 //             the chunk end, or 511 bytes
@@ -78,12 +79,17 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
     size_t s = 0;
     while (s + (size_t)minlen < clen) {
         size_t m0 = s;
-        if (!gscan_match_at(db, content, clen, (uint32_t)s)) {
+        uint32_t e = 0;
+        int kind = gscan_match_info(db, content, clen, (uint32_t)s, &e);
+        if (!kind) {
             cur = std::upper_bound(cur, last, s, [](size_t key, uint32_t v) { return key < (size_t)v; });
             if (cur == last) break;
             m0 = *cur;
+            kind = gscan_match_info(db, content, clen, (uint32_t)m0, &e);
+            if (!kind) break; // cannot happen: the engine reports candidates only
         }
-        const size_t m1 = gscan_match_end(db, content, clen, (uint32_t)m0);
+        if (kind == 2) break; // the match sets a capturing group: rc == 0 with ovector[3], the reference leaves the chunk (grab.cc:179)
+        const size_t m1 = e;
 
         if (flags & GRAB_PREFIX) {
             out += path;

@@ -20,6 +20,7 @@ struct Node {
     std::vector<Node> kids;
     uint32_t min = 1, max = 1; // REP; max == kInf: unbounded
     int mode = 0;              // REP: 0 greedy, 1 lazy, 2 possessive
+    bool cap = false;          // the node is the body of a capturing group
 };
 
 // One path through the pattern: window classes + optional variable repeat at the end.
@@ -29,7 +30,8 @@ struct Seq {
     ByteSet tail;
     uint32_t tail_extra = 0;
     int tail_mode = 0;
-    bool empty() const { return win.empty() && !has_tail; }
+    bool cap = false; // the path runs through a capturing group
+    bool empty() const { return win.empty() && !has_tail && !cap; }
 };
 
 // C-locale character tables, as pcre_maketables() builds them without setlocale()
@@ -378,9 +380,10 @@ struct Parser {
     // "(?" just consumed.  Either an option setting "(?i)" (returns with is_group = false), or the
     // opening of a non-capturing group "(?:" / "(?i:" (is_group = true; options already applied,
     // the caller restores them at the closing parenthesis).
-    bool group_head(bool &is_group)
+    bool group_head(bool &is_group, bool &named)
     {
         is_group = false;
+        named = false;
         if (eof()) return fail(-1, "unrecognized character after (?");
         int c = p[i];
         if (c == '#') { // comment
@@ -394,11 +397,24 @@ struct Parser {
             is_group = true;
             return true;
         }
-        if (c == '=' || c == '!' || c == '<') return fail(1, "look-around / named group");
+        if (c == '=' || c == '!') return fail(1, "look-ahead");
+        if (c == '<' && i + 1 < n && (p[i + 1] == '=' || p[i + 1] == '!')) return fail(1, "look-behind");
+        if (c == '<' || c == '\'' || (c == 'P' && i + 1 < n && p[i + 1] == '<')) { // (?<name>  (?'name'  (?P<name> : capturing
+            if (c == 'P') i++;
+            const int close = p[i] == '<' ? '>' : '\'';
+            size_t j = i + 1;
+            if (j < n && isdigit(p[j])) return fail(-1, "group name must not start with a digit");
+            while (j < n && (isalnum(p[j]) || p[j] == '_')) j++;
+            if (j == i + 1 || j >= n || p[j] != close) return fail(-1, "syntax error in group name");
+            i = j + 1;
+            is_group = true;
+            named = true;
+            return true;
+        }
         if (c == '>') return fail(1, "atomic group");
         if (c == '|') return fail(1, "branch-reset group");
-        if (c == 'P' || c == '\'' || c == 'R' || c == '&' || c == '(' || c == 'C' || c == '+' || (c >= '0' && c <= '9'))
-            return fail(1, "named group / recursion / conditional / callout");
+        if (c == 'P' || c == 'R' || c == '&' || c == '(' || c == 'C' || c == '+' || (c >= '0' && c <= '9'))
+            return fail(1, "recursion / conditional / callout / named reference");
         bool on = true, ci = caseless, da = dotall;
         for (;; i++) {
             if (eof()) return fail(-1, "missing ) after option setting");
@@ -505,14 +521,17 @@ struct Parser {
                     i++;
                     if (eof()) return fail(-1, "missing )");
                     if (p[i] == '*') return fail(1, "backtracking control verb");
-                    if (p[i] != '?') return fail(1, "capturing group (the reference prints nothing for a pattern with one: ovector[3])");
-                    i++;
                     const bool ci = caseless, da = dotall;
-                    bool is_group;
-                    if (!group_head(is_group)) return false;
-                    if (!is_group) { // "(?i)": stays in force to the end of the enclosing group
-                        if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?')) return fail(-1, "nothing to repeat");
-                        continue;
+                    bool capture = true;
+                    if (p[i] == '?') {
+                        i++;
+                        bool is_group, named;
+                        if (!group_head(is_group, named)) return false;
+                        if (!is_group) { // "(?i)": stays in force to the end of the enclosing group
+                            if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?')) return fail(-1, "nothing to repeat");
+                            continue;
+                        }
+                        capture = named;
                     }
                     depth++;
                     if (!parse_alt(a)) return false;
@@ -521,6 +540,13 @@ struct Parser {
                     i++;
                     caseless = ci;
                     dotall = da;
+                    if (capture) { // wrap: the body keeps its own kind, the wrapper carries the flag
+                        Node w;
+                        w.kind = Node::CAT;
+                        w.cap = true;
+                        w.kids.push_back(std::move(a));
+                        a = std::move(w);
+                    }
                     break;
                 }
                 case '^': return fail(1, "anchor ^");
@@ -631,6 +657,7 @@ struct Unfold {
                     Seq h;
                     h.win = a.win;
                     h.win.insert(h.win.end(), t, a.tail);
+                    h.cap = a.cap;
                     heads.push_back(std::move(h));
                 }
             }
@@ -642,6 +669,7 @@ struct Unfold {
                     s.tail = b.tail;
                     s.tail_extra = b.tail_extra;
                     s.tail_mode = b.tail_mode;
+                    s.cap = a.cap || b.cap;
                     if (s.win.size() > (size_t)kMaxWindow) return fail("window longer than the engine supports");
                     out.push_back(std::move(s));
                     if (!room(out.size())) return false;
@@ -689,6 +717,8 @@ struct Unfold {
                 if (!concat(out, kid, joined)) return false;
                 out.swap(joined);
             }
+            if (nd.cap) // every path through a capturing group sets it, even an empty one
+                for (Seq &s : out) s.cap = true;
             return true;
         }
         case Node::ALT:
@@ -854,6 +884,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         a.has_tail = s.has_tail;
         a.tail = s.tail;
         a.tail_extra = s.has_tail ? s.tail_extra : 0;
+        a.captures = s.cap;
         db.alts.push_back(std::move(a));
     }
     db.minlen = (int)minm;

@@ -3,7 +3,7 @@
 // Replaces the reference's pcre_compile/pcre_study/pcre_fullinfo(MINLENGTH) step
 // (/root/reference/src/grab.cc:101-123) for the patterns the GPU engine can scan.
 // Accepted: single-byte atoms (literal, '.', escape class, [...] class), repeats,
-// alternation, non-capturing groups and the inline options i / s / m -- as long as the
+// alternation, groups and the inline options i / s / m -- as long as the
 // pattern unfolds into a short, PRIORITY-ORDERED list of alternatives, each of which is
 // a fixed class window optionally ending in ONE variable repeat of a single class
 // ("tail": * + ? {n,} {n,m}, greedy/lazy/possessive).  Optional and bounded repeats
@@ -13,10 +13,13 @@
 // window end plus the tail's extension.  For that shape "pcre_exec reports a match
 // starting at p" is a pure function of the bytes at p (and of the chunk end), which
 // is what makes the "GPU emits all candidate starts, host walks the restart orbit"
-// split exact.  Everything else -- capturing groups (for which
-// the reference prints nothing), anchors, \b, look-around, back
-// references, an unbounded repeat before the end of an alternative -- is reported as
-// GSCAN_UNSUPPORTED.
+// split exact.  Capturing groups are taken too: the reference gives
+// pcre_exec room for one offset pair only (int ovector[3], src/grab.cc:171), so a match whose
+// path closes a group comes back as rc == 0 and ENDS the chunk silently, while a match that
+// bypasses every group prints as usual (both libpcre builds agree) -- each
+// alternative simply remembers whether it runs through a group.  Everything else -- anchors,
+// \b, look-around, back references, an unbounded repeat before the end of an alternative --
+// is reported as GSCAN_UNSUPPORTED.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -109,6 +112,7 @@ struct AltSeq {
     bool has_tail = false;
     uint32_t tail_extra = 0;     // max bytes beyond the window (UINT32_MAX = unbounded)
     ByteSet tail;
+    bool captures = false;       // the path closes a capturing group: pcre_exec with the reference's ovector[3] returns 0 for such a match
 };
 
 struct Database {

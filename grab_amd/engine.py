@@ -19,7 +19,7 @@ SLOTS = 2
 
 # every symbol include/gscan.h declares
 SYMBOLS = [
-    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end",
+    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_match_info",
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
     "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
@@ -71,6 +71,7 @@ def lib():
         L.gscan_match_at.restype = C.c_int
         L.gscan_match_end.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
         L.gscan_match_end.restype = C.c_uint32
+        L.gscan_match_info.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32)]
         L.gscan_open.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
         L.gscan_close.argtypes = [C.c_void_p]
         L.gscan_close.restype = None
@@ -148,6 +149,12 @@ class Database:
     def match_end(self, content, start):
         buf = np.frombuffer(content, np.uint8)
         return int(lib().gscan_match_end(self._h, buf.ctypes.data, buf.size, start))
+
+    def match_info(self, content, start):
+        """(kind, end): kind 0 no match at start, 1 match, 2 match through a capturing group (the reference ends the chunk there)."""
+        buf = np.frombuffer(content, np.uint8)
+        e = C.c_uint32()
+        return int(lib().gscan_match_info(self._h, buf.ctypes.data, buf.size, start, C.byref(e))), e.value
 
     def close(self):
         if self._h:

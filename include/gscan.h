@@ -106,6 +106,10 @@ int gscan_db_alt_class(const gscan_db *db, int alt, int pos, uint8_t table[256],
 int gscan_match_at(const gscan_db *db, const void *content, size_t clen, uint32_t p);
 /* ovector[1] for a match starting at `start` of content[0..clen): src/grab.cc:178 semantics */
 uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, uint32_t start);
+/* pcre_exec's verdict on a match attempt AT `start`:  0 no match starts there;  1 match, *end = ovector[1];
+ * 2 match whose path closes a capturing group -- with the reference's int ovector[3] (src/grab.cc:171)
+ * pcre_exec returns 0 for it and the chunk loop ends without printing (src/grab.cc:179). */
+int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint32_t start, uint32_t *end);
 
 /* ---- device context: one per worker thread ---- */
 int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out);

@@ -111,7 +111,7 @@ def scan_chunk(rx, minlen, flags, path, content, off):
     s = 0
     while s + minlen < clen:  # strict (Q3)
         m = rx.search(content, s)
-        if m is None:
+        if m is None or m.lastindex:  # a set capturing group: pcre_exec returns 0 with ovector[3] (grab.cc:171,179, quirk Q5)
             break
         b, e = m.start(), m.end()
         if flags & F_PREFIX:
@@ -174,7 +174,7 @@ def offsets_nl(pattern, data, chunk=DEFAULT_CHUNK):
         end = off + clen
         while s + minlen < clen:
             m = rx.search(data, off + s, end)
-            if m is None:
+            if m is None or m.lastindex:
                 break
             out.append(m.start())
             s = m.end() - off

@@ -45,6 +45,10 @@ SUPPORTED = [
     ("a{2,}?", engine.TIER_LITERAL, 2),
     ("a++", engine.TIER_LITERAL, 1),
     ("ab{2,5}?c|x", engine.TIER_BUCKET, 1),
+    ("(foo)", engine.TIER_LITERAL, 3),
+    ("(foo|bar)", engine.TIER_BUCKET, 3),
+    ("(?P<n>a)c|c", engine.TIER_BUCKET, 1),
+    ("x(a){0,2}c", engine.TIER_BUCKET, 2),
     (r"(?i)\Qab\E+", engine.TIER_CLASSRUN, 2),
     ("a{3}", engine.TIER_LITERAL, 3),
     ("x{0}abc", engine.TIER_LITERAL, 3),
@@ -58,9 +62,9 @@ SUPPORTED = [
 
 NULL_TIER = ["a?", "x*", "", "a{0}", "[a-z]{0,3}", "x{0}", "a|", "(?:foo|b?)", "a??", "(?:ab)?", "x*?y{0}"]
 
-UNSUPPORTED = ["(foo)", "(foo|bar)", "^foo", "foo$", r"\bfoo", "a+b", "ab*c", "a{2,}b", "a{1,40}b", "a++b", r"\1", r"\pL",
+UNSUPPORTED = ["^foo", "foo$", r"\bfoo", "a+b", "ab*c", "a{2,}b", "a{1,40}b", "a++b", r"\1", r"\pL",
                r"\Rfoo", "a{2}{3}", "x" * 300, r"\Afoo", r"foo\z", "(?=foo)", "(?<!a)b", "(?>ab)c", "(?x)a b", "(?:ab)+", "(?:a|b)*c",
-               "(?:ab)?+c", "(?:a|)+b", "(?P<n>a)", "(?|a|b)", "(?:a|b|c|d){4}", "(*UTF8)a", "(?i)[[:^upper:]]a", "a(?R)?b"]
+               "(?:ab)?+c", "(?:a|)+b", "(a)+", "(?|a|b)", r"(a)\1", "(?P=n)", "(?<=a)b", "(?:a|b|c|d){4}", "(*UTF8)a", "(?i)[[:^upper:]]a", "a(?R)?b"]
 
 # "a(" is reported as unsupported (groups) by the engine alone; FileGrep::prepare asks libpcre first and
 # gives the reference's "pcre_compile error" for it (tests/test_gpu_filegrep.py, golden case bad_regex)
@@ -162,7 +166,8 @@ ALT_PATTERNS = ["foo|bar", "colou?r", "(?i)linus", "[ab]{1,3}c", "(?:foo|bar)baz
                 "a??b", "(?m)foo", "a|ab", "ab|a", "(?:a|b)(?:c|d)e*", "(?:ab){1,3}?c", "a(?:b|c){0,2}a", "foo|fo|f", "f|fo|foo",
                 "(?:a?b){2}", "(?i)a[b-d]+|X{2}", "(?-i)ab|(?i)cd", r"(?i)\x41b", "(?#c)ab", "a(?#x)b|c", "(?:foo|bar){0}ab", "ab{0}|c",
                 "[[:upper:]]b|(?i)[[:upper:]]c", r"\Qa|b\E|c", r"(?i)\Qab\E+", "a{0,3}b{0,2}c", "(?:a|b|c|d|e|f|x|y|0|1)x",
-                "(?:ab|ba){2,3}x", "(?i)(?:li|LI)nus|(?-i:Foo)", "a(?:b(?:c|d)|e)f", "(?:a|b){2}(?:c|d){2}"]
+                "(?:ab|ba){2,3}x", "(?i)(?:li|LI)nus|(?-i:Foo)", "a(?:b(?:c|d)|e)f", "(?:a|b){2}(?:c|d){2}",
+                "(a|b)c|ad", "(a)?c", "x(a){0,2}c", "(?<n>a)c|c", "((a))c|c", "ba(?:r|(z))|foo", "(?'q'ab){1,2}x|ab"]
 
 
 @pytest.mark.parametrize("pattern", ALT_PATTERNS)
@@ -186,12 +191,14 @@ def test_alternatives_match_pcre(pattern, built, liboracle):
     s = np.zeros(len(buf) + 1, np.uint32)
     e = np.zeros(len(buf) + 1, np.uint32)
     n = liboracle.oracle_all_starts(pattern.encode("latin-1"), buf, len(buf), s.ctypes.data, e.ctypes.data, len(buf) + 1)
-    want = dict(zip(s[:n].tolist(), e[:n].tolist()))
-    got = {p: db.match_end(buf, p) for p in range(len(buf)) if db.match_at(buf, p)}
+    want = dict(zip(s[:n].tolist(), e[:n].tolist()))  # pcre_exec with the reference's ovector[3]: rc > 0 only
+    info = {p: db.match_info(buf, p) for p in range(len(buf)) if db.match_at(buf, p)}
+    got = {p: end for p, (kind, end) in info.items() if kind == 1}  # kind 2 = the match sets a capturing group: rc == 0 there
     assert got == want
+    assert all(db.match_end(buf, p) == end for p, (kind, end) in info.items())
     # the device-side view of the same thing: the union of the alternatives' windows is the candidate set
     from inputs import db_candidates
-    assert db_candidates(db, data).tolist() == sorted(want)
+    assert db_candidates(db, data).tolist() == sorted(info)
 
 
 def test_alternative_order_and_limits(built):
@@ -206,3 +213,42 @@ def test_alternative_order_and_limits(built):
     with pytest.raises(engine.Unsupported):
         engine.Database("|".join("w%03d" % i for i in range(65)))  # > 64 alternatives
     assert engine.Database("|".join("w%03d" % i for i in range(64))).info.n_alts == 64
+
+
+CAPTURE = ["(a|b)c|ad", "(a)?c", "x(a){0,2}c", "(?<n>a)c|c", "((a))c|c", "ba(?:r|(z))|foo", "(foo)", "(?:(a)|b)c", "(a)b|ac", "()ab|b", "(?P<w>ab)?c"]
+
+
+@pytest.mark.parametrize("pattern", CAPTURE)
+def test_capture_groups_end_the_chunk(pattern, built, liboracle):
+    """The reference calls pcre_exec with int ovector[3] (grab.cc:171): a match that sets a capturing group comes back
+    as 0 and the chunk loop ends.  match_info's kind 2 must mark exactly those matches: compared, start by start, with
+    pcre_exec(ovecsize 3) run by the oracle the way the reference runs it (oracle_scan_chunk, -O -l -s from each offset)."""
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"abcdxzfor \n", np.uint8)
+    data = alpha[rng.integers(0, alpha.size, 3000)]
+    for w in [b"foo", b"bar", b"baz", b"ad", b"ac", b"bc", b"xaac", b"xc", b"abc", b"ababx"]:
+        for _ in range(15):
+            o = int(rng.integers(0, data.size - 8))
+            data[o:o + len(w)] = np.frombuffer(w, np.uint8)
+    buf = data.tobytes()
+    db = engine.Database(pattern)
+    n_cap = 0
+    for p in range(len(buf)):
+        kind, end = db.match_info(buf, p)
+        if kind == 0:
+            continue
+        # what the reference prints for the chunk buf[p:] in -O -l -s mode: one offset line if pcre_exec returned > 0 at the
+        # leftmost match -- which is p itself here -- and nothing if it returned 0
+        out = C.c_void_p()
+        outlen = C.c_size_t()
+        assert liboracle.oracle_scan_chunk(pattern.encode(), b"", buf[p:], len(buf) - p, p, 1 | 2 | 4, C.byref(out), C.byref(outlen)) == 0
+        text = C.string_at(out, outlen.value) if outlen.value else b""
+        liboracle.oracle_free(out)
+        if p + db.minlen >= len(buf):
+            continue  # the strict loop bound (Q3) keeps the reference from looking here at all
+        if kind == 2:
+            assert text == b"", (pattern, p)
+            n_cap += 1
+        else:
+            assert text == b"Match at offset %d\n" % p, (pattern, p, text)
+    assert n_cap > 0

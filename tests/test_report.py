@@ -79,7 +79,8 @@ def test_report_matches_python_oracle_random(built):
     rng = np.random.default_rng(11)
     alphabet = np.frombuffer(b"abcdeffoo0123456789_AZ \n\n", np.uint8)
     for pattern in ["foo", "ff", "f", "[a-z]{2,5}", "abc[0-9]*", "e+", "[A-Za-z_][A-Za-z0-9_]{3,}", r"\d\d", "[^\\n]{4}", "[a-f]{3}",
-                    "foo|ab", "a|ab", "ab|a", "fo?o", "(?:f|e){1,3}0", "(?i)Az|f+", "[a-f]{1,2}[0-9]", "(?:ab|cd)?e", "f{2,4}?o", "0|1|2|[3-9]+"]:
+                    "foo|ab", "a|ab", "ab|a", "fo?o", "(?:f|e){1,3}0", "(?i)Az|f+", "[a-f]{1,2}[0-9]", "(?:ab|cd)?e", "f{2,4}?o", "0|1|2|[3-9]+",
+                    "(a|b)0|af", "(f)?o", "f(o){0,2}0", "(?P<w>ab)?c|e"]:
         db = engine.Database(pattern)
         for trial in range(6):
             n = int(rng.integers(0, 3000))
