@@ -22,7 +22,9 @@
 //     global atomicAdd per tile that has any candidate reserves a contiguous run in
 //     the record buffer (8 counters, one per record-buffer shard, tile t uses shard
 //     t&7, so dense outputs do not serialise on one address); lanes then expand their
-//     masks in text order using a wave prefix sum, and the tile's descriptor
+//     masks in text order using a wave prefix sum (K2, whose outputs are the dense
+//     ones, first transposes the masks through LDS so that one scan serves the whole
+//     sub-tile: emit_tile_t), and the tile's descriptor
 //     {count, base} is written at desc[tile].  Tiles are in text order, so walking
 //     desc[] yields ascending offsets with no sort and no second pass over the text.
 //
@@ -264,6 +266,70 @@ __device__ __forceinline__ void emit_tile(const ScanArgs &a, uint32_t t, const u
     }
 }
 
+// Dense-output epilogue: the same reservation protocol as emit_tile, but the per-step masks are first
+// transposed through a wave-private strip of LDS so that lane L owns ITER consecutive (step, lane) cells,
+// i.e. a contiguous piece of text.  One wave scan then places every lane's records; emit_tile pays a
+// ballot + rank + branch for each of the ITER steps instead, which is what limits the kernels when most
+// steps carry records (identifier regex: 3.6 records per KiB).
+template <int ITER, int NWAVES>
+__device__ __forceinline__ void emit_tile_t(const ScanArgs &a, uint32_t t, const uint32_t (&hits)[(ITER + 1) / 2], uint32_t cnt,
+                                            int sub_off, uint32_t bias, uint32_t lane, uint32_t wave, uint32_t *s_cnt,
+                                            uint32_t *s_base, uint16_t *s_xp)
+{
+    static_assert(ITER % 4 == 0, "a lane reads its ITER masks as 64-bit words");
+    uint16_t *xp = s_xp + wave * (ITER * 64);
+#pragma unroll
+    for (int k = 0; k < ITER; k++) xp[k * 64 + lane] = (uint16_t)(hits[k >> 1] >> (16 * (k & 1)));
+    uint32_t wtot = wave_sum(cnt);
+    if (lane == 0) s_cnt[wave] = wtot;
+    __syncthreads(); // also orders the strip's writes before its reads
+    uint32_t total = 0, before = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; w++) {
+        uint32_t c = s_cnt[w];
+        total += c;
+        if ((uint32_t)w < wave) before += c;
+    }
+    if (total == 0) {
+        if (threadIdx.x == 0) a.desc[t] = 0ull;
+        __syncthreads();
+        return;
+    }
+    const uint32_t shard = t & (kShards - 1);
+    if (threadIdx.x == 0) {
+        uint32_t b = atomicAdd(a.counter + shard, total);
+        *s_base = b;
+        a.desc[t] = (unsigned long long)total | ((unsigned long long)(shard * a.cap_shard + b) << 32);
+        if ((unsigned long long)b + total > (unsigned long long)a.cap_shard) atomicOr(a.counter + kShards, 1u);
+    }
+    __syncthreads();
+    uint32_t base = *s_base;
+    // cells lane*ITER .. lane*ITER+ITER-1 of the strip, 4 masks per 64-bit word
+    unsigned long long w[ITER / 4];
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xp + lane * ITER);
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < ITER / 4; q++) {
+        w[q] = src[q];
+        c += (uint32_t)__popcll(w[q]);
+    }
+    __syncthreads(); // s_base / s_cnt / the strip are free for the next tile
+    if ((unsigned long long)base + total > (unsigned long long)a.cap_shard) return; // overflow: host re-runs bigger
+    if (wtot == 0) return;
+    const uint32_t inc = wave_scan(c);
+    uint32_t idx = shard * a.cap_shard + base + before + inc - c;
+#pragma unroll
+    for (int q = 0; q < ITER / 4; q++) {
+        unsigned long long bitsq = w[q];
+        while (bitsq) {
+            const uint32_t b = (uint32_t)__ffsll((long long)bitsq) - 1u;
+            bitsq &= bitsq - 1ull;
+            const uint32_t cell = lane * ITER + q * 4 + (b >> 4); // = step * 64 + lane of the mask's producer
+            a.recs[idx++] = (uint32_t)sub_off + (cell >> 6) * 1024u + (cell & 63u) * 16u + (b & 15u) - bias;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // K1: literal / anchored window.
 // ------------------------------------------------------------------------------------
@@ -384,6 +450,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
 {
     constexpr int kNW = PAIR ? 8 : 4; // waves per workgroup
     __shared__ uint32_t tbl[PAIR ? 65536 / 4 : 256 * 32];
+    __shared__ __attribute__((aligned(8))) uint16_t s_xp[kNW * ITER * 64]; // epilogue transposition strip, 2 bytes per (step, lane)
     __shared__ uint32_t s_cnt[kNW];
     __shared__ uint32_t s_base;
     constexpr uint32_t kTile = kNW * ITER * 1024;
@@ -507,7 +574,8 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
                 cnt += (uint32_t)__popc(bits);
             }
         }
-        emit_tile<ITER, kNW>(a, t, hits, cnt, sub_off, 0u, lane, wave, s_cnt, &s_base);
+        // K2's outputs are the dense ones: transposed epilogue (+8 % on the identifier scan, neutral without matches)
+        emit_tile_t<ITER, kNW>(a, t, hits, cnt, sub_off, 0u, lane, wave, s_cnt, &s_base, s_xp);
     }
 }
 #undef GS_LUT
@@ -661,6 +729,19 @@ uint32_t scan_min_tile_bytes() { return (uint32_t)(kWaves * 8 * 1024); }
 // resident workgroups per CU the kernel is designed for when it runs as a persistent grid (0 = no preference)
 uint32_t scan_persistent_blocks(int tier, uint32_t n_classes) { return (tier == GSCAN_TIER_CLASSRUN && n_classes <= 2) ? 2u : 0u; }
 
+template <int ITER, bool NT>
+static void launch_k2(bool wide, bool pair, const ScanArgs &a, dim3 g, hipStream_t st)
+{
+    const TileDesc *tiles = a.tiles;
+    if (pair) {
+        if (wide) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, true, true>), g, dim3(512), 0, st, a, tiles);
+        else hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, true>), g, dim3(512), 0, st, a, tiles);
+    } else {
+        if (wide) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, true, false>), g, dim3(kWG), 0, st, a, tiles);
+        else hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, false>), g, dim3(kWG), 0, st, a, tiles);
+    }
+}
+
 template <int ITER>
 static hipError_t launch_iter(int tier, bool nt, bool wide, const ScanArgs &a, uint32_t grid, hipStream_t st)
 {
@@ -672,22 +753,9 @@ static hipError_t launch_iter(int tier, bool nt, bool wide, const ScanArgs &a, u
     } else if (tier == GSCAN_TIER_LITERAL) {
         if (nt) hipLaunchKernelGGL((k1_anchor_scan<ITER, true>), g, dim3(kWG), 0, st, a, tiles);
         else hipLaunchKernelGGL((k1_anchor_scan<ITER, false>), g, dim3(kWG), 0, st, a, tiles);
-    } else if (k2_pair(a)) {
-        if (wide) {
-            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, true, true>), g, dim3(512), 0, st, a, tiles);
-            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, true, true>), g, dim3(512), 0, st, a, tiles);
-        } else {
-            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, false, true>), g, dim3(512), 0, st, a, tiles);
-            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, false, true>), g, dim3(512), 0, st, a, tiles);
-        }
     } else {
-        if (wide) {
-            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, true, false>), g, dim3(kWG), 0, st, a, tiles);
-            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, true, false>), g, dim3(kWG), 0, st, a, tiles);
-        } else {
-            if (nt) hipLaunchKernelGGL((k2_classrun_scan<ITER, true, false, false>), g, dim3(kWG), 0, st, a, tiles);
-            else hipLaunchKernelGGL((k2_classrun_scan<ITER, false, false, false>), g, dim3(kWG), 0, st, a, tiles);
-        }
+        if (nt) launch_k2<ITER, true>(wide, k2_pair(a), a, g, st);
+        else launch_k2<ITER, false>(wide, k2_pair(a), a, g, st);
     }
     return hipGetLastError();
 }
