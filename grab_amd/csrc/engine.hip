@@ -601,6 +601,7 @@ int gscan_db_info(const gscan_db *db, gscan_info *info)
     info->anchor_len = (int)d.prog.anchor_len;
     info->is_literal = (int)d.prog.is_literal;
     info->n_alts = (int)d.alts.size();
+    info->has_context = (d.dev_pre ? 1 : 0) | (d.dev_post ? 2 : 0);
     return GSCAN_OK;
 }
 
@@ -626,9 +627,11 @@ int gscan_db_alt_class(const gscan_db *db, int alt, int pos, uint8_t table[256],
 int gscan_db_class(const gscan_db *db, int pos, uint8_t table[256]) { return gscan_db_alt_class(db, 0, pos, table, nullptr); }
 
 namespace {
-// The alternative pcre_exec's match at p goes through: the first one, in priority order, whose
-// window fits into the chunk and matches there (pattern.h).  nullptr: no match starts at p.
-const gscan::AltSeq *alt_at(const Database &d, const uint8_t *content, size_t clen, size_t p)
+// The alternative pcre_exec's match at p goes through: the first one, in priority order, whose window fits
+// into the chunk and matches there with its context conditions (pattern.h).  at_start: p is the subject
+// start, i.e. the position the reference restarted pcre_exec at (src/grab.cc:178: subject = start), so there
+// is nothing before it.  nullptr: no match starts at p.
+const gscan::AltSeq *alt_at(const Database &d, const uint8_t *content, size_t clen, size_t p, bool at_start)
 {
     for (const gscan::AltSeq &a : d.alts) {
         const size_t m = a.window.size();
@@ -636,9 +639,34 @@ const gscan::AltSeq *alt_at(const Database &d, const uint8_t *content, size_t cl
         const uint8_t *t = content + p;
         size_t i = 0;
         while (i < m && d.classes[a.window[i]].test(t[i])) i++;
-        if (i == m) return &a;
+        if (i < m) continue;
+        if (at_start) {
+            if (!a.pre_start) continue;
+        } else if (p == 0 || !a.pre.test(content[p - 1])) {
+            continue;
+        }
+        const size_t e = p + m;
+        if (e == clen) {
+            if (!a.post_end) continue;
+        } else if (!a.post.test(content[e]) && !(a.post_final_nl && content[e] == '\n' && e + 1 == clen)) {
+            continue;
+        }
+        return &a;
     }
     return nullptr;
+}
+
+uint32_t end_of(const gscan::AltSeq &a, const uint8_t *t, size_t clen, size_t start)
+{
+    size_t e = start + a.window.size();
+    if (a.has_tail) {
+        uint64_t extra = 0;
+        while (e < clen && extra < (uint64_t)a.tail_extra && a.tail.test(t[e])) {
+            e++;
+            extra++;
+        }
+    }
+    return (uint32_t)e;
 }
 } // namespace
 
@@ -646,16 +674,17 @@ int gscan_match_at(const gscan_db *db, const void *content, size_t clen, uint32_
 {
     const Database &d = db->db;
     if (d.minlen <= 0) return 0;
-    return alt_at(d, (const uint8_t *)content, clen, p) != nullptr;
+    return alt_at(d, (const uint8_t *)content, clen, p, true) != nullptr;
 }
 
-int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint32_t start, uint32_t *end)
+int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p, uint32_t *end)
 {
     const Database &d = db->db;
     const uint8_t *t = (const uint8_t *)content;
-    const gscan::AltSeq *a = d.minlen > 0 ? alt_at(d, t, clen, start) : nullptr;
+    if (d.minlen <= 0 || p < subject_start) return 0;
+    const gscan::AltSeq *a = alt_at(d, t, clen, p, p == subject_start);
     if (!a) return 0;
-    if (end) *end = gscan_match_end(db, content, clen, start);
+    if (end) *end = end_of(*a, t, clen, p);
     return a->captures ? 2 : 1;
 }
 
@@ -663,17 +692,41 @@ uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, u
 {
     const Database &d = db->db;
     const uint8_t *t = (const uint8_t *)content;
-    const gscan::AltSeq *a = d.minlen > 0 ? alt_at(d, t, clen, start) : nullptr;
-    if (!a) return start; // not a match start
-    size_t e = (size_t)start + a->window.size();
-    if (a->has_tail) {
-        uint64_t extra = 0;
-        while (e < clen && extra < (uint64_t)a->tail_extra && a->tail.test(t[e])) {
-            e++;
-            extra++;
+    const gscan::AltSeq *a = d.minlen > 0 ? alt_at(d, t, clen, start, true) : nullptr;
+    return a ? end_of(*a, t, clen, start) : start; // start itself: not a match start
+}
+
+size_t gscan_tail_positions(const gscan_db *db, size_t clen, uint32_t *out, size_t cap)
+{
+    const Database &d = db->db;
+    if (!d.dev_post || d.minlen <= 0) return 0;
+    // windows that end at the chunk end, or one byte before it ($ in front of a final newline): the kernels ask for a
+    // real byte after the window, so these positions are never in their lists
+    std::vector<uint32_t> v;
+    for (const gscan::AltSeq &a : d.alts)
+        for (size_t back = 0; back < 2; back++) {
+            const size_t need = a.window.size() + back;
+            if (need <= clen) v.push_back((uint32_t)(clen - need));
         }
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    for (size_t i = 0; i < v.size() && i < cap; i++) out[i] = v[i];
+    return v.size();
+}
+
+int gscan_db_dev_window(const gscan_db *db, int alt, int pos, uint8_t table[256], int *len, int *shift)
+{
+    if (!db) return GSCAN_EINVAL;
+    const Database &d = db->db;
+    if (alt < 0 || (size_t)alt >= d.dev_windows.size()) return GSCAN_EINVAL;
+    const std::vector<uint8_t> &w = d.dev_windows[(size_t)alt];
+    if (len) *len = (int)w.size();
+    if (shift) *shift = d.dev_pre ? 1 : 0;
+    if (table) {
+        if (pos < 0 || (size_t)pos >= w.size()) return GSCAN_EINVAL;
+        for (int b = 0; b < 256; b++) table[b] = d.classes[w[(size_t)pos]].test((unsigned)b);
     }
-    return (uint32_t)e;
+    return GSCAN_OK;
 }
 
 int gscan_device_count(void)
@@ -815,7 +868,7 @@ size_t gscan_block_size(void) { return kBlock; }
 int gscan_submit(gscan_ctx *c, const gscan_db *db, const void *host_bytes, size_t len, uint64_t tag)
 {
     if (!c || !db || (!host_bytes && len)) return GSCAN_EINVAL;
-    if (db->db.tier == GSCAN_TIER_NULL) return fail(c, GSCAN_EINVAL, "a pattern that can match the empty string scans nothing");
+    if (db->db.tier == GSCAN_TIER_NULL || db->db.tier == GSCAN_TIER_ANCHORED) return fail(c, GSCAN_EINVAL, "nothing to scan for this pattern (it matches \"\", or only at the restart position / chunk end)");
     if (len > c->max_chunk) return fail(c, GSCAN_ETOOBIG, "chunk of %zu bytes exceeds max_chunk %zu", len, c->max_chunk);
     HIPCHK(c, hipSetDevice(c->device));
     Slot *s = nullptr;
@@ -883,7 +936,7 @@ int gscan_submit_segs(gscan_ctx *c, const gscan_db *db, const void *pinned, cons
                       uint64_t tag)
 {
     if (!c || !db || !pinned || (!segs && nseg)) return GSCAN_EINVAL;
-    if (db->db.tier == GSCAN_TIER_NULL) return fail(c, GSCAN_EINVAL, "a pattern that can match the empty string scans nothing");
+    if (db->db.tier == GSCAN_TIER_NULL || db->db.tier == GSCAN_TIER_ANCHORED) return fail(c, GSCAN_EINVAL, "nothing to scan for this pattern (it matches \"\", or only at the restart position / chunk end)");
     HIPCHK(c, hipSetDevice(c->device));
     Slot *s = nullptr;
     for (Slot &x : c->slot)
@@ -922,7 +975,7 @@ int gscan_submit_segs(gscan_ctx *c, const gscan_db *db, const void *pinned, cons
 int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off, size_t len, uint64_t tag)
 {
     if (!c || !db || fd < 0 || file_off < 0) return GSCAN_EINVAL;
-    if (db->db.tier == GSCAN_TIER_NULL) return fail(c, GSCAN_EINVAL, "a pattern that can match the empty string scans nothing");
+    if (db->db.tier == GSCAN_TIER_NULL || db->db.tier == GSCAN_TIER_ANCHORED) return fail(c, GSCAN_EINVAL, "nothing to scan for this pattern (it matches \"\", or only at the restart position / chunk end)");
     if (len > c->max_chunk) return fail(c, GSCAN_ETOOBIG, "chunk of %zu bytes exceeds max_chunk %zu", len, c->max_chunk);
     HIPCHK(c, hipSetDevice(c->device));
     Slot *s = nullptr;
@@ -1074,7 +1127,7 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
                       void *stream, gscan_dev_result *res)
 {
     if (!c || !db || !res || (!segs && nseg)) return GSCAN_EINVAL;
-    if (db->db.tier == GSCAN_TIER_NULL) return fail(c, GSCAN_EINVAL, "a pattern that can match the empty string scans nothing");
+    if (db->db.tier == GSCAN_TIER_NULL || db->db.tier == GSCAN_TIER_ANCHORED) return fail(c, GSCAN_EINVAL, "nothing to scan for this pattern (it matches \"\", or only at the restart position / chunk end)");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->compute;
     c->dv_stream = st;

@@ -74,19 +74,44 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
                        size_t clen, long long off, const uint32_t *starts, size_t nstarts, std::string &out)
 {
     if (minlen < 0) return;
+    gscan_info info;
+    gscan_db_info(db, &info);
+    const bool context = info.has_context != 0; // \b ^ $ ...: a match depends on the byte before / after it
+    // windows that end at the chunk end (or just before its final newline) are never in the engine's list
+    uint32_t tails[2 * 64 + 2];
+    const size_t ntails = std::min(gscan_tail_positions(db, clen, tails, sizeof tails / sizeof tails[0]), sizeof tails / sizeof tails[0]);
+    size_t ti = 0;
     const uint32_t *cur = starts, *const last = starts + nstarts;
     char line[64];
     size_t s = 0;
     while (s + (size_t)minlen < clen) {
+        // The leftmost match in content[s..clen) with the subject starting at s (grab.cc:178):
+        //   s itself, tested with nothing before it;
+        //   else s + 1 if it matches (with context the engine's groups are built from the real bytes, so s can sit
+        //   inside a group -- whose later members need not be in the list -- without matching as a subject start);
+        //   else the first listed start after s (it heads a group, so it is listed) or the first matching tail offset.
         size_t m0 = s;
         uint32_t e = 0;
-        int kind = gscan_match_info(db, content, clen, (uint32_t)s, &e);
+        int kind = gscan_match_info(db, content, clen, (uint32_t)s, (uint32_t)s, &e);
+        if (!kind && context && s + 1 < clen) {
+            kind = gscan_match_info(db, content, clen, (uint32_t)s, (uint32_t)s + 1, &e);
+            if (kind) m0 = s + 1;
+        }
         if (!kind) {
             cur = std::upper_bound(cur, last, s, [](size_t key, uint32_t v) { return key < (size_t)v; });
-            if (cur == last) break;
-            m0 = *cur;
-            kind = gscan_match_info(db, content, clen, (uint32_t)m0, &e);
-            if (!kind) break; // cannot happen: the engine reports candidates only
+            size_t best = cur == last ? SIZE_MAX : (size_t)*cur;
+            while (ti < ntails && (size_t)tails[ti] <= s) ti++;
+            for (size_t tj = ti; tj < ntails && (size_t)tails[tj] < best; tj++) {
+                uint32_t te = 0;
+                if (gscan_match_info(db, content, clen, (uint32_t)s, tails[tj], &te)) {
+                    best = tails[tj];
+                    break;
+                }
+            }
+            if (best == SIZE_MAX) break;
+            m0 = best;
+            kind = gscan_match_info(db, content, clen, (uint32_t)s, (uint32_t)m0, &e);
+            if (!kind) break; // cannot happen: the engine lists candidates only
         }
         if (kind == 2) break; // the match sets a capturing group: rc == 0 with ovector[3], the reference leaves the chunk (grab.cc:179)
         const size_t m1 = e;
@@ -205,6 +230,12 @@ int FileGrep::prepare(const std::string &regex)
     }
     minlen_ = got;
     if (minlen_ < 0) return 0; // can match "": every file is skipped (Q2), nothing to open
+    {
+        gscan_info info;
+        gscan_db_info(db_, &info);
+        anchored_ = info.tier == GSCAN_TIER_ANCHORED;
+        context_ = info.has_context != 0;
+    }
 
     if (ctx_) gscan_close(ctx_);
     ctx_ = nullptr;
@@ -298,8 +329,9 @@ int FileGrep::retire_oldest(bool print)
     if (job.files.empty()) { // one window of a big file
         FileRef &f = *job.file;
         // no candidate start at all -> nothing is printed (a match at s = 0 would head a group and be in the list),
-        // and the file's bytes are never touched by the host
-        if (!f.done && first[nseg] > 0) {
+        // and the file's bytes are never touched by the host.  Not so for patterns with context (\b ^ $ ...): a match
+        // at offset 0 or at the very end of the window is the host's to find
+        if (!f.done && (first[nseg] > 0 || context_)) {
             void *map = mmap(nullptr, job.len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, f.fd, job.off); // grab.cc:161
             if (map == MAP_FAILED) {
                 err_ = std::string("FileGrep::find::mmap: ") + strerror(errno);
@@ -315,7 +347,7 @@ int FileGrep::retire_oldest(bool print)
         }
     } else { // a batch: every segment is a whole small file, i.e. its one and only chunk
         for (size_t i = 0; i < job.files.size(); i++) {
-            if (first[i + 1] == first[i]) continue;
+            if (first[i + 1] == first[i] && !context_) continue;
             grab_report_chunk(db_, minlen_, rflags, job.files[i]->path.c_str(), (const char *)bytes + job.segs[i].offset, job.segs[i].len, 0,
                               starts + first[i], first[i + 1] - first[i], text);
         }
@@ -409,7 +441,29 @@ int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
 
     int status = 0;
     bool keep_fd = false;
-    if ((size_t)size <= batch_max_ && (size_t)size <= gscan_block_size() && (size_t)size <= chunk_size_) {
+    if (anchored_) {
+        // ^foo, foo$ ...: a match can only start at a restart position or end at the chunk end; there is nothing to
+        // scan (pcre_exec does not scan for an anchored pattern either): map each window and walk it with an empty list
+        if (flush() < 0) status = -1;
+        const unsigned rflags = report_flags();
+        std::string text;
+        const off_t stride = (off_t)chunk_size_ - kOverlap;
+        for (off_t off = 0; off < size && status == 0; off += stride) {
+            const size_t len = (size_t)std::min<off_t>(size - off, (off_t)chunk_size_);
+            void *map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, fd, off);
+            if (map == MAP_FAILED) {
+                err_ = std::string("FileGrep::find::mmap: ") + strerror(errno);
+                status = -1;
+                break;
+            }
+            grab_report_chunk(db_, minlen_, rflags, path, (const char *)map, len, (long long)off, nullptr, 0, text);
+            munmap(map, len);
+            if (!text.empty()) {
+                emit(text);
+                if (single_) break;
+            }
+        }
+    } else if ((size_t)size <= batch_max_ && (size_t)size <= gscan_block_size() && (size_t)size <= chunk_size_) {
         status = batch_add(path, fd, (size_t)size);
     } else {
         if (submit_batch() < 0) status = -1; // keeps the submission order == walk order

@@ -75,6 +75,8 @@ private:
     size_t chunk_size_ = 1u << 30; // grab.h:48
     bool offsets_ = false, noline_ = false, single_ = false, color_ = false, low_mem_ = false;
     bool recursive_ = false, show_path_ = false, literal_ = false;
+    bool anchored_ = false; // the pattern can only match at a restart position / chunk end: nothing goes to the GPU
+    bool context_ = false;  // the pattern looks at the byte before / after its match
     uid_t uid_;
     int device_ = 0, out_fd_ = 1;
     // GRAB_TIMING=1 in the environment: per-instance wall-clock split, printed to stderr by the destructor

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a, const TileDesc
 #undef GS_MIN3
             }
         }
-        emit_tile<ITER, kWaves>(a, t, hits, cnt, sub_off, aoff, lane, wave, s_cnt, &s_base);
+        emit_tile<ITER, kWaves>(a, t, hits, cnt, sub_off, aoff - a.report_shift, lane, wave, s_cnt, &s_base);
     }
 }
 
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
             }
         }
         // K2's outputs are the dense ones: transposed epilogue (+8 % on the identifier scan, neutral without matches)
-        emit_tile_t<ITER, kNW>(a, t, hits, cnt, sub_off, 0u, lane, wave, s_cnt, &s_base, s_xp);
+        emit_tile_t<ITER, kNW>(a, t, hits, cnt, sub_off, 0u - a.report_shift, lane, wave, s_cnt, &s_base, s_xp);
     }
 }
 #undef GS_LUT
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(kWG) void k3_bucket_scan(ScanArgs a, const TileDesc
                 }
             }
         }
-        emit_tile<ITER, kWaves>(a, t, hits, cnt, sub_off, koff, lane, wave, s_cnt, &s_base);
+        emit_tile<ITER, kWaves>(a, t, hits, cnt, sub_off, koff - a.report_shift, lane, wave, s_cnt, &s_base);
     }
 }
 
@@ -771,6 +771,7 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
     a.n_classes = pg.n_classes;
     a.nruns = pg.nruns;
     a.k3_off = pg.k3_off;
+    a.report_shift = pg.report_shift;
     // the filter IS the pattern when every alternative has its own bucket and lies inside the filtered positions
     a.k3_exact = pg.n_alts <= (uint32_t)kK3Buckets && pg.k3_off == 0;
     for (uint32_t i = 0; i < pg.n_alts; i++)

@@ -13,9 +13,31 @@ namespace {
 
 constexpr uint32_t kInf = UINT32_MAX;
 
+ByteSet set_all()
+{
+    ByteSet s;
+    s.negate();
+    return s;
+}
+ByteSet set_and(ByteSet a, const ByteSet &b)
+{
+    for (int i = 0; i < 8; i++) a.w[i] &= b.w[i];
+    return a;
+}
+
+// Zero-width assertions, with the inline option (?m) already folded in.
+enum { A_BOS = 1, // ^ without (?m), \A, \G: the subject start (the restart position: src/grab.cc:178 passes subject = start)
+       A_MBOL,    // (?m)^: subject start, or just after a newline
+       A_EOL,     // $ without (?m), \Z: the very end of the chunk, or just before a newline that is its last byte
+       A_MEOL,    // (?m)$: the very end, or just before any newline
+       A_EOS,     // \z: the very end only
+       A_WB,      // \b
+       A_NWB };   // \B
+
 // Parse tree.  SET = one byte drawn from a class; REP repeats its single child.
 struct Node {
-    enum Kind { SET, CAT, ALT, REP } kind = SET;
+    enum Kind { SET, CAT, ALT, REP, ASSERT } kind = SET;
+    int acode = 0;             // ASSERT: one of the A_* codes
     ByteSet set;
     std::vector<Node> kids;
     uint32_t min = 1, max = 1; // REP; max == kInf: unbounded
@@ -31,7 +53,11 @@ struct Seq {
     uint32_t tail_extra = 0;
     int tail_mode = 0;
     bool cap = false; // the path runs through a capturing group
-    bool empty() const { return win.empty() && !has_tail && !cap; }
+    std::vector<std::pair<uint32_t, int>> asserts; // (window position the assertion stands in front of, A_* code)
+    // the assertions at the two ends, resolved into one byte of context each (see AltSeq)
+    ByteSet pre = set_all(), post = set_all();
+    bool pre_start = true, post_end = true, post_final_nl = false;
+    bool empty() const { return win.empty() && !has_tail && !cap && asserts.empty(); }
 };
 
 // C-locale character tables, as pcre_maketables() builds them without setlocale()
@@ -119,7 +145,7 @@ struct Parser {
     int rc = 0; // 0 ok, 1 unsupported, -1 malformed
     // inline options in force (PCRE: a change made inside a group lasts to the end of that
     // group, and carries into the alternatives that follow it there)
-    bool caseless = false, dotall = false;
+    bool caseless = false, dotall = false, multiline = false;
     bool quoting = false; // inside \Q...\E
     int depth = 0;
 
@@ -415,7 +441,7 @@ struct Parser {
         if (c == '|') return fail(1, "branch-reset group");
         if (c == 'P' || c == 'R' || c == '&' || c == '(' || c == 'C' || c == '+' || (c >= '0' && c <= '9'))
             return fail(1, "recursion / conditional / callout / named reference");
-        bool on = true, ci = caseless, da = dotall;
+        bool on = true, ci = caseless, da = dotall, ml = multiline;
         for (;; i++) {
             if (eof()) return fail(-1, "missing ) after option setting");
             c = p[i];
@@ -427,7 +453,7 @@ struct Parser {
             } else if (c == 's') {
                 da = on;
             } else if (c == 'm') {
-                // multiline only changes ^ and $, which the engine does not take anyway
+                ml = on;
             } else if (c == 'x' || c == 'J' || c == 'U' || c == 'X') {
                 return fail(1, "inline option outside the engine's subset");
             } else if (c == ')' || c == ':') {
@@ -438,6 +464,7 @@ struct Parser {
         }
         caseless = ci;
         dotall = da;
+        multiline = ml;
         is_group = (p[i] == ':');
         i++;
         return true;
@@ -490,6 +517,29 @@ struct Parser {
                     if (depth == 0) return fail(-1, "unmatched parentheses");
                     break;
                 }
+                int acode = 0;
+                if (c == '^') acode = multiline ? A_MBOL : A_BOS;
+                else if (c == '$') acode = multiline ? A_MEOL : A_EOL;
+                else if (c == '\\' && i + 1 < n) {
+                    switch (p[i + 1]) {
+                    case 'b': acode = A_WB; break;
+                    case 'B': acode = A_NWB; break;
+                    case 'A': case 'G': acode = A_BOS; break;
+                    case 'Z': acode = A_EOL; break;
+                    case 'z': acode = A_EOS; break;
+                    }
+                }
+                if (acode) {
+                    i += (c == '\\') ? 2 : 1;
+                    if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?')) return fail(1, "quantified assertion");
+                    uint32_t mn, mx;
+                    size_t end;
+                    if (!eof() && p[i] == '{' && counted(mn, mx, end)) return fail(1, "quantified assertion");
+                    a.kind = Node::ASSERT;
+                    a.acode = acode;
+                    out.kids.push_back(std::move(a));
+                    continue;
+                }
                 switch (c) {
                 case '\\':
                     if (i + 1 < n && p[i + 1] == 'Q') {
@@ -521,7 +571,7 @@ struct Parser {
                     i++;
                     if (eof()) return fail(-1, "missing )");
                     if (p[i] == '*') return fail(1, "backtracking control verb");
-                    const bool ci = caseless, da = dotall;
+                    const bool ci = caseless, da = dotall, ml = multiline;
                     bool capture = true;
                     if (p[i] == '?') {
                         i++;
@@ -540,6 +590,7 @@ struct Parser {
                     i++;
                     caseless = ci;
                     dotall = da;
+                    multiline = ml;
                     if (capture) { // wrap: the body keeps its own kind, the wrapper carries the flag
                         Node w;
                         w.kind = Node::CAT;
@@ -549,8 +600,6 @@ struct Parser {
                     }
                     break;
                 }
-                case '^': return fail(1, "anchor ^");
-                case '$': return fail(1, "anchor $");
                 case '*':
                 case '+':
                 case '?': return fail(-1, "nothing to repeat");
@@ -635,6 +684,29 @@ struct Unfold {
     }
     bool room(size_t count) { return count <= (size_t)kMaxAlts * 4 ? true : fail("pattern unfolds into too many alternatives"); }
 
+    // An unbounded greedy repeat of class T followed by nothing but assertions that are TRUE wherever that repeat stops
+    // (so no backtracking into it ever happens and the repeat is still the end of the match):
+    //   \w+\b   T is exactly the word characters and the byte before the repeat is a word character too: the repeat stops
+    //            in front of a non-word byte or the chunk end, which is a boundary
+    //   .*$ under (?m)   T is everything but newline: the repeat stops in front of a newline or at the chunk end
+    static bool tail_settles(const Seq &a, const std::vector<Seq> &B)
+    {
+        if (a.tail_extra != kInf || a.tail_mode == 1 || a.win.empty() || B.size() != 1) return false;
+        const Seq &b = B[0];
+        if (!b.win.empty() || b.has_tail || b.cap || b.asserts.empty()) return false;
+        const ByteSet word = set_word();
+        for (const auto &as : b.asserts) {
+            if (as.second == A_WB) {
+                if (!(a.tail == word) || !(set_and(a.win.back(), word) == a.win.back())) return false;
+            } else if (as.second == A_MEOL) {
+                if (!(a.tail == set_dot())) return false;
+            } else {
+                return false;
+            }
+        }
+        return true;
+    }
+
     // every path of `a` followed by every path of `b`.  PCRE backtracks the most recent choice
     // first, so the order is: a's choices major (a variable repeat at the end of `a` counts as one:
     // longest first when greedy, shortest first when lazy), b's choices minor.
@@ -649,6 +721,10 @@ struct Unfold {
             std::vector<Seq> heads;
             if (!a.has_tail) {
                 heads.push_back(a);
+            } else if (tail_settles(a, B)) {
+                out.push_back(a); // \w+\b, (?m).*$: the assertion holds wherever the greedy repeat stops; nothing to add
+                if (!room(out.size())) return false;
+                continue;
             } else { // the repeat is no longer at the end: unfold it into explicit counts
                 if (a.tail_mode == 2) return fail("possessive repeat before the end of the pattern");
                 if (a.tail_extra == kInf || a.tail_extra > kMaxMidRepeat) return fail("variable repeat before the end of the pattern");
@@ -658,12 +734,14 @@ struct Unfold {
                     h.win = a.win;
                     h.win.insert(h.win.end(), t, a.tail);
                     h.cap = a.cap;
+                    h.asserts = a.asserts;
                     heads.push_back(std::move(h));
                 }
             }
             for (const Seq &h : heads)
                 for (const Seq &b : B) {
                     Seq s = h;
+                    for (const auto &as : b.asserts) s.asserts.emplace_back(as.first + (uint32_t)h.win.size(), as.second);
                     s.win.insert(s.win.end(), b.win.begin(), b.win.end());
                     s.has_tail = b.has_tail;
                     s.tail = b.tail;
@@ -709,6 +787,12 @@ struct Unfold {
             out.push_back(std::move(s));
             return true;
         }
+        case Node::ASSERT: {
+            Seq s;
+            s.asserts.emplace_back(0u, nd.acode);
+            out.push_back(std::move(s));
+            return true;
+        }
         case Node::CAT: {
             out.push_back(Seq());
             for (const Node &k : nd.kids) {
@@ -750,8 +834,10 @@ struct Unfold {
             }
             std::vector<Seq> E;
             if (!run(k, E)) return false;
-            for (const Seq &e : E)
+            for (const Seq &e : E) {
                 if (e.win.empty()) return fail("repeated group that can match the empty string");
+                if (!e.asserts.empty() && (nd.min != 1 || nd.max != 1)) return fail("repeated group with an assertion inside");
+            }
             if (nd.mode == 2) return fail("possessive repeat of a group");
             if (nd.max == kInf) return fail("unbounded repeat of a group");
             if (nd.max > 2 * kMaxMidRepeat) return fail("pattern unfolds into too many alternatives");
@@ -759,6 +845,98 @@ struct Unfold {
         }
         }
         return fail("internal: unknown node");
+    }
+};
+
+// ---- assertions -> context conditions -------------------------------------------------------------
+// Every assertion of an unfolded path is either decided on the spot (it stands between two window
+// positions whose classes settle it, possibly after narrowing a class or splitting it into its word
+// and non-word parts), or it stands at one end of the window and becomes a condition on the single
+// byte before / after the match.  Paths that can never match are dropped.  rc: 0 ok, 1 unsupported.
+struct Resolver {
+    std::string why;
+    std::vector<Seq> out;
+    ByteSet word = set_word(), nonword = set_not(set_word()), nl;
+    Resolver() { nl.set('\n'); }
+
+    bool fail(const char *msg)
+    {
+        if (why.empty()) why = msg;
+        return false;
+    }
+
+    // s.asserts[k..] still to do; eol/eos remember a trailing $ / \z, post_set collects the other trailing conditions
+    bool step(Seq s, size_t k, bool eol, bool eos)
+    {
+        if (k == s.asserts.size()) {
+            if (eol || eos) {
+                s.post_final_nl = eol && !eos && s.post.test('\n');
+                s.post = ByteSet();
+            }
+            for (const ByteSet &b : s.win)
+                if (b.count() == 0) return true; // narrowed to nothing: this path never matches
+            s.asserts.clear();
+            out.push_back(std::move(s));
+            return true;
+        }
+        const uint32_t pos = s.asserts[k].first;
+        const int code = s.asserts[k].second;
+        const size_t L = s.win.size();
+        if (L == 0) return step(std::move(s), k + 1, eol, eos); // empty window: the pattern can match "" and every file is skipped anyway (Q2)
+        const bool lead = pos == 0, trail = pos == L;
+        // (an assertion AFTER a variable repeat never gets here: the repeat was no longer at the end of its path and was
+        // unfolded, or refused, in Unfold::concat; with has_tail set the assertion stands between the window and the tail)
+        switch (code) {
+        case A_BOS:
+            if (!lead) return true; // something must come before the subject start: never
+            s.pre = ByteSet();
+            return step(std::move(s), k + 1, eol, eos);
+        case A_MBOL:
+            if (lead) {
+                s.pre = set_and(s.pre, nl);
+            } else {
+                if (trail) return fail("(?m)^ at the end of an alternative");
+                s.win[pos - 1] = set_and(s.win[pos - 1], nl);
+            }
+            return step(std::move(s), k + 1, eol, eos);
+        case A_EOS:
+            if (!trail) return true;
+            return step(std::move(s), k + 1, eol, true);
+        case A_EOL:
+            if (!trail) return fail("$ before the end of an alternative");
+            return step(std::move(s), k + 1, true, eos);
+        case A_MEOL:
+            if (trail) s.post = set_and(s.post, nl);
+            else s.win[pos] = set_and(s.win[pos], nl);
+            return step(std::move(s), k + 1, eol, eos);
+        case A_WB:
+        case A_NWB: {
+            // the bytes on the two sides: a window class, or the context byte (lead: before, trail: after)
+            // split both sides into their word / non-word parts and keep the combinations the assertion allows
+            for (int lw = 0; lw < 2; lw++)
+                for (int rw = 0; rw < 2; rw++) {
+                    const bool boundary = lw != rw;
+                    if (boundary != (code == A_WB)) continue;
+                    Seq v = s;
+                    const ByteSet &lset = lw ? word : nonword, &rset = rw ? word : nonword;
+                    if (lead) {
+                        v.pre = set_and(v.pre, lset);
+                        if (lw) v.pre_start = false; // the subject start counts as a non-word character
+                    } else {
+                        v.win[pos - 1] = set_and(v.win[pos - 1], lset);
+                    }
+                    if (trail) {
+                        v.post = set_and(v.post, rset);
+                        if (rw) v.post_end = false; // so does the chunk end
+                    } else {
+                        v.win[pos] = set_and(v.win[pos], rset);
+                    }
+                    if (!step(std::move(v), k + 1, eol, eos)) return false;
+                }
+            return true;
+        }
+        }
+        return fail("internal: unknown assertion");
     }
 };
 
@@ -825,6 +1003,28 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
                 why = "empty character class";
                 return 1;
             }
+    }
+    // assertions -> one byte of context at each end (or decided / narrowed / split on the spot)
+    {
+        Resolver rs;
+        bool any = false;
+        for (Seq &s : seqs) {
+            any = any || !s.asserts.empty();
+            std::stable_sort(s.asserts.begin(), s.asserts.end(), [](const std::pair<uint32_t, int> &x, const std::pair<uint32_t, int> &y) { return x.first < y.first; });
+            if (!rs.step(s, 0, false, false)) {
+                why = rs.why;
+                return 1;
+            }
+        }
+        if (any) {
+            if (rs.out.empty()) {
+                why = "the pattern's assertions can never hold";
+                return 1;
+            }
+            seqs.swap(rs.out);
+        }
+    }
+    for (const Seq &s : seqs) {
         if (s.has_tail && s.tail.count() == 0) {
             why = "empty character class";
             return 1;
@@ -837,7 +1037,8 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             bool dup = false;
             for (const Seq &u : uniq)
                 if (u.win.size() == s.win.size() && u.has_tail == s.has_tail &&
-                    (!u.has_tail || (u.tail == s.tail && u.tail_extra == s.tail_extra)) &&
+                    (!u.has_tail || (u.tail == s.tail && u.tail_extra == s.tail_extra)) && u.pre == s.pre && u.post == s.post &&
+                    u.pre_start == s.pre_start && u.post_end == s.post_end && u.post_final_nl == s.post_final_nl &&
                     std::equal(u.win.begin(), u.win.end(), s.win.begin()))
                     dup = true;
             if (!dup) uniq.push_back(std::move(s));
@@ -885,26 +1086,85 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         a.tail = s.tail;
         a.tail_extra = s.has_tail ? s.tail_extra : 0;
         a.captures = s.cap;
+        a.pre = s.pre;
+        a.pre_start = s.pre_start;
+        a.post = s.post;
+        a.post_end = s.post_end;
+        a.post_final_nl = s.post_final_nl;
         db.alts.push_back(std::move(a));
     }
     db.minlen = (int)minm;
 
+    // Device windows: the alternative's window, plus one context position in front (behind) when ANY alternative
+    // looks at the byte before (after) its match -- its own condition there, "any byte" for the others.
+    for (const AltSeq &a : db.alts) {
+        db.dev_pre = db.dev_pre || a.has_pre();
+        db.dev_post = db.dev_post || a.has_post();
+    }
+    auto class_id = [&](const ByteSet &b) -> int {
+        for (size_t c = 0; c < db.classes.size(); c++)
+            if (db.classes[c] == b) return (int)c;
+        if ((int)db.classes.size() >= kMaxClasses) return -1;
+        db.classes.push_back(b);
+        return (int)db.classes.size() - 1;
+    };
+    size_t min_dev = SIZE_MAX, total_dev = 0;
+    bool can_hit = false; // some alternative can match away from the subject start and the chunk end
+    for (const AltSeq &a : db.alts) {
+        std::vector<uint8_t> w;
+        if (db.dev_pre) {
+            const int id = class_id(a.pre);
+            if (id < 0) {
+                why = "too many distinct classes";
+                return 1;
+            }
+            w.push_back((uint8_t)id);
+        }
+        w.insert(w.end(), a.window.begin(), a.window.end());
+        if (db.dev_post) {
+            const int id = class_id(a.post);
+            if (id < 0) {
+                why = "too many distinct classes";
+                return 1;
+            }
+            w.push_back((uint8_t)id);
+        }
+        if (w.size() > (size_t)kMaxWindow) {
+            why = "window longer than the engine supports";
+            return 1;
+        }
+        can_hit = can_hit || (a.pre.count() > 0 && a.post.count() > 0);
+        min_dev = std::min(min_dev, w.size());
+        total_dev += w.size();
+        db.dev_windows.push_back(std::move(w));
+    }
+    if (total_dev > (size_t)kAltWindowBytes) {
+        why = "pattern unfolds into too many alternatives";
+        return 1;
+    }
+
     DevProgram &pg = db.prog;
-    const std::vector<uint8_t> &w0 = db.alts[0].window;
+    const std::vector<uint8_t> &w0 = db.dev_windows[0];
     const size_t m = w0.size();
-    pg.m = (uint32_t)minm;
+    pg.m = (uint32_t)min_dev;
+    pg.report_shift = db.dev_pre ? 1u : 0u;
     pg.n_classes = (uint32_t)db.classes.size();
     for (size_t c = 0; c < db.classes.size(); c++) memcpy(pg.cls_bits[c], db.classes[c].w, 32);
     pg.n_alts = (uint32_t)db.alts.size();
     {
         size_t at = 0;
         for (size_t i = 0; i < db.alts.size(); i++) {
+            const std::vector<uint8_t> &w = db.dev_windows[i];
             pg.alt_off[i] = (uint16_t)at;
-            pg.alt_len[i] = (uint16_t)db.alts[i].window.size();
+            pg.alt_len[i] = (uint16_t)w.size();
             pg.alt_bucket[i] = (uint8_t)(i % kK3Buckets);
-            memcpy(pg.alt_window + at, db.alts[i].window.data(), db.alts[i].window.size());
-            at += db.alts[i].window.size();
+            memcpy(pg.alt_window + at, w.data(), w.size());
+            at += w.size();
         }
+    }
+    if (!can_hit) { // ^foo, foo$ and the like: a match can only sit at the subject start / chunk end, which is the host's job
+        db.tier = GSCAN_TIER_ANCHORED;
+        return 0;
     }
 
     // K3 filter: the kK3Depth window positions from k3_off on, per bucket.  The offset is common to
@@ -912,15 +1172,15 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     // to make the filter as selective as possible.  Positions beyond an alternative's end accept
     // any byte.
     {
-        const size_t max_off = minm > (size_t)kK3Depth ? minm - kK3Depth : 0;
+        const size_t max_off = min_dev > (size_t)kK3Depth ? min_dev - kK3Depth : 0;
         double best = -1;
         size_t best_off = 0;
         for (size_t off = 0; off <= max_off; off++) {
             double score = 0;
-            for (const AltSeq &a : db.alts) {
+            for (const std::vector<uint8_t> &w : db.dev_windows) {
                 double prod = 1;
                 for (int k = 0; k < kK3Depth; k++)
-                    prod *= off + k < a.window.size() ? db.classes[a.window[off + k]].count() / 256.0 : 1.0;
+                    prod *= off + k < w.size() ? db.classes[w[off + k]].count() / 256.0 : 1.0;
                 score += prod;
             }
             if (best < 0 || score < best) {
@@ -932,10 +1192,10 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         for (int b = 0; b < 256; b++) {
             uint32_t e = 0;
             for (size_t i = 0; i < db.alts.size(); i++) {
-                const AltSeq &a = db.alts[i];
+                const std::vector<uint8_t> &w = db.dev_windows[i];
                 for (int k = 0; k < kK3Depth; k++) {
                     const size_t pos = best_off + k;
-                    if (pos >= a.window.size() || db.classes[a.window[pos]].test((unsigned)b))
+                    if (pos >= w.size() || db.classes[w[pos]].test((unsigned)b))
                         e |= 1u << (8 * k + pg.alt_bucket[i]);
                 }
             }
@@ -946,15 +1206,15 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             for (int b = 0; b < 256; b++) {
                 uint32_t e = 0;
                 for (size_t i = 0; i < db.alts.size(); i++) {
-                    const AltSeq &a = db.alts[i];
-                    if ((size_t)k >= a.window.size() || db.classes[a.window[(size_t)k]].test((unsigned)b)) e |= 1u << pg.alt_bucket[i];
+                    const std::vector<uint8_t> &w = db.dev_windows[i];
+                    if ((size_t)k >= w.size() || db.classes[w[(size_t)k]].test((unsigned)b)) e |= 1u << pg.alt_bucket[i];
                 }
                 pg.k3_pos[k][b] = (uint8_t)e;
             }
         pg.k3_confirm_exact = db.alts.size() <= (size_t)kK3Buckets;
         for (size_t i = 0; i < db.alts.size(); i++) {
-            if (db.alts[i].window.size() > (size_t)kK3Confirm) pg.k3_confirm_exact = 0;
-            if (i < (size_t)kK3Buckets) pg.k3_blen[i] = (uint8_t)std::min<size_t>(db.alts[i].window.size(), 255);
+            if (db.dev_windows[i].size() > (size_t)kK3Confirm) pg.k3_confirm_exact = 0;
+            if (i < (size_t)kK3Buckets) pg.k3_blen[i] = (uint8_t)std::min<size_t>(db.dev_windows[i].size(), 255);
         }
     }
 

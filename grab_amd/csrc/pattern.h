@@ -104,6 +104,7 @@ struct DevProgram {
     uint8_t k3_pos[kK3Confirm][256];     // K3 confirm: [window position][byte] -> buckets that accept it there (all, past an alternative's end)
     uint8_t k3_blen[kK3Buckets];         // K3 confirm: window length of the bucket's alternative when k3_confirm_exact
     uint32_t k3_confirm_exact;           // every alternative has its own bucket and fits kK3Confirm positions: the tables ARE the pattern
+    uint32_t report_shift;               // 1 when the device windows start one byte before the match (context position)
 };
 
 // One alternative: a fixed class window + an optional variable repeat of one class at its end.
@@ -113,13 +114,36 @@ struct AltSeq {
     uint32_t tail_extra = 0;     // max bytes beyond the window (UINT32_MAX = unbounded)
     ByteSet tail;
     bool captures = false;       // the path closes a capturing group: pcre_exec with the reference's ovector[3] returns 0 for such a match
+    // Zero-width assertions at the two ends of the alternative (^ $ \b \B \A \z \Z, (?m)), reduced to one byte of
+    // context each.  The reference restarts pcre_exec with the subject beginning AT the restart position
+    // (src/grab.cc:178), so "before the match" is either a real byte or the subject start:
+    ByteSet pre;                 // bytes that may precede the match ...
+    bool pre_start = true;       // ... and whether the match may sit at the subject start (the restart position)
+    ByteSet post;                // bytes that may follow the window ...
+    bool post_end = true;        // ... whether the window may end exactly at the chunk end ...
+    bool post_final_nl = false;  // ... and whether "\n as the very last byte of the chunk" may follow ($ without (?m), \Z)
+    bool has_pre() const;        // pre / pre_start restrict anything
+    bool has_post() const;
+    AltSeq()
+    {
+        pre.negate();
+        post.negate();
+    }
 };
+inline bool AltSeq::has_pre() const { return pre.count() != 256 || !pre_start; }
+inline bool AltSeq::has_post() const { return post.count() != 256 || !post_end; }
 
 struct Database {
     int tier = 0;
     int minlen = -1;             // shortest alternative == PCRE_INFO_MINLENGTH; -1 if "" can match
     std::vector<ByteSet> classes;
     std::vector<AltSeq> alts;    // priority order: the first one whose window matches at p is PCRE's match at p
+    // What the kernels scan: when some alternative looks at the byte before (after) its window, EVERY alternative's
+    // device window gets a leading (trailing) context position -- its own condition, or "any byte".  A device hit at q
+    // is reported as q + dev_pre.  Matches at the restart position and windows ending at the chunk end have no such
+    // byte and are the host's to find (filegrep.cc).
+    bool dev_pre = false, dev_post = false;
+    std::vector<std::vector<uint8_t>> dev_windows; // class ids, per alternative
     DevProgram prog;
     uint64_t id = 0; // unique per compile; contexts key their device copy on it
 };

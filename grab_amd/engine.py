@@ -14,12 +14,12 @@ from .build import lib_path
 OK, UNSUPPORTED = 0, 1
 EINVAL, ENOMEM, EHIP, EBUSY, EEMPTY, ETOOBIG, EIO = -1, -2, -3, -4, -5, -6, -7
 LITERAL = 1
-TIER_NULL, TIER_LITERAL, TIER_CLASSRUN, TIER_BUCKET = 0, 1, 2, 3
+TIER_NULL, TIER_LITERAL, TIER_CLASSRUN, TIER_BUCKET, TIER_ANCHORED = 0, 1, 2, 3, 4
 SLOTS = 2
 
 # every symbol include/gscan.h declares
 SYMBOLS = [
-    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_match_info",
+    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_match_info", "gscan_tail_positions", "gscan_db_dev_window",
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
     "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
@@ -30,7 +30,7 @@ SYMBOLS = [
 class Info(C.Structure):
     _fields_ = [("tier", C.c_int), ("minlen", C.c_int), ("n_classes", C.c_int), ("has_tail", C.c_int),
                 ("tail_extra", C.c_uint32), ("anchor_off", C.c_int), ("anchor_len", C.c_int),
-                ("is_literal", C.c_int), ("n_alts", C.c_int)]
+                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int)]
 
 
 class Seg(C.Structure):
@@ -71,7 +71,10 @@ def lib():
         L.gscan_match_at.restype = C.c_int
         L.gscan_match_end.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
         L.gscan_match_end.restype = C.c_uint32
-        L.gscan_match_info.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.gscan_match_info.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.gscan_tail_positions.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.gscan_tail_positions.restype = C.c_size_t
+        L.gscan_db_dev_window.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gscan_open.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
         L.gscan_close.argtypes = [C.c_void_p]
         L.gscan_close.restype = None
@@ -150,11 +153,30 @@ class Database:
         buf = np.frombuffer(content, np.uint8)
         return int(lib().gscan_match_end(self._h, buf.ctypes.data, buf.size, start))
 
-    def match_info(self, content, start):
-        """(kind, end): kind 0 no match at start, 1 match, 2 match through a capturing group (the reference ends the chunk there)."""
+    def match_info(self, content, p, subject_start=None):
+        """(kind, end) of a match attempt AT p with the subject starting at subject_start (default: at p itself):
+        kind 0 no match, 1 match, 2 match through a capturing group (the reference ends the chunk there)."""
         buf = np.frombuffer(content, np.uint8)
         e = C.c_uint32()
-        return int(lib().gscan_match_info(self._h, buf.ctypes.data, buf.size, start, C.byref(e))), e.value
+        s0 = p if subject_start is None else subject_start
+        return int(lib().gscan_match_info(self._h, buf.ctypes.data, buf.size, s0, p, C.byref(e))), e.value
+
+    def dev_window(self, alt):
+        """What the kernels scan for alternative `alt`: ([membership table per device window position], shift)."""
+        n, sh = C.c_int(), C.c_int()
+        if lib().gscan_db_dev_window(self._h, alt, 0, None, C.byref(n), C.byref(sh)) != OK:
+            raise ValueError("no alternative %d" % alt)
+        tabs = []
+        for pos in range(n.value):
+            t = np.zeros(256, np.uint8)
+            lib().gscan_db_dev_window(self._h, alt, pos, t.ctypes.data, None, None)
+            tabs.append(t.astype(bool))
+        return tabs, sh.value
+
+    def tail_positions(self, clen):
+        out = np.zeros(130, np.uint32)
+        n = lib().gscan_tail_positions(self._h, clen, out.ctypes.data, out.size)
+        return out[:n]
 
     def close(self):
         if self._h:

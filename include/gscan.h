@@ -59,6 +59,8 @@ extern "C" {
 #define GSCAN_TIER_LITERAL 1 /* K1: 4-byte anchor compare + class-sequence verify */
 #define GSCAN_TIER_CLASSRUN 2 /* K2: LDS class table -> per-class bitmaps -> run detection */
 #define GSCAN_TIER_BUCKET 3  /* K3: several alternatives (or > 4 classes): LDS bucket filter on 4 window positions + verify */
+#define GSCAN_TIER_ANCHORED 4 /* ^foo, foo$ ...: a match can only sit at the restart position or at the chunk end; nothing to scan,
+                                 the host's window tests (gscan_match_info, gscan_tail_positions) find everything */
 
 typedef struct gscan_db gscan_db;
 typedef struct gscan_ctx gscan_ctx;
@@ -73,6 +75,7 @@ typedef struct gscan_info {
     int anchor_len;      /* K1: 1..4 bytes */
     int is_literal;      /* 1 if every window position is a single byte value */
     int n_alts;          /* alternatives the pattern unfolds into (priority order); the fields above describe alternative 0 */
+    int has_context;     /* bit 0: some alternative looks at the byte BEFORE its match (\b ^ ...), bit 1: at the byte AFTER it */
 } gscan_info;
 
 /* one scan unit inside a device-resident arena (gscan_scan_device) */
@@ -102,14 +105,24 @@ int gscan_db_info(const gscan_db *db, gscan_info *info);
 int gscan_db_class(const gscan_db *db, int pos, uint8_t table[256]);
 /* the same for alternative `alt`; *len (optional) receives that alternative's window length */
 int gscan_db_alt_class(const gscan_db *db, int alt, int pos, uint8_t table[256], int *len);
-/* 1 if the pattern matches AT offset p of content[0..clen) (window test on the host), else 0 */
+/* 1 if the pattern matches AT offset p of content[0..clen) with the subject starting at p, else 0 */
 int gscan_match_at(const gscan_db *db, const void *content, size_t clen, uint32_t p);
-/* ovector[1] for a match starting at `start` of content[0..clen): src/grab.cc:178 semantics */
+/* ovector[1] for a match starting at `start` of content[0..clen), subject starting there: src/grab.cc:178 semantics */
 uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, uint32_t start);
-/* pcre_exec's verdict on a match attempt AT `start`:  0 no match starts there;  1 match, *end = ovector[1];
- * 2 match whose path closes a capturing group -- with the reference's int ovector[3] (src/grab.cc:171)
- * pcre_exec returns 0 for it and the chunk loop ends without printing (src/grab.cc:179). */
-int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint32_t start, uint32_t *end);
+/* pcre_exec's verdict on a match attempt AT p when the subject starts at subject_start <= p (the position the
+ * reference restarted at: src/grab.cc:178 passes subject = start, so ^ \b \B see nothing before it):
+ * 0 no match starts at p;  1 match, *end = ovector[1];  2 match whose path closes a capturing group -- with the
+ * reference's int ovector[3] (src/grab.cc:171) pcre_exec returns 0 for it and the chunk loop ends (src/grab.cc:179). */
+int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p,
+                     uint32_t *end);
+/* Patterns with look-ahead context (gscan_info.has_context & 2: foo\b, foo$ ...): the offsets, ascending, at which a
+ * window would end at the chunk end or one byte before it.  The kernels require a real byte after the window, so a
+ * match there is never in gscan_wait's list; the caller tests these few offsets itself with gscan_match_info.
+ * Returns how many there are (0 for patterns without such context); fills at most cap. */
+size_t gscan_tail_positions(const gscan_db *db, size_t clen, uint32_t *out, size_t cap);
+/* What the kernels scan for alternative `alt`: the membership table of DEVICE window position `pos` (the window plus
+ * its context positions), the device window length, and the shift from a device hit to the reported match start. */
+int gscan_db_dev_window(const gscan_db *db, int alt, int pos, uint8_t table[256], int *len, int *shift);
 
 /* ---- device context: one per worker thread ---- */
 int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out);

@@ -105,15 +105,18 @@ def check_reported(got, cands):
 
 
 def scan_chunk(rx, minlen, flags, path, content, off):
-    """grab.cc:171-213 for one chunk; returns the bytes the reference appends to its ostringstream."""
+    """grab.cc:171-213 for one chunk; returns the bytes the reference appends to its ostringstream.
+    Every search runs on content[s:] -- the subject STARTS at the restart position (grab.cc:178 passes subject =
+    start, startoffset 0), which is what ^ \\b \\B and look-behind see (quirk Q4); a zero-copy memoryview slice."""
     out = []
     clen = len(content)
+    view = memoryview(content)
     s = 0
     while s + minlen < clen:  # strict (Q3)
-        m = rx.search(content, s)
+        m = rx.search(view[s:])
         if m is None or m.lastindex:  # a set capturing group: pcre_exec returns 0 with ovector[3] (grab.cc:171,179, quirk Q5)
             break
-        b, e = m.start(), m.end()
+        b, e = s + m.start(), s + m.end()
         if flags & F_PREFIX:
             out.append(path + b":")
         if flags & F_OFFSETS:
@@ -171,11 +174,11 @@ def offsets_nl(pattern, data, chunk=DEFAULT_CHUNK):
     out = []
     for off, clen in chunks(size, chunk):
         s = 0
-        end = off + clen
+        view = memoryview(data)[off:off + clen]
         while s + minlen < clen:
-            m = rx.search(data, off + s, end)
+            m = rx.search(view[s:])  # the subject starts at the restart position (Q4)
             if m is None or m.lastindex:
                 break
-            out.append(m.start())
-            s = m.end() - off
+            out.append(off + s + m.start())
+            s += m.end()
     return np.asarray(out, np.int64)

@@ -104,6 +104,20 @@ CASES = [
     dict(name="cap_all_paths", inputs={"t1.txt": lit(T1)}, args=["-O", "(foo|tail)", "t1.txt"]),
     dict(name="cap_big_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "NEEDLE|(\\n)\\.{79}\\n\\.{3}N", "big.txt"], big=True,
          jit_only=True),  # the interpreter build keeps its overflow flag from FAILED attempts that closed the group and then returns 0 for the NEEDLE match too; the JIT build (timing build, golden source) does not
+    # zero-width assertions (the subject restarts at every match: Q4)
+    dict(name="asrt_wordb", inputs={"t1.txt": lit(T1)}, args=["-O", "\\bfoo\\b", "t1.txt"]),
+    dict(name="asrt_nonwordb", inputs={"f": lit("foofoo xfoo foo\nfoofoofoo\n")}, args=["-O", "-l", "\\Bfoo", "f"]),
+    dict(name="asrt_caret", inputs={"f": lit("foofoo\nfoo\nxfoo foo\n")}, args=["-O", "-l", "^foo", "f"]),
+    dict(name="asrt_caret_m", inputs={"f": lit("foofoo\nfoo\nxfoo foo\n")}, args=["-O", "(?m)^foo", "f"]),
+    dict(name="asrt_dollar_m", inputs={"f": lit("foo\nfoox\nxfoo\nfoo")}, args=["-O", "-l", "(?m)foo$", "f"]),
+    dict(name="asrt_dollar_nl", inputs={"f": lit("foo\nfoo\n")}, args=["-O", "-l", "foo$", "f"]),
+    dict(name="asrt_z", inputs={"f": lit("foo\nfoo\n")}, args=["-O", "-l", "foo\\z", "f"]),
+    dict(name="asrt_Z", inputs={"f": lit("foo\nfoo\n")}, args=["-O", "-l", "foo\\Z", "f"]),
+    dict(name="asrt_words", inputs={"t1.txt": lit(T1)}, args=["-O", "-l", "\\b\\w+\\b", "t1.txt"]),
+    dict(name="asrt_alt", inputs={"f": lit("foo bar baz\nbar foo\nxbaz bar")}, args=["-O", "-l", "^foo|bar$|\\bbaz", "f"]),
+    dict(name="asrt_line", inputs={"f": lit("foo\n foo\nfoo \nfoo\n")}, args=["-O", "(?m)^foo$", "f"]),
+    dict(name="syn8_words", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 2}}, args=["-O", "-l", "\\b[a-z]{12,}\\b", "syn"]),
+    dict(name="syn8_bol", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 2}}, args=["-O", "(?m)^[a-z]{4}\\b|;$", "syn"]),
     dict(name="syn8_alt_Ol", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 3, "plant": [NEEDLE, 64]}},
          args=["-O", "-l", "foobardoes(?:not)?exist|[0-9A-F]{7}[a-z]?|(?i:xyzzy)", "syn"]),
     dict(name="syn8_alt_O", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 3, "plant": [NEEDLE, 64]}},
@@ -135,6 +149,10 @@ CASES = [
     dict(name="big_alt_Ol_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "NEE?DLE|DLE|\\n\\.{79}\\n\\.{3}N", "big.txt"], big=True),
     dict(name="big_alt_O_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "NEE?DLE|DLE", "big.txt"], big=True),
     dict(name="big2_alt_L5", inputs={"big2.txt": {"kind": "big2"}}, args=L5 + ["-O", "-l", "a{30,}|NEEDLE|a{5}\\.", "big2.txt"], big=True),
+    dict(name="big_wordb_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "\\bNEEDLE\\b", "big.txt"], big=True),
+    dict(name="big_dollar_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "NEEDLE$", "big.txt"], big=True),  # only where a window ends with the chunk
+    dict(name="big_lines_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "(?m)^\\.{79}$|NEEDLE", "big.txt"], big=True),
+    dict(name="big_caret_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "^\\.{10}NEE|^\\.{4090}|DLE\\B", "big.txt"], big=True),
     dict(name="big_s_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-s", "-O", "-l", "NEEDLE", "big.txt"], big=True),
     dict(name="big_l_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-l", "NEEDLE", "big.txt"], big=True),
 ]

@@ -65,9 +65,11 @@ def materialize(recipe, path, cache=None):
 
 
 def db_candidates(db, data):
-    """Every offset at which the compiled pattern matches (the candidate set), from the database's own class
-    tables: the union over its alternatives of the offsets where that alternative's window fits and matches.
-    (The tables themselves are pinned against libpcre and Python's re in tests/test_pattern.py.)"""
+    """Every offset the engine may report for `data` (the candidate set), from the database's own class tables: the
+    union over its alternatives of the offsets where that alternative's DEVICE window -- the window plus, for patterns
+    with \\b ^ $ ..., one context byte before / after it -- fits and matches, shifted to the match start.  For patterns
+    without context that is every offset at which the pattern matches.  (The tables themselves are pinned against libpcre
+    and Python's re in tests/test_pattern.py; the host's part of context patterns against the reference's outputs.)"""
     import os
     import sys
 
@@ -78,6 +80,6 @@ def db_candidates(db, data):
 
     out = [np.zeros(0, np.int64)]
     for a in range(db.info.n_alts):
-        tables = [db.class_table(i, a) for i in range(db.alt_len(a))]
-        out.append(so.window_starts(data, tables))
+        tables, shift = db.dev_window(a)
+        out.append(so.window_starts(data, tables) + shift)
     return np.unique(np.concatenate(out))

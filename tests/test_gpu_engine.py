@@ -23,7 +23,9 @@ PATTERNS = ["foobardoesnotexist", "foo", "e", "xy", "[A-Za-z_][A-Za-z0-9_]{15,}"
             # K3 (bucket filter): alternations, optional / bounded repeats in the middle, (?i), > 4 classes
             "foo|bar", "foobardoesnotexist|Linus|555-1234", "colou?r|axc", "(?i)linus", "[ab]{1,3}c", "(?:foo|bar)baz?",
             "a|ab", "(?:a|b|c|d|e|f|x|y|0|1)x", "[a-z][0-9][A-Z][.,][;:]", "(?i)foobar|k7Q,;q|[0-9]{12}x?", "e|ee|eee",
-            "(?:ab|cd|ef|gh|ij|kl|mn|op){2}", "a 1 b|ABCDEF012x|acegg+", "[0-9a-f]{30}(?:ab|cd)"]
+            "(?:ab|cd|ef|gh|ij|kl|mn|op){2}", "a 1 b|ABCDEF012x|acegg+", "[0-9a-f]{30}(?:ab|cd)",
+            # context positions (\b ^ $ ...): device windows carry the byte before / after the match
+            r"\bfoo\b", r"\Bfoo", "(?m)^[a-z]{3}", "(?m)[a-z]{3}$", r"\b\w+\b", r"\b[a-z.]o|Linus$|^abc", r"\bfoobardoesnotexist\b", r"e\B"]
 
 
 @pytest.fixture(scope="module")

@@ -92,7 +92,7 @@ def _tree(root, rng, nfiles):
 
 @pytest.mark.parametrize("args", [["-r", "-O"], ["-r", "-O", "-l"], ["-r"], ["-r", "-l"], ["-r", "-s"], ["-n", "2", "-r", "-O", "-l"], ["-n", "3", "-r"]])
 @pytest.mark.parametrize("pattern", ["foobardoesnotexist", "[A-Za-z_][A-Za-z0-9_]{15,}", "[0-9A-F]{6}[a-z]",
-                                     "foobardoes(?:not)?exist|[0-9A-F]{7}[a-z]?|(?i:xyzzy)"])
+                                     "foobardoes(?:not)?exist|[0-9A-F]{7}[a-z]?|(?i:xyzzy)", r"(?m)^[a-z]{3}\b|\b[0-9A-F]{5}$|^foo"])
 def test_tree_differential(args, pattern, built, oracle_built, tmp_path):
     """Random tree, recursive + threaded modes: sorted output == the oracle's (the reference's own
     criterion for -n, README.md:206-216); the real reference binary is compared too when present."""

@@ -49,6 +49,23 @@ SUPPORTED = [
     ("(foo|bar)", engine.TIER_BUCKET, 3),
     ("(?P<n>a)c|c", engine.TIER_BUCKET, 1),
     ("x(a){0,2}c", engine.TIER_BUCKET, 2),
+    # zero-width assertions: one byte of context in front of / behind the window
+    (r"\bfoo", engine.TIER_LITERAL, 3),
+    (r"foo\b", engine.TIER_LITERAL, 3),
+    (r"\Bfoo\B", engine.TIER_LITERAL, 3),
+    ("(?m)^foo", engine.TIER_LITERAL, 3),
+    ("(?m)foo$", engine.TIER_LITERAL, 3),
+    ("^foo", engine.TIER_ANCHORED, 3),
+    ("foo$", engine.TIER_ANCHORED, 3),
+    (r"\Afoo", engine.TIER_ANCHORED, 3),
+    (r"foo\z", engine.TIER_ANCHORED, 3),
+    (r"foo\Z", engine.TIER_ANCHORED, 3),
+    ("^foo|bar", engine.TIER_BUCKET, 3),
+    (r"\b\w+\b", engine.TIER_CLASSRUN, 1),
+    (r"\b[a-z.]o", engine.TIER_BUCKET, 2),   # mixed first class: split into its word / non-word parts
+    (r"\bfoo\w*\b", engine.TIER_LITERAL, 3),
+    ("(?m)^fo.*$", engine.TIER_LITERAL, 2),
+    (r"a\b b", engine.TIER_LITERAL, 3),       # decided on the spot: always true
     (r"(?i)\Qab\E+", engine.TIER_CLASSRUN, 2),
     ("a{3}", engine.TIER_LITERAL, 3),
     ("x{0}abc", engine.TIER_LITERAL, 3),
@@ -62,12 +79,14 @@ SUPPORTED = [
 
 NULL_TIER = ["a?", "x*", "", "a{0}", "[a-z]{0,3}", "x{0}", "a|", "(?:foo|b?)", "a??", "(?:ab)?", "x*?y{0}"]
 
-UNSUPPORTED = ["^foo", "foo$", r"\bfoo", "a+b", "ab*c", "a{2,}b", "a{1,40}b", "a++b", r"\1", r"\pL",
-               r"\Rfoo", "a{2}{3}", "x" * 300, r"\Afoo", r"foo\z", "(?=foo)", "(?<!a)b", "(?>ab)c", "(?x)a b", "(?:ab)+", "(?:a|b)*c",
+UNSUPPORTED = ["a+b", "ab*c", "a{2,}b", "a{1,40}b", "a++b", r"\1", r"\pL",
+               r"\Rfoo", "a{2}{3}", "x" * 300, "(?=foo)", "(?<!a)b", "(?>ab)c", "(?x)a b", "(?:ab)+", "(?:a|b)*c",
                "(?:ab)?+c", "(?:a|)+b", "(a)+", "(?|a|b)", r"(a)\1", "(?P=n)", "(?<=a)b", "(?:a|b|c|d){4}", "(*UTF8)a", "(?i)[[:^upper:]]a", "a(?R)?b"]
 
 # "a(" is reported as unsupported (groups) by the engine alone; FileGrep::prepare asks libpcre first and
 # gives the reference's "pcre_compile error" for it (tests/test_gpu_filegrep.py, golden case bad_regex)
+UNSUPPORTED += [r"fo+\b", r"[a-z]+\b", "fo.*$", r"\b*a", "fo$o", r"fo\bo", r"(?:a\b){2}", "(?<=a)b"]
+
 MALFORMED = ["[abc", "*a", "+", "?x", "a{3,2}", "[z-a]", "\\", "a)", "[[:nope:]]", "(?:a", "(?i", "(?:a|*b)", "a|+", "(?z)a", "(?i)+a"]
 
 
@@ -252,3 +271,50 @@ def test_capture_groups_end_the_chunk(pattern, built, liboracle):
         else:
             assert text == b"Match at offset %d\n" % p, (pattern, p, text)
     assert n_cap > 0
+
+
+ASSERT_PATTERNS = [r"\bfoo", r"\Bfoo", r"foo\b", r"foo\B", "^foo", "(?m)^foo", "foo$", "(?m)foo$", r"\Afoo", r"foo\z", r"foo\Z", r"\b[a-z.]o",
+                   r"o[a-z.]\b", r"a\b b", "^foo|bar", r"[x\n](?m)^y", r"x(?m)$\ny", r"\B[a-z]{2}", r"foo\b|fo", r"\bfo{1,3}\b", "(?m)^[a-z]+",
+                   r"\b\w+", r"(?m)^\s?foo", r"foo\b.*", r"\b(?:foo|ba)\b", "(?m)^foo$", r"(?i)\bFOO\b|x$", r"\Bo\B", r"\b.\b", "(?m)^.|o$",
+                   r"(a\b)|b", "^(foo)|o", r"\Gfo", r"(?m)$\nf", r"\w+\b", r"\bfoo\w*\b", r"\b\w+\b", "(?m)^fo.*$", r"o\w+\b|x",
+                   r"a{1,3}\b", r"\ba{1,3}?\b", r"\bfoo\b[a-z ]{0,3}", "(?m)^foo$.?"]
+
+
+@pytest.mark.parametrize("pattern", ASSERT_PATTERNS)
+def test_assertions_match_reference_loop(pattern, built, liboracle):
+    """^ $ \\b \\B \\A \\z \\Z (?m): the product's chunk walk (grab_report_chunk) fed with exactly what the kernels are
+    specified to report (device windows, tests/inputs.py:db_candidates; nothing for the ANCHORED tier) prints what the
+    reference's loop prints -- the oracle runs pcre_exec the way grab.cc:175-213 does, subject restarted at every match
+    (quirk Q4) -- on fixed and random texts, in all output modes."""
+    from grab_amd import filegrep
+    from inputs import db_candidates
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import scan_oracle as so
+
+    rng = np.random.default_rng(3)
+    alpha = np.frombuffer(b"fooab xy.\n\n  ", np.uint8)
+    texts = [b"foofoo xfoo foo", b"foofoo\nfoo", b"foo\nfoo\n", b"foo\nfoox\nfoo", b"xo .o ao.o", b"oa o. oab o.a", b"a b ab", b"foobar foo bar",
+             b"x\ny xy\n\ny", b"xabcd", b"foox foo fo", b"  foo\nfoo bar\n\tfoo", b"foo", b"xfoo", b"foo\n", b"\n", b"o", b"fo"]
+    texts += [alpha[rng.integers(0, alpha.size, int(rng.integers(1, 200)))].tobytes() for _ in range(100)]
+    ml = C.c_int()
+    assert liboracle.oracle_minlen(pattern.encode("latin-1"), C.byref(ml)) == 0
+    db = engine.Database(pattern)
+    assert db.minlen == ml.value
+    for text in texts:
+        data = np.frombuffer(text, np.uint8)
+        if db.info.tier == engine.TIER_ANCHORED or db.minlen < 0:
+            starts = np.zeros(0, np.uint32)
+        else:
+            starts = so.group_starts(db_candidates(db, data)).astype(np.uint32)
+        for f in (1 | 2, 1, 0, 1 | 2 | 4, 2):
+            want = b""
+            if 0 <= ml.value <= len(text):
+                out = C.c_void_p()
+                n = C.c_size_t()
+                assert liboracle.oracle_scan_chunk(pattern.encode("latin-1"), b"", text, len(text), 0, f, C.byref(out), C.byref(n)) == 0
+                want = C.string_at(out, n.value) if n.value else b""
+                liboracle.oracle_free(out)
+            got = filegrep.report_chunk(db, f, b"", data, 0, starts) if 0 <= db.minlen <= len(text) else b""
+            assert got == want, (pattern, text, f)

@@ -49,7 +49,8 @@ def host_find(db, data, flags, chunk, path=b"", minimal=True):
     return b"".join(out)
 
 
-_CASES = [c for c in GOLDEN if not c["name"].startswith("syn256")]
+# (the 72 MB fixtures with 80+ byte windows cost ~40 s each in the numpy stand-in for the kernels; the GPU suite runs them through the CLI)
+_CASES = [c for c in GOLDEN if not c["name"].startswith("syn256") and c["name"] not in ("big_lines_L5", "big_alt_Ol_L5", "cap_big_L5")]
 
 
 @pytest.mark.parametrize("case", _CASES, ids=golden_ids(_CASES))
@@ -80,7 +81,8 @@ def test_report_matches_python_oracle_random(built):
     alphabet = np.frombuffer(b"abcdeffoo0123456789_AZ \n\n", np.uint8)
     for pattern in ["foo", "ff", "f", "[a-z]{2,5}", "abc[0-9]*", "e+", "[A-Za-z_][A-Za-z0-9_]{3,}", r"\d\d", "[^\\n]{4}", "[a-f]{3}",
                     "foo|ab", "a|ab", "ab|a", "fo?o", "(?:f|e){1,3}0", "(?i)Az|f+", "[a-f]{1,2}[0-9]", "(?:ab|cd)?e", "f{2,4}?o", "0|1|2|[3-9]+",
-                    "(a|b)0|af", "(f)?o", "f(o){0,2}0", "(?P<w>ab)?c|e"]:
+                    "(a|b)0|af", "(f)?o", "f(o){0,2}0", "(?P<w>ab)?c|e",
+                    r"\bfoo", r"\Bf", r"o\b", "(?m)^f", "(?m)o$", "^f|e$", r"\b\w+\b", r"\b[a-f_]{2}\B"]:
         db = engine.Database(pattern)
         for trial in range(6):
             n = int(rng.integers(0, 3000))
