@@ -213,6 +213,8 @@ __device__ __forceinline__ void emit_tile(const ScanArgs &a, uint32_t t, const u
                                           uint32_t cnt, int sub_off, uint32_t bias, uint32_t lane, uint32_t wave,
                                           uint32_t *s_cnt, uint32_t *s_base)
 {
+    // (one wave per workgroup -- no LDS, no barrier here -- was measured too: 4 % slower, the extra dispatches cost
+    // more than the barriers: profiles/r01_n_sweep_k1_solo.txt)
     uint32_t wtot = wave_sum(cnt);
     if (lane == 0) s_cnt[wave] = wtot;
     __syncthreads();
@@ -374,11 +376,11 @@ __global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a, const TileDesc
                 acc = GS_MIN3(acc, GS_X(d2, d3, 2), GS_X(d2, d3, 3));
                 acc = GS_MIN3(acc, (d3 ^ anchor) & amask, GS_X(d3, d4, 1));
                 acc = GS_MIN3(acc, GS_X(d3, d4, 2), GS_X(d3, d4, 3));
+                uint32_t bits = 0;
                 if (acc == 0) { // cold: find which alignments hit, bounds-check, verify the window
                     const int pos0 = sub_off + k * 1024 + (int)lane * 16;
                     const uint32_t vm = valid16(pos0, lo, hi);
                     const uint32_t dd[5] = {d0, d1, d2, d3, d4};
-                    uint32_t bits = 0;
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
                         uint32_t u = (j & 3) ? __builtin_amdgcn_alignbyte(dd[j / 4 + 1], dd[j / 4], j & 3) : dd[j / 4];
@@ -395,9 +397,10 @@ __global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a, const TileDesc
                         bits = keep;
                     }
                     bits &= ~(bits << 1); // keep group starts (within the lane; a superset of them is fine)
-                    hits[k >> 1] |= bits << (16 * (k & 1));
-                    cnt += (uint32_t)__popc(bits);
                 }
+                // outside the branch: one shift-or per step instead of moving the whole hit array through the join
+                hits[k >> 1] |= bits << (16 * (k & 1));
+                cnt += (uint32_t)__popc(bits);
 #undef GS_X
 #undef GS_MIN3
             }
