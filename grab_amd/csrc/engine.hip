@@ -50,9 +50,7 @@ using gscan::Database;
 using gscan::DevProgram;
 using gscan::ScanArgs;
 
-struct gscan_db {
-    Database db;
-};
+#include "db.h"
 
 namespace {
 
@@ -625,109 +623,6 @@ int gscan_db_alt_class(const gscan_db *db, int alt, int pos, uint8_t table[256],
 }
 
 int gscan_db_class(const gscan_db *db, int pos, uint8_t table[256]) { return gscan_db_alt_class(db, 0, pos, table, nullptr); }
-
-namespace {
-// The alternative pcre_exec's match at p goes through: the first one, in priority order, whose window fits
-// into the chunk and matches there with its context conditions (pattern.h).  at_start: p is the subject
-// start, i.e. the position the reference restarted pcre_exec at (src/grab.cc:178: subject = start), so there
-// is nothing before it.  nullptr: no match starts at p.
-const gscan::AltSeq *alt_at(const Database &d, const uint8_t *content, size_t clen, size_t p, bool at_start)
-{
-    for (const gscan::AltSeq &a : d.alts) {
-        const size_t m = a.window.size();
-        if (p + m > clen) continue;
-        const uint8_t *t = content + p;
-        size_t i = 0;
-        while (i < m && d.classes[a.window[i]].test(t[i])) i++;
-        if (i < m) continue;
-        if (at_start) {
-            if (!a.pre_start) continue;
-        } else if (p == 0 || !a.pre.test(content[p - 1])) {
-            continue;
-        }
-        const size_t e = p + m;
-        if (e == clen) {
-            if (!a.post_end) continue;
-        } else if (!a.post.test(content[e]) && !(a.post_final_nl && content[e] == '\n' && e + 1 == clen)) {
-            continue;
-        }
-        return &a;
-    }
-    return nullptr;
-}
-
-uint32_t end_of(const gscan::AltSeq &a, const uint8_t *t, size_t clen, size_t start)
-{
-    size_t e = start + a.window.size();
-    if (a.has_tail) {
-        uint64_t extra = 0;
-        while (e < clen && extra < (uint64_t)a.tail_extra && a.tail.test(t[e])) {
-            e++;
-            extra++;
-        }
-    }
-    return (uint32_t)e;
-}
-} // namespace
-
-int gscan_match_at(const gscan_db *db, const void *content, size_t clen, uint32_t p)
-{
-    const Database &d = db->db;
-    if (d.minlen <= 0) return 0;
-    return alt_at(d, (const uint8_t *)content, clen, p, true) != nullptr;
-}
-
-int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p, uint32_t *end)
-{
-    const Database &d = db->db;
-    const uint8_t *t = (const uint8_t *)content;
-    if (d.minlen <= 0 || p < subject_start) return 0;
-    const gscan::AltSeq *a = alt_at(d, t, clen, p, p == subject_start);
-    if (!a) return 0;
-    if (end) *end = end_of(*a, t, clen, p);
-    return a->captures ? 2 : 1;
-}
-
-uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, uint32_t start)
-{
-    const Database &d = db->db;
-    const uint8_t *t = (const uint8_t *)content;
-    const gscan::AltSeq *a = d.minlen > 0 ? alt_at(d, t, clen, start, true) : nullptr;
-    return a ? end_of(*a, t, clen, start) : start; // start itself: not a match start
-}
-
-size_t gscan_tail_positions(const gscan_db *db, size_t clen, uint32_t *out, size_t cap)
-{
-    const Database &d = db->db;
-    if (!d.dev_post || d.minlen <= 0) return 0;
-    // windows that end at the chunk end, or one byte before it ($ in front of a final newline): the kernels ask for a
-    // real byte after the window, so these positions are never in their lists
-    std::vector<uint32_t> v;
-    for (const gscan::AltSeq &a : d.alts)
-        for (size_t back = 0; back < 2; back++) {
-            const size_t need = a.window.size() + back;
-            if (need <= clen) v.push_back((uint32_t)(clen - need));
-        }
-    std::sort(v.begin(), v.end());
-    v.erase(std::unique(v.begin(), v.end()), v.end());
-    for (size_t i = 0; i < v.size() && i < cap; i++) out[i] = v[i];
-    return v.size();
-}
-
-int gscan_db_dev_window(const gscan_db *db, int alt, int pos, uint8_t table[256], int *len, int *shift)
-{
-    if (!db) return GSCAN_EINVAL;
-    const Database &d = db->db;
-    if (alt < 0 || (size_t)alt >= d.dev_windows.size()) return GSCAN_EINVAL;
-    const std::vector<uint8_t> &w = d.dev_windows[(size_t)alt];
-    if (len) *len = (int)w.size();
-    if (shift) *shift = d.dev_pre ? 1 : 0;
-    if (table) {
-        if (pos < 0 || (size_t)pos >= w.size()) return GSCAN_EINVAL;
-        for (int b = 0; b < 256; b++) table[b] = d.classes[w[(size_t)pos]].test((unsigned)b);
-    }
-    return GSCAN_OK;
-}
 
 int gscan_device_count(void)
 {

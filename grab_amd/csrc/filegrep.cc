@@ -74,47 +74,16 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
                        size_t clen, long long off, const uint32_t *starts, size_t nstarts, std::string &out)
 {
     if (minlen < 0) return;
-    gscan_info info;
-    gscan_db_info(db, &info);
-    const bool context = info.has_context != 0; // \b ^ $ ...: a match depends on the byte before / after it
-    // windows that end at the chunk end (or just before its final newline) are never in the engine's list
-    uint32_t tails[2 * 64 + 2];
-    const size_t ntails = std::min(gscan_tail_positions(db, clen, tails, sizeof tails / sizeof tails[0]), sizeof tails / sizeof tails[0]);
-    size_t ti = 0;
-    const uint32_t *cur = starts, *const last = starts + nstarts;
+    gscan_cursor cur;
+    cur.ready = 0;
     char line[64];
     size_t s = 0;
     while (s + (size_t)minlen < clen) {
-        // The leftmost match in content[s..clen) with the subject starting at s (grab.cc:178):
-        //   s itself, tested with nothing before it;
-        //   else s + 1 if it matches (with context the engine's groups are built from the real bytes, so s can sit
-        //   inside a group -- whose later members need not be in the list -- without matching as a subject start);
-        //   else the first listed start after s (it heads a group, so it is listed) or the first matching tail offset.
-        size_t m0 = s;
-        uint32_t e = 0;
-        int kind = gscan_match_info(db, content, clen, (uint32_t)s, (uint32_t)s, &e);
-        if (!kind && context && s + 1 < clen) {
-            kind = gscan_match_info(db, content, clen, (uint32_t)s, (uint32_t)s + 1, &e);
-            if (kind) m0 = s + 1;
-        }
-        if (!kind) {
-            cur = std::upper_bound(cur, last, s, [](size_t key, uint32_t v) { return key < (size_t)v; });
-            size_t best = cur == last ? SIZE_MAX : (size_t)*cur;
-            while (ti < ntails && (size_t)tails[ti] <= s) ti++;
-            for (size_t tj = ti; tj < ntails && (size_t)tails[tj] < best; tj++) {
-                uint32_t te = 0;
-                if (gscan_match_info(db, content, clen, (uint32_t)s, tails[tj], &te)) {
-                    best = tails[tj];
-                    break;
-                }
-            }
-            if (best == SIZE_MAX) break;
-            m0 = best;
-            kind = gscan_match_info(db, content, clen, (uint32_t)s, (uint32_t)m0, &e);
-            if (!kind) break; // cannot happen: the engine lists candidates only
-        }
-        if (kind == 2) break; // the match sets a capturing group: rc == 0 with ovector[3], the reference leaves the chunk (grab.cc:179)
-        const size_t m1 = e;
+        // rc = pcre_exec(d_pcreh, d_extra, start, end - start, 0, 0, ovector, 3)            (grab.cc:178)
+        uint32_t b0 = 0, b1 = 0;
+        const int rc = gscan_next_match(db, content, clen, starts, nstarts, &cur, (uint32_t)s, &b0, &b1);
+        if (rc != 1) break; // no match -- or one that sets a capturing group: 0 with ovector[3], same exit (grab.cc:179)
+        const size_t m0 = b0, m1 = b1;
 
         if (flags & GRAB_PREFIX) {
             out += path;

@@ -19,7 +19,7 @@ SLOTS = 2
 
 # every symbol include/gscan.h declares
 SYMBOLS = [
-    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_match_info", "gscan_tail_positions", "gscan_db_dev_window",
+    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_match_info", "gscan_next_match", "gscan_tail_positions", "gscan_db_dev_window",
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
     "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",

@@ -115,10 +115,27 @@ uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, u
  * reference's int ovector[3] (src/grab.cc:171) pcre_exec returns 0 for it and the chunk loop ends (src/grab.cc:179). */
 int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p,
                      uint32_t *end);
-/* Patterns with look-ahead context (gscan_info.has_context & 2: foo\b, foo$ ...): the offsets, ascending, at which a
- * window would end at the chunk end or one byte before it.  The kernels require a real byte after the window, so a
- * match there is never in gscan_wait's list; the caller tests these few offsets itself with gscan_match_info.
- * Returns how many there are (0 for patterns without such context); fills at most cap. */
+/*
+ * The reference's inner loop, one step:  rc = pcre_exec(h, extra, start, end - start, 0, 0, ovector, 3)
+ * (src/grab.cc:178) -- the leftmost match in content[s..clen) when the subject STARTS at s.  `starts` is
+ * the list gscan_wait returned for this chunk; `cur` is zero-initialised by the caller once per chunk and
+ * handed back on every call (s may only grow from call to call, as it does in the reference's loop).
+ * Returns 0: no match (rc < 0);  1: match, [*m0, *m1) = ovector[0..1] as chunk offsets;  2: a match whose
+ * path closes a capturing group -- with the reference's int ovector[3] (src/grab.cc:171) pcre_exec returns 0
+ * for it and the chunk loop ends (src/grab.cc:179).
+ * This is the whole rule, including what is not a function of a byte window: the restart position (nothing
+ * before it), group members the kernels do not list, windows that end with the chunk.
+ */
+#define GSCAN_MAX_TAILS 132
+typedef struct gscan_cursor {
+    size_t li;                      /* first list entry > the last s */
+    uint32_t ntails, ready;
+    uint32_t tails[GSCAN_MAX_TAILS]; /* offsets whose window ends with the chunk: never listed by the kernels */
+} gscan_cursor;
+int gscan_next_match(const gscan_db *db, const void *content, size_t clen, const uint32_t *starts, size_t n,
+                     gscan_cursor *cur, uint32_t s, uint32_t *m0, uint32_t *m1);
+/* the offsets gscan_next_match tests itself because a window there would end with the chunk (patterns with
+ * look-ahead context only: foo\b, foo$ ...); exported for tests.  Returns how many there are; fills at most cap. */
 size_t gscan_tail_positions(const gscan_db *db, size_t clen, uint32_t *out, size_t cap);
 /* What the kernels scan for alternative `alt`: the membership table of DEVICE window position `pos` (the window plus
  * its context positions), the device window length, and the shift from a device hit to the reported match start. */
