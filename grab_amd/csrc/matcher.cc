@@ -19,38 +19,43 @@ using gscan::Database;
 
 namespace {
 
-// does alternative a match AT p?  at_start: p is the subject start (the position the reference restarted
-// pcre_exec at), so there is no byte before it.
-bool alt_matches(const Database &d, const AltSeq &a, const uint8_t *content, size_t clen, size_t p, bool at_start)
+// Context in front of a match that starts at p.  at_start: p is the subject start (the position the reference
+// restarted pcre_exec at), so there is no byte before it.
+bool pre_ok(const AltSeq &a, const uint8_t *content, size_t p, bool at_start)
 {
-    const size_t m = a.window.size();
+    if (at_start) return a.pre_start;
+    return p > 0 && a.pre.test(content[p - 1]);
+}
+
+bool window_at(const Database &d, const std::vector<uint8_t> &w, const uint8_t *content, size_t clen, size_t p)
+{
+    const size_t m = w.size();
     if (p + m > clen) return false;
     const uint8_t *t = content + p;
     size_t i = 0;
-    while (i < m && d.classes[a.window[i]].test(t[i])) i++;
-    if (i < m) return false;
-    if (at_start) {
-        if (!a.pre_start) return false;
-    } else if (p == 0 || !a.pre.test(content[p - 1])) {
-        return false;
-    }
-    const size_t e = p + m;
+    while (i < m && d.classes[w[i]].test(t[i])) i++;
+    return i == m;
+}
+
+// a.window (for a gapped path: the part behind the repeat) at pos, with the context behind it
+bool rest_at(const Database &d, const AltSeq &a, const uint8_t *content, size_t clen, size_t pos)
+{
+    if (!window_at(d, a.window, content, clen, pos)) return false;
+    const size_t e = pos + a.window.size();
     if (e == clen) return a.post_end;
     return a.post.test(content[e]) || (a.post_final_nl && content[e] == '\n' && e + 1 == clen);
 }
 
-// The alternative pcre_exec's match at p goes through: the first one, in priority order, that matches there
-// (pattern.h).  nullptr: no match starts at p.
-const AltSeq *alt_at(const Database &d, const uint8_t *content, size_t clen, size_t p, bool at_start)
+// does the plain (not gapped) alternative a match AT p?
+bool alt_matches(const Database &d, const AltSeq &a, const uint8_t *content, size_t clen, size_t p, bool at_start)
 {
-    for (const AltSeq &a : d.alts)
-        if (alt_matches(d, a, content, clen, p, at_start)) return &a;
-    return nullptr;
+    return rest_at(d, a, content, clen, p) && pre_ok(a, content, p, at_start);
 }
 
-uint32_t end_of(const AltSeq &a, const uint8_t *t, size_t clen, size_t start)
+// end of the match whose window part a.window sits at pos: + the greedy repeat at the very end, if any
+uint32_t end_of(const AltSeq &a, const uint8_t *t, size_t clen, size_t pos)
 {
-    size_t e = start + a.window.size();
+    size_t e = pos + a.window.size();
     if (a.has_tail) {
         uint64_t extra = 0;
         while (e < clen && extra < (uint64_t)a.tail_extra && a.tail.test(t[e])) {
@@ -59,6 +64,46 @@ uint32_t end_of(const AltSeq &a, const uint8_t *t, size_t clen, size_t start)
         }
     }
     return (uint32_t)e;
+}
+
+// The match pcre_exec reports AT p, if any: its end and whether its path closes a capturing group.
+// Alternatives are tried in priority order (pattern.h); consecutive gapped alternatives that share one instance of
+// the unbounded repeat (gap_id) are tried the way PCRE backtracks -- repeat count first (longest first when greedy),
+// then the paths behind it in order.
+struct MatchAt {
+    uint32_t end;
+    bool captures;
+};
+bool match_at(const Database &d, const uint8_t *content, size_t clen, size_t p, bool at_start, MatchAt &out)
+{
+    const size_t na = d.alts.size();
+    for (size_t i = 0; i < na; i++) {
+        const AltSeq &a = d.alts[i];
+        if (!a.gapped) {
+            if (alt_matches(d, a, content, clen, p, at_start)) {
+                out = {end_of(a, content, clen, p), a.captures};
+                return true;
+            }
+            continue;
+        }
+        size_t j = i + 1;
+        while (j < na && d.alts[j].gapped && d.alts[j].gap_id == a.gap_id) j++;
+        if (window_at(d, a.pwindow, content, clen, p) && pre_ok(a, content, p, at_start)) {
+            const size_t g = p + a.pwindow.size();
+            size_t kmax = 0;
+            while (g + kmax < clen && a.gap.test(content[g + kmax])) kmax++;
+            for (size_t step = 0; step < kmax; step++) {
+                const size_t k = a.gap_mode == 1 ? step + 1 : kmax - step;
+                for (size_t r = i; r < j; r++)
+                    if (rest_at(d, d.alts[r], content, clen, g + k)) {
+                        out = {end_of(d.alts[r], content, clen, g + k), d.alts[r].captures};
+                        return true;
+                    }
+            }
+        }
+        i = j - 1;
+    }
+    return false;
 }
 
 // is x an offset the kernels report (before group-start suppression): some alternative's DEVICE window -- the
@@ -126,7 +171,7 @@ size_t tail_positions(const Database &d, size_t clen, uint32_t *out, size_t cap)
     std::vector<uint32_t> v;
     for (const AltSeq &a : d.alts)
         for (size_t back = 0; back < 2; back++) {
-            const size_t need = a.window.size() + back;
+            const size_t need = a.window.size() + (a.gapped ? 1 : 0) + back; // a gapped path's device window: one repeat byte + the rest
             if (need <= clen) v.push_back((uint32_t)(clen - need));
         }
     std::sort(v.begin(), v.end());
@@ -142,27 +187,24 @@ extern "C" {
 int gscan_match_at(const gscan_db *db, const void *content, size_t clen, uint32_t p)
 {
     const Database &d = db->db;
-    if (d.minlen <= 0) return 0;
-    return alt_at(d, (const uint8_t *)content, clen, p, true) != nullptr;
+    MatchAt m;
+    return d.minlen > 0 && match_at(d, (const uint8_t *)content, clen, p, true, m);
 }
 
 int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p, uint32_t *end)
 {
     const Database &d = db->db;
-    const uint8_t *t = (const uint8_t *)content;
-    if (d.minlen <= 0 || p < subject_start) return 0;
-    const AltSeq *a = alt_at(d, t, clen, p, p == subject_start);
-    if (!a) return 0;
-    if (end) *end = end_of(*a, t, clen, p);
-    return a->captures ? 2 : 1;
+    MatchAt m;
+    if (d.minlen <= 0 || p < subject_start || !match_at(d, (const uint8_t *)content, clen, p, p == subject_start, m)) return 0;
+    if (end) *end = m.end;
+    return m.captures ? 2 : 1;
 }
 
 uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, uint32_t start)
 {
     const Database &d = db->db;
-    const uint8_t *t = (const uint8_t *)content;
-    const AltSeq *a = d.minlen > 0 ? alt_at(d, t, clen, start, true) : nullptr;
-    return a ? end_of(*a, t, clen, start) : start; // start itself: not a match start
+    MatchAt m;
+    return d.minlen > 0 && match_at(d, (const uint8_t *)content, clen, start, true, m) ? m.end : start; // start itself: not a match start
 }
 
 size_t gscan_tail_positions(const gscan_db *db, size_t clen, uint32_t *out, size_t cap) { return tail_positions(db->db, clen, out, cap); }
@@ -180,21 +222,64 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
     }
     while (cur->li < n && starts[cur->li] <= s) cur->li++; // s only moves forward: the cursor is kept across calls
 
-    // the subject start itself: nothing before it
-    const AltSeq *a = alt_at(d, content, clen, s, true);
-    size_t at = s;
-    if (!a) {
-        Walk w(d, content, clen, starts, n, cur->li, cur->tails, cur->ntails, (size_t)s + 1);
-        for (;;) {
-            at = w.next();
-            if (at == Walk::kEnd) return 0;
-            a = alt_at(d, content, clen, at, false);
-            if (a) break;
+    // 1. the leftmost start among the plain alternatives: the subject start itself (nothing before it), else the first
+    //    offset of the walk at which one of them matches
+    bool any_plain = false, any_gapped = false;
+    for (const AltSeq &a : d.alts) (a.gapped ? any_gapped : any_plain) = true;
+    size_t best = Walk::kEnd;
+    if (any_plain) {
+        for (const AltSeq &a : d.alts)
+            if (!a.gapped && alt_matches(d, a, content, clen, s, true)) best = s;
+        if (best == Walk::kEnd) {
+            Walk w(d, content, clen, starts, n, cur->li, cur->tails, cur->ntails, (size_t)s + 1);
+            for (size_t at = w.next(); at != Walk::kEnd && best == Walk::kEnd; at = w.next())
+                for (const AltSeq &a : d.alts)
+                    if (!a.gapped && alt_matches(d, a, content, clen, at, false)) {
+                        best = at;
+                        break;
+                    }
         }
     }
-    *m0 = (uint32_t)at;
-    *m1 = end_of(*a, content, clen, at);
-    return a->captures ? 2 : 1;
+    // 2. the gapped alternatives  P . C{1,} . R : the device window is  C . R  (one repeat byte + the rest).  For every such
+    //    hit h, in ascending order: the run of C bytes that ends at h reaches back to r0; a match starts wherever P ends
+    //    inside [r0, h].  The first hit that has such a start gives the leftmost start of the alternative (a later hit
+    //    lies in the same run, or in a later one).
+    if (any_gapped) {
+        for (size_t i = 0; i < d.alts.size(); i++) {
+            const AltSeq &a = d.alts[i];
+            if (!a.gapped) continue;
+            const size_t plen = a.pwindow.size(), t = (size_t)s + plen;
+            if (t >= clen) continue;
+            Walk w(d, content, clen, starts, n, cur->li, cur->tails, cur->ntails, t);
+            // the cursor skipped entries <= s, but a hit may sit AT t == s when P is empty: the walk has to see it
+            if (plen == 0 && a.gap.test(content[t]) && rest_at(d, a, content, clen, t + 1)) {
+                if (pre_ok(a, content, s, true)) best = std::min(best, (size_t)s);
+            }
+            for (size_t h = w.next(); h != Walk::kEnd; h = w.next()) {
+                if (h < t || !a.gap.test(content[h]) || !rest_at(d, a, content, clen, h + 1)) continue;
+                size_t r0 = h;
+                while (r0 > t && a.gap.test(content[r0 - 1])) r0--;
+                if (r0 - plen >= best) break; // nothing this alternative can still find lies left of the best so far
+                bool found = false;
+                for (size_t g = r0; g <= h && !found; g++) {
+                    const size_t p = g - plen;
+                    if (p >= best) break;
+                    if (window_at(d, a.pwindow, content, clen, p) && pre_ok(a, content, p, p == (size_t)s)) {
+                        best = p;
+                        found = true;
+                    }
+                }
+                if (found) break;
+            }
+        }
+    }
+    if (best == Walk::kEnd) return 0;
+    // 3. which alternative wins AT that offset, and where its match ends
+    MatchAt m;
+    if (!match_at(d, content, clen, best, best == (size_t)s, m)) return 0; // cannot happen
+    *m0 = (uint32_t)best;
+    *m1 = m.end;
+    return m.captures ? 2 : 1;
 }
 
 int gscan_db_dev_window(const gscan_db *db, int alt, int pos, uint8_t table[256], int *len, int *shift)

@@ -57,7 +57,14 @@ struct Seq {
     // the assertions at the two ends, resolved into one byte of context each (see AltSeq)
     ByteSet pre = set_all(), post = set_all();
     bool pre_start = true, post_end = true, post_final_nl = false;
-    bool empty() const { return win.empty() && !has_tail && !cap && asserts.empty(); }
+    // one unbounded repeat in the middle:  pwin . gap{1,} . win   (win, tail, asserts, post then describe the part AFTER the gap)
+    bool gapped = false;
+    std::vector<ByteSet> pwin;
+    ByteSet gap;
+    int gap_mode = 0; // 0 greedy, 1 lazy
+    int gap_id = 0;   // paths that share one instance of the repeat: PCRE tries them count-major (see matcher.cc)
+    std::vector<int> p_asserts; // assertions in front of pwin (A_* codes)
+    bool empty() const { return win.empty() && !has_tail && !cap && asserts.empty() && !gapped; }
 };
 
 // C-locale character tables, as pcre_maketables() builds them without setlocale()
@@ -674,6 +681,7 @@ struct Parser {
 struct Unfold {
     std::string why;
     int rc = 0;
+    int gap_ids = 0;
     bool fail(const char *msg)
     {
         if (rc == 0) {
@@ -725,16 +733,38 @@ struct Unfold {
                 out.push_back(a); // \w+\b, (?m).*$: the assertion holds wherever the greedy repeat stops; nothing to add
                 if (!room(out.size())) return false;
                 continue;
+            } else if (a.tail_extra == kInf || a.tail_extra > kMaxMidRepeat) {
+                // An UNBOUNDED repeat with more pattern behind it: the path becomes  P . C{1,} . R  ("gapped": one per path).
+                // Zero repetitions are the plain path P . R, tried last by a greedy repeat and first by a lazy one.
+                if (a.tail_extra != kInf) return fail("large bounded repeat before the end of the pattern");
+                if (a.tail_mode == 2) return fail("possessive repeat before the end of the pattern");
+                if (a.gapped) return fail("a second unbounded repeat before the end of the pattern");
+                for (const auto &as : a.asserts)
+                    if (as.first != 0) return fail("assertion inside the part in front of an unbounded repeat");
+                Seq g;
+                g.gapped = true;
+                g.pwin = a.win;
+                for (const auto &as : a.asserts) g.p_asserts.push_back(as.second);
+                g.gap = a.tail;
+                g.gap_mode = a.tail_mode;
+                g.gap_id = ++gap_ids;
+                g.cap = a.cap;
+                Seq plain = a;
+                plain.has_tail = false;
+                if (a.tail_mode == 1) {
+                    heads.push_back(std::move(plain));
+                    heads.push_back(std::move(g));
+                } else {
+                    heads.push_back(std::move(g));
+                    heads.push_back(std::move(plain));
+                }
             } else { // the repeat is no longer at the end: unfold it into explicit counts
                 if (a.tail_mode == 2) return fail("possessive repeat before the end of the pattern");
-                if (a.tail_extra == kInf || a.tail_extra > kMaxMidRepeat) return fail("variable repeat before the end of the pattern");
                 for (uint32_t k = 0; k <= a.tail_extra; k++) {
                     const uint32_t t = a.tail_mode == 1 ? k : a.tail_extra - k;
-                    Seq h;
-                    h.win = a.win;
+                    Seq h = a;
+                    h.has_tail = false;
                     h.win.insert(h.win.end(), t, a.tail);
-                    h.cap = a.cap;
-                    h.asserts = a.asserts;
                     heads.push_back(std::move(h));
                 }
             }
@@ -748,6 +778,18 @@ struct Unfold {
                     s.tail_extra = b.tail_extra;
                     s.tail_mode = b.tail_mode;
                     s.cap = a.cap || b.cap;
+                    if (b.gapped) { // the unbounded repeat sits in b: everything of h goes in front of it
+                        if (h.gapped) return fail("a second unbounded repeat before the end of the pattern");
+                        for (const auto &as : h.asserts)
+                            if (as.first != 0) return fail("assertion inside the part in front of an unbounded repeat");
+                        s = b;
+                        s.pwin = h.win;
+                        s.pwin.insert(s.pwin.end(), b.pwin.begin(), b.pwin.end());
+                        if (!b.p_asserts.empty() && !h.win.empty()) return fail("assertion inside the part in front of an unbounded repeat");
+                        for (const auto &as : h.asserts) s.p_asserts.insert(s.p_asserts.begin(), as.second);
+                        s.cap = h.cap || b.cap;
+                        if (s.pwin.size() > (size_t)kMaxWindow) return fail("window longer than the engine supports");
+                    }
                     if (s.win.size() > (size_t)kMaxWindow) return fail("window longer than the engine supports");
                     out.push_back(std::move(s));
                     if (!room(out.size())) return false;
@@ -865,6 +907,74 @@ struct Resolver {
         return false;
     }
 
+    // An assertion right behind the unbounded repeat of a gapped path: the byte in front of it is a repeat byte, which
+    // cannot be narrowed -- the repeat's class has to settle that side on its own.  Behind it: the first byte of the
+    // rest, or, when the rest is empty, the byte after the match (post context).
+    bool step_after_gap(Seq s, size_t k, bool eol, bool eos)
+    {
+        const int code = s.asserts[k].second;
+        const bool trail = s.win.empty();
+        if (trail && s.has_tail) return fail("assertion between two repeats");
+        const bool gap_word = set_and(s.gap, word) == s.gap, gap_nonword = set_and(s.gap, nonword) == s.gap;
+        switch (code) {
+        case A_BOS: return true; // something in front of the subject start: never
+        case A_MBOL:
+            if (s.gap == nl) return step(std::move(s), k + 1, eol, eos);
+            if (!s.gap.test('\n')) return true;
+            return fail("(?m)^ behind a repeat that may or may not end in a newline");
+        case A_EOS:
+            if (!trail) return true;
+            return step(std::move(s), k + 1, eol, true);
+        case A_EOL:
+            if (!trail) return fail("$ before the end of an alternative");
+            return step(std::move(s), k + 1, true, eos);
+        case A_MEOL:
+            if (trail) s.post = set_and(s.post, nl);
+            else s.win[0] = set_and(s.win[0], nl);
+            return step(std::move(s), k + 1, eol, eos);
+        case A_WB:
+        case A_NWB: {
+            if (!gap_word && !gap_nonword) return fail("\\b behind a repeat of word and non-word characters");
+            const int lw = gap_word ? 1 : 0;
+            const int rw = (code == A_WB) ? 1 - lw : lw; // the other side must (not) differ
+            const ByteSet &rset = rw ? word : nonword;
+            if (trail) {
+                s.post = set_and(s.post, rset);
+                if (rw) s.post_end = false;
+            } else {
+                s.win[0] = set_and(s.win[0], rset);
+            }
+            return step(std::move(s), k + 1, eol, eos);
+        }
+        }
+        return fail("internal: unknown assertion");
+    }
+
+    // the assertions in front of a gapped path's first part: conditions on the byte before the match
+    bool lead_of_gapped(Seq &s, bool &alive)
+    {
+        alive = true;
+        for (int code : s.p_asserts) {
+            ByteSet &first = s.pwin.empty() ? s.gap : s.pwin[0];
+            switch (code) {
+            case A_BOS: s.pre = ByteSet(); break;
+            case A_MBOL: s.pre = set_and(s.pre, nl); break;
+            case A_WB:
+            case A_NWB: {
+                const bool fw = set_and(first, word) == first, fn = set_and(first, nonword) == first;
+                if (!fw && !fn) return fail("\\b in front of a class of word and non-word characters followed by an unbounded repeat");
+                const bool prev_word = (code == A_WB) ? !fw : fw;
+                s.pre = set_and(s.pre, prev_word ? word : nonword);
+                if (prev_word) s.pre_start = false;
+                break;
+            }
+            default: alive = false; return true; // $ \\z in front of something: never
+            }
+        }
+        s.p_asserts.clear();
+        return true;
+    }
+
     // s.asserts[k..] still to do; eol/eos remember a trailing $ / \z, post_set collects the other trailing conditions
     bool step(Seq s, size_t k, bool eol, bool eos)
     {
@@ -875,6 +985,11 @@ struct Resolver {
             }
             for (const ByteSet &b : s.win)
                 if (b.count() == 0) return true; // narrowed to nothing: this path never matches
+            if (s.gapped) {
+                bool alive;
+                if (!lead_of_gapped(s, alive)) return false;
+                if (!alive) return true;
+            }
             s.asserts.clear();
             out.push_back(std::move(s));
             return true;
@@ -882,6 +997,7 @@ struct Resolver {
         const uint32_t pos = s.asserts[k].first;
         const int code = s.asserts[k].second;
         const size_t L = s.win.size();
+        if (s.gapped && pos == 0) return step_after_gap(std::move(s), k, eol, eos);
         if (L == 0) return step(std::move(s), k + 1, eol, eos); // empty window: the pattern can match "" and every file is skipped anyway (Q2)
         const bool lead = pos == 0, trail = pos == L;
         // (an assertion AFTER a variable repeat never gets here: the repeat was no longer at the end of its path and was
@@ -1004,12 +1120,23 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
                 return 1;
             }
     }
+    for (const Seq &s : seqs) {
+        for (const ByteSet &b : s.pwin)
+            if (b.count() == 0) {
+                why = "empty character class";
+                return 1;
+            }
+        if (s.gapped && s.gap.count() == 0) {
+            why = "empty character class";
+            return 1;
+        }
+    }
     // assertions -> one byte of context at each end (or decided / narrowed / split on the spot)
     {
         Resolver rs;
         bool any = false;
         for (Seq &s : seqs) {
-            any = any || !s.asserts.empty();
+            any = any || !s.asserts.empty() || !s.p_asserts.empty();
             std::stable_sort(s.asserts.begin(), s.asserts.end(), [](const std::pair<uint32_t, int> &x, const std::pair<uint32_t, int> &y) { return x.first < y.first; });
             if (!rs.step(s, 0, false, false)) {
                 why = rs.why;
@@ -1039,6 +1166,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
                 if (u.win.size() == s.win.size() && u.has_tail == s.has_tail &&
                     (!u.has_tail || (u.tail == s.tail && u.tail_extra == s.tail_extra)) && u.pre == s.pre && u.post == s.post &&
                     u.pre_start == s.pre_start && u.post_end == s.post_end && u.post_final_nl == s.post_final_nl &&
+                    u.gapped == s.gapped && !s.gapped && // gapped paths are kept as they are: their order inside a repeat instance matters
                     std::equal(u.win.begin(), u.win.end(), s.win.begin()))
                     dup = true;
             if (!dup) uniq.push_back(std::move(s));
@@ -1052,8 +1180,8 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
 
     size_t minm = SIZE_MAX, total = 0;
     for (const Seq &s : seqs) {
-        minm = std::min(minm, s.win.size());
-        total += s.win.size();
+        minm = std::min(minm, s.win.size() + (s.gapped ? s.pwin.size() + 1 : 0));
+        total += s.win.size() + s.pwin.size();
     }
     if (seqs.empty() || minm == 0) { // can match the empty string: PCRE_INFO_MINLENGTH == -1
         db.tier = GSCAN_TIER_NULL;
@@ -1066,22 +1194,35 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     }
 
     // class table + alternatives
+    auto intern = [&](const ByteSet &b) -> int {
+        for (size_t c = 0; c < db.classes.size(); c++)
+            if (db.classes[c] == b) return (int)c;
+        if ((int)db.classes.size() >= kMaxClasses) return -1;
+        db.classes.push_back(b);
+        return (int)db.classes.size() - 1;
+    };
     for (const Seq &s : seqs) {
         AltSeq a;
         for (const ByteSet &b : s.win) {
-            int id = -1;
-            for (size_t c = 0; c < db.classes.size(); c++)
-                if (db.classes[c] == b) id = (int)c;
+            const int id = intern(b);
             if (id < 0) {
-                if ((int)db.classes.size() >= kMaxClasses) {
-                    why = "too many distinct classes";
-                    return 1;
-                }
-                db.classes.push_back(b);
-                id = (int)db.classes.size() - 1;
+                why = "too many distinct classes";
+                return 1;
             }
             a.window.push_back((uint8_t)id);
         }
+        for (const ByteSet &b : s.pwin) {
+            const int id = intern(b);
+            if (id < 0) {
+                why = "too many distinct classes";
+                return 1;
+            }
+            a.pwindow.push_back((uint8_t)id);
+        }
+        a.gapped = s.gapped;
+        a.gap = s.gap;
+        a.gap_mode = s.gap_mode;
+        a.gap_id = s.gap_id;
         a.has_tail = s.has_tail;
         a.tail = s.tail;
         a.tail_extra = s.has_tail ? s.tail_extra : 0;
@@ -1098,7 +1239,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     // Device windows: the alternative's window, plus one context position in front (behind) when ANY alternative
     // looks at the byte before (after) its match -- its own condition there, "any byte" for the others.
     for (const AltSeq &a : db.alts) {
-        db.dev_pre = db.dev_pre || a.has_pre();
+        db.dev_pre = db.dev_pre || (a.has_pre() && !a.gapped); // a gapped path's start is not where its device window is
         db.dev_post = db.dev_post || a.has_post();
     }
     auto class_id = [&](const ByteSet &b) -> int {
@@ -1113,7 +1254,15 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     for (const AltSeq &a : db.alts) {
         std::vector<uint8_t> w;
         if (db.dev_pre) {
-            const int id = class_id(a.pre);
+            const int id = class_id(a.gapped ? set_all() : a.pre);
+            if (id < 0) {
+                why = "too many distinct classes";
+                return 1;
+            }
+            w.push_back((uint8_t)id);
+        }
+        if (a.gapped) { // the kernels look for one repeat byte + the rest
+            const int id = class_id(a.gap);
             if (id < 0) {
                 why = "too many distinct classes";
                 return 1;
@@ -1133,7 +1282,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             why = "window longer than the engine supports";
             return 1;
         }
-        can_hit = can_hit || (a.pre.count() > 0 && a.post.count() > 0);
+        can_hit = can_hit || ((a.gapped || a.pre.count() > 0) && a.post.count() > 0);
         min_dev = std::min(min_dev, w.size());
         total_dev += w.size();
         db.dev_windows.push_back(std::move(w));

@@ -122,6 +122,16 @@ struct AltSeq {
     ByteSet post;                // bytes that may follow the window ...
     bool post_end = true;        // ... whether the window may end exactly at the chunk end ...
     bool post_final_nl = false;  // ... and whether "\n as the very last byte of the chunk" may follow ($ without (?m), \Z)
+    // One unbounded repeat in the middle of the path ("gapped"):  pwindow . gap{1,} . window [. tail].
+    // pre then refers to the byte before pwindow (the match start), post/tail to what follows `window`.  The kernels look
+    // for  gap . window  (one repeat byte + the rest); the host finds the start by walking the run of repeat bytes back
+    // to pwindow (matcher.cc).
+    bool gapped = false;
+    std::vector<uint8_t> pwindow; // class ids
+    ByteSet gap;
+    int gap_mode = 0;             // 0 greedy, 1 lazy
+    int gap_id = 0;               // consecutive alternatives with the same id share ONE instance of the repeat
+    size_t min_len() const { return window.size() + (gapped ? pwindow.size() + 1 : 0); }
     bool has_pre() const;        // pre / pre_start restrict anything
     bool has_post() const;
     AltSeq()

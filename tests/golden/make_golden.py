@@ -118,6 +118,19 @@ CASES = [
     dict(name="asrt_line", inputs={"f": lit("foo\n foo\nfoo \nfoo\n")}, args=["-O", "(?m)^foo$", "f"]),
     dict(name="syn8_words", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 2}}, args=["-O", "-l", "\\b[a-z]{12,}\\b", "syn"]),
     dict(name="syn8_bol", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 2}}, args=["-O", "(?m)^[a-z]{4}\\b|;$", "syn"]),
+    # one unbounded repeat in the middle of the pattern ("gapped" alternatives)
+    dict(name="gap_plus", inputs={"f": lit("ab aab b aaab abc\naabc xaab\n")}, args=["-O", "-l", "a+b", "f"]),
+    dict(name="gap_float", inputs={"f": lit("pi 3.14 v1.5.25 x12y .5 5. 10.02\n")}, args=["-O", "\\d+\\.\\d+", "f"]),
+    dict(name="gap_dotstar", inputs={"f": lit("foo bar\nfoo x bar bar\nfoobar barfoo\nfoo\nbar\n")}, args=["-O", "foo.*bar", "f"]),
+    dict(name="gap_dotstar_lazy", inputs={"f": lit("foo x bar bar foo bar\n")}, args=["-O", "-l", "foo.*?bar", "f"]),
+    dict(name="gap_word_end", inputs={"t1.txt": lit(T1)}, args=["-O", "-l", "[a-z]+\\b", "t1.txt"]),
+    dict(name="gap_count_major", inputs={"f": lit("aabc aab aaab abc\n")}, args=["-O", "-l", "a+(?:ab|bc)", "f"]),
+    dict(name="gap_mail", inputs={"f": lit("a@b.com x@y.org z@w.net\nfoo@bar.com.\n")}, args=["-O", "\\w+@[a-z]\\.(?:com|org)", "f"]),
+    dict(name="gap_assign", inputs={"f": lit("ab = 12;\nb = 1\n c = 3;\nxyz = 77\n")}, args=["-O", "(?m)^[a-z]+ = \\d\\d?;?$", "f"]),
+    dict(name="gap_capture", inputs={"f": lit("ac aab ab\n")}, args=["-O", "-l", "a+(b)|a+c", "f"]),
+    dict(name="syn8_gap_float", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 4}}, args=["-O", "-l", "[0-9]+\\.[0-9]+", "syn"]),
+    dict(name="syn8_gap_assign", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 4}}, args=["-O", "\\b[a-z_]+ ?= ?[0-9A-F]{1,4};", "syn"]),
+    dict(name="syn8_gap_call", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 4}}, args=["-O", "-l", "[a-z]{3}\\(.*\\)", "syn"]),
     dict(name="syn8_alt_Ol", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 3, "plant": [NEEDLE, 64]}},
          args=["-O", "-l", "foobardoes(?:not)?exist|[0-9A-F]{7}[a-z]?|(?i:xyzzy)", "syn"]),
     dict(name="syn8_alt_O", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 3, "plant": [NEEDLE, 64]}},
@@ -153,6 +166,8 @@ CASES = [
     dict(name="big_dollar_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "NEEDLE$", "big.txt"], big=True),  # only where a window ends with the chunk
     dict(name="big_lines_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "(?m)^\\.{79}$|NEEDLE", "big.txt"], big=True),
     dict(name="big_caret_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "^\\.{10}NEE|^\\.{4090}|DLE\\B", "big.txt"], big=True),
+    dict(name="big_gap_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "\\.+NEEDLE", "big.txt"], big=True),   # runs of dots reach back across lines? no: up to the newline
+    dict(name="big2_gap_L5", inputs={"big2.txt": {"kind": "big2"}}, args=L5 + ["-O", "-l", "a+\\.|\\.+N", "big2.txt"], big=True),
     dict(name="big_s_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-s", "-O", "-l", "NEEDLE", "big.txt"], big=True),
     dict(name="big_l_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-l", "NEEDLE", "big.txt"], big=True),
 ]

@@ -25,7 +25,9 @@ PATTERNS = ["foobardoesnotexist", "foo", "e", "xy", "[A-Za-z_][A-Za-z0-9_]{15,}"
             "a|ab", "(?:a|b|c|d|e|f|x|y|0|1)x", "[a-z][0-9][A-Z][.,][;:]", "(?i)foobar|k7Q,;q|[0-9]{12}x?", "e|ee|eee",
             "(?:ab|cd|ef|gh|ij|kl|mn|op){2}", "a 1 b|ABCDEF012x|acegg+", "[0-9a-f]{30}(?:ab|cd)",
             # context positions (\b ^ $ ...): device windows carry the byte before / after the match
-            r"\bfoo\b", r"\Bfoo", "(?m)^[a-z]{3}", "(?m)[a-z]{3}$", r"\b\w+\b", r"\b[a-z.]o|Linus$|^abc", r"\bfoobardoesnotexist\b", r"e\B"]
+            r"\bfoo\b", r"\Bfoo", "(?m)^[a-z]{3}", "(?m)[a-z]{3}$", r"\b\w+\b", r"\b[a-z.]o|Linus$|^abc", r"\bfoobardoesnotexist\b", r"e\B",
+            # gapped alternatives: the device window is one repeat byte + the rest
+            "e+f", r"[0-9]+\.[0-9]+", "foo.*bar", r"[a-z]+\b", r"\w+@\w", "a 1.*c"]
 
 
 @pytest.fixture(scope="module")

@@ -66,6 +66,14 @@ SUPPORTED = [
     (r"\bfoo\w*\b", engine.TIER_LITERAL, 3),
     ("(?m)^fo.*$", engine.TIER_LITERAL, 2),
     (r"a\b b", engine.TIER_LITERAL, 3),       # decided on the spot: always true
+    # one unbounded repeat in the middle ("gapped"): the kernels look for one repeat byte + the rest
+    ("a+b", engine.TIER_BUCKET, 2),
+    (r"\d+\.\d+", engine.TIER_BUCKET, 3),
+    ("foo.*bar", engine.TIER_BUCKET, 6),
+    (r"[a-z]+\b", engine.TIER_BUCKET, 1),
+    ("a*b", engine.TIER_BUCKET, 1),
+    ("a{2,}b", engine.TIER_BUCKET, 3),
+    ("fo.*$", engine.TIER_ANCHORED, 2),
     (r"(?i)\Qab\E+", engine.TIER_CLASSRUN, 2),
     ("a{3}", engine.TIER_LITERAL, 3),
     ("x{0}abc", engine.TIER_LITERAL, 3),
@@ -79,13 +87,13 @@ SUPPORTED = [
 
 NULL_TIER = ["a?", "x*", "", "a{0}", "[a-z]{0,3}", "x{0}", "a|", "(?:foo|b?)", "a??", "(?:ab)?", "x*?y{0}"]
 
-UNSUPPORTED = ["a+b", "ab*c", "a{2,}b", "a{1,40}b", "a++b", r"\1", r"\pL",
+UNSUPPORTED = ["a+b+c", "a{1,40}b", "a++b", r"\1", r"\pL",
                r"\Rfoo", "a{2}{3}", "x" * 300, "(?=foo)", "(?<!a)b", "(?>ab)c", "(?x)a b", "(?:ab)+", "(?:a|b)*c",
                "(?:ab)?+c", "(?:a|)+b", "(a)+", "(?|a|b)", r"(a)\1", "(?P=n)", "(?<=a)b", "(?:a|b|c|d){4}", "(*UTF8)a", "(?i)[[:^upper:]]a", "a(?R)?b"]
 
 # "a(" is reported as unsupported (groups) by the engine alone; FileGrep::prepare asks libpcre first and
 # gives the reference's "pcre_compile error" for it (tests/test_gpu_filegrep.py, golden case bad_regex)
-UNSUPPORTED += [r"fo+\b", r"[a-z]+\b", "fo.*$", r"\b*a", "fo$o", r"fo\bo", r"(?:a\b){2}", "(?<=a)b"]
+UNSUPPORTED += [r"fo+\bx?", "a.*b.*c", "(?:a+b){2}", r"\b.+x", r"\b*a", "fo$o", r"fo\bo", r"(?:a\b){2}", "(?<=a)b"]
 
 MALFORMED = ["[abc", "*a", "+", "?x", "a{3,2}", "[z-a]", "\\", "a)", "[[:nope:]]", "(?:a", "(?i", "(?:a|*b)", "a|+", "(?z)a", "(?i)+a"]
 
@@ -273,6 +281,11 @@ def test_capture_groups_end_the_chunk(pattern, built, liboracle):
     assert n_cap > 0
 
 
+GAP_PATTERNS = ["a+b", r"\d+\.\d+", "fo.*b", "foo.*bar", r"[a-z]+\b", r"x[a-z]+\b", r"\bfo+\b", "a*b", "a+?b", "a*?b", "ba*b", "a+(?:ab|bc)", "a+b|a+c",
+                "a+(?:b|c)", "o+ |x", r"(?m)^\s*foo", "(?i)fo+bar", "a{2,}b", ".+x", "fo.*$", r"\w+ \w", "(a+)b", "a+(b)|a+c", r"\bo+\b",
+                r"[0-9]+\.[0-9]+|x\d*y", r"(?m)^[a-z]+ = \d\d?;?$", "f.*?o", r"\w+@[a-z]\.(?:com|org)", r"(?m)^.*foo", "[ab]+b{2}", r"\s+\S", r"1+\b\.|o+$",
+                r"\d+\b", r"\Bo+x?\b| +\bf"]
+
 ASSERT_PATTERNS = [r"\bfoo", r"\Bfoo", r"foo\b", r"foo\B", "^foo", "(?m)^foo", "foo$", "(?m)foo$", r"\Afoo", r"foo\z", r"foo\Z", r"\b[a-z.]o",
                    r"o[a-z.]\b", r"a\b b", "^foo|bar", r"[x\n](?m)^y", r"x(?m)$\ny", r"\B[a-z]{2}", r"foo\b|fo", r"\bfo{1,3}\b", "(?m)^[a-z]+",
                    r"\b\w+", r"(?m)^\s?foo", r"foo\b.*", r"\b(?:foo|ba)\b", "(?m)^foo$", r"(?i)\bFOO\b|x$", r"\Bo\B", r"\b.\b", "(?m)^.|o$",
@@ -280,7 +293,7 @@ ASSERT_PATTERNS = [r"\bfoo", r"\Bfoo", r"foo\b", r"foo\B", "^foo", "(?m)^foo", "
                    r"a{1,3}\b", r"\ba{1,3}?\b", r"\bfoo\b[a-z ]{0,3}", "(?m)^foo$.?"]
 
 
-@pytest.mark.parametrize("pattern", ASSERT_PATTERNS)
+@pytest.mark.parametrize("pattern", ASSERT_PATTERNS + GAP_PATTERNS)
 def test_assertions_match_reference_loop(pattern, built, liboracle):
     """^ $ \\b \\B \\A \\z \\Z (?m): the product's chunk walk (grab_report_chunk) fed with exactly what the kernels are
     specified to report (device windows, tests/inputs.py:db_candidates; nothing for the ANCHORED tier) prints what the
@@ -294,8 +307,9 @@ def test_assertions_match_reference_loop(pattern, built, liboracle):
     import scan_oracle as so
 
     rng = np.random.default_rng(3)
-    alpha = np.frombuffer(b"fooab xy.\n\n  ", np.uint8)
-    texts = [b"foofoo xfoo foo", b"foofoo\nfoo", b"foo\nfoo\n", b"foo\nfoox\nfoo", b"xo .o ao.o", b"oa o. oab o.a", b"a b ab", b"foobar foo bar",
+    alpha = np.frombuffer(b"fooab xy.\n\n  11=;@cm", np.uint8)
+    texts = [b"ab aab b aaab abc aabc", b"3.14 1.5.25 x12y .5 5. 10.02", b"foo bar\nfoo x bar bar\nfoobar", b"a@b.com x@y.org z@w.net\n", b"ab = 12;\nb = 1\n c = 3;",
+             b"foofoo xfoo foo", b"foofoo\nfoo", b"foo\nfoo\n", b"foo\nfoox\nfoo", b"xo .o ao.o", b"oa o. oab o.a", b"a b ab", b"foobar foo bar",
              b"x\ny xy\n\ny", b"xabcd", b"foox foo fo", b"  foo\nfoo bar\n\tfoo", b"foo", b"xfoo", b"foo\n", b"\n", b"o", b"fo"]
     texts += [alpha[rng.integers(0, alpha.size, int(rng.integers(1, 200)))].tobytes() for _ in range(100)]
     ml = C.c_int()
