@@ -42,8 +42,8 @@
 //   filter.  The alternatives share 8 buckets; one LDS lookup per text byte (same
 //   bank-replicated 32 KiB table layout as K2) returns, for each of 4 window positions,
 //   the set of buckets that accept the byte there; position q is a hit when some bucket
-//   accepts bytes q..q+3 at positions 0..3 (2 VALU ops per byte to align and AND the four
-//   bucket sets).  Hits are verified against the full windows of their buckets'
+//   accepts bytes q..q+3 at positions 0..3 (3 VALU ops per byte to AND the four bucket
+//   sets: the byte selects ride on SDWA operand modifiers).  Hits are verified against the full windows of their buckets'
 //   alternatives in a cold path, unless the filter is already exact.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -587,9 +587,20 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
 // K3: bucket filter over 4 window positions (alternations; class sequences with > 4 classes).
 // ------------------------------------------------------------------------------------
 // Table entry of byte b: byte k = buckets that accept b at window position k3_off + k.
-// With e_j the entry of text byte j:   hit(j) = e_j.b0 & e_{j+1}.b1 & e_{j+2}.b2 & e_{j+3}.b3 != 0.
-//   g_j = e_j & rotr(e_{j+1}, 8)        byte 0: positions 0,1 at j     byte 2: positions 2,3 at j-2... i.e. at j: e_j.b2 & e_{j+1}.b3
-//   h_j = g_j & (g_{j+2} >> 16)         byte 0 = the four-way AND
+// With e_j the entry of text byte j:   hit(j) = e_j.b0 & e_{j+1}.b1 & e_{j+2}.b2 & e_{j+3}.b3 != 0,
+// three VALU ops per byte: two v_and_b32_sdwa (the byte selects are operand modifiers) and one v_and_b32.
+__device__ __forceinline__ uint32_t and_b0_b1(uint32_t x, uint32_t y)
+{
+    uint32_t r;
+    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ uint32_t and_b2_b3(uint32_t x, uint32_t y)
+{
+    uint32_t r;
+    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_3" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 template <int ITER, bool NT>
 __global__ __launch_bounds__(kWG) void k3_bucket_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
@@ -649,22 +660,28 @@ __global__ __launch_bounds__(kWG) void k3_bucket_scan(ScanArgs a, const TileDesc
                 e[16] = down1(e[0], n0);
                 e[17] = down1(e[1], n1);
                 e[18] = down1(e[2], n2);
-                uint32_t g[18];
-#pragma unroll
-                for (int j = 0; j < 18; j++) g[j] = e[j] & __builtin_amdgcn_alignbit(e[j + 1], e[j + 1], 8);
+                // byte selects come for free with SDWA: A_j = e_j.b0 & e_{j+1}.b1, B_j = e_j.b2 & e_{j+1}.b3, h_j = A_j & B_{j+2}
+                // (plain shift + and in place of the byte selects: 4 ops per byte, 14 % slower -- profiles/r01_o_sweep_k3_sdwa.txt)
                 uint32_t h[16], any = 0;
+                {
+                    uint32_t A[16], B[18];
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    h[j] = g[j] & (g[j + 2] >> 16);
-                    any |= h[j];
+                    for (int j = 0; j < 16; j++) A[j] = and_b0_b1(e[j], e[j + 1]);
+#pragma unroll
+                    for (int j = 2; j < 18; j++) B[j] = and_b2_b3(e[j], e[j + 1]);
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        h[j] = A[j] & B[j + 2];
+                        any |= h[j];
+                    }
                 }
-                if (any & 0xffu) { // cold: which positions, bounds, full windows
+                if (any) { // cold: which positions, bounds, full windows
                     const int pos0 = sub_off + k * 1024 + (int)lane * 16;
                     const uint32_t vm = valid16(pos0, lo, hi);
                     const bool direct = exact && pos0 + 16 + kK3Depth <= c.slen; // filter == pattern, windows in bounds
                     uint32_t hm = 0;
 #pragma unroll
-                    for (int j = 0; j < 16; j++) hm |= (h[j] & 0xffu) ? 1u << j : 0u;
+                    for (int j = 0; j < 16; j++) hm |= h[j] ? 1u << j : 0u;
                     hm &= vm;
                     uint32_t bits = hm;
                     if (!direct) {
