@@ -57,7 +57,7 @@ namespace {
 constexpr size_t kPad = 4096;          // slack behind every text buffer
 constexpr size_t kSpecPer = 2048;       // records of EACH shard region fetched speculatively with the header
 constexpr size_t kSpecRecs = kSpecPer * gscan::kShards;
-constexpr size_t kCounterWords = gscan::kShards + 1; // per-shard counts + overflow flag
+constexpr size_t kCounterWords = gscan::kShards + 2; // per-shard counts + overflow flag + records struck out by the second pass
 constexpr size_t kCopyPiece = 32u << 20; // memcpy/H2D pipelining granule for foreign host buffers
 constexpr size_t kMaxChunk = (1ull << 30) + 4096;
 
@@ -532,6 +532,7 @@ int slot_launch(gscan_ctx *c, Slot &s)
     a.prog = c->d_prog;
     gscan::fill_program(a, db.prog);
     if (s.n_tiles) HIPCHK(c, gscan::launch_scan(db.tier, c->variant, a, grid_for(c, db, s.n_tiles), c->compute));
+    if (s.n_tiles && gscan::scan_needs_settle(db.tier, db.prog)) HIPCHK(c, gscan::launch_settle(a, tile_bytes, c->compute));
     HIPCHK(c, hipMemcpyAsync(s.h_counter, s.d_counter, kCounterWords * 4, hipMemcpyDeviceToHost, c->compute));
     if (s.n_tiles)
         HIPCHK(c, hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)s.n_tiles * 8, hipMemcpyDeviceToHost, c->compute));
@@ -940,6 +941,7 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
         HIPCHK(c, hipEventSynchronize(s->done));
     }
     const size_t cap_shard = s->rec_cap / K;
+    const size_t struck = s->h_counter[K + 1]; // records the second pass struck out (kStruck in the buffer)
     size_t total = 0;
     bool spec_ok = true;
     for (size_t k = 0; k < K; k++) {
@@ -967,9 +969,14 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
         size_t base = (size_t)(d >> 32);
         if (!cnt) continue;
         const uint32_t *src = spec_ok ? s->h_spec + (base / cap_shard) * kSpecPer + base % cap_shard : s->raw.data() + base;
-        s->sorted.insert(s->sorted.end(), src, src + cnt);
+        if (struck == 0) {
+            s->sorted.insert(s->sorted.end(), src, src + cnt);
+        } else {
+            for (uint32_t i = 0; i < cnt; i++)
+                if (src[i] != gscan::kStruck) s->sorted.push_back(src[i]);
+        }
     }
-    if (s->sorted.size() != total) return fail(c, GSCAN_EHIP, "descriptor total %zu != counter %zu", s->sorted.size(), total);
+    if (s->sorted.size() + struck != total) return fail(c, GSCAN_EHIP, "descriptor total %zu + struck %zu != counter %zu", s->sorted.size(), struck, total);
     while (seg < ns) s->seg_first[++seg] = s->sorted.size(); // trailing segments without tiles / records
     if (tag) *tag = s->tag;
     *starts = s->sorted.data();
@@ -1101,6 +1108,7 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
     bool timed = c->ev_used < c->ev_pool.size();
     if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used].a, st));
     if (n_tiles) HIPCHK(c, gscan::launch_scan(db->db.tier, c->variant, a, grid_for(c, db->db, n_tiles), st));
+    if (n_tiles && gscan::scan_needs_settle(db->db.tier, db->db.prog)) HIPCHK(c, gscan::launch_settle(a, tile_bytes, st)); // inside the timed region
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used].b, st));
         c->ev_used++;
@@ -1125,6 +1133,7 @@ int gscan_dev_sync(gscan_ctx *c, gscan_dev_result *res)
     res->total = 0;
     for (size_t k = 0; k < (size_t)gscan::kShards; k++) res->total += h[k];
     res->overflow = h[gscan::kShards] != 0;
+    if (!res->overflow) res->total -= h[gscan::kShards + 1]; // records struck out by the second pass
     return GSCAN_OK;
 }
 
@@ -1145,8 +1154,15 @@ long gscan_dev_fetch(gscan_ctx *c, const gscan_dev_result *res, size_t seg, uint
         size_t base = (size_t)(v >> 32);
         if (!cnt) continue;
         if (base % cap_shard + cnt > cap_shard) return fail(c, GSCAN_EHIP, "record buffer overflowed; raise gscan_set_capacity");
-        if (out && n + cnt <= cap) HIPCHK(c, hipMemcpy(out + n, c->dv_recs + base, (size_t)cnt * 4, hipMemcpyDeviceToHost));
-        n += cnt;
+        if (out && n + cnt <= cap) {
+            HIPCHK(c, hipMemcpy(out + n, c->dv_recs + base, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+            size_t kept = 0;
+            for (uint32_t i = 0; i < cnt; i++)
+                if (out[n + i] != gscan::kStruck) out[n + kept++] = out[n + i];
+            n += kept;
+        } else {
+            n += cnt; // sizing call: an upper bound
+        }
     }
     return (long)n;
 }

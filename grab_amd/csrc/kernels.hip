@@ -714,13 +714,17 @@ __global__ __launch_bounds__(kWG) void k3_bucket_scan(ScanArgs a, const TileDesc
                                         if (p + s_blen[b] <= (uint32_t)c.slen) ok = true;
                                     }
                                 } else {
-                                    ok = verify_alts(c.seg, (uint32_t)c.slen, a.prog, p, 0xffu);
+                                    // shared buckets (> 8 alternatives) or windows longer than the tables: the tables may let a
+                                    // cross-product through.  Accept the hit here; k3_settle decides it, record by record.
+                                    ok = p + m <= (uint32_t)c.slen;
                                 }
                             }
                             if (ok) bits |= 1u << j;
                         }
                     }
-                    bits &= ~(bits << 1); // keep group starts (within the lane; a superset of them is fine)
+                    // keep group starts (within the lane; a superset of them is fine) -- unless hits may still be struck
+                    // out by k3_settle: a real hit must not be dropped for following a false one
+                    if (direct || confirm_exact) bits &= ~(bits << 1);
                     hits[k >> 1] |= bits << (16 * (k & 1));
                     cnt += (uint32_t)__popc(bits);
                 }
@@ -728,6 +732,43 @@ __global__ __launch_bounds__(kWG) void k3_bucket_scan(ScanArgs a, const TileDesc
         }
         emit_tile<ITER, kWaves>(a, t, hits, cnt, sub_off, koff - a.report_shift, lane, wave, s_cnt, &s_base);
     }
+}
+
+// ------------------------------------------------------------------------------------
+// K3, second pass for patterns whose filter tables are not the whole truth (more than 8 alternatives share the 8
+// buckets, or a window is longer than the confirm tables): every record of the first pass is checked against the
+// alternatives themselves.  One thread per tile -- almost all tiles have no record -- walking that tile's records; a
+// record that is no match is overwritten with kStruck and counted, the readers of the record buffer skip it.
+// Doing this inside the scan kernel costs its hot loop 18 % (registers): profiles/r01_o_sweep_k3_compare_word_confirm_rejected.txt.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k3_settle(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t tile_bytes)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= a.n_tiles) return;
+    const unsigned long long d = a.desc[t];
+    const uint32_t cnt = (uint32_t)d;
+    if (cnt == 0) return;
+    if (a.counter[kShards] != 0) return; // some shard overflowed: the host rescans with a bigger buffer (and settles then)
+    const uint32_t base = (uint32_t)(d >> 32);
+    uint64_t seg_off;
+    uint32_t slen;
+    if (tiles) {
+        seg_off = tiles[t].seg_off;
+        slen = tiles[t].seg_len;
+    } else {
+        seg_off = a.seg0_off;
+        slen = a.seg0_len;
+    }
+    const uint8_t *seg = a.base + seg_off;
+    uint32_t struck = 0;
+    for (uint32_t i = 0; i < cnt; i++) {
+        const uint32_t p = a.recs[base + i] - a.report_shift; // device window start
+        if (!verify_alts(seg, slen, a.prog, p, 0xffu)) {
+            a.recs[base + i] = kStruck;
+            struck++;
+        }
+    }
+    if (struck) atomicAdd(a.counter + kShards + 1, struck);
 }
 
 } // namespace
@@ -798,6 +839,19 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
         if (pg.alt_len[i] > (uint32_t)kK3Depth) a.k3_exact = 0;
     for (int r = 0; r < kK2MaxRuns; r++)
         a.run_desc[r] = (uint32_t)pg.run_cls[r] | ((uint32_t)pg.run_len[r] << 8) | ((uint32_t)pg.run_off[r] << 16);
+}
+
+// does the pattern need the second pass?  (the same condition the scan kernel reads as !k3_confirm_exact)
+bool scan_needs_settle(int tier, const DevProgram &pg)
+{
+    return tier == GSCAN_TIER_BUCKET && !pg.k3_confirm_exact;
+}
+
+hipError_t launch_settle(const ScanArgs &a, uint32_t tile_bytes, hipStream_t st)
+{
+    if (a.n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k3_settle, dim3((a.n_tiles + 255u) / 256u), dim3(256), 0, st, a, a.tiles, tile_bytes);
+    return hipGetLastError();
 }
 
 hipError_t launch_scan(int tier, int variant, const ScanArgs &a, uint32_t grid, hipStream_t st)

@@ -9,6 +9,7 @@
 namespace gscan {
 
 constexpr int kShards = 8; // record-buffer regions, each with its own reservation counter
+constexpr uint32_t kStruck = 0xffffffffu; // a record the second pass (k3_settle) found to be no match: readers skip it
 
 // One scan unit of the launch: a tile of one segment.  16 bytes so a workgroup fetches it
 // with a single scalar load.
@@ -29,7 +30,7 @@ struct ScanArgs {
     uint32_t cap_shard;      // record capacity of ONE shard region (regions are back to back)
     uint32_t *recs;          // candidate starts, segment-relative
     unsigned long long *desc; // [n_tiles] count | base<<32 (base = absolute record index)
-    uint32_t *counter;       // [0..kShards) records reserved per shard, [kShards] overflow flag
+    uint32_t *counter;       // [0..kShards) records reserved per shard, [kShards] overflow flag, [kShards+1] records struck out by k3_settle
     const DevProgram *prog;  // cold paths only (K1 verify, K2 table staging)
     // pattern program, hot-loop copy
     uint32_t m;              // window length
@@ -46,5 +47,7 @@ uint32_t scan_min_tile_bytes();
 uint32_t scan_persistent_blocks(int tier, uint32_t n_classes);
 void fill_program(ScanArgs &a, const DevProgram &pg);
 hipError_t launch_scan(int tier, int variant, const ScanArgs &a, uint32_t grid, hipStream_t st);
+bool scan_needs_settle(int tier, const DevProgram &pg);
+hipError_t launch_settle(const ScanArgs &a, uint32_t tile_bytes, hipStream_t st);
 
 } // namespace gscan

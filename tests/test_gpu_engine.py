@@ -296,3 +296,38 @@ def test_submit_batch_segments(ctx):
     ctx.submit_batch(db, parts[:5], tag=1)
     ctx.submit(db, base[:5000], tag=2)
     assert ctx.wait_segs()[0] == 1 and ctx.wait()[0] == 2
+
+
+def test_shared_buckets_second_pass(ctx):
+    """More than 8 alternatives share K3's 8 filter buckets: the tables alone would accept cross-products of a bucket's
+    alternatives ("alota" from alpha + iota).  The second pass (k3_settle) strikes them out; also with a record buffer
+    that overflows first (regrow -> rescan -> settle again) and through the device-resident API (total excludes them)."""
+    import torch
+
+    words = ["alpha", "betaa", "gamma", "delta", "epsil", "zetaa", "etaaa", "theta", "iotaa", "kappa", "lambd", "muuuu"]
+    pattern = "|".join(words)
+    db = engine.Database(pattern)
+    assert db.info.tier == engine.TIER_BUCKET and db.info.n_alts == 12
+    data = sample(2_000_003, 31)
+    rng = np.random.default_rng(31)
+    crosses = [b"alpaa", b"iotha", b"iopha", b"alota", b"betpa", b"kapaa", b"kaaaa", b"betaa", b"iotaa", b"alpha", b"muuuu", b"lambd"]
+    for i in range(3000):
+        w = crosses[i % len(crosses)]
+        at = int(rng.integers(0, data.size - 8))
+        data[at:at + len(w)] = np.frombuffer(w, np.uint8)
+    want = oracle_starts(db, data)
+    got = ctx.scan(db, data)
+    assert same(got, want) and len(got) > 500
+    # dense: every byte is a hit of some single-letter alternative -> overflow -> regrow -> settle on the rescan
+    dense = "|".join("abcdefghijkl") + "|zz"
+    db2 = engine.Database(dense)
+    assert db2.info.n_alts == 13
+    got = ctx.scan(db2, data[:700_001])
+    assert same(got, oracle_starts(db2, data[:700_001]))
+    # device-resident: total counts the survivors only, fetch skips the struck records
+    arena = torch.from_numpy(data).cuda()
+    ctx.set_capacity(1 << 20)
+    res = ctx.scan_device(db, arena.data_ptr(), [(0, data.size)])
+    total, overflow = ctx.dev_sync(res)
+    fetched = ctx.dev_fetch(res, 0)
+    assert not overflow and total == len(fetched) and same(fetched, want)
