@@ -222,6 +222,20 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
     }
     while (cur->li < n && starts[cur->li] <= s) cur->li++; // s only moves forward: the cursor is kept across calls
 
+    // The common case -- one alternative, no context, no gap -- needs none of the machinery below: s itself if the
+    // window matches there, else the first listed start after s.  (If s is no match, the next candidate after it begins
+    // a group and is therefore listed; the kernels list candidates only, so it is not tested again.)
+    if (d.alts.size() == 1 && !d.alts[0].gapped && !d.dev_pre && !d.dev_post) {
+        const AltSeq &a0 = d.alts[0];
+        size_t at = s;
+        if (!window_at(d, a0.window, content, clen, s)) {
+            if (cur->li >= n) return 0;
+            at = starts[cur->li];
+        }
+        *m0 = (uint32_t)at;
+        *m1 = end_of(a0, content, clen, at);
+        return a0.captures ? 2 : 1;
+    }
     // 1. the leftmost start among the plain alternatives: the subject start itself (nothing before it), else the first
     //    offset of the walk at which one of them matches
     bool any_plain = false, any_gapped = false;
