@@ -24,7 +24,9 @@ extern "C" int gscan_kernel_time(gscan_ctx *, double *, uint64_t *, int);
 // ITER x 1 KiB via buffer_load_dwordx4 issued up front) with a trivial reduction instead of the
 // scan.  What this reaches is the practical ceiling for "read every byte once" on this box.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <int ITER, bool NT>
+// NT: false = default cache policy, true = nontemporal; AUX >= 0 overrides with an explicit cache-policy operand
+// (gfx940+: bit 0 sc0, bit 1 nt, bit 4 sc1)
+template <int ITER, bool NT, int AUX = -1>
 __global__ __launch_bounds__(256) void k0_read_probe(const uint8_t *base, uint32_t n_tiles, uint32_t *sink)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -37,14 +39,14 @@ __global__ __launch_bounds__(256) void k0_read_probe(const uint8_t *base, uint32
         u32x4 buf[ITER];
         const int v0 = (int)(wave * ITER * 1024 + lane * 16);
 #pragma unroll
-        for (int k = 0; k < ITER; k++) buf[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + k * 1024, 0, NT ? 2 : 0));
+        for (int k = 0; k < ITER; k++) buf[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + k * 1024, 0, AUX >= 0 ? AUX : (NT ? 2 : 0)));
 #pragma unroll
         for (int k = 0; k < ITER; k++) acc ^= buf[k].x ^ buf[k].y ^ buf[k].z ^ buf[k].w;
     }
     if (acc == 0x9e3779b9u) sink[0] = acc; // never true on text; keeps the loads alive
 }
 
-template <int ITER, bool NT>
+template <int ITER, bool NT, int AUX = -1>
 static float probe(const uint8_t *arena, size_t total, uint32_t *sink, int bpc, int iters)
 {
     const uint32_t n_tiles = (uint32_t)(total / (4 * ITER * 1024));
@@ -55,7 +57,7 @@ static float probe(const uint8_t *arena, size_t total, uint32_t *sink, int bpc, 
     float best = 1e30f;
     for (int i = 0; i < iters + 1; i++) {
         (void)hipEventRecord(a, 0);
-        hipLaunchKernelGGL((k0_read_probe<ITER, NT>), dim3(grid), dim3(256), 0, 0, arena, n_tiles, sink);
+        hipLaunchKernelGGL((k0_read_probe<ITER, NT, AUX>), dim3(grid), dim3(256), 0, 0, arena, n_tiles, sink);
         (void)hipEventRecord(b, 0);
         (void)hipEventSynchronize(b);
         float ms;
@@ -126,6 +128,15 @@ int main(int argc, char **argv)
             printf("probe ITER8  nt   bpc %2d : %8.1f GB/s\n", bpc, total / probe<8, true>(arena, total, sink, bpc, iters) / 1e6);
             printf("probe ITER32 nt   bpc %2d : %8.1f GB/s\n", bpc, total / probe<32, true>(arena, total, sink, bpc, iters) / 1e6);
         }
+        // cache-policy operand of the loads (ITER 12, one workgroup per tile -- the scan kernels' shape)
+        printf("probe ITER12 aux 0 (default)    : %8.1f GB/s\n", total / probe<12, false, 0>(arena, total, sink, 0, iters) / 1e6);
+        printf("probe ITER12 aux 1 (sc0)        : %8.1f GB/s\n", total / probe<12, false, 1>(arena, total, sink, 0, iters) / 1e6);
+        printf("probe ITER12 aux 2 (nt)         : %8.1f GB/s\n", total / probe<12, false, 2>(arena, total, sink, 0, iters) / 1e6);
+        printf("probe ITER12 aux 3 (sc0 nt)     : %8.1f GB/s\n", total / probe<12, false, 3>(arena, total, sink, 0, iters) / 1e6);
+        printf("probe ITER12 aux 16 (sc1)       : %8.1f GB/s\n", total / probe<12, false, 16>(arena, total, sink, 0, iters) / 1e6);
+        printf("probe ITER12 aux 17 (sc0 sc1)   : %8.1f GB/s\n", total / probe<12, false, 17>(arena, total, sink, 0, iters) / 1e6);
+        printf("probe ITER12 aux 18 (nt sc1)    : %8.1f GB/s\n", total / probe<12, false, 18>(arena, total, sink, 0, iters) / 1e6);
+        printf("probe ITER12 aux 19 (sc0 nt sc1): %8.1f GB/s\n", total / probe<12, false, 19>(arena, total, sink, 0, iters) / 1e6);
         (void)hipFree(sink);
     }
 

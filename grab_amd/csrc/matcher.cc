@@ -135,6 +135,7 @@ struct Walk {
     size_t nt, ti;
     size_t x;      // next offset to look at
     bool in_group; // x - 1 was a device hit: x may belong to the same group without being listed
+    bool first0;   // offset 0 is still to be handed out (see the constructor)
 
     static constexpr size_t kEnd = SIZE_MAX;
 
@@ -142,10 +143,19 @@ struct Walk {
         : d(db), content(c), clen(cl), starts(st), n(nst), li(li0), tails(tl), nt(ntl), ti(0), x(from)
     {
         in_group = from > 0 && dev_hit(d, content, clen, from - 1);
+        // device windows with a leading context position start one byte before the offset they report: offset 0 can
+        // never be listed.  A walk that starts there has to look at it itself.
+        first0 = from == 0 && d.dev_pre;
     }
 
     size_t next()
     {
+        if (first0) {
+            first0 = false;
+            x = 1;
+            in_group = false; // offset 1, if it is a hit, has no listed predecessor: it is listed itself
+            return 0;
+        }
         for (;;) {
             if (in_group) {
                 if (x < clen && dev_hit(d, content, clen, x)) return x++;
@@ -220,7 +230,7 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
         cur->ntails = (uint32_t)std::min(tail_positions(d, clen, cur->tails, GSCAN_MAX_TAILS), (size_t)GSCAN_MAX_TAILS);
         cur->ready = 1;
     }
-    while (cur->li < n && starts[cur->li] <= s) cur->li++; // s only moves forward: the cursor is kept across calls
+    while (cur->li < n && starts[cur->li] < s) cur->li++; // first entry >= s; s only moves forward: the cursor is kept across calls
 
     // The common case -- one alternative, no context, no gap -- needs none of the machinery below: s itself if the
     // window matches there, else the first listed start after s.  (If s is no match, the next candidate after it begins
@@ -229,8 +239,10 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
         const AltSeq &a0 = d.alts[0];
         size_t at = s;
         if (!window_at(d, a0.window, content, clen, s)) {
-            if (cur->li >= n) return 0;
-            at = starts[cur->li];
+            size_t li = cur->li;
+            while (li < n && starts[li] <= s) li++;
+            if (li >= n) return 0;
+            at = starts[li];
         }
         *m0 = (uint32_t)at;
         *m1 = end_of(a0, content, clen, at);
@@ -265,10 +277,6 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
             const size_t plen = a.pwindow.size(), t = (size_t)s + plen;
             if (t >= clen) continue;
             Walk w(d, content, clen, starts, n, cur->li, cur->tails, cur->ntails, t);
-            // the cursor skipped entries <= s, but a hit may sit AT t == s when P is empty: the walk has to see it
-            if (plen == 0 && a.gap.test(content[t]) && rest_at(d, a, content, clen, t + 1)) {
-                if (pre_ok(a, content, s, true)) best = std::min(best, (size_t)s);
-            }
             for (size_t h = w.next(); h != Walk::kEnd; h = w.next()) {
                 if (h < t || !a.gap.test(content[h]) || !rest_at(d, a, content, clen, h + 1)) continue;
                 size_t r0 = h;

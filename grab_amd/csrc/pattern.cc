@@ -968,7 +968,23 @@ struct Resolver {
                 if (prev_word) s.pre_start = false;
                 break;
             }
-            default: alive = false; return true; // $ \\z in front of something: never
+            case A_MEOL: // (?m)$ in front of something: that something starts with a newline
+                if (!s.pwin.empty()) {
+                    s.pwin[0] = set_and(s.pwin[0], nl);
+                    if (s.pwin[0].count() == 0) {
+                        alive = false;
+                        return true;
+                    }
+                } else if (!(s.gap == nl)) {
+                    if (!s.gap.test('\n')) {
+                        alive = false;
+                        return true;
+                    }
+                    return fail("(?m)$ in front of a repeat that may or may not start with a newline");
+                }
+                break;
+            case A_EOL: return fail("$ before the end of an alternative");
+            default: alive = false; return true; // \\z in front of something: never
             }
         }
         s.p_asserts.clear();
@@ -1131,6 +1147,10 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             return 1;
         }
     }
+    // PCRE_INFO_MINLENGTH counts every branch, also those whose assertions can never hold (\\z followed by a byte ...):
+    // take it before such paths are dropped -- the reference's loop bound and file-skip rule use it (grab.cc:133,175)
+    size_t pcre_min = SIZE_MAX;
+    for (const Seq &s : seqs) pcre_min = std::min(pcre_min, s.win.size() + (s.gapped ? s.pwin.size() + 1 : 0));
     // assertions -> one byte of context at each end (or decided / narrowed / split on the spot)
     {
         Resolver rs;
@@ -1178,11 +1198,8 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     db.id = g_next_id.fetch_add(1);
     memset(&db.prog, 0, sizeof db.prog);
 
-    size_t minm = SIZE_MAX, total = 0;
-    for (const Seq &s : seqs) {
-        minm = std::min(minm, s.win.size() + (s.gapped ? s.pwin.size() + 1 : 0));
-        total += s.win.size() + s.pwin.size();
-    }
+    size_t minm = pcre_min, total = 0;
+    for (const Seq &s : seqs) total += s.win.size() + s.pwin.size();
     if (seqs.empty() || minm == 0) { // can match the empty string: PCRE_INFO_MINLENGTH == -1
         db.tier = GSCAN_TIER_NULL;
         db.minlen = -1;

@@ -1,0 +1,128 @@
+"""Grammar-based differential fuzz of the pattern compiler + host match rule against libpcre.
+
+Random patterns are drawn from the grammar the engine claims to take (byte classes, greedy / lazy / possessive repeats,
+alternation, plain / capturing / option-scoped groups, ^ $ \\b \\B \\A \\z \\Z, (?i) (?m) (?s)).  For every pattern PCRE
+accepts and the engine does not refuse, the product's chunk walk (grab_report_chunk -> gscan_next_match) -- fed with
+exactly what the kernels are specified to report for the text (device windows: tests/inputs.py:db_candidates) -- must
+print what the reference's loop prints; the oracle runs pcre_exec the way /root/reference/src/grab.cc:175-213 does, with
+ovector[3] and the subject restarted at every match.  minlen must equal PCRE_INFO_MINLENGTH.
+
+Seeds are fixed; the campaign that found the bugs pinned in REGRESSIONS ran a few hundred thousand patterns."""
+import ctypes as C
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from grab_amd import engine, filegrep
+from inputs import db_candidates
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import scan_oracle as so  # noqa: E402
+
+ATOMS = ["a", "b", "c", "x", " ", "\\n", ".", "0", "1", "[ab]", "[^a]", "[a-c]", "\\w", "\\d", "\\s", "\\W", "[b0 ]", "\\.", "[^\\n]", "A", "[x.]"]
+QUANTS = ["?", "*", "+", "{2}", "{1,2}", "{0,2}", "{2,}", "{1,3}", "??", "+?", "*?", "{1,2}?", "?+", "?"]
+
+
+def gen(rng):
+    def atom(d):
+        r = rng.random()
+        if r < 0.70 or d > 2:
+            return rng.choice(ATOMS)
+        if r < 0.85:
+            return "(?:" + alt(d + 1) + ")"
+        if r < 0.93:
+            return "(" + alt(d + 1) + ")"
+        return "(?i:" + alt(d + 1) + ")"
+
+    def piece(d):
+        a = atom(d)
+        return a if rng.random() < 0.55 else a + rng.choice(QUANTS)
+
+    def seq(d):
+        parts = []
+        for _ in range(rng.choice([1, 1, 2, 2, 3, 4])):
+            if rng.random() < 0.12:
+                parts.append(rng.choice(["\\b", "\\B", "^", "$", "\\A", "\\z", "\\Z"]))
+            parts.append(piece(d))
+        if rng.random() < 0.10:
+            parts.append(rng.choice(["\\b", "$", "\\B", "\\z"]))
+        return "".join(parts)
+
+    def alt(d):
+        return "|".join(seq(d) for _ in range(rng.choice([1, 1, 1, 2, 2, 3])))
+
+    p = alt(0)
+    if rng.random() < 0.25:
+        p = rng.choice(["(?i)", "(?m)", "(?s)", "(?im)", "(?ms)"]) + p
+    return p
+
+
+def ref_chunk(liboracle, pat, text, flags):
+    out = C.c_void_p()
+    n = C.c_size_t()
+    assert liboracle.oracle_scan_chunk(pat, b"", text, len(text), 0, flags, C.byref(out), C.byref(n)) == 0
+    r = C.string_at(out, n.value) if n.value else b""
+    liboracle.oracle_free(out)
+    return r
+
+
+def check(liboracle, pat, texts):
+    """None if the pattern is outside what is compared, else the number of texts compared (asserts on any difference)."""
+    pb = pat.encode("latin-1")
+    ml = C.c_int(-9)
+    if liboracle.oracle_minlen(pb, C.byref(ml)) != 0:
+        return None  # PCRE rejects it (FileGrep::prepare asks PCRE first and reports its error)
+    try:
+        db = engine.Database(pat)
+    except engine.Unsupported:
+        return None
+    assert db.minlen == ml.value, (pat, db.minlen, ml.value)
+    if db.minlen < 0:
+        return None  # can match "": every file is skipped (Q2)
+    for text in texts:
+        data = np.frombuffer(text, np.uint8)
+        starts = np.zeros(0, np.uint32) if db.info.tier == engine.TIER_ANCHORED else so.group_starts(db_candidates(db, data)).astype(np.uint32)
+        for f in (1 | 2, 1, 0):
+            want = ref_chunk(liboracle, pb, text, f) if ml.value <= len(text) else b""
+            got = filegrep.report_chunk(db, f, b"", data, 0, starts) if db.minlen <= len(text) else b""
+            assert got == want, (pat, text, f)
+    return len(texts)
+
+
+def make_texts(seed):
+    nrng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"abcxA01 .\n\nab  ", np.uint8)
+    return [alpha[nrng.integers(0, alpha.size, int(nrng.integers(1, 120)))].tobytes() for _ in range(14)] + \
+           [b"a", b"ab", b"\n", b"abcabc abc\nabc", b"aaaa", b"a.b a1b ab\n"]
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_random_patterns_match_pcre(seed, built, liboracle):
+    rng = random.Random(seed)
+    texts = make_texts(seed)
+    tested = 0
+    for _ in range(1500):
+        tested += check(liboracle, gen(rng), texts) is not None
+    assert tested > 300  # the grammar is wider than the engine's subset; a third of the draws are comparable
+
+
+# found by the campaign (each one printed something else than the reference before its fix)
+REGRESSIONS = [
+    (r"\W*?0|\b\n", b"  \n0a c A0x0c\n 0\nbaAacA11 c  a"),                      # a group of hits starting AT the restart position (list cursor)
+    (r"(?ms)1c{2}|b{2,}[ab]|$[^a]{2,}\n.", b"bb.bA1a.  .1a  a\n\nc  \nAA\nc...a.\n b bac x"),  # (?m)$ in front of a gapped path
+    (r"^\W*?\w[^a]", b"\nc \n\n ab1cca\na \n0aA c."),                            # a device window with context cannot report offset 0
+    (r"\Bc{0,2} *?[^a]\W", b" 1\nA\n1\n\n  b.b.bbc c..b.x  \naaxa"),
+    (r"\b0{1,2}|[b0 ]*0", b"b0\nxxcb\n0caAa01 \nxb0a0.aabbax  c00x\n"),
+    (r"(?m)\z |\d[^a]", b"1b 2  \n"),                                           # PCRE_INFO_MINLENGTH counts branches that can never match
+    (r"(?m)[a-c]{2,}.|x*?0{1,2}.", b"bb1ax01Axb\n\n A\nbx1b 0bbAc.0xbbxAa\n"),
+    (r"(?i:0?? *?\b[b0 ]?[^a])|x|0a", b".bx0a \nac 0ac0ac0  a\n 1ca.."),
+]
+
+
+@pytest.mark.parametrize("pattern,text", REGRESSIONS)
+def test_fuzz_regressions(pattern, text, built, liboracle):
+    assert check(liboracle, pattern, [text] + make_texts(7)) is not None
