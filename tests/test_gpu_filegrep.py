@@ -133,3 +133,39 @@ def test_literal_flag_S(built, tmp_path):
     assert rc == 0 and out == b"Match at offset 0\nMatch at offset 8\nMatch at offset 15\n"
     rc, out, _ = _run(built.bin_path(), ["-H", "-2", "-S", "-O", "-l", "(a.c)", "f"], str(tmp_path))
     assert rc == 0 and out == b"Match at offset 14\n"
+
+
+def test_random_patterns_cli_vs_oracle(built, oracle_built, tmp_path):
+    """End to end on the GPU with random patterns of the supported grammar (tests/test_fuzz.py's generator): whatever tier
+    the compiler picks, `grab` prints what the oracle (libpcre under the reference's loop) prints for the same file."""
+    import random
+
+    from test_fuzz import gen
+
+    rng = random.Random(2024)
+    nrng = np.random.default_rng(2024)
+    alpha = np.frombuffer(b"abcxA01 .\n\nab  ", np.uint8)
+    data = alpha[nrng.integers(0, alpha.size, 300_000)]
+    data[1000:1003] = np.frombuffer(b"abc", np.uint8)
+    p = tmp_path / "f"
+    data.tofile(str(p))
+    done = 0
+    for _ in range(400):
+        pat = gen(rng)
+        try:
+            db = engine.Database(pat)
+        except ValueError:
+            continue
+        if db.minlen < 0:
+            continue
+        flags = [["-O", "-l"], ["-O"], []][done % 3]
+        orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), flags + [pat, "f"], str(tmp_path))
+        if orc != 0:
+            continue  # libpcre rejects the pattern (the product reports the same error; covered elsewhere)
+        rc, out, err = _run(built.bin_path(), flags + [pat, "f"], str(tmp_path))
+        assert rc == 0, (pat, err)
+        assert out == oout, (pat, flags, len(out), len(oout))
+        done += 1
+        if done == 45:
+            break
+    assert done == 45
