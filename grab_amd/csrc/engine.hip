@@ -304,6 +304,12 @@ struct Slot {
     size_t h_desc_cap = 0;
     uint32_t *h_spec = nullptr; // pinned, kShards rows of kSpecPer
     std::vector<uint32_t> raw, sorted;
+    // line extents (k_lines): 3 words per record, parallel to the records
+    uint32_t *d_ext = nullptr;
+    size_t ext_cap = 0;          // records
+    uint32_t *h_ext_spec = nullptr; // pinned, kShards rows of kSpecPer * 3
+    std::vector<uint32_t> raw_ext, sorted_ext;
+    bool has_ext = false;
     const void *ext = nullptr;  // caller's buffer this chunk was copied from (gscan_wait hands it back as *content)
     void *ext_reg = nullptr;    // ... registered with the runtime for direct DMA until the scan is done
     PinBlock *blk = nullptr; // pool block serving as this slot's pinned buffer (acquires of <= kBlock bytes)
@@ -348,6 +354,8 @@ struct gscan_ctx {
     int variant = 6;
     int blocks_per_cu = 0;
     size_t register_min = 1u << 20; // caller buffers of at least this many bytes are registered and DMA'd in place
+    bool line_extents = false;      // run k_lines after the scan when the pattern allows it ("line_extents" option)
+    const Slot *last_waited = nullptr;
     // device-resident path
     size_t dev_cap_req = 0;
     uint32_t *dv_recs = nullptr;
@@ -533,6 +541,20 @@ int slot_launch(gscan_ctx *c, Slot &s)
     gscan::fill_program(a, db.prog);
     if (s.n_tiles) HIPCHK(c, gscan::launch_scan(db.tier, c->variant, a, grid_for(c, db, s.n_tiles), c->compute));
     if (s.n_tiles && gscan::scan_needs_settle(db.tier, db.prog)) HIPCHK(c, gscan::launch_settle(a, tile_bytes, c->compute));
+    s.has_ext = c->line_extents && db.prog.lines_ok && s.n_tiles;
+    if (s.has_ext) {
+        if (s.ext_cap < s.rec_cap) {
+            if (s.d_ext) hipFree(s.d_ext);
+            s.d_ext = nullptr;
+            s.ext_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&s.d_ext, s.rec_cap * 12));
+            s.ext_cap = s.rec_cap;
+        }
+        if (!s.h_ext_spec) HIPCHK(c, hipHostMalloc((void **)&s.h_ext_spec, kSpecRecs * 12, hipHostMallocDefault));
+        HIPCHK(c, gscan::launch_lines(a, tile_bytes, s.d_ext, c->compute));
+        HIPCHK(c, hipMemcpy2DAsync(s.h_ext_spec, kSpecPer * 12, s.d_ext, (size_t)a.cap_shard * 12, kSpecPer * 12, gscan::kShards,
+                                   hipMemcpyDeviceToHost, c->compute));
+    }
     HIPCHK(c, hipMemcpyAsync(s.h_counter, s.d_counter, kCounterWords * 4, hipMemcpyDeviceToHost, c->compute));
     if (s.n_tiles)
         HIPCHK(c, hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)s.n_tiles * 8, hipMemcpyDeviceToHost, c->compute));
@@ -549,6 +571,8 @@ void free_slot(gscan_ctx *c, Slot &s)
     if (s.blk && c->ingest) c->ingest->give_slot_block(s.blk); // back to the process-wide cache
     if (s.d_tiles) hipFree(s.d_tiles);
     if (s.h_tiles) hipHostFree(s.h_tiles);
+    if (s.d_ext) hipFree(s.d_ext);
+    if (s.h_ext_spec) hipHostFree(s.h_ext_spec);
     if (s.pinned) hipHostFree(s.pinned);
     if (s.d_text) hipFree(s.d_text);
     if (s.d_recs) hipFree(s.d_recs);
@@ -601,6 +625,7 @@ int gscan_db_info(const gscan_db *db, gscan_info *info)
     info->is_literal = (int)d.prog.is_literal;
     info->n_alts = (int)d.alts.size();
     info->has_context = (d.dev_pre ? 1 : 0) | (d.dev_post ? 2 : 0);
+    info->lines_ok = (int)d.prog.lines_ok;
     return GSCAN_OK;
 }
 
@@ -955,6 +980,15 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
                 HIPCHK(c, hipMemcpy(s->raw.data() + k * cap_shard, s->d_recs + k * cap_shard, (size_t)s->h_counter[k] * 4,
                                     hipMemcpyDeviceToHost));
     }
+    if (s->has_ext && !spec_ok) {
+        s->raw_ext.resize(s->rec_cap * 3);
+        for (size_t k = 0; k < K; k++)
+            if (s->h_counter[k])
+                HIPCHK(c, hipMemcpy(s->raw_ext.data() + k * cap_shard * 3, s->d_ext + k * cap_shard * 3, (size_t)s->h_counter[k] * 12,
+                                    hipMemcpyDeviceToHost));
+    }
+    s->sorted_ext.clear();
+    if (s->has_ext) s->sorted_ext.reserve(total * 3);
     s->sorted.clear();
     s->sorted.reserve(total);
     const bool multi = !s->segs.empty();
@@ -969,6 +1003,10 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
         size_t base = (size_t)(d >> 32);
         if (!cnt) continue;
         const uint32_t *src = spec_ok ? s->h_spec + (base / cap_shard) * kSpecPer + base % cap_shard : s->raw.data() + base;
+        if (s->has_ext) { // (patterns that take the line pass never need the second K3 pass: struck == 0)
+            const uint32_t *ex = spec_ok ? s->h_ext_spec + ((base / cap_shard) * kSpecPer + base % cap_shard) * 3 : s->raw_ext.data() + base * 3;
+            s->sorted_ext.insert(s->sorted_ext.end(), ex, ex + (size_t)cnt * 3);
+        }
         if (struck == 0) {
             s->sorted.insert(s->sorted.end(), src, src + cnt);
         } else {
@@ -983,8 +1021,15 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     *seg_first = s->seg_first.data();
     *nseg = ns;
     if (content) *content = s->no_content ? nullptr : s->ext;
+    c->last_waited = s;
     s->state = FREE;
     return GSCAN_OK;
+}
+
+const uint32_t *gscan_last_ext(const gscan_ctx *c)
+{
+    if (!c || !c->last_waited || !c->last_waited->has_ext) return nullptr;
+    return c->last_waited->sorted_ext.data();
 }
 
 int gscan_wait(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, size_t *n, const void **content)
@@ -1015,6 +1060,10 @@ int gscan_set_option(gscan_ctx *c, const char *name, long value)
     if (!strcmp(name, "register_min")) { // 0 = register everything; a huge value = always stage through pinned memory
         if (value < 0) return GSCAN_EINVAL;
         c->register_min = (size_t)value;
+        return GSCAN_OK;
+    }
+    if (!strcmp(name, "line_extents")) {
+        c->line_extents = value != 0;
         return GSCAN_OK;
     }
     if (!strcmp(name, "blocks_per_cu")) {

@@ -71,7 +71,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 //   :211      -s stops after one match
 // ------------------------------------------------------------------------------------
 void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const char *path, const char *content,
-                       size_t clen, long long off, const uint32_t *starts, size_t nstarts, std::string &out)
+                       size_t clen, long long off, const uint32_t *starts, size_t nstarts, std::string &out, const uint32_t *ext)
 {
     if (minlen < 0) return;
     gscan_cursor cur;
@@ -81,14 +81,7 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
     char line[48];
     static const char kHead[] = "Match at offset ";
     const size_t plen = (flags & GRAB_PREFIX) ? strlen(path) : 0;
-    size_t s = 0;
-    while (s + (size_t)minlen < clen) {
-        // rc = pcre_exec(d_pcreh, d_extra, start, end - start, 0, 0, ovector, 3)            (grab.cc:178)
-        uint32_t b0 = 0, b1 = 0;
-        const int rc = gscan_next_match(db, content, clen, starts, nstarts, &cur, (uint32_t)s, &b0, &b1);
-        if (rc != 1) break; // no match -- or one that sets a capturing group: 0 with ovector[3], same exit (grab.cc:179)
-        const size_t m0 = b0, m1 = b1;
-
+    auto put_head = [&](size_t m0) { // "path:" and "Match at offset N\n" (grab.cc:182-186)
         if (flags & GRAB_PREFIX) {
             out.append(path, plen);
             out += ':';
@@ -105,6 +98,39 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
             memcpy(q, kHead, sizeof kHead - 1);
             out.append(q, (size_t)(line + sizeof line - q));
         }
+    };
+    size_t s = 0;
+    if (ext && !(flags & GRAB_NOLINE)) {
+        // The device already decided which candidates the loop prints and where their lines begin and end (k_lines):
+        // nothing to search here, only to copy.  It stops at the first record that needs the loop itself.
+        size_t i = 0;
+        for (; i < nstarts; i++) {
+            const uint32_t m1 = ext[3 * i], lb = ext[3 * i + 1], le = ext[3 * i + 2];
+            if (m1 == 0) continue;
+            if (lb == 0xffffffffu) break;
+            if (!(s + (size_t)minlen < clen)) return; // grab.cc:175
+            const size_t m0 = starts[i];
+            put_head(m0);
+            out.append(content + lb, m0 - lb);
+            if (flags & GRAB_COLOR) out += kInvOn;
+            out.append(content + m0, m1 - m0);
+            if (flags & GRAB_COLOR) out += kInvOff;
+            out.append(content + m1, le - m1);
+            out += '\n';
+            s = le; // grab.cc:209
+            if (flags & GRAB_SINGLE) return;
+        }
+        if (i == nstarts) return; // whatever follows the last listed start belongs to its group, i.e. to its line
+        // fall through: the reference's loop from s
+    }
+    while (s + (size_t)minlen < clen) {
+        // rc = pcre_exec(d_pcreh, d_extra, start, end - start, 0, 0, ovector, 3)            (grab.cc:178)
+        uint32_t b0 = 0, b1 = 0;
+        const int rc = gscan_next_match(db, content, clen, starts, nstarts, &cur, (uint32_t)s, &b0, &b1);
+        if (rc != 1) break; // no match -- or one that sets a capturing group: 0 with ovector[3], same exit (grab.cc:179)
+        const size_t m0 = b0, m1 = b1;
+
+        put_head(m0);
 
         size_t tail = 0;
         if (!(flags & GRAB_NOLINE)) {
@@ -219,6 +245,7 @@ int FileGrep::prepare(const std::string &regex)
         gscan_db_info(db_, &info);
         anchored_ = info.tier == GSCAN_TIER_ANCHORED;
         context_ = info.has_context != 0;
+        lines_ = info.lines_ok != 0;
     }
 
     if (ctx_) gscan_close(ctx_);
@@ -228,6 +255,8 @@ int FileGrep::prepare(const std::string &regex)
         err_ = "FileGrep::prepare::gscan_open: no usable HIP device " + std::to_string(device_) + " (rc " + std::to_string(orc) + ")";
         return -1;
     }
+    // line-printing modes: let the device pick the printed matches and find their line extents where the pattern allows it
+    if (lines_ && !noline_ && !getenv("GRAB_NO_LINE_PASS")) gscan_set_option(ctx_, "line_extents", 1);
     return 0;
 }
 
@@ -321,7 +350,8 @@ int FileGrep::retire_oldest(bool print)
                 err_ = std::string("FileGrep::find::mmap: ") + strerror(errno);
                 status = -1;
             } else {
-                grab_report_chunk(db_, minlen_, rflags, f.path.c_str(), (const char *)map, job.len, (long long)job.off, starts, first[nseg], text);
+                grab_report_chunk(db_, minlen_, rflags, f.path.c_str(), (const char *)map, job.len, (long long)job.off, starts, first[nseg], text,
+                                  gscan_last_ext(ctx_));
                 munmap(map, job.len); // grab.cc:215
                 if (!text.empty()) {
                     emit(text);
@@ -332,8 +362,9 @@ int FileGrep::retire_oldest(bool print)
     } else { // a batch: every segment is a whole small file, i.e. its one and only chunk
         for (size_t i = 0; i < job.files.size(); i++) {
             if (first[i + 1] == first[i] && !context_) continue;
+            const uint32_t *ext = gscan_last_ext(ctx_);
             grab_report_chunk(db_, minlen_, rflags, job.files[i]->path.c_str(), (const char *)bytes + job.segs[i].offset, job.segs[i].len, 0,
-                              starts + first[i], first[i + 1] - first[i], text);
+                              starts + first[i], first[i + 1] - first[i], text, ext ? ext + 3 * first[i] : nullptr);
         }
         if (!text.empty()) emit(text); // one lock per batch; per-file output stays contiguous and in order
     }

@@ -77,6 +77,7 @@ private:
     bool recursive_ = false, show_path_ = false, literal_ = false;
     bool anchored_ = false; // the pattern can only match at a restart position / chunk end: nothing goes to the GPU
     bool context_ = false;  // the pattern looks at the byte before / after its match
+    bool lines_ = false;    // the device's line-extent pass applies to the pattern
     uid_t uid_;
     int device_ = 0, out_fd_ = 1;
     // GRAB_TIMING=1 in the environment: per-instance wall-clock split, printed to stderr by the destructor
@@ -98,4 +99,4 @@ private:
 // ascending candidate list instead of repeated pcre_exec calls.  Pure host function.
 void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const char *path,
                        const char *content, size_t clen, long long off, const uint32_t *starts,
-                       size_t nstarts, std::string &out);
+                       size_t nstarts, std::string &out, const uint32_t *ext = nullptr);

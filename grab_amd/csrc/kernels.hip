@@ -771,6 +771,114 @@ __global__ __launch_bounds__(256) void k3_settle(ScanArgs a, const TileDesc *__r
     if (struck) atomicAdd(a.counter + kShards + 1, struck);
 }
 
+// ------------------------------------------------------------------------------------
+// Line extents and orbit selection on the device, for the reference's line-printing modes
+// (/root/reference/src/grab.cc:188-209: print the line around the match, then restart at the END OF THAT LINE).
+// Applies to patterns with one plain alternative none of whose classes contains a newline (DevProgram::lines_ok): a
+// match then lies inside one line, the restart position after a printed match is that line's newline, and the matches
+// that get printed are exactly THE FIRST CANDIDATE OF EVERY LINE -- a per-line question.  (A candidate that is first in
+// its line heads a group of consecutive candidates, so it is in the record list.)
+// One thread per tile walks the tile's records in order and writes, parallel to the records, ext[i] = {m1, lb, le}:
+//   m1 == 0           the record is not printed (an earlier candidate sits in the same line)
+//   lb == kLineAsk    "ask the host": something here needs the reference's loop itself -- the 511-byte caps of
+//                     grab.cc:173 (a line that runs on past the printed context may print again), a line start or a
+//                     tail further away than this pass looks.  The host falls back to its walk from there on.
+//   else              print bytes [lb, m0) + match [m0, m1) + [m1, le); the loop restarts at le.
+// ------------------------------------------------------------------------------------
+constexpr uint32_t kLineAsk = 0xffffffffu;
+constexpr uint32_t kLineBack = 4096; // how far a line start / a tail end is searched before the host is asked
+
+__global__ __launch_bounds__(256) void k_lines(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t tile_bytes, uint32_t *__restrict__ ext)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= a.n_tiles) return;
+    const unsigned long long d = a.desc[t];
+    const uint32_t cnt = (uint32_t)d;
+    if (cnt == 0 || a.counter[kShards] != 0) return; // (overflow: the host rescans with a bigger buffer and this pass runs again)
+    const uint32_t base = (uint32_t)(d >> 32);
+    uint64_t seg_off;
+    uint32_t slen, tile_off;
+    if (tiles) {
+        seg_off = tiles[t].seg_off;
+        slen = tiles[t].seg_len;
+        tile_off = tiles[t].tile_off;
+    } else {
+        seg_off = a.seg0_off;
+        slen = a.seg0_len;
+        tile_off = t * tile_bytes;
+    }
+    const uint8_t *seg = a.base + seg_off;
+    const DevProgram *pg = a.prog;
+    const uint32_t m = a.m, tail_extra = pg->tail_extra;
+    uint32_t busy_until = 0; // candidates below this offset share a line with a match this tile already printed
+    for (uint32_t i = 0; i < cnt; i++) {
+        const uint32_t p = a.recs[base + i];
+        uint32_t *e = ext + 3ull * (base + i);
+        if (p < busy_until) {
+            e[0] = 0;
+            continue;
+        }
+        // start of p's line
+        uint32_t ls = p, steps = 0;
+        while (ls > 0 && seg[ls - 1] != '\n' && steps < kLineBack) {
+            ls--;
+            steps++;
+        }
+        if (ls > 0 && seg[ls - 1] != '\n') {
+            e[0] = 1;
+            e[1] = kLineAsk;
+            continue;
+        }
+        // an earlier candidate in [ls, p)?  In this tile: the previous record.  Before it: the last record of the nearest
+        // earlier tile of this segment that has one (tiles of a segment are consecutive, t - k is tile_off / tile_bytes - k).
+        bool first = true;
+        if (i > 0) {
+            first = a.recs[base + i - 1] < ls;
+        } else if (ls < tile_off) {
+            uint32_t u = t, uoff = tile_off;
+            while (uoff > ls) { // tile u - 1 covers [uoff - tile_bytes, uoff)
+                u--;
+                uoff -= tile_bytes;
+                const unsigned long long du = a.desc[u];
+                if ((uint32_t)du) {
+                    first = a.recs[(uint32_t)(du >> 32) + (uint32_t)du - 1u] < ls;
+                    break;
+                }
+            }
+        }
+        if (!first) {
+            e[0] = 0;
+            continue;
+        }
+        // the match: window + greedy tail
+        uint32_t m1 = p + m, extra = 0;
+        bool ask = false;
+        while (m1 < slen && extra < tail_extra) {
+            const uint32_t b = seg[m1];
+            if (!((pg->tail_bits[b >> 5] >> (b & 31)) & 1u)) break;
+            m1++;
+            extra++;
+            if (extra >= kLineBack && extra < tail_extra) {
+                ask = true;
+                break;
+            }
+        }
+        // the rest of the line, at most 511 bytes of it (grab.cc:173,194-196)
+        uint32_t le = m1;
+        while (le < slen && seg[le] != '\n' && le - m1 < 511u) le++;
+        if (le < slen && seg[le] != '\n') ask = true; // the line runs on: what follows may print again
+        if (ask) {
+            e[0] = 1;
+            e[1] = kLineAsk;
+            continue;
+        }
+        e[0] = m1;
+        e[1] = p - ls > 511u ? p - 511u : ls; // at most 511 bytes in front of the match (grab.cc:173,190-193)
+        e[2] = le;
+        busy_until = le;
+    }
+}
+
 } // namespace
 
 // ---- host-callable launchers (engine.hip) ----
@@ -851,6 +959,13 @@ hipError_t launch_settle(const ScanArgs &a, uint32_t tile_bytes, hipStream_t st)
 {
     if (a.n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k3_settle, dim3((a.n_tiles + 255u) / 256u), dim3(256), 0, st, a, a.tiles, tile_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_lines(const ScanArgs &a, uint32_t tile_bytes, uint32_t *ext, hipStream_t st)
+{
+    if (a.n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lines, dim3((a.n_tiles + 255u) / 256u), dim3(256), 0, st, a, a.tiles, tile_bytes, ext);
     return hipGetLastError();
 }
 

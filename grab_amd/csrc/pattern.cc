@@ -1384,6 +1384,18 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         }
     }
 
+    // The line-extent pass: a match then lies inside one line, and "which matches get printed" is decided line by line.
+    if (db.alts.size() == 1 && !db.alts[0].gapped && !db.dev_pre && !db.dev_post) {
+        const AltSeq &a0 = db.alts[0];
+        bool ok = !(a0.has_tail && a0.tail.test('\n')) && !a0.captures; // (a match that sets a capturing group ends the chunk: grab.cc:171,179)
+        for (uint8_t c : a0.window) ok = ok && !db.classes[c].test('\n');
+        pg.lines_ok = ok;
+        if (a0.has_tail) {
+            memcpy(pg.tail_bits, a0.tail.w, 32);
+            pg.tail_extra = a0.tail_extra;
+        }
+    }
+
     if (db.alts.size() > 1) { // several alternatives: the bucket filter is the one kernel that takes them
         db.tier = GSCAN_TIER_BUCKET;
         return 0;

@@ -105,6 +105,10 @@ struct DevProgram {
     uint8_t k3_blen[kK3Buckets];         // K3 confirm: window length of the bucket's alternative when k3_confirm_exact
     uint32_t k3_confirm_exact;           // every alternative has its own bucket and fits kK3Confirm positions: the tables ARE the pattern
     uint32_t report_shift;               // 1 when the device windows start one byte before the match (context position)
+    // line-extent pass (k_lines): the greedy repeat at the end of alternative 0, and whether the pass applies at all
+    uint32_t tail_bits[8];
+    uint32_t tail_extra;                 // 0: no tail
+    uint32_t lines_ok;                   // one plain alternative, no context, and no class of it contains a newline
 };
 
 // One alternative: a fixed class window + an optional variable repeat of one class at its end.

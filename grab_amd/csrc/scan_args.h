@@ -49,5 +49,8 @@ void fill_program(ScanArgs &a, const DevProgram &pg);
 hipError_t launch_scan(int tier, int variant, const ScanArgs &a, uint32_t grid, hipStream_t st);
 bool scan_needs_settle(int tier, const DevProgram &pg);
 hipError_t launch_settle(const ScanArgs &a, uint32_t tile_bytes, hipStream_t st);
+// line extents + orbit selection for the line-printing modes: ext[3 * record index] = {m1, lb, le} (kernels.hip, k_lines)
+hipError_t launch_lines(const ScanArgs &a, uint32_t tile_bytes, uint32_t *ext, hipStream_t st);
+constexpr uint32_t kLineAskHost = 0xffffffffu;
 
 } // namespace gscan

@@ -21,7 +21,7 @@ SLOTS = 2
 SYMBOLS = [
     "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_match_info", "gscan_next_match", "gscan_tail_positions", "gscan_db_dev_window",
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
-    "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs",
+    "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs", "gscan_last_ext",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
     "gscan_set_option", "gscan_kernel_time",
 ]
@@ -30,7 +30,7 @@ SYMBOLS = [
 class Info(C.Structure):
     _fields_ = [("tier", C.c_int), ("minlen", C.c_int), ("n_classes", C.c_int), ("has_tail", C.c_int),
                 ("tail_extra", C.c_uint32), ("anchor_off", C.c_int), ("anchor_len", C.c_int),
-                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int)]
+                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int), ("lines_ok", C.c_int)]
 
 
 class Seg(C.Structure):
@@ -86,6 +86,8 @@ def lib():
         L.gscan_wait.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint32)),
                                  C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         L.gscan_block_size.restype = C.c_size_t
+        L.gscan_last_ext.argtypes = [C.c_void_p]
+        L.gscan_last_ext.restype = C.POINTER(C.c_uint32)
         L.gscan_submit_segs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Seg), C.c_size_t, C.c_uint64]
         L.gscan_submit_fd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_size_t, C.c_uint64]
         L.gscan_wait_segs.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint32)),
@@ -229,6 +231,13 @@ class Context:
         """Candidate group starts of one chunk (ascending uint32; see gscan_wait in include/gscan.h)."""
         self.submit(db, data)
         return self.wait()[1]
+
+    def last_ext(self, n):
+        """The line extents {m1, lb, le} of the n records the last wait() returned (option "line_extents"), or None."""
+        p = lib().gscan_last_ext(self._h)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(p, shape=(n * 3,)).copy().reshape(n, 3) if n else np.zeros((0, 3), np.uint32)
 
     def submit_fd(self, db, fd, offset, length, tag=0):
         """A range of an open file, read by the engine's reader threads straight into pinned blocks (gscan_submit_fd)."""

@@ -76,6 +76,7 @@ typedef struct gscan_info {
     int is_literal;      /* 1 if every window position is a single byte value */
     int n_alts;          /* alternatives the pattern unfolds into (priority order); the fields above describe alternative 0 */
     int has_context;     /* bit 0: some alternative looks at the byte BEFORE its match (\b ^ ...), bit 1: at the byte AFTER it */
+    int lines_ok;        /* 1 if the line-extent pass applies (gscan_set_option "line_extents"): one plain alternative, no newline in its classes */
 } gscan_info;
 
 /* one scan unit inside a device-resident arena (gscan_scan_device) */
@@ -187,6 +188,18 @@ int gscan_submit_fd(gscan_ctx *ctx, const gscan_db *db, int fd, long long file_o
  * gscan_submit* after this call reuses the slot. */
 int gscan_wait(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, size_t *n,
                const void **content);
+/*
+ * Line extents and orbit selection on the device, for the reference's line-printing modes (src/grab.cc:188-209: print
+ * the line around the match, restart at the end of that line).  With gscan_set_option(ctx, "line_extents", 1) and a
+ * pattern whose gscan_info.lines_ok is set, every chunk also carries ext[3*i .. 3*i+2] = {m1, lb, le} for starts[i]:
+ *   m1 == 0            starts[i] is not printed (an earlier candidate sits in the same line);
+ *   lb == 0xffffffff   ask the host: from here on the reference's loop itself is needed (gscan_next_match) -- a line
+ *                      that runs on past the 511 bytes of printed context, a line start or tail too far away;
+ *   else               print [lb, starts[i]) + the match [starts[i], m1) + [m1, le) + '\n'; the loop restarts at le.
+ * gscan_last_ext returns the array for the chunk the last gscan_wait / gscan_wait_segs call handed out (parallel to its
+ * starts, same lifetime), or NULL if that chunk has none.
+ */
+const uint32_t *gscan_last_ext(const gscan_ctx *ctx);
 /* the same for a chunk of several segments: the records of segment i are
  * starts[seg_first[i] .. seg_first[i+1]), segment-relative; seg_first has *nseg + 1 entries
  * (a single-segment chunk reports *nseg = 1). */
@@ -209,7 +222,7 @@ long gscan_dev_fetch(gscan_ctx *ctx, const gscan_dev_result *res, size_t seg, ui
 /* record-buffer capacity (records, split into 8 equal shard regions) for device scans;
  * default = arena bytes / 16 */
 int gscan_set_capacity(gscan_ctx *ctx, size_t n_records);
-/* tuning knobs for A/B runs: name in {"variant","blocks_per_cu","register_min"}; see DESIGN.md */
+/* tuning knobs for A/B runs: name in {"variant","blocks_per_cu","register_min","line_extents"}; see DESIGN.md */
 int gscan_set_option(gscan_ctx *ctx, const char *name, long value);
 /* scan-kernel time of the gscan_scan_device launches since the last reset: HIP events recorded
  * around each launch on the launch's own stream.  Waits for the launches to finish. */

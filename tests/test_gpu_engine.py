@@ -331,3 +331,69 @@ def test_shared_buckets_second_pass(ctx):
     total, overflow = ctx.dev_sync(res)
     fetched = ctx.dev_fetch(res, 0)
     assert not overflow and total == len(fetched) and same(fetched, want)
+
+
+def _orbit_lines(pattern, data):
+    """The reference's loop in line-printing mode (grab.cc:171-213) as (m0, m1, lb, le) tuples: scan_oracle's restatement, unformatted."""
+    import re
+    rx = re.compile(pattern.encode())
+    minlen = so.py_minlen(pattern)
+    content = data.tobytes()
+    clen = len(content)
+    view = memoryview(content)
+    out, s = [], 0
+    while s + minlen < clen:
+        m = rx.search(view[s:])
+        if m is None:
+            break
+        b, e = s + m.start(), s + m.end()
+        lo = b
+        while lo - 1 >= s and content[lo - 1] != 0x0A and b - lo < so.CONTEXT:
+            lo -= 1
+        a = 0
+        while e + a < clen and content[e + a] != 0x0A and a < so.CONTEXT:
+            a += 1
+        out.append((b, e, lo, e + a))
+        s = e + a
+    return out
+
+
+def test_line_extents_on_device(ctx):
+    """k_lines: for patterns whose classes exclude newline the device marks the records the reference's
+    line-printing loop prints and gives their line extents; where it answers "ask the host" (lines running past the
+    511-byte caps) everything before that point must still be exact."""
+    data = sample(900_001, 41)
+    data[200_000:203_000] = ord("q")                      # a 3000-byte line: the caps of grab.cc:173 come into play
+    data[200_100:200_118] = np.frombuffer(b"foobardoesnotexist", np.uint8)
+    data[201_500:201_518] = np.frombuffer(b"foobardoesnotexist", np.uint8)
+    data[500_000:500_050] = ord("\n")                     # empty lines
+    ctx.set_option("line_extents", 1)
+    try:
+        for pattern in ["foobardoesnotexist", "foo", "[A-Za-z_][A-Za-z0-9_]{15,}", "[0-9A-F]{6}[a-z]", "e+", "[a-z]{2,5}"]:
+            db = engine.Database(pattern)
+            assert db.info.lines_ok
+            for variant in (1, 6):
+                ctx.set_option("variant", variant)
+                starts = ctx.scan(db, data)
+                ext = ctx.last_ext(len(starts))
+                assert ext is not None and ext.shape == (len(starts), 3)
+                want = _orbit_lines(pattern, data)
+                got = []
+                asked = False
+                for p, (m1, lb, le) in zip(starts.tolist(), ext.tolist()):
+                    if m1 == 0:
+                        continue
+                    if lb == 0xFFFFFFFF:
+                        asked = True
+                        break
+                    got.append((p, m1, lb, le))
+                assert got == want[:len(got)], (pattern, variant)
+                if not asked:
+                    assert len(got) == len(want), (pattern, variant)
+                else:
+                    assert len(got) >= sum(1 for w in want if w[0] < 199_000)  # nothing before the long line at 200000 needs the host
+        for pattern in ["fo[^x]", "(foo)", r"\bfoo", "foo|bar", "a+b"]:  # newline in a class / capture / context / several alternatives
+            assert not engine.Database(pattern).info.lines_ok
+    finally:
+        ctx.set_option("line_extents", 0)
+        ctx.set_option("variant", 6)

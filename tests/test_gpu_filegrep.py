@@ -169,3 +169,30 @@ def test_random_patterns_cli_vs_oracle(built, oracle_built, tmp_path):
         if done == 45:
             break
     assert done == 45
+
+
+def test_line_pass_equals_host_walk(built, oracle_built, tmp_path):
+    """Line-printing modes with and without the device's line pass (GRAB_NO_LINE_PASS=1 = the host's walk only) print the
+    same bytes, and both equal the oracle: long lines (511-byte caps), empty lines, dense matches, several chunks, batches."""
+    rng = np.random.default_rng(9)
+    buf = synth.text(70 << 20, 11)
+    buf[1_000_000:1_004_000] = ord("z")                   # one 4000-byte line with two needles in it
+    buf[1_000_700:1_000_718] = np.frombuffer(b"foobardoesnotexist", np.uint8)
+    buf[1_002_900:1_002_918] = np.frombuffer(b"foobardoesnotexist", np.uint8)
+    buf[(32 << 20) - 5000:(32 << 20) + 3000] = ord("k")   # a long line across the first 32 MiB chunk boundary
+    buf[(32 << 20) - 10:(32 << 20) + 8] = np.frombuffer(b"foobardoesnotexist", np.uint8)
+    synth.plant(buf[2_000_000:], b"foobardoesnotexist", 200, 3, gap=300)
+    (tmp_path / "d").mkdir()
+    buf.tofile(str(tmp_path / "d" / "big"))
+    for i in range(40):                                   # small files: the batched path
+        n = int(rng.integers(1, 200_000))
+        synth.text(n, 500 + i).tofile(str(tmp_path / "d" / ("s%02d" % i)))
+    for pattern in ["foobardoesnotexist", "[A-Za-z_][A-Za-z0-9_]{15,}"]:
+        for flags in (["-r", "-O"], ["-r"], ["-L", "-L", "-L", "-L", "-L", "-r", "-O"], ["-r", "-s"]):
+            argv = flags + [pattern, "d"]
+            rc, out, err = _run(built.bin_path(), argv, str(tmp_path))
+            r = subprocess.run([built.bin_path()] + argv, cwd=str(tmp_path), capture_output=True, env=dict(os.environ, GRAB_NO_LINE_PASS="1"))
+            orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), argv, str(tmp_path))
+            assert rc == r.returncode == orc == 0, err
+            assert out == r.stdout, (pattern, flags)
+            assert out == oout, (pattern, flags)
