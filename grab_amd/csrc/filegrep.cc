@@ -255,8 +255,10 @@ int FileGrep::prepare(const std::string &regex)
         err_ = "FileGrep::prepare::gscan_open: no usable HIP device " + std::to_string(device_) + " (rc " + std::to_string(orc) + ")";
         return -1;
     }
-    // line-printing modes: let the device pick the printed matches and find their line extents where the pattern allows it
-    if (lines_ && !noline_ && !getenv("GRAB_NO_LINE_PASS")) gscan_set_option(ctx_, "line_extents", 1);
+    // Line-printing modes: the device can pick the printed matches and find their line extents where the pattern allows it
+    // (k_lines).  Exact, but measured to buy nothing end to end -- the host's share of a printed line is
+    // copying it, not finding it -- so it is opt-in: GRAB_LINE_PASS=1.
+    if (lines_ && !noline_ && getenv("GRAB_LINE_PASS")) gscan_set_option(ctx_, "line_extents", 1);
     return 0;
 }
 
@@ -337,7 +339,8 @@ int FileGrep::retire_oldest(bool print)
     }
     if (!print) return 0;
     const unsigned rflags = report_flags();
-    std::string text;
+    std::string &text = report_buf_; // kept across jobs: dense outputs are tens of MB per window, no point in growing it anew each time
+    text.clear();
     int status = 0;
     if (job.files.empty()) { // one window of a big file
         FileRef &f = *job.file;
@@ -345,7 +348,7 @@ int FileGrep::retire_oldest(bool print)
         // and the file's bytes are never touched by the host.  Not so for patterns with context (\b ^ $ ...): a match
         // at offset 0 or at the very end of the window is the host's to find
         if (!f.done && (first[nseg] > 0 || context_)) {
-            void *map = mmap(nullptr, job.len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, f.fd, job.off); // grab.cc:161
+            void *map = mmap(nullptr, job.len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, f.fd, job.off); // grab.cc:161 (MAP_POPULATE: no gain, measured)
             if (map == MAP_FAILED) {
                 err_ = std::string("FileGrep::find::mmap: ") + strerror(errno);
                 status = -1;

@@ -86,6 +86,7 @@ private:
     double t_map_ = 0, t_read_ = 0, t_submit_ = 0, t_wait_ = 0, t_report_ = 0, t_unmap_ = 0;
     // pipeline state
     std::deque<Job> flight_;
+    std::string report_buf_;
     size_t batch_max_ = size_t(2) << 20; // files up to this size are batched ("batch" config key; 0 = never)
     void *batch_buf_ = nullptr;          // the engine's pinned block being filled
     size_t batch_used_ = 0;

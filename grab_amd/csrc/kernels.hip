@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void k3_settle(ScanArgs a, const TileDesc *__r
 // match then lies inside one line, the restart position after a printed match is that line's newline, and the matches
 // that get printed are exactly THE FIRST CANDIDATE OF EVERY LINE -- a per-line question.  (A candidate that is first in
 // its line heads a group of consecutive candidates, so it is in the record list.)
-// One thread per tile walks the tile's records in order and writes, parallel to the records, ext[i] = {m1, lb, le}:
+// One wave per tile, one lane per record; written parallel to the records, ext[i] = {m1, lb, le}:
 //   m1 == 0           the record is not printed (an earlier candidate sits in the same line)
 //   lb == kLineAsk    "ask the host": something here needs the reference's loop itself -- the 511-byte caps of
 //                     grab.cc:173 (a line that runs on past the printed context may print again), a line start or a
@@ -788,10 +788,25 @@ __global__ __launch_bounds__(256) void k3_settle(ScanArgs a, const TileDesc *__r
 constexpr uint32_t kLineAsk = 0xffffffffu;
 constexpr uint32_t kLineBack = 4096; // how far a line start / a tail end is searched before the host is asked
 
-__global__ __launch_bounds__(256) void k_lines(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t tile_bytes, uint32_t *__restrict__ ext)
+// exact "which bytes of x are zero" (bit 7 of every zero byte), no borrow across bytes
+__device__ __forceinline__ unsigned long long zero_bytes(unsigned long long x)
 {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= a.n_tiles) return;
+    const unsigned long long k7f = 0x7f7f7f7f7f7f7f7full;
+    return ~(((x & k7f) + k7f) | x | k7f);
+}
+__device__ __forceinline__ unsigned long long load8(const uint8_t *q) // any alignment
+{
+    unsigned long long v;
+    __builtin_memcpy(&v, q, 8);
+    return v;
+}
+
+// One wave per tile, one lane per record (round-robin): whether a record is printed depends only on the record in front
+// of it -- it is the first candidate of its line iff the previous record lies before the line's start -- so nothing is
+// carried from record to record.  Newlines are searched 8 bytes at a time.
+__global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t tile_bytes, uint32_t *__restrict__ ext)
+{
+    const uint32_t t = blockIdx.x;
     const unsigned long long d = a.desc[t];
     const uint32_t cnt = (uint32_t)d;
     if (cnt == 0 || a.counter[kShards] != 0) return; // (overflow: the host rescans with a bigger buffer and this pass runs again)
@@ -810,27 +825,33 @@ __global__ __launch_bounds__(256) void k_lines(ScanArgs a, const TileDesc *__res
     const uint8_t *seg = a.base + seg_off;
     const DevProgram *pg = a.prog;
     const uint32_t m = a.m, tail_extra = pg->tail_extra;
-    uint32_t busy_until = 0; // candidates below this offset share a line with a match this tile already printed
-    for (uint32_t i = 0; i < cnt; i++) {
+    const unsigned long long kNl = 0x0a0a0a0a0a0a0a0aull;
+    for (uint32_t i = threadIdx.x; i < cnt; i += 64) {
         const uint32_t p = a.recs[base + i];
         uint32_t *e = ext + 3ull * (base + i);
-        if (p < busy_until) {
-            e[0] = 0;
-            continue;
+        // start of p's line: the byte after the last newline before p
+        uint32_t ls = p;
+        bool found = false;
+        while (!found && ls >= 8 && p - ls < kLineBack) {
+            const unsigned long long z = zero_bytes(load8(seg + ls - 8) ^ kNl);
+            if (z) {
+                ls = ls - 8 + (uint32_t)((63 - __clzll((long long)z)) >> 3) + 1; // highest zero byte = the nearest newline
+                found = true;
+            } else {
+                ls -= 8;
+            }
         }
-        // start of p's line
-        uint32_t ls = p, steps = 0;
-        while (ls > 0 && seg[ls - 1] != '\n' && steps < kLineBack) {
-            ls--;
-            steps++;
+        while (!found && ls > 0 && p - ls < kLineBack + 8) {
+            if (seg[ls - 1] == '\n') found = true;
+            else ls--;
         }
-        if (ls > 0 && seg[ls - 1] != '\n') {
+        if (!found && ls > 0) { // no line start within reach
             e[0] = 1;
             e[1] = kLineAsk;
             continue;
         }
         // an earlier candidate in [ls, p)?  In this tile: the previous record.  Before it: the last record of the nearest
-        // earlier tile of this segment that has one (tiles of a segment are consecutive, t - k is tile_off / tile_bytes - k).
+        // earlier tile of this segment that has one (tiles of a segment are consecutive: tile t - k starts k tiles earlier).
         bool first = true;
         if (i > 0) {
             first = a.recs[base + i - 1] < ls;
@@ -865,7 +886,17 @@ __global__ __launch_bounds__(256) void k_lines(ScanArgs a, const TileDesc *__res
         }
         // the rest of the line, at most 511 bytes of it (grab.cc:173,194-196)
         uint32_t le = m1;
-        while (le < slen && seg[le] != '\n' && le - m1 < 511u) le++;
+        found = false;
+        while (!found && le + 8 <= slen && le - m1 < 504u) {
+            const unsigned long long z = zero_bytes(load8(seg + le) ^ kNl);
+            if (z) {
+                le += (uint32_t)(__ffsll((long long)z) - 1) >> 3; // lowest zero byte = the next newline
+                found = true;
+            } else {
+                le += 8;
+            }
+        }
+        while (!found && le < slen && seg[le] != '\n' && le - m1 < 511u) le++;
         if (le < slen && seg[le] != '\n') ask = true; // the line runs on: what follows may print again
         if (ask) {
             e[0] = 1;
@@ -875,7 +906,6 @@ __global__ __launch_bounds__(256) void k_lines(ScanArgs a, const TileDesc *__res
         e[0] = m1;
         e[1] = p - ls > 511u ? p - 511u : ls; // at most 511 bytes in front of the match (grab.cc:173,190-193)
         e[2] = le;
-        busy_until = le;
     }
 }
 
@@ -965,7 +995,7 @@ hipError_t launch_settle(const ScanArgs &a, uint32_t tile_bytes, hipStream_t st)
 hipError_t launch_lines(const ScanArgs &a, uint32_t tile_bytes, uint32_t *ext, hipStream_t st)
 {
     if (a.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_lines, dim3((a.n_tiles + 255u) / 256u), dim3(256), 0, st, a, a.tiles, tile_bytes, ext);
+    hipLaunchKernelGGL(k_lines, dim3(a.n_tiles), dim3(64), 0, st, a, a.tiles, tile_bytes, ext);
     return hipGetLastError();
 }
 
