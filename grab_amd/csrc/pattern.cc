@@ -64,6 +64,8 @@ struct Seq {
     int gap_mode = 0; // 0 greedy, 1 lazy
     int gap_id = 0;   // paths that share one instance of the repeat: PCRE tries them count-major (see matcher.cc)
     std::vector<int> p_asserts; // assertions in front of pwin (A_* codes)
+    bool settled = false;       // assertions behind the tail were dropped because they hold wherever the greedy repeat stops:
+                                // true only as long as NOTHING follows (with more pattern behind, PCRE backtracks into the repeat)
     bool empty() const { return win.empty() && !has_tail && !cap && asserts.empty() && !gapped; }
 };
 
@@ -729,8 +731,11 @@ struct Unfold {
             std::vector<Seq> heads;
             if (!a.has_tail) {
                 heads.push_back(a);
+            } else if (a.settled) {
+                return fail("assertion behind a variable repeat, with more pattern behind it");
             } else if (tail_settles(a, B)) {
                 out.push_back(a); // \w+\b, (?m).*$: the assertion holds wherever the greedy repeat stops; nothing to add
+                out.back().settled = true;
                 if (!room(out.size())) return false;
                 continue;
             } else if (a.tail_extra == kInf || a.tail_extra > kMaxMidRepeat) {
@@ -777,6 +782,7 @@ struct Unfold {
                     s.tail = b.tail;
                     s.tail_extra = b.tail_extra;
                     s.tail_mode = b.tail_mode;
+                    s.settled = b.settled;
                     s.cap = a.cap || b.cap;
                     if (b.gapped) { // the unbounded repeat sits in b: everything of h goes in front of it
                         if (h.gapped) return fail("a second unbounded repeat before the end of the pattern");

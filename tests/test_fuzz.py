@@ -120,7 +120,19 @@ REGRESSIONS = [
     (r"(?m)\z |\d[^a]", b"1b 2  \n"),                                           # PCRE_INFO_MINLENGTH counts branches that can never match
     (r"(?m)[a-c]{2,}.|x*?0{1,2}.", b"bb1ax01Axb\n\n A\nbx1b 0bbAc.0xbbxAa\n"),
     (r"(?i:0?? *?\b[b0 ]?[^a])|x|0a", b".bx0a \nac 0ac0ac0  a\n 1ca.."),
+    (r"\A[^a]\n|x\d", b"c\n. cba .  x1 c \nb1.ab1c 1b \n"),
 ]
+
+# ... and patterns that were accepted wrongly: an assertion that always holds where a greedy repeat stops (\w+\b, (?m).*$)
+# had been dropped although more pattern followed the repeat (PCRE then backtracks into it and the assertion decides)
+REFUSED = [r"(?im)[^\n]+$[^\n]{2}", r"\B\W\.?\w{2,}\b\d|\A[^a]\n", r"(?i:\w+\b|  )1|A{2,}\d\z", r"\w+\bx", r"(?m)a.*$\nb"]
+
+
+@pytest.mark.parametrize("pattern", REFUSED)
+def test_fuzz_refused(pattern, built):
+    with pytest.raises(engine.Unsupported):
+        engine.Database(pattern)
+
 
 
 @pytest.mark.parametrize("pattern,text", REGRESSIONS)
