@@ -8,7 +8,8 @@ Workload (default = BASELINE.json configs[1]): 1024 files x 64 MiB of synthetic 
 (SURVEY.md 8d alphabet, generated on the device), literal needle 'foobardoesnotexist' planted
 64x per file; one "step" = one pass of the scan kernel over the whole 64 GiB arena (one launch,
 1024 segments, candidate offsets compacted into HBM).  `--config cfg3` switches to the
-identifier regex (class-run kernel).  Multi-GPU: every rank scans its own corpus (files are
+identifier regex (class-run kernel), `--config alt` to a 3-way alternation (bucket-filter
+kernel; not a BASELINE config).  Multi-GPU: every rank scans its own corpus (files are
 independent units; no data-path collective) -> "scaling": "weak".
 
 One JSON line on rank 0: the driver's contract fields + "roofline" (algorithmic bytes per launch
@@ -37,8 +38,9 @@ REC_BYTES = 4           # one u32 candidate start per record
 
 CONFIGS = {
     # name: (pattern, needles planted per file, record capacity per GiB of text)
-    "cfg2": (synth.NEEDLE.decode(), 64, 1 << 14),
-    "cfg3": (synth.IDENT_RE, 0, 12 << 20),
+    "cfg2": (synth.NEEDLE.decode(), 64, 1 << 14),          # BASELINE configs[1]: literal needle (K1)
+    "cfg3": (synth.IDENT_RE, 0, 12 << 20),                 # BASELINE configs[2]: identifier regex (K2)
+    "alt": (synth.NEEDLE.decode() + "|Linus|555-1234", 64, 1 << 14),  # not a BASELINE config: an alternation (K3), for its roofline line
 }
 
 
@@ -256,7 +258,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %d x %d MiB files per GPU, pattern '%s'%s, one launch over all segments, offsets compacted in HBM" % (
                 a.config, a.files, a.file_mib, pattern, (", %d needles planted per file" % needles) if needles else ""),
-                "bytes_per_gpu": nbytes, "kernel": "K1 anchor scan" if db.info.tier == engine.TIER_LITERAL else "K2 class-run scan",
+                "bytes_per_gpu": nbytes, "kernel": {engine.TIER_LITERAL: "K1 anchor scan", engine.TIER_CLASSRUN: "K2 class-run scan"}.get(db.info.tier, "K3 bucket filter"),
                 "parallelism": "files sharded per GPU, no collective"},
             "matches_per_step": int(matches_all),
             "matches_per_s": round(matches_all / (elapsed / a.steps), 1),
