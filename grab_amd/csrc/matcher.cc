@@ -8,6 +8,8 @@
 // the restart position (nothing before it: SURVEY.md Q4), windows that end with the chunk, priority among
 // alternatives, the one-pair ovector (Q5).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -74,7 +76,7 @@ struct MatchAt {
     uint32_t end;
     bool captures;
 };
-bool match_at(const Database &d, const uint8_t *content, size_t clen, size_t p, bool at_start, MatchAt &out)
+bool match_at_alts(const Database &d, const uint8_t *content, size_t clen, size_t p, bool at_start, MatchAt &out)
 {
     const size_t na = d.alts.size();
     for (size_t i = 0; i < na; i++) {
@@ -104,6 +106,165 @@ bool match_at(const Database &d, const uint8_t *content, size_t clen, size_t p, 
         i = j - 1;
     }
     return false;
+}
+
+// ---- the backtracking matcher over the parse tree -----------------------------------------------------------------
+// PCRE's semantics by construction for everything the parser takes: alternatives left to right, greedy repeats longest
+// first, lazy ones shortest first, possessive ones never given back, depth first -- so "the match reported AT p" (its
+// end, and whether its path closed a capturing group: ovector[3], src/grab.cc:171,179) does not depend on how the
+// pattern was unfolded for the kernels.  A repeat of a single byte class is a loop over counts, not a recursion, so
+// the stack depth is bounded by the pattern's size (times the iteration count of repeated GROUPS, which are small).
+using gscan::Node;
+
+struct TreeMatch {
+    const uint8_t *c;
+    size_t clen, s0; // s0: the subject start (nothing before it)
+    size_t end = 0;
+    bool captured = false;
+
+    // what is still to be matched after the current node
+    struct Cont {
+        enum Kind { SEQ, REPG, ATOMIC_END } kind;
+        const Node *n;
+        size_t i;     // SEQ: next child;  REPG: iterations done
+        size_t start; // REPG: where the iteration that just ended began
+        const Cont *next;
+    };
+
+    static bool is_word(uint8_t b) { return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_'; }
+
+    bool holds(int code, size_t pos) const
+    {
+        switch (code) {
+        case gscan::A_BOS: return pos == s0;
+        case gscan::A_MBOL: return pos == s0 || (pos > s0 && c[pos - 1] == '\n' && pos < clen);
+        case gscan::A_EOL: return pos == clen || (c[pos] == '\n' && pos + 1 == clen);
+        case gscan::A_MEOL: return pos == clen || c[pos] == '\n';
+        case gscan::A_EOS: return pos == clen;
+        case gscan::A_WB:
+        case gscan::A_NWB: {
+            const bool l = pos > s0 && is_word(c[pos - 1]), r = pos < clen && is_word(c[pos]);
+            return (l != r) == (code == gscan::A_WB);
+        }
+        }
+        return false;
+    }
+
+    bool run(const Cont *k, size_t pos, bool cap)
+    {
+        if (!k) {
+            end = pos;
+            captured = cap;
+            return true;
+        }
+        switch (k->kind) {
+        case Cont::SEQ:
+            if (k->i == k->n->kids.size()) return run(k->next, pos, cap || k->n->cap); // a capturing group closes here
+            {
+                const Cont f{Cont::SEQ, k->n, k->i + 1, 0, k->next};
+                return m(&k->n->kids[k->i], pos, cap, &f);
+            }
+        case Cont::REPG:
+            if (pos == k->start) return run(k->next, pos, cap); // an iteration that matched "": PCRE leaves the loop
+            return rep_group(k->n, k->i, pos, cap, k->next);
+        case Cont::ATOMIC_END: // the atomic (possessive) part is matched: remember where, do not continue from inside it
+            end = pos;
+            captured = cap;
+            return true;
+        }
+        return false;
+    }
+
+    bool rep_group(const Node *n, size_t count, size_t pos, bool cap, const Cont *k)
+    {
+        const Node *kid = &n->kids[0];
+        const bool can_more = count < (size_t)n->max, can_stop = count >= (size_t)n->min;
+        if (n->mode == 1) { // lazy: stop first
+            if (can_stop && run(k, pos, cap)) return true;
+            if (!can_more) return false;
+            const Cont f{Cont::REPG, n, count + 1, pos, k};
+            return m(kid, pos, cap, &f);
+        }
+        if (can_more) {
+            const Cont f{Cont::REPG, n, count + 1, pos, k};
+            if (m(kid, pos, cap, &f)) return true;
+        }
+        return can_stop && run(k, pos, cap);
+    }
+
+    bool m(const Node *n, size_t pos, bool cap, const Cont *k)
+    {
+        switch (n->kind) {
+        case Node::SET:
+            return pos < clen && n->set.test(c[pos]) && run(k, pos + 1, cap);
+        case Node::ASSERT:
+            return holds(n->acode, pos) && run(k, pos, cap);
+        case Node::CAT: {
+            const Cont f{Cont::SEQ, n, 0, 0, k};
+            return run(&f, pos, cap);
+        }
+        case Node::ALT:
+            for (const Node &kid : n->kids)
+                if (m(&kid, pos, cap, k)) return true;
+            return false;
+        case Node::REP: {
+            const Node *kid = &n->kids[0];
+            if (n->max == 0) return run(k, pos, cap);
+            if (kid->kind == Node::SET) { // a loop over counts
+                size_t kmax = 0;
+                while (kmax < (size_t)n->max && pos + kmax < clen && kid->set.test(c[pos + kmax])) kmax++;
+                if (kmax < (size_t)n->min) return false;
+                if (n->mode == 2) return run(k, pos + kmax, cap); // possessive: all of it, no giving back
+                if (n->mode == 1) {
+                    for (size_t j = n->min; j <= kmax; j++)
+                        if (run(k, pos + j, cap)) return true;
+                    return false;
+                }
+                for (size_t j = kmax + 1; j-- > (size_t)n->min;)
+                    if (run(k, pos + j, cap)) return true;
+                return false;
+            }
+            if (n->mode == 2) { // possessive group repeat: match the repeat on its own (greedily), then never re-enter it
+                Node greedy = *n;
+                greedy.mode = 0;
+                const Cont stop{Cont::ATOMIC_END, nullptr, 0, 0, nullptr};
+                TreeMatch inner{c, clen, s0};
+                if (!inner.rep_group(&greedy, 0, pos, cap, &stop)) return false;
+                return run(k, inner.end, inner.captured);
+            }
+            return rep_group(n, 0, pos, cap, k);
+        }
+        }
+        return false;
+    }
+};
+
+bool tree_match_at(const Database &d, const uint8_t *content, size_t clen, size_t p, size_t subject_start, MatchAt &out)
+{
+    if (!d.tree) return false;
+    TreeMatch t{content, clen, subject_start};
+    if (!t.m(d.tree.get(), p, false, nullptr)) return false;
+    if (t.end == p) return false; // (patterns that can match "" never get here: minlen -1, every file skipped)
+    out = {(uint32_t)t.end, t.captured};
+    return true;
+}
+
+// "The match reported AT p": the tree matcher decides; GSCAN_CHECK_TREE=1 (tests) also runs the rule on the unfolded
+// alternatives and aborts on any difference between the two.
+bool match_at(const Database &d, const uint8_t *content, size_t clen, size_t p, bool at_start, MatchAt &out)
+{
+    static const bool check = getenv("GSCAN_CHECK_TREE") != nullptr;
+    const bool hit = tree_match_at(d, content, clen, p, at_start ? p : (p > 0 ? p - 1 : 0), out);
+    if (check) {
+        MatchAt o2{0, false};
+        const bool h2 = match_at_alts(d, content, clen, p, at_start, o2);
+        if (h2 != hit || (hit && (o2.end != out.end || o2.captures != out.captures))) {
+            fprintf(stderr, "gscan: tree matcher and alternatives disagree at %zu (at_start %d): tree %d end %u cap %d / alts %d end %u cap %d\n", p,
+                    (int)at_start, (int)hit, out.end, (int)out.captures, (int)h2, o2.end, (int)o2.captures);
+            abort();
+        }
+    }
+    return hit;
 }
 
 // is x an offset the kernels report (before group-start suppression): some alternative's DEVICE window -- the

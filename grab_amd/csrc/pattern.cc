@@ -25,26 +25,6 @@ ByteSet set_and(ByteSet a, const ByteSet &b)
     return a;
 }
 
-// Zero-width assertions, with the inline option (?m) already folded in.
-enum { A_BOS = 1, // ^ without (?m), \A, \G: the subject start (the restart position: src/grab.cc:178 passes subject = start)
-       A_MBOL,    // (?m)^: subject start, or just after a newline
-       A_EOL,     // $ without (?m), \Z: the very end of the chunk, or just before a newline that is its last byte
-       A_MEOL,    // (?m)$: the very end, or just before any newline
-       A_EOS,     // \z: the very end only
-       A_WB,      // \b
-       A_NWB };   // \B
-
-// Parse tree.  SET = one byte drawn from a class; REP repeats its single child.
-struct Node {
-    enum Kind { SET, CAT, ALT, REP, ASSERT } kind = SET;
-    int acode = 0;             // ASSERT: one of the A_* codes
-    ByteSet set;
-    std::vector<Node> kids;
-    uint32_t min = 1, max = 1; // REP; max == kInf: unbounded
-    int mode = 0;              // REP: 0 greedy, 1 lazy, 2 possessive
-    bool cap = false;          // the node is the body of a capturing group
-};
-
 // One path through the pattern: window classes + optional variable repeat at the end.
 struct Seq {
     std::vector<ByteSet> win;
@@ -1105,12 +1085,17 @@ std::atomic<uint64_t> g_next_id{1};
 int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, std::string &why)
 {
     std::vector<Seq> seqs;
+    Node root;
     if (flags & GSCAN_LITERAL) {
         Seq s;
+        root.kind = Node::CAT;
         for (size_t k = 0; k < len; k++) {
             ByteSet b;
             b.set((unsigned char)pat[k]);
             s.win.push_back(b);
+            Node leaf;
+            leaf.set = b;
+            root.kids.push_back(leaf);
         }
         if (s.win.size() > (size_t)kMaxWindow) {
             why = "window longer than the engine supports";
@@ -1119,7 +1104,6 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         seqs.push_back(std::move(s));
     } else {
         Parser ps{(const unsigned char *)pat, len};
-        Node root;
         if (!ps.parse(root)) {
             why = ps.why;
             return ps.rc;
@@ -1201,6 +1185,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     }
 
     db = Database();
+    db.tree = std::make_shared<Node>(std::move(root));
     db.id = g_next_id.fetch_add(1);
     memset(&db.prog, 0, sizeof db.prog);
 

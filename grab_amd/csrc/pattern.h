@@ -22,6 +22,7 @@
 // is reported as GSCAN_UNSUPPORTED.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -62,6 +63,26 @@ struct ByteSet {
             if (w[i]) return i * 32 + __builtin_ctz(w[i]);
         return -1;
     }
+};
+
+// Zero-width assertions, with the inline option (?m) already folded in.
+enum { A_BOS = 1, // ^ without (?m), \A, \G: the subject start (the restart position: src/grab.cc:178 passes subject = start)
+       A_MBOL,    // (?m)^: subject start, or just after a newline
+       A_EOL,     // $ without (?m), \Z: the very end of the chunk, or just before a newline that is its last byte
+       A_MEOL,    // (?m)$: the very end, or just before any newline
+       A_EOS,     // \z: the very end only
+       A_WB,      // \b
+       A_NWB };   // \B
+
+// Parse tree.  SET = one byte drawn from a class; REP repeats its single child (max == UINT32_MAX: unbounded).
+struct Node {
+    enum Kind { SET, CAT, ALT, REP, ASSERT } kind = SET;
+    int acode = 0;             // ASSERT: one of the A_* codes
+    ByteSet set;
+    std::vector<Node> kids;
+    uint32_t min = 1, max = 1; // REP; max == kInf: unbounded
+    int mode = 0;              // REP: 0 greedy, 1 lazy, 2 possessive
+    bool cap = false;          // the node is the body of a capturing group
 };
 
 constexpr int kMaxWindow = 256; // window positions a database may hold
@@ -152,6 +173,7 @@ struct Database {
     int minlen = -1;             // shortest alternative == PCRE_INFO_MINLENGTH; -1 if "" can match
     std::vector<ByteSet> classes;
     std::vector<AltSeq> alts;    // priority order: the first one whose window matches at p is PCRE's match at p
+    std::shared_ptr<Node> tree;  // the parse tree: matcher.cc's backtracking matcher walks it (match end, capturing groups)
     // What the kernels scan: when some alternative looks at the byte before (after) its window, EVERY alternative's
     // device window gets a leading (trailing) context position -- its own condition, or "any byte".  A device hit at q
     // is reported as q + dev_pre.  Matches at the restart position and windows ending at the chunk end have no such
