@@ -626,6 +626,7 @@ int gscan_db_info(const gscan_db *db, gscan_info *info)
     info->n_alts = (int)d.alts.size();
     info->has_context = (d.dev_pre ? 1 : 0) | (d.dev_post ? 2 : 0);
     info->lines_ok = (int)d.prog.lines_ok;
+    info->exact = d.exact ? 1 : 0;
     return GSCAN_OK;
 }
 

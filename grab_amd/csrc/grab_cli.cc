@@ -226,5 +226,9 @@ int main(int argc, char **argv)
     const int rc = o.workers > 1 ? run_workers(o) : run_serial(o);
     mark("scan done, contexts closed");
     std::cout.flush();
+    // GRAB_DIAG=1: say when the host matcher abandoned attempts at its resource limit (each ends its chunk silently, as a
+    // pcre_exec error does in the reference: src/grab.cc:179); the differential tests skip such inputs
+    if (getenv("GRAB_DIAG") && gscan_resource_errors())
+        fprintf(stderr, "grab: %llu match attempts abandoned at the matcher's resource limit\n", (unsigned long long)gscan_resource_errors());
     return rc; // -1 -> exit status 255, like the reference's `return -1` from main
 }

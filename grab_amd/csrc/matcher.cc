@@ -8,6 +8,7 @@
 // the restart position (nothing before it: SURVEY.md Q4), windows that end with the chunk, priority among
 // alternatives, the one-pair ovector (Q5).
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -75,6 +76,7 @@ uint32_t end_of(const AltSeq &a, const uint8_t *t, size_t clen, size_t pos)
 struct MatchAt {
     uint32_t end;
     bool captures;
+    bool gave_up = false; // the attempt ran into the matcher's resource limits
 };
 bool match_at_alts(const Database &d, const uint8_t *content, size_t clen, size_t p, bool at_start, MatchAt &out)
 {
@@ -83,7 +85,7 @@ bool match_at_alts(const Database &d, const uint8_t *content, size_t clen, size_
         const AltSeq &a = d.alts[i];
         if (!a.gapped) {
             if (alt_matches(d, a, content, clen, p, at_start)) {
-                out = {end_of(a, content, clen, p), a.captures};
+                out = {end_of(a, content, clen, p), a.captures, false};
                 return true;
             }
             continue;
@@ -98,7 +100,7 @@ bool match_at_alts(const Database &d, const uint8_t *content, size_t clen, size_
                 const size_t k = a.gap_mode == 1 ? step + 1 : kmax - step;
                 for (size_t r = i; r < j; r++)
                     if (rest_at(d, d.alts[r], content, clen, g + k)) {
-                        out = {end_of(d.alts[r], content, clen, g + k), d.alts[r].captures};
+                        out = {end_of(d.alts[r], content, clen, g + k), d.alts[r].captures, false};
                         return true;
                     }
             }
@@ -115,12 +117,25 @@ bool match_at_alts(const Database &d, const uint8_t *content, size_t clen, size_
 // pattern was unfolded for the kernels.  A repeat of a single byte class is a loop over counts, not a recursion, so
 // the stack depth is bounded by the pattern's size (times the iteration count of repeated GROUPS, which are small).
 using gscan::Node;
+std::atomic<uint64_t> g_given_up{0}; // match attempts abandoned at a resource limit (gscan_resource_errors)
 
 struct TreeMatch {
     const uint8_t *c;
     size_t clen, s0; // s0: the subject start (nothing before it)
     size_t end = 0;
     bool captured = false;
+    // Resource limits, in the spirit of libpcre's match_limit / JIT stack: a match attempt that exceeds them is given up
+    // and ENDS the chunk, as every pcre_exec error does in the reference (rc <= 0: break, src/grab.cc:178-180).  The
+    // thresholds are this matcher's own.
+    static uint64_t max_steps()
+    {
+        static const uint64_t v = getenv("GSCAN_MATCH_LIMIT") ? strtoull(getenv("GSCAN_MATCH_LIMIT"), nullptr, 10) : (uint64_t)1 << 30;
+        return v;
+    }
+    static constexpr uint32_t kMaxDepth = 12000; // nested group iterations (each costs a few stack frames)
+    uint64_t steps = 0;
+    uint32_t depth = 0;
+    bool gave_up = false;
 
     // what is still to be matched after the current node
     struct Cont {
@@ -165,7 +180,10 @@ struct TreeMatch {
                 return m(&k->n->kids[k->i], pos, cap, &f);
             }
         case Cont::REPG:
-            if (pos == k->start) return run(k->next, pos, cap); // an iteration that matched "": PCRE leaves the loop
+            // An iteration of the UNBOUNDED part of a repeat that matched "": PCRE leaves the loop (OP_KETRMAX / OP_KETRMIN
+            // with eptr == saved_eptr).  The copies a {n,m} count is compiled into have no such check: an empty iteration
+            // is followed by the next one like any other.
+            if (pos == k->start && k->n->max == UINT32_MAX && k->i >= (size_t)k->n->min) return run(k->next, pos, cap);
             return rep_group(k->n, k->i, pos, cap, k->next);
         case Cont::ATOMIC_END: // the atomic (possessive) part is matched: remember where, do not continue from inside it
             end = pos;
@@ -177,6 +195,13 @@ struct TreeMatch {
 
     bool rep_group(const Node *n, size_t count, size_t pos, bool cap, const Cont *k)
     {
+        if (depth >= kMaxDepth) gave_up = true;
+        if (gave_up) return false;
+        struct Nest {
+            uint32_t &d;
+            explicit Nest(uint32_t &x) : d(x) { d++; }
+            ~Nest() { d--; }
+        } nest(depth);
         const Node *kid = &n->kids[0];
         const bool can_more = count < (size_t)n->max, can_stop = count >= (size_t)n->min;
         if (n->mode == 1) { // lazy: stop first
@@ -194,6 +219,8 @@ struct TreeMatch {
 
     bool m(const Node *n, size_t pos, bool cap, const Cont *k)
     {
+        if (++steps > max_steps()) gave_up = true;
+        if (gave_up) return false;
         switch (n->kind) {
         case Node::SET:
             return pos < clen && n->set.test(c[pos]) && run(k, pos + 1, cap);
@@ -229,7 +256,12 @@ struct TreeMatch {
                 greedy.mode = 0;
                 const Cont stop{Cont::ATOMIC_END, nullptr, 0, 0, nullptr};
                 TreeMatch inner{c, clen, s0};
-                if (!inner.rep_group(&greedy, 0, pos, cap, &stop)) return false;
+                inner.steps = steps;
+                inner.depth = depth;
+                const bool got = inner.rep_group(&greedy, 0, pos, cap, &stop);
+                steps = inner.steps;
+                gave_up = gave_up || inner.gave_up;
+                if (!got || gave_up) return false;
                 return run(k, inner.end, inner.captured);
             }
             return rep_group(n, 0, pos, cap, k);
@@ -243,9 +275,12 @@ bool tree_match_at(const Database &d, const uint8_t *content, size_t clen, size_
 {
     if (!d.tree) return false;
     TreeMatch t{content, clen, subject_start};
-    if (!t.m(d.tree.get(), p, false, nullptr)) return false;
+    const bool hit = t.m(d.tree.get(), p, false, nullptr);
+    out.gave_up = t.gave_up;
+    if (t.gave_up) g_given_up.fetch_add(1, std::memory_order_relaxed);
+    if (!hit || t.gave_up) return false;
     if (t.end == p) return false; // (patterns that can match "" never get here: minlen -1, every file skipped)
-    out = {(uint32_t)t.end, t.captured};
+    out = {(uint32_t)t.end, t.captured, false};
     return true;
 }
 
@@ -255,7 +290,7 @@ bool match_at(const Database &d, const uint8_t *content, size_t clen, size_t p, 
 {
     static const bool check = getenv("GSCAN_CHECK_TREE") != nullptr;
     const bool hit = tree_match_at(d, content, clen, p, at_start ? p : (p > 0 ? p - 1 : 0), out);
-    if (check) {
+    if (check && d.exact && !out.gave_up) { // (an inexact database's alternatives are necessary conditions only)
         MatchAt o2{0, false};
         const bool h2 = match_at_alts(d, content, clen, p, at_start, o2);
         if (h2 != hit || (hit && (o2.end != out.end || o2.captures != out.captures))) {
@@ -351,6 +386,62 @@ size_t tail_positions(const Database &d, size_t clen, uint32_t *out, size_t cap)
     return v.size();
 }
 
+// The leftmost offset p >= x at which some alternative's condition holds (s: the subject start -- nothing lies before it).
+size_t leftmost(const Database &d, const uint8_t *content, size_t clen, const uint32_t *starts, size_t n, size_t li, const gscan_cursor *cur,
+                size_t s, size_t x, bool any_plain, bool any_gapped)
+{
+    size_t best = Walk::kEnd;
+    // 1. the plain alternatives: the subject start itself (nothing before it), else the first offset of the walk at which
+    //    one of them matches
+    if (any_plain) {
+        size_t from = x;
+        if (x == s) {
+            for (const AltSeq &a : d.alts)
+                if (!a.gapped && alt_matches(d, a, content, clen, s, true)) best = s;
+            from = s + 1;
+        }
+        if (best == Walk::kEnd) {
+            Walk w(d, content, clen, starts, n, li, cur->tails, cur->ntails, from);
+            for (size_t at = w.next(); at != Walk::kEnd && best == Walk::kEnd; at = w.next())
+                for (const AltSeq &a : d.alts)
+                    if (!a.gapped && alt_matches(d, a, content, clen, at, false)) {
+                        best = at;
+                        break;
+                    }
+        }
+    }
+    // 2. the gapped alternatives  P . C{1,} . R : the device window is  C . R  (one repeat byte + the rest).  For every such
+    //    hit h, in ascending order: the run of C bytes that ends at h reaches back to r0; a match starts wherever P ends
+    //    inside [r0, h].  The first hit that has such a start gives the leftmost start of the alternative (a later hit
+    //    lies in the same run, or in a later one).
+    if (any_gapped) {
+        for (size_t i = 0; i < d.alts.size(); i++) {
+            const AltSeq &a = d.alts[i];
+            if (!a.gapped) continue;
+            const size_t plen = a.pwindow.size(), t = x + plen;
+            if (t >= clen) continue;
+            Walk w(d, content, clen, starts, n, li, cur->tails, cur->ntails, t);
+            for (size_t h = w.next(); h != Walk::kEnd; h = w.next()) {
+                if (h < t || !a.gap.test(content[h]) || !rest_at(d, a, content, clen, h + 1)) continue;
+                size_t r0 = h;
+                while (r0 > t && a.gap.test(content[r0 - 1])) r0--;
+                if (r0 - plen >= best) break; // nothing this alternative can still find lies left of the best so far
+                bool found = false;
+                for (size_t g = r0; g <= h && !found; g++) {
+                    const size_t p = g - plen;
+                    if (p >= best) break;
+                    if (window_at(d, a.pwindow, content, clen, p) && pre_ok(a, content, p, p == s)) {
+                        best = p;
+                        found = true;
+                    }
+                }
+                if (found) break;
+            }
+        }
+    }
+    return best;
+}
+
 } // namespace
 
 extern "C" {
@@ -378,6 +469,8 @@ uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, u
     return d.minlen > 0 && match_at(d, (const uint8_t *)content, clen, start, true, m) ? m.end : start; // start itself: not a match start
 }
 
+uint64_t gscan_resource_errors(void) { return g_given_up.load(std::memory_order_relaxed); }
+
 size_t gscan_tail_positions(const gscan_db *db, size_t clen, uint32_t *out, size_t cap) { return tail_positions(db->db, clen, out, cap); }
 
 int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, const uint32_t *starts, size_t n, gscan_cursor *cur,
@@ -396,7 +489,7 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
     // The common case -- one alternative, no context, no gap -- needs none of the machinery below: s itself if the
     // window matches there, else the first listed start after s.  (If s is no match, the next candidate after it begins
     // a group and is therefore listed; the kernels list candidates only, so it is not tested again.)
-    if (d.alts.size() == 1 && !d.alts[0].gapped && !d.dev_pre && !d.dev_post) {
+    if (d.exact && d.alts.size() == 1 && !d.alts[0].gapped && !d.dev_pre && !d.dev_post) {
         const AltSeq &a0 = d.alts[0];
         size_t at = s;
         if (!window_at(d, a0.window, content, clen, s)) {
@@ -409,60 +502,26 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
         *m1 = end_of(a0, content, clen, at);
         return a0.captures ? 2 : 1;
     }
-    // 1. the leftmost start among the plain alternatives: the subject start itself (nothing before it), else the first
-    //    offset of the walk at which one of them matches
     bool any_plain = false, any_gapped = false;
     for (const AltSeq &a : d.alts) (a.gapped ? any_gapped : any_plain) = true;
-    size_t best = Walk::kEnd;
-    if (any_plain) {
-        for (const AltSeq &a : d.alts)
-            if (!a.gapped && alt_matches(d, a, content, clen, s, true)) best = s;
-        if (best == Walk::kEnd) {
-            Walk w(d, content, clen, starts, n, cur->li, cur->tails, cur->ntails, (size_t)s + 1);
-            for (size_t at = w.next(); at != Walk::kEnd && best == Walk::kEnd; at = w.next())
-                for (const AltSeq &a : d.alts)
-                    if (!a.gapped && alt_matches(d, a, content, clen, at, false)) {
-                        best = at;
-                        break;
-                    }
+    // The leftmost offset >= x at which some alternative holds, then the matcher's verdict AT that offset.  For an exact
+    // database the verdict is always "match" (the alternatives are the pattern) and the loop runs once; for an inexact
+    // one the alternatives only say where a match may begin, and a refused offset sends the search on behind it.
+    size_t li = cur->li;
+    for (size_t x = s;;) {
+        const size_t best = leftmost(d, content, clen, starts, n, li, cur, s, x, any_plain, any_gapped);
+        if (best == Walk::kEnd) return 0;
+        MatchAt m;
+        if (match_at(d, content, clen, best, best == (size_t)s, m)) {
+            *m0 = (uint32_t)best;
+            *m1 = m.end;
+            return m.captures ? 2 : 1;
         }
+        if (d.exact || m.gave_up) return 0; // (exact: cannot happen.)  A given-up attempt ends the chunk: rc <= 0, src/grab.cc:179
+        x = best + 1;
+        if (x >= clen) return 0;
+        while (li < n && (size_t)starts[li] < x) li++;
     }
-    // 2. the gapped alternatives  P . C{1,} . R : the device window is  C . R  (one repeat byte + the rest).  For every such
-    //    hit h, in ascending order: the run of C bytes that ends at h reaches back to r0; a match starts wherever P ends
-    //    inside [r0, h].  The first hit that has such a start gives the leftmost start of the alternative (a later hit
-    //    lies in the same run, or in a later one).
-    if (any_gapped) {
-        for (size_t i = 0; i < d.alts.size(); i++) {
-            const AltSeq &a = d.alts[i];
-            if (!a.gapped) continue;
-            const size_t plen = a.pwindow.size(), t = (size_t)s + plen;
-            if (t >= clen) continue;
-            Walk w(d, content, clen, starts, n, cur->li, cur->tails, cur->ntails, t);
-            for (size_t h = w.next(); h != Walk::kEnd; h = w.next()) {
-                if (h < t || !a.gap.test(content[h]) || !rest_at(d, a, content, clen, h + 1)) continue;
-                size_t r0 = h;
-                while (r0 > t && a.gap.test(content[r0 - 1])) r0--;
-                if (r0 - plen >= best) break; // nothing this alternative can still find lies left of the best so far
-                bool found = false;
-                for (size_t g = r0; g <= h && !found; g++) {
-                    const size_t p = g - plen;
-                    if (p >= best) break;
-                    if (window_at(d, a.pwindow, content, clen, p) && pre_ok(a, content, p, p == (size_t)s)) {
-                        best = p;
-                        found = true;
-                    }
-                }
-                if (found) break;
-            }
-        }
-    }
-    if (best == Walk::kEnd) return 0;
-    // 3. which alternative wins AT that offset, and where its match ends
-    MatchAt m;
-    if (!match_at(d, content, clen, best, best == (size_t)s, m)) return 0; // cannot happen
-    *m0 = (uint32_t)best;
-    *m1 = m.end;
-    return m.captures ? 2 : 1;
 }
 
 int gscan_db_dev_window(const gscan_db *db, int alt, int pos, uint8_t table[256], int *len, int *shift)

@@ -44,9 +44,13 @@ struct Seq {
     int gap_mode = 0; // 0 greedy, 1 lazy
     int gap_id = 0;   // paths that share one instance of the repeat: PCRE tries them count-major (see matcher.cc)
     std::vector<int> p_asserts; // assertions in front of pwin (A_* codes)
+    bool frozen = false;        // the unfolder stopped here: what follows in the pattern is NOT part of this path's windows.
+                                // The path is then a necessary condition only ("inexact"): the host confirms candidates
+                                // with the backtracking matcher (matcher.cc)
+    bool inexact = false;       // frozen, or an assertion of the path was left to the matcher
     bool settled = false;       // assertions behind the tail were dropped because they hold wherever the greedy repeat stops:
                                 // true only as long as NOTHING follows (with more pattern behind, PCRE backtracks into the repeat)
-    bool empty() const { return win.empty() && !has_tail && !cap && asserts.empty() && !gapped; }
+    bool empty() const { return win.empty() && !has_tail && !cap && asserts.empty() && !gapped && !frozen && !inexact; }
 };
 
 // C-locale character tables, as pcre_maketables() builds them without setlocale()
@@ -672,7 +676,40 @@ struct Unfold {
         }
         return false;
     }
-    bool room(size_t count) { return count <= (size_t)kMaxAlts * 4 ? true : fail("pattern unfolds into too many alternatives"); }
+    bool overflow = false; // the failure is "too many paths": compile_pattern tries again with a window cap
+    bool room(size_t count)
+    {
+        if (count <= (size_t)kMaxAlts * 4) return true;
+        overflow = true;
+        return fail("pattern unfolds into too many alternatives");
+    }
+
+    size_t cap_len = SIZE_MAX; // paths are frozen once their window has this many bytes (compile_pattern's second attempts)
+
+    // freeze(a) appended to `out`, unless an identical frozen path is there already (order does not matter between
+    // paths that are necessary conditions only)
+    bool push_frozen(std::vector<Seq> &out, const Seq &a)
+    {
+        Seq f = freeze(a);
+        for (const Seq &o : out)
+            if (o.frozen && o.gapped == f.gapped && o.win.size() == f.win.size() && o.pwin.size() == f.pwin.size() && o.asserts == f.asserts &&
+                o.p_asserts == f.p_asserts && (!f.gapped || o.gap == f.gap) && std::equal(o.win.begin(), o.win.end(), f.win.begin()) &&
+                std::equal(o.pwin.begin(), o.pwin.end(), f.pwin.begin()))
+                return true;
+        out.push_back(std::move(f));
+        return room(out.size());
+    }
+
+    // The path as far as it got: its variable repeat (if any) and everything behind it are left to the matcher.
+    static Seq freeze(const Seq &a)
+    {
+        Seq f = a;
+        f.has_tail = false;
+        f.settled = false;
+        f.frozen = true;
+        f.inexact = true;
+        return f;
+    }
 
     // An unbounded greedy repeat of class T followed by nothing but assertions that are TRUE wherever that repeat stops
     // (so no backtracking into it ever happens and the repeat is still the end of the match):
@@ -709,10 +746,20 @@ struct Unfold {
         }
         for (const Seq &a : A) {
             std::vector<Seq> heads;
+            if (a.frozen) { // whatever follows is the matcher's business
+                if (!push_frozen(out, a)) return false;
+                continue;
+            }
+            if (a.win.size() >= cap_len) { // second attempt at a pattern that unfolded into too many paths: short prefixes only
+                if (!push_frozen(out, a)) return false;
+                continue;
+            }
             if (!a.has_tail) {
                 heads.push_back(a);
             } else if (a.settled) {
-                return fail("assertion behind a variable repeat, with more pattern behind it");
+                // assertion behind a variable repeat, with more pattern behind it: PCRE may backtrack into the repeat
+                if (!push_frozen(out, a)) return false;
+                continue;
             } else if (tail_settles(a, B)) {
                 out.push_back(a); // \w+\b, (?m).*$: the assertion holds wherever the greedy repeat stops; nothing to add
                 out.back().settled = true;
@@ -721,21 +768,29 @@ struct Unfold {
             } else if (a.tail_extra == kInf || a.tail_extra > kMaxMidRepeat) {
                 // An UNBOUNDED repeat with more pattern behind it: the path becomes  P . C{1,} . R  ("gapped": one per path).
                 // Zero repetitions are the plain path P . R, tried last by a greedy repeat and first by a lazy one.
-                if (a.tail_extra != kInf) return fail("large bounded repeat before the end of the pattern");
-                if (a.tail_mode == 2) return fail("possessive repeat before the end of the pattern");
-                if (a.gapped) return fail("a second unbounded repeat before the end of the pattern");
-                for (const auto &as : a.asserts)
-                    if (as.first != 0) return fail("assertion inside the part in front of an unbounded repeat");
+                // a large bounded or possessive repeat, a second unbounded one, an assertion inside the part in front of the
+                // repeat: the path is frozen in front of this repeat -- its windows so far are what the kernels look for
+                bool stop = a.gapped;
+                for (const auto &as : a.asserts) stop = stop || as.first != 0;
+                if (stop) {
+                    if (!push_frozen(out, a)) return false;
+                    continue;
+                }
+                // (a large bounded repeat is looked for as an unbounded one, a possessive one as a greedy one: wider than
+                // the pattern, so the matcher has the last word)
+                const bool wider = a.tail_extra != kInf || a.tail_mode == 2;
                 Seq g;
                 g.gapped = true;
                 g.pwin = a.win;
                 for (const auto &as : a.asserts) g.p_asserts.push_back(as.second);
                 g.gap = a.tail;
-                g.gap_mode = a.tail_mode;
+                g.gap_mode = a.tail_mode == 1 ? 1 : 0;
                 g.gap_id = ++gap_ids;
                 g.cap = a.cap;
+                g.inexact = a.inexact || wider;
                 Seq plain = a;
                 plain.has_tail = false;
+                plain.inexact = a.inexact || wider;
                 if (a.tail_mode == 1) {
                     heads.push_back(std::move(plain));
                     heads.push_back(std::move(g));
@@ -744,11 +799,12 @@ struct Unfold {
                     heads.push_back(std::move(plain));
                 }
             } else { // the repeat is no longer at the end: unfold it into explicit counts
-                if (a.tail_mode == 2) return fail("possessive repeat before the end of the pattern");
+                // (a possessive one never gives bytes back: every count is still something a match may begin with)
                 for (uint32_t k = 0; k <= a.tail_extra; k++) {
                     const uint32_t t = a.tail_mode == 1 ? k : a.tail_extra - k;
                     Seq h = a;
                     h.has_tail = false;
+                    h.inexact = a.inexact || a.tail_mode == 2;
                     h.win.insert(h.win.end(), t, a.tail);
                     heads.push_back(std::move(h));
                 }
@@ -763,17 +819,22 @@ struct Unfold {
                     s.tail_extra = b.tail_extra;
                     s.tail_mode = b.tail_mode;
                     s.settled = b.settled;
+                    s.frozen = b.frozen;
+                    s.inexact = h.inexact || b.inexact;
                     s.cap = a.cap || b.cap;
                     if (b.gapped) { // the unbounded repeat sits in b: everything of h goes in front of it
-                        if (h.gapped) return fail("a second unbounded repeat before the end of the pattern");
-                        for (const auto &as : h.asserts)
-                            if (as.first != 0) return fail("assertion inside the part in front of an unbounded repeat");
+                        bool stop = h.gapped || (!b.p_asserts.empty() && !h.win.empty());
+                        for (const auto &as : h.asserts) stop = stop || as.first != 0;
+                        if (stop) { // a second unbounded repeat, or an assertion that would end up inside the front part
+                            if (!push_frozen(out, h)) return false;
+                            continue;
+                        }
                         s = b;
                         s.pwin = h.win;
                         s.pwin.insert(s.pwin.end(), b.pwin.begin(), b.pwin.end());
-                        if (!b.p_asserts.empty() && !h.win.empty()) return fail("assertion inside the part in front of an unbounded repeat");
                         for (const auto &as : h.asserts) s.p_asserts.insert(s.p_asserts.begin(), as.second);
                         s.cap = h.cap || b.cap;
+                        s.inexact = h.inexact || b.inexact;
                         if (s.pwin.size() > (size_t)kMaxWindow) return fail("window longer than the engine supports");
                     }
                     if (s.win.size() > (size_t)kMaxWindow) return fail("window longer than the engine supports");
@@ -862,14 +923,37 @@ struct Unfold {
             }
             std::vector<Seq> E;
             if (!run(k, E)) return false;
+            bool plain = nd.mode != 2 && nd.max != kInf && nd.max <= 2 * kMaxMidRepeat;
             for (const Seq &e : E) {
-                if (e.win.empty()) return fail("repeated group that can match the empty string");
-                if (!e.asserts.empty() && (nd.min != 1 || nd.max != 1)) return fail("repeated group with an assertion inside");
+                if (e.win.empty() && !e.gapped) plain = false;                                  // an iteration may match ""
+                if ((!e.asserts.empty() || !e.p_asserts.empty()) && (nd.min != 1 || nd.max != 1)) plain = false; // an assertion inside
+                if (e.frozen) plain = false;
             }
-            if (nd.mode == 2) return fail("possessive repeat of a group");
-            if (nd.max == kInf) return fail("unbounded repeat of a group");
-            if (nd.max > 2 * kMaxMidRepeat) return fail("pattern unfolds into too many alternatives");
-            return repeat_paths(E, nd.min, nd.max, nd.mode == 1, out);
+            if (plain) return repeat_paths(E, nd.min, nd.max, nd.mode == 1, out);
+            // A repeat of a group that cannot be unfolded (unbounded, possessive, may match "", ...): every path of ONE
+            // iteration, frozen -- the kernels look for the first iteration, the matcher does the rest -- plus, if zero
+            // iterations are allowed, the path that skips the group.
+            // An iteration that consumes nothing contributes no bytes: the first byte a match takes then comes from a later
+            // iteration (same paths) or from what follows the group -- the path that skips the group stands for that.
+            bool skip = nd.min == 0;
+            for (const Seq &e : E) {
+                if (!e.win.empty() || e.gapped) {
+                    if (!push_frozen(out, e)) return false;
+                    continue;
+                }
+                skip = true;
+                if (e.has_tail) { // (?:a*)+ : an iteration that does consume begins with a byte of the repeat
+                    Seq one = e;
+                    one.win.push_back(e.tail);
+                    if (!push_frozen(out, one)) return false;
+                }
+            }
+            if (skip) {
+                Seq none;
+                none.inexact = true;
+                out.push_back(none);
+            }
+            return room(out.size());
         }
         }
         return fail("internal: unknown node");
@@ -892,6 +976,13 @@ struct Resolver {
         if (why.empty()) why = msg;
         return false;
     }
+    // An assertion that cannot be turned into a condition on the path's bytes is left out: the path then only says where
+    // a match MAY be, and the matcher decides (Database::exact == false).
+    bool skip(Seq s, size_t k, bool eol, bool eos)
+    {
+        s.inexact = true;
+        return step(std::move(s), k + 1, eol, eos);
+    }
 
     // An assertion right behind the unbounded repeat of a gapped path: the byte in front of it is a repeat byte, which
     // cannot be narrowed -- the repeat's class has to settle that side on its own.  Behind it: the first byte of the
@@ -900,19 +991,19 @@ struct Resolver {
     {
         const int code = s.asserts[k].second;
         const bool trail = s.win.empty();
-        if (trail && s.has_tail) return fail("assertion between two repeats");
+        if (trail && s.has_tail) return skip(std::move(s), k, eol, eos); // assertion between two repeats
         const bool gap_word = set_and(s.gap, word) == s.gap, gap_nonword = set_and(s.gap, nonword) == s.gap;
         switch (code) {
         case A_BOS: return true; // something in front of the subject start: never
         case A_MBOL:
             if (s.gap == nl) return step(std::move(s), k + 1, eol, eos);
             if (!s.gap.test('\n')) return true;
-            return fail("(?m)^ behind a repeat that may or may not end in a newline");
+            return skip(std::move(s), k, eol, eos); // (?m)^ behind a repeat that may or may not end in a newline
         case A_EOS:
             if (!trail) return true;
             return step(std::move(s), k + 1, eol, true);
         case A_EOL:
-            if (!trail) return fail("$ before the end of an alternative");
+            if (!trail) return skip(std::move(s), k, eol, eos); // $ before the end of an alternative
             return step(std::move(s), k + 1, true, eos);
         case A_MEOL:
             if (trail) s.post = set_and(s.post, nl);
@@ -920,7 +1011,7 @@ struct Resolver {
             return step(std::move(s), k + 1, eol, eos);
         case A_WB:
         case A_NWB: {
-            if (!gap_word && !gap_nonword) return fail("\\b behind a repeat of word and non-word characters");
+            if (!gap_word && !gap_nonword) return skip(std::move(s), k, eol, eos); // \b behind a repeat of word and non-word characters
             const int lw = gap_word ? 1 : 0;
             const int rw = (code == A_WB) ? 1 - lw : lw; // the other side must (not) differ
             const ByteSet &rset = rw ? word : nonword;
@@ -948,7 +1039,10 @@ struct Resolver {
             case A_WB:
             case A_NWB: {
                 const bool fw = set_and(first, word) == first, fn = set_and(first, nonword) == first;
-                if (!fw && !fn) return fail("\\b in front of a class of word and non-word characters followed by an unbounded repeat");
+                if (!fw && !fn) { // \b in front of a class of word and non-word characters followed by an unbounded repeat
+                    s.inexact = true;
+                    break;
+                }
                 const bool prev_word = (code == A_WB) ? !fw : fw;
                 s.pre = set_and(s.pre, prev_word ? word : nonword);
                 if (prev_word) s.pre_start = false;
@@ -966,10 +1060,10 @@ struct Resolver {
                         alive = false;
                         return true;
                     }
-                    return fail("(?m)$ in front of a repeat that may or may not start with a newline");
+                    s.inexact = true; // (?m)$ in front of a repeat that may or may not start with a newline
                 }
                 break;
-            case A_EOL: return fail("$ before the end of an alternative");
+            case A_EOL: s.inexact = true; break; // $ before the end of an alternative
             default: alive = false; return true; // \\z in front of something: never
             }
         }
@@ -1013,7 +1107,7 @@ struct Resolver {
             if (lead) {
                 s.pre = set_and(s.pre, nl);
             } else {
-                if (trail) return fail("(?m)^ at the end of an alternative");
+                if (trail) return skip(std::move(s), k, eol, eos); // (?m)^ at the end of an alternative
                 s.win[pos - 1] = set_and(s.win[pos - 1], nl);
             }
             return step(std::move(s), k + 1, eol, eos);
@@ -1021,7 +1115,7 @@ struct Resolver {
             if (!trail) return true;
             return step(std::move(s), k + 1, eol, true);
         case A_EOL:
-            if (!trail) return fail("$ before the end of an alternative");
+            if (!trail) return skip(std::move(s), k, eol, eos); // $ before the end of an alternative
             return step(std::move(s), k + 1, true, eos);
         case A_MEOL:
             if (trail) s.post = set_and(s.post, nl);
@@ -1080,14 +1174,77 @@ int byte_rank(unsigned b)
 
 std::atomic<uint64_t> g_next_id{1};
 
+uint64_t node_minlen(const Node &n);
+
+// libpcre quirk (8.39 and 8.45 alike): a greedy repeat of a single class that is followed -- directly, or across group
+// brackets and items that may match "" -- by a possessive group repeat with a variable count ((?:0)?+, (..){1,2}+: compiled
+// as an atomic group whose last item is optional) is made possessive by pcre_compile's auto-possessification whenever
+// the group's first bytes cannot continue the repeat, WITHOUT looking at what follows the group:  b[x.]{0,2}(?:0)?+[x.] x
+// never matches "b.x x".  Such patterns are refused rather than imitated.  Returns whether the node can END with a
+// greedy variable repeat of a class (`prev`: whether what precedes it can); sets `quirk` when the construct is met.
+bool ends_in_greedy_repeat(const Node &n, bool prev, bool &quirk)
+{
+    switch (n.kind) {
+    case Node::SET: return false;
+    case Node::ASSERT: return prev;
+    case Node::CAT: {
+        bool f = prev;
+        for (const Node &k : n.kids) f = ends_in_greedy_repeat(k, f, quirk);
+        return f;
+    }
+    case Node::ALT: {
+        bool f = false;
+        for (const Node &k : n.kids) f = ends_in_greedy_repeat(k, prev, quirk) || f;
+        return f;
+    }
+    case Node::REP: {
+        const Node &k = n.kids[0];
+        if (n.max == 0) return prev;
+        if (k.kind == Node::SET) {
+            if (n.max > n.min && n.mode == 0) return true;
+            return n.min == 0 ? prev : false;
+        }
+        if (n.mode == 2 && n.max > n.min && prev) quirk = true;
+        bool f = ends_in_greedy_repeat(k, prev, quirk);
+        if (n.max > 1) f = ends_in_greedy_repeat(k, f || prev, quirk) || f; // the end of one iteration precedes the next
+        return (n.min == 0 || node_minlen(k) == 0) ? (f || prev) : f;
+    }
+    }
+    return false;
+}
+
+// The shortest subject a match needs, the way pcre_study's find_minlength() counts it: alternatives take the minimum,
+// repeats multiply, assertions count nothing (and are not checked for consistency).
+uint64_t node_minlen(const Node &n)
+{
+    constexpr uint64_t cap = 1u << 30;
+    switch (n.kind) {
+    case Node::SET: return 1;
+    case Node::ASSERT: return 0;
+    case Node::CAT: {
+        uint64_t t = 0;
+        for (const Node &k : n.kids) t = std::min(cap, t + node_minlen(k));
+        return t;
+    }
+    case Node::ALT: {
+        uint64_t t = cap;
+        for (const Node &k : n.kids) t = std::min(t, node_minlen(k));
+        return t;
+    }
+    case Node::REP: return std::min(cap, (uint64_t)n.min * node_minlen(n.kids[0]));
+    }
+    return 0;
+}
+
 } // namespace
 
 int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, std::string &why)
 {
     std::vector<Seq> seqs;
+    Seq literal_seq;
     Node root;
     if (flags & GSCAN_LITERAL) {
-        Seq s;
+        Seq &s = literal_seq;
         root.kind = Node::CAT;
         for (size_t k = 0; k < len; k++) {
             ByteSet b;
@@ -1101,105 +1258,150 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             why = "window longer than the engine supports";
             return 1;
         }
-        seqs.push_back(std::move(s));
     } else {
         Parser ps{(const unsigned char *)pat, len};
         if (!ps.parse(root)) {
             why = ps.why;
             return ps.rc;
         }
-        Unfold uf;
-        if (!uf.run(root, seqs)) {
-            why = uf.why;
-            return uf.rc;
-        }
-    }
-
-    // a lazy repeat at the very end takes its minimum, a possessive one behaves like a greedy one
-    for (Seq &s : seqs)
-        if (s.has_tail && s.tail_mode == 1) s.has_tail = false;
-    // an atom that can match no byte at all makes its alternative unmatchable
-    for (const Seq &s : seqs) {
-        for (const ByteSet &b : s.win)
-            if (b.count() == 0) {
-                why = "empty character class";
-                return 1;
-            }
-    }
-    for (const Seq &s : seqs) {
-        for (const ByteSet &b : s.pwin)
-            if (b.count() == 0) {
-                why = "empty character class";
-                return 1;
-            }
-        if (s.gapped && s.gap.count() == 0) {
-            why = "empty character class";
+        bool quirk = false;
+        ends_in_greedy_repeat(root, false, quirk);
+        if (quirk) {
+            why = "possessive group repeat behind a greedy repeat (libpcre's auto-possessification treats it inconsistently)";
             return 1;
         }
     }
+
     // PCRE_INFO_MINLENGTH counts every branch, also those whose assertions can never hold (\\z followed by a byte ...):
-    // take it before such paths are dropped -- the reference's loop bound and file-skip rule use it (grab.cc:133,175)
-    size_t pcre_min = SIZE_MAX;
-    for (const Seq &s : seqs) pcre_min = std::min(pcre_min, s.win.size() + (s.gapped ? s.pwin.size() + 1 : 0));
-    // assertions -> one byte of context at each end (or decided / narrowed / split on the spot)
-    {
-        Resolver rs;
-        bool any = false;
-        for (Seq &s : seqs) {
-            any = any || !s.asserts.empty() || !s.p_asserts.empty();
-            std::stable_sort(s.asserts.begin(), s.asserts.end(), [](const std::pair<uint32_t, int> &x, const std::pair<uint32_t, int> &y) { return x.first < y.first; });
-            if (!rs.step(s, 0, false, false)) {
-                why = rs.why;
-                return 1;
-            }
-        }
-        if (any) {
-            if (rs.out.empty()) {
-                why = "the pattern's assertions can never hold";
-                return 1;
-            }
-            seqs.swap(rs.out);
-        }
-    }
-    for (const Seq &s : seqs) {
-        if (s.has_tail && s.tail.count() == 0) {
-            why = "empty character class";
-            return 1;
-        }
-    }
-    // a later duplicate of an alternative can never be the first one to match
-    {
-        std::vector<Seq> uniq;
-        for (Seq &s : seqs) {
-            bool dup = false;
-            for (const Seq &u : uniq)
-                if (u.win.size() == s.win.size() && u.has_tail == s.has_tail &&
-                    (!u.has_tail || (u.tail == s.tail && u.tail_extra == s.tail_extra)) && u.pre == s.pre && u.post == s.post &&
-                    u.pre_start == s.pre_start && u.post_end == s.post_end && u.post_final_nl == s.post_final_nl &&
-                    u.gapped == s.gapped && !s.gapped && // gapped paths are kept as they are: their order inside a repeat instance matters
-                    std::equal(u.win.begin(), u.win.end(), s.win.begin()))
-                    dup = true;
-            if (!dup) uniq.push_back(std::move(s));
-        }
-        seqs.swap(uniq);
-    }
-
-    db = Database();
-    db.tree = std::make_shared<Node>(std::move(root));
-    db.id = g_next_id.fetch_add(1);
-    memset(&db.prog, 0, sizeof db.prog);
-
-    size_t minm = pcre_min, total = 0;
-    for (const Seq &s : seqs) total += s.win.size() + s.pwin.size();
-    if (seqs.empty() || minm == 0) { // can match the empty string: PCRE_INFO_MINLENGTH == -1
+    // it comes from the parse tree, not from the unfolded paths -- the reference's loop bound and file-skip rule use it
+    // (grab.cc:133,175).
+    const size_t pcre_min = (size_t)node_minlen(root);
+    if (pcre_min == 0) { // can match the empty string: PCRE_INFO_MINLENGTH == -1 and every file is skipped
+        db = Database();
+        db.tree = std::make_shared<Node>(std::move(root));
+        db.id = g_next_id.fetch_add(1);
+        memset(&db.prog, 0, sizeof db.prog);
         db.tier = GSCAN_TIER_NULL;
         db.minlen = -1;
         return 0;
     }
-    if (seqs.size() > (size_t)kMaxAlts || total > (size_t)kAltWindowBytes) {
-        why = "pattern unfolds into too many alternatives";
-        return 1;
+
+    // Unfold into paths, resolve their assertions, drop duplicates.  A pattern that unfolds into too many paths gets
+    // further attempts in which every path is cut off ("frozen") once its window has `cap` bytes: short prefixes of what
+    // a match must begin with, fewer of them, and the matcher confirms (Database::exact == false).
+    auto build = [&](size_t cap, std::vector<Seq> &seqs) -> int { // 0 ok, 1 refused, 2 too many paths
+        seqs.clear();
+        if (flags & GSCAN_LITERAL) {
+            seqs.push_back(literal_seq);
+        } else {
+            Unfold uf;
+            uf.cap_len = cap;
+            if (!uf.run(root, seqs)) {
+                why = uf.why;
+                return uf.overflow ? 2 : uf.rc;
+            }
+        }
+        // a lazy repeat at the very end takes its minimum, a possessive one behaves like a greedy one
+        for (Seq &s : seqs)
+            if (s.has_tail && s.tail_mode == 1) s.has_tail = false;
+        // an atom that can match no byte at all makes its alternative unmatchable
+        for (const Seq &s : seqs) {
+            for (const ByteSet &b : s.win)
+                if (b.count() == 0) {
+                    why = "empty character class";
+                    return 1;
+                }
+        }
+        for (const Seq &s : seqs) {
+            for (const ByteSet &b : s.pwin)
+                if (b.count() == 0) {
+                    why = "empty character class";
+                    return 1;
+                }
+            if (s.gapped && s.gap.count() == 0) {
+                why = "empty character class";
+                return 1;
+            }
+        }
+        // assertions -> one byte of context at each end (or decided / narrowed / split on the spot)
+        {
+            Resolver rs;
+            bool any = false;
+            for (Seq &s : seqs) {
+                any = any || !s.asserts.empty() || !s.p_asserts.empty();
+                std::stable_sort(s.asserts.begin(), s.asserts.end(), [](const std::pair<uint32_t, int> &x, const std::pair<uint32_t, int> &y) { return x.first < y.first; });
+                if (!rs.step(s, 0, false, false)) {
+                    why = rs.why;
+                    return 1;
+                }
+            }
+            if (any) {
+                if (rs.out.empty()) {
+                    why = "the pattern's assertions can never hold";
+                    return 1;
+                }
+                seqs.swap(rs.out);
+            }
+        }
+        for (const Seq &s : seqs) {
+            if (s.has_tail && s.tail.count() == 0) {
+                why = "empty character class";
+                return 1;
+            }
+        }
+        // a later duplicate of an alternative can never be the first one to match
+        {
+            std::vector<Seq> uniq;
+            for (Seq &s : seqs) {
+                bool dup = false;
+                for (const Seq &u : uniq)
+                    if (u.win.size() == s.win.size() && u.has_tail == s.has_tail &&
+                        (!u.has_tail || (u.tail == s.tail && u.tail_extra == s.tail_extra)) && u.pre == s.pre && u.post == s.post &&
+                        u.pre_start == s.pre_start && u.post_end == s.post_end && u.post_final_nl == s.post_final_nl &&
+                        u.gapped == s.gapped && !s.gapped && // gapped paths are kept as they are: their order inside a repeat instance matters
+                        std::equal(u.win.begin(), u.win.end(), s.win.begin()))
+                        dup = true;
+                if (!dup) uniq.push_back(std::move(s));
+            }
+            seqs.swap(uniq);
+        }
+
+        size_t total = 0;
+        for (const Seq &s : seqs) total += s.win.size() + s.pwin.size() + 2;
+        if (seqs.size() > (size_t)kMaxAlts || total > (size_t)kAltWindowBytes) {
+            why = "pattern unfolds into too many alternatives";
+            return 2;
+        }
+        return 0;
+    };
+    {
+        int rc = 2;
+        for (size_t cap : {(size_t)SIZE_MAX, (size_t)12, (size_t)8, (size_t)5, (size_t)3, (size_t)2, (size_t)1}) {
+            rc = build(cap, seqs);
+            if (rc != 2 || (flags & GSCAN_LITERAL)) break;
+        }
+        if (rc != 0) return rc == 2 ? 1 : rc;
     }
+
+    bool exact = true;
+    for (const Seq &s : seqs) exact = exact && !s.inexact && !s.frozen;
+    if (getenv("GSCAN_DUMP"))
+        for (const Seq &s : seqs)
+            fprintf(stderr, "seq: win %zu pwin %zu gapped %d tail %d frozen %d inexact %d cap %d\n", s.win.size(), s.pwin.size(), (int)s.gapped,
+                    (int)s.has_tail, (int)s.frozen, (int)s.inexact, (int)s.cap);
+    for (const Seq &s : seqs)
+        if (s.win.empty() && !s.gapped) {
+            why = "nothing fixed to look for in front of a repeated group";
+            return 1;
+        }
+
+    db = Database();
+    db.exact = exact;
+    db.tree = std::make_shared<Node>(std::move(root));
+    db.id = g_next_id.fetch_add(1);
+    memset(&db.prog, 0, sizeof db.prog);
+
+    const size_t minm = pcre_min;
 
     // class table + alternatives
     auto intern = [&](const ByteSet &b) -> int {
@@ -1376,7 +1578,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     }
 
     // The line-extent pass: a match then lies inside one line, and "which matches get printed" is decided line by line.
-    if (db.alts.size() == 1 && !db.alts[0].gapped && !db.dev_pre && !db.dev_post) {
+    if (db.exact && db.alts.size() == 1 && !db.alts[0].gapped && !db.dev_pre && !db.dev_post) {
         const AltSeq &a0 = db.alts[0];
         bool ok = !(a0.has_tail && a0.tail.test('\n')) && !a0.captures; // (a match that sets a capturing group ends the chunk: grab.cc:171,179)
         for (uint8_t c : a0.window) ok = ok && !db.classes[c].test('\n');

@@ -173,6 +173,9 @@ struct Database {
     int minlen = -1;             // shortest alternative == PCRE_INFO_MINLENGTH; -1 if "" can match
     std::vector<ByteSet> classes;
     std::vector<AltSeq> alts;    // priority order: the first one whose window matches at p is PCRE's match at p
+    bool exact = true;           // false: some alternative stops in front of a construct the unfolder leaves alone (a second
+                                 // unbounded repeat, a repeated group, ...).  The alternatives then only say where a match
+                                 // MAY start; matcher.cc's backtracking matcher confirms every such offset
     std::shared_ptr<Node> tree;  // the parse tree: matcher.cc's backtracking matcher walks it (match end, capturing groups)
     // What the kernels scan: when some alternative looks at the byte before (after) its window, EVERY alternative's
     // device window gets a leading (trailing) context position -- its own condition, or "any byte".  A device hit at q

@@ -23,14 +23,14 @@ SYMBOLS = [
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
     "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs", "gscan_last_ext",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
-    "gscan_set_option", "gscan_kernel_time",
+    "gscan_set_option", "gscan_kernel_time", "gscan_resource_errors",
 ]
 
 
 class Info(C.Structure):
     _fields_ = [("tier", C.c_int), ("minlen", C.c_int), ("n_classes", C.c_int), ("has_tail", C.c_int),
                 ("tail_extra", C.c_uint32), ("anchor_off", C.c_int), ("anchor_len", C.c_int),
-                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int), ("lines_ok", C.c_int)]
+                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int), ("lines_ok", C.c_int), ("exact", C.c_int)]
 
 
 class Seg(C.Structure):
@@ -100,6 +100,8 @@ def lib():
         L.gscan_set_capacity.argtypes = [C.c_void_p, C.c_size_t]
         L.gscan_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         L.gscan_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        L.gscan_resource_errors.argtypes = []
+        L.gscan_resource_errors.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -326,3 +328,8 @@ class Context:
 
 def device_count():
     return int(lib().gscan_device_count())
+
+
+def resource_errors():
+    """Match attempts the host matcher abandoned at its resource limits so far (process-wide)."""
+    return int(lib().gscan_resource_errors())

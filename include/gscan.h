@@ -77,6 +77,9 @@ typedef struct gscan_info {
     int n_alts;          /* alternatives the pattern unfolds into (priority order); the fields above describe alternative 0 */
     int has_context;     /* bit 0: some alternative looks at the byte BEFORE its match (\b ^ ...), bit 1: at the byte AFTER it */
     int lines_ok;        /* 1 if the line-extent pass applies (gscan_set_option "line_extents"): one plain alternative, no newline in its classes */
+    int exact;           /* 1: the alternatives ARE the pattern.  0: they are what every match must begin with (the pattern goes on
+                            with a second unbounded repeat, a repeated group ...); the host confirms each offset with its
+                            backtracking matcher (gscan_next_match does) */
 } gscan_info;
 
 /* one scan unit inside a device-resident arena (gscan_scan_device) */
@@ -135,6 +138,12 @@ typedef struct gscan_cursor {
 } gscan_cursor;
 int gscan_next_match(const gscan_db *db, const void *content, size_t clen, const uint32_t *starts, size_t n,
                      gscan_cursor *cur, uint32_t s, uint32_t *m0, uint32_t *m1);
+/* Match attempts this process abandoned at the matcher's resource limits (its counterpart of PCRE_ERROR_MATCHLIMIT /
+ * PCRE_ERROR_JIT_STACKLIMIT): gscan_next_match then answers 0, which ends the chunk exactly as every pcre_exec error
+ * does in the reference (rc <= 0: break, src/grab.cc:179).  WHERE an engine gives up is its own business -- libpcre's
+ * interpreter, its JIT and this matcher all differ -- so differential tests skip inputs on which either side did.
+ * Limit: 2^30 matcher steps per attempt (GSCAN_MATCH_LIMIT in the environment overrides it), 12000 nested group iterations. */
+uint64_t gscan_resource_errors(void);
 /* the offsets gscan_next_match tests itself because a window there would end with the chunk (patterns with
  * look-ahead context only: foo\b, foo$ ...); exported for tests.  Returns how many there are; fills at most cap. */
 size_t gscan_tail_positions(const gscan_db *db, size_t clen, uint32_t *out, size_t cap);

@@ -10,6 +10,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+# the host matcher's step limit per attempt (include/gscan.h: gscan_resource_errors): the differential tests skip inputs
+# on which an engine gives up, so a low limit only makes the pathological random patterns cheap
+os.environ.setdefault("GSCAN_MATCH_LIMIT", "5000000")
 
 
 def pytest_configure(config):
@@ -43,6 +46,7 @@ def liboracle(oracle_built):
     L.oracle_all_starts.restype = C.c_long
     L.oracle_free.argtypes = [C.c_void_p]
     L.oracle_free.restype = None
+    L.oracle_resource_errors.restype = C.c_long
     return L
 
 

@@ -27,7 +27,9 @@ PATTERNS = ["foobardoesnotexist", "foo", "e", "xy", "[A-Za-z_][A-Za-z0-9_]{15,}"
             # context positions (\b ^ $ ...): device windows carry the byte before / after the match
             r"\bfoo\b", r"\Bfoo", "(?m)^[a-z]{3}", "(?m)[a-z]{3}$", r"\b\w+\b", r"\b[a-z.]o|Linus$|^abc", r"\bfoobardoesnotexist\b", r"e\B",
             # gapped alternatives: the device window is one repeat byte + the rest
-            "e+f", r"[0-9]+\.[0-9]+", "foo.*bar", r"[a-z]+\b", r"\w+@\w", "a 1.*c"]
+            "e+f", r"[0-9]+\.[0-9]+", "foo.*bar", r"[a-z]+\b", r"\w+@\w", "a 1.*c",
+            # inexact: the alternatives are what a match must begin with (the host matcher confirms); the kernels' job is the same
+            r"\w+@\w+\.com", "(?:foo|bar)+baz", "a.*b.*c", "(?:ab|cd)+?e", "e++f", "[0-9]{1,40}x"]
 
 
 @pytest.fixture(scope="module")
