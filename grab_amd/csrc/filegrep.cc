@@ -244,6 +244,7 @@ int FileGrep::prepare(const std::string &regex)
         gscan_info info;
         gscan_db_info(db_, &info);
         anchored_ = info.tier == GSCAN_TIER_ANCHORED;
+        never_ = anchored_ && info.n_alts == 0; // assertions that can never hold (a\Ab): nothing matches anywhere
         context_ = info.has_context != 0;
         lines_ = info.lines_ok != 0;
     }
@@ -466,7 +467,7 @@ int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
         const unsigned rflags = report_flags();
         std::string text;
         const off_t stride = (off_t)chunk_size_ - kOverlap;
-        for (off_t off = 0; off < size && status == 0; off += stride) {
+        for (off_t off = 0; off < size && status == 0 && !never_; off += stride) {
             const size_t len = (size_t)std::min<off_t>(size - off, (off_t)chunk_size_);
             void *map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, fd, off);
             if (map == MAP_FAILED) {

@@ -76,6 +76,7 @@ private:
     bool offsets_ = false, noline_ = false, single_ = false, color_ = false, low_mem_ = false;
     bool recursive_ = false, show_path_ = false, literal_ = false;
     bool anchored_ = false; // the pattern can only match at a restart position / chunk end: nothing goes to the GPU
+    bool never_ = false;    // ... and not even there: the pattern's assertions contradict each other
     bool context_ = false;  // the pattern looks at the byte before / after its match
     bool lines_ = false;    // the device's line-extent pass applies to the pattern
     uid_t uid_;

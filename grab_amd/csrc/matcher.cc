@@ -387,59 +387,84 @@ size_t tail_positions(const Database &d, size_t clen, uint32_t *out, size_t cap)
 }
 
 // The leftmost offset p >= x at which some alternative's condition holds (s: the subject start -- nothing lies before it).
-size_t leftmost(const Database &d, const uint8_t *content, size_t clen, const uint32_t *starts, size_t n, size_t li, const gscan_cursor *cur,
-                size_t s, size_t x, bool any_plain, bool any_gapped)
+// Every kind of alternative keeps its own answer in the cursor: it is computed by walking the device hits from x on until
+// that kind has a candidate -- possibly far ahead -- and stays valid until the search position passes it.
+constexpr uint32_t kNoCand = UINT32_MAX;
+
+// the plain alternatives: the subject start itself (nothing before it), else the first offset of the walk at which one of
+// them matches
+uint32_t next_plain(const Database &d, const uint8_t *content, size_t clen, const uint32_t *starts, size_t n, size_t li, const gscan_cursor *cur,
+                    size_t s, size_t x)
 {
-    size_t best = Walk::kEnd;
-    // 1. the plain alternatives: the subject start itself (nothing before it), else the first offset of the walk at which
-    //    one of them matches
-    if (any_plain) {
-        size_t from = x;
-        if (x == s) {
-            for (const AltSeq &a : d.alts)
-                if (!a.gapped && alt_matches(d, a, content, clen, s, true)) best = s;
-            from = s + 1;
-        }
-        if (best == Walk::kEnd) {
-            Walk w(d, content, clen, starts, n, li, cur->tails, cur->ntails, from);
-            for (size_t at = w.next(); at != Walk::kEnd && best == Walk::kEnd; at = w.next())
-                for (const AltSeq &a : d.alts)
-                    if (!a.gapped && alt_matches(d, a, content, clen, at, false)) {
-                        best = at;
-                        break;
-                    }
+    size_t from = x;
+    if (x == s) {
+        for (const AltSeq &a : d.alts)
+            if (!a.gapped && alt_matches(d, a, content, clen, s, true)) return (uint32_t)s;
+        from = s + 1;
+    }
+    Walk w(d, content, clen, starts, n, li, cur->tails, cur->ntails, from);
+    for (size_t at = w.next(); at != Walk::kEnd; at = w.next())
+        for (const AltSeq &a : d.alts)
+            if (!a.gapped && alt_matches(d, a, content, clen, at, false)) return (uint32_t)at;
+    return kNoCand;
+}
+
+// a gapped alternative  P . C{1,} . R : the device window is  C . R  (one repeat byte + the rest).  For every such hit h, in
+// ascending order: the run of C bytes that ends at h reaches back to r0; a match starts wherever P ends inside [r0, h].
+// The first hit that has such a start gives the leftmost start of the alternative (a later hit lies in the same run, or
+// in a later one).
+uint32_t next_gapped(const Database &d, const AltSeq &a, const uint8_t *content, size_t clen, const uint32_t *starts, size_t n, size_t li,
+                     const gscan_cursor *cur, size_t s, size_t x)
+{
+    const size_t plen = a.pwindow.size(), t = x + plen;
+    if (t >= clen) return kNoCand;
+    Walk w(d, content, clen, starts, n, li, cur->tails, cur->ntails, t);
+    for (size_t h = w.next(); h != Walk::kEnd; h = w.next()) {
+        if (h < t || !a.gap.test(content[h]) || !rest_at(d, a, content, clen, h + 1)) continue;
+        size_t r0 = h;
+        while (r0 > t && a.gap.test(content[r0 - 1])) r0--;
+        for (size_t g = r0; g <= h; g++) {
+            const size_t p = g - plen;
+            if (window_at(d, a.pwindow, content, clen, p) && pre_ok(a, content, p, p == s)) return (uint32_t)p;
         }
     }
-    // 2. the gapped alternatives  P . C{1,} . R : the device window is  C . R  (one repeat byte + the rest).  For every such
-    //    hit h, in ascending order: the run of C bytes that ends at h reaches back to r0; a match starts wherever P ends
-    //    inside [r0, h].  The first hit that has such a start gives the leftmost start of the alternative (a later hit
-    //    lies in the same run, or in a later one).
-    if (any_gapped) {
-        for (size_t i = 0; i < d.alts.size(); i++) {
-            const AltSeq &a = d.alts[i];
-            if (!a.gapped) continue;
-            const size_t plen = a.pwindow.size(), t = x + plen;
-            if (t >= clen) continue;
-            Walk w(d, content, clen, starts, n, li, cur->tails, cur->ntails, t);
-            for (size_t h = w.next(); h != Walk::kEnd; h = w.next()) {
-                if (h < t || !a.gap.test(content[h]) || !rest_at(d, a, content, clen, h + 1)) continue;
-                size_t r0 = h;
-                while (r0 > t && a.gap.test(content[r0 - 1])) r0--;
-                if (r0 - plen >= best) break; // nothing this alternative can still find lies left of the best so far
-                bool found = false;
-                for (size_t g = r0; g <= h && !found; g++) {
-                    const size_t p = g - plen;
-                    if (p >= best) break;
-                    if (window_at(d, a.pwindow, content, clen, p) && pre_ok(a, content, p, p == s)) {
-                        best = p;
-                        found = true;
-                    }
-                }
-                if (found) break;
+    return kNoCand;
+}
+
+size_t leftmost(const Database &d, const uint8_t *content, size_t clen, const uint32_t *starts, size_t n, size_t li, gscan_cursor *cur, size_t s,
+                size_t x, bool any_plain)
+{
+    // an answer is still good if it lies at or beyond x -- except AT the subject start, where "nothing before it" replaces
+    // the byte before (the answer was found for an earlier subject start)
+    if (x == s) { // the subject start has its own rule ("nothing before it"): the remembered answers know nothing about it
+        for (const AltSeq &a : d.alts) {
+            if (!a.gapped) {
+                if (alt_matches(d, a, content, clen, s, true)) return s;
+                continue;
             }
+            if (!window_at(d, a.pwindow, content, clen, s) || !pre_ok(a, content, s, true)) continue;
+            for (size_t g = s + a.pwindow.size(); g < clen && a.gap.test(content[g]); g++)
+                if (rest_at(d, a, content, clen, g + 1)) return s;
         }
     }
-    return best;
+    auto good = [&](size_t slot) { return cur->next_known[slot] && (cur->next_at[slot] == kNoCand || (cur->next_at[slot] >= x && cur->next_at[slot] != s)); };
+    uint32_t best = kNoCand;
+    if (any_plain) {
+        if (!good(0)) {
+            cur->next_at[0] = next_plain(d, content, clen, starts, n, li, cur, s, x);
+            cur->next_known[0] = 1;
+        }
+        best = cur->next_at[0];
+    }
+    for (size_t i = 0; i < d.alts.size(); i++) {
+        if (!d.alts[i].gapped) continue;
+        if (!good(1 + i)) {
+            cur->next_at[1 + i] = next_gapped(d, d.alts[i], content, clen, starts, n, li, cur, s, x);
+            cur->next_known[1 + i] = 1;
+        }
+        best = std::min(best, cur->next_at[1 + i]);
+    }
+    return best == kNoCand ? Walk::kEnd : (size_t)best;
 }
 
 } // namespace
@@ -482,6 +507,7 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
     if (!cur->ready) { // first call for this chunk
         cur->li = 0;
         cur->ntails = (uint32_t)std::min(tail_positions(d, clen, cur->tails, GSCAN_MAX_TAILS), (size_t)GSCAN_MAX_TAILS);
+        memset(cur->next_known, 0, sizeof cur->next_known);
         cur->ready = 1;
     }
     while (cur->li < n && starts[cur->li] < s) cur->li++; // first entry >= s; s only moves forward: the cursor is kept across calls
@@ -502,14 +528,14 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
         *m1 = end_of(a0, content, clen, at);
         return a0.captures ? 2 : 1;
     }
-    bool any_plain = false, any_gapped = false;
-    for (const AltSeq &a : d.alts) (a.gapped ? any_gapped : any_plain) = true;
+    bool any_plain = false;
+    for (const AltSeq &a : d.alts) any_plain = any_plain || !a.gapped;
     // The leftmost offset >= x at which some alternative holds, then the matcher's verdict AT that offset.  For an exact
     // database the verdict is always "match" (the alternatives are the pattern) and the loop runs once; for an inexact
     // one the alternatives only say where a match may begin, and a refused offset sends the search on behind it.
     size_t li = cur->li;
     for (size_t x = s;;) {
-        const size_t best = leftmost(d, content, clen, starts, n, li, cur, s, x, any_plain, any_gapped);
+        const size_t best = leftmost(d, content, clen, starts, n, li, cur, s, x, any_plain);
         if (best == Walk::kEnd) return 0;
         MatchAt m;
         if (match_at(d, content, clen, best, best == (size_t)s, m)) {

@@ -1335,13 +1335,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
                     return 1;
                 }
             }
-            if (any) {
-                if (rs.out.empty()) {
-                    why = "the pattern's assertions can never hold";
-                    return 1;
-                }
-                seqs.swap(rs.out);
-            }
+            if (any) seqs.swap(rs.out); // (possibly nothing is left: the pattern's assertions can never hold)
         }
         for (const Seq &s : seqs) {
             if (s.has_tail && s.tail.count() == 0) {
@@ -1402,6 +1396,11 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     memset(&db.prog, 0, sizeof db.prog);
 
     const size_t minm = pcre_min;
+    if (seqs.empty()) { // no path can ever match (a\\Ab, x^y ...): pcre_exec finds nothing, and neither is there anything to scan for
+        db.minlen = (int)minm;
+        db.tier = GSCAN_TIER_ANCHORED;
+        return 0;
+    }
 
     // class table + alternatives
     auto intern = [&](const ByteSet &b) -> int {

@@ -131,10 +131,15 @@ int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint3
  * before it), group members the kernels do not list, windows that end with the chunk.
  */
 #define GSCAN_MAX_TAILS 132
+#define GSCAN_MAX_ALTS 64
 typedef struct gscan_cursor {
     size_t li;                      /* first list entry > the last s */
-    uint32_t ntails, ready;
+    uint32_t ntails, ready;         /* ready: set to 0 by the caller before the first call for a chunk; the rest is the callee's */
     uint32_t tails[GSCAN_MAX_TAILS]; /* offsets whose window ends with the chunk: never listed by the kernels */
+    /* the next offset at which each kind of alternative can start a match (slot 0: the plain ones together, 1 + i: gapped
+     * alternative i), remembered from call to call: s only grows, so an answer beyond s stays the answer */
+    uint32_t next_at[GSCAN_MAX_ALTS + 1];
+    uint8_t next_known[GSCAN_MAX_ALTS + 1];
 } gscan_cursor;
 int gscan_next_match(const gscan_db *db, const void *content, size_t clen, const uint32_t *starts, size_t n,
                      gscan_cursor *cur, uint32_t s, uint32_t *m0, uint32_t *m1);

@@ -108,9 +108,9 @@ def test_random_patterns_match_pcre(seed, built, liboracle):
     rng = random.Random(seed)
     texts = make_texts(seed)
     tested = 0
-    for _ in range(1500):
+    for _ in range(1000):
         tested += check(liboracle, gen(rng), texts) is not None
-    assert tested > 300  # the grammar is wider than the engine's subset; a third of the draws are comparable
+    assert tested > 600  # (the rest: patterns that can match "" -- every file is skipped, Q2 -- and a few per cent refused)
 
 
 # found by the campaign (each one printed something else than the reference before its fix)

@@ -93,7 +93,19 @@ UNSUPPORTED = [r"\1", r"\pL",
 
 # "a(" is reported as unsupported (groups) by the engine alone; FileGrep::prepare asks libpcre first and
 # gives the reference's "pcre_compile error" for it (tests/test_gpu_filegrep.py, golden case bad_regex)
-UNSUPPORTED += [r"\b*a", r"fo\bo", "(?<=a)b"]
+UNSUPPORTED += [r"\b*a", "(?<=a)b"]
+
+# assertions that contradict each other: pcre_exec never matches, and neither does the engine (nothing is scanned at all)
+NEVER = [r"fo\bo", r"a\Ab", r"x^y|a\zb", r"(?m)a$b"]
+
+
+@pytest.mark.parametrize("pattern", NEVER)
+def test_never_matching(pattern, built, liboracle):
+    from test_fuzz import check
+    db = engine.Database(pattern)
+    assert db.info.tier == engine.TIER_ANCHORED and db.info.n_alts == 0
+    assert check(liboracle, pattern, [b"fo o a\nb ab xy x\ny", b"ab", b"a\nb\n"]) == 3
+
 
 # Patterns whose alternatives stop in front of something the unfolder leaves alone -- a second unbounded repeat, a
 # repeated group, a possessive or large bounded repeat or an awkward assertion with more pattern behind it.  The kernels
