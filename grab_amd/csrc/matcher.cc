@@ -146,6 +146,32 @@ struct TreeMatch {
         const Cont *next;
     };
 
+    // the fixed length of a look-behind alternative (the parser has checked that it has one)
+    static long look_len(const Node &nd)
+    {
+        switch (nd.kind) {
+        case Node::SET: return 1;
+        case Node::ASSERT:
+        case Node::LOOK: return 0;
+        case Node::ATOMIC: return look_len(nd.kids[0]);
+        case Node::CAT: {
+            long t = 0;
+            for (const Node &k : nd.kids) {
+                const long l = look_len(k);
+                if (l < 0) return -1;
+                t += l;
+            }
+            return t;
+        }
+        case Node::ALT: return nd.kids.empty() ? 0 : look_len(nd.kids[0]);
+        case Node::REP: {
+            const long l = look_len(nd.kids[0]);
+            return l < 0 || nd.min != nd.max ? -1 : l * (long)nd.min;
+        }
+        }
+        return -1;
+    }
+
     static bool is_word(uint8_t b) { return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_'; }
 
     bool holds(int code, size_t pos) const
@@ -226,6 +252,52 @@ struct TreeMatch {
             return pos < clen && n->set.test(c[pos]) && run(k, pos + 1, cap);
         case Node::ASSERT:
             return holds(n->acode, pos) && run(k, pos, cap);
+        case Node::LOOK: {
+            // The body is matched on its own, to its first success (assertions are atomic).  A look-behind body has a
+            // fixed length per top-level alternative and may not reach back over the subject start (the restart
+            // position: src/grab.cc:178 hands pcre_exec the subject FROM there).
+            const Node *body = &n->kids[0];
+            bool ok = false, inner_cap = cap;
+            auto attempt = [&](const Node *alt, size_t at) {
+                const Cont stop{Cont::ATOMIC_END, nullptr, 0, 0, nullptr};
+                TreeMatch inner{c, clen, s0};
+                inner.steps = steps;
+                inner.depth = depth;
+                const bool got = inner.m(alt, at, cap, &stop);
+                steps = inner.steps;
+                gave_up = gave_up || inner.gave_up;
+                if (got && !gave_up && (!n->behind || inner.end == pos)) {
+                    ok = true;
+                    inner_cap = inner.captured;
+                }
+            };
+            if (!n->behind) {
+                attempt(body, pos);
+            } else if (body->kind == Node::ALT) {
+                for (const Node &alt : body->kids) {
+                    const long len = look_len(alt);
+                    if (len >= 0 && pos >= s0 + (size_t)len) attempt(&alt, pos - (size_t)len);
+                    if (ok || gave_up) break;
+                }
+            } else {
+                const long len = look_len(*body);
+                if (len >= 0 && pos >= s0 + (size_t)len) attempt(body, pos - (size_t)len);
+            }
+            if (gave_up) return false;
+            if (n->neg) return !ok && run(k, pos, cap); // (groups set inside a failed assertion are unset again)
+            return ok && run(k, pos, inner_cap);
+        }
+        case Node::ATOMIC: { // matched on its own to its first success; no way back into it
+            const Cont stop{Cont::ATOMIC_END, nullptr, 0, 0, nullptr};
+            TreeMatch inner{c, clen, s0};
+            inner.steps = steps;
+            inner.depth = depth;
+            const bool got = inner.m(&n->kids[0], pos, cap, &stop);
+            steps = inner.steps;
+            gave_up = gave_up || inner.gave_up;
+            if (!got || gave_up) return false;
+            return run(k, inner.end, inner.captured);
+        }
         case Node::CAT: {
             const Cont f{Cont::SEQ, n, 0, 0, k};
             return run(&f, pos, cap);
@@ -286,10 +358,11 @@ bool tree_match_at(const Database &d, const uint8_t *content, size_t clen, size_
 
 // "The match reported AT p": the tree matcher decides; GSCAN_CHECK_TREE=1 (tests) also runs the rule on the unfolded
 // alternatives and aborts on any difference between the two.
-bool match_at(const Database &d, const uint8_t *content, size_t clen, size_t p, bool at_start, MatchAt &out)
+bool match_at(const Database &d, const uint8_t *content, size_t clen, size_t p, size_t subject_start, MatchAt &out)
 {
     static const bool check = getenv("GSCAN_CHECK_TREE") != nullptr;
-    const bool hit = tree_match_at(d, content, clen, p, at_start ? p : (p > 0 ? p - 1 : 0), out);
+    const bool at_start = p == subject_start;
+    const bool hit = tree_match_at(d, content, clen, p, subject_start, out);
     if (check && d.exact && !out.gave_up) { // (an inexact database's alternatives are necessary conditions only)
         MatchAt o2{0, false};
         const bool h2 = match_at_alts(d, content, clen, p, at_start, o2);
@@ -475,14 +548,14 @@ int gscan_match_at(const gscan_db *db, const void *content, size_t clen, uint32_
 {
     const Database &d = db->db;
     MatchAt m;
-    return d.minlen > 0 && match_at(d, (const uint8_t *)content, clen, p, true, m);
+    return d.minlen > 0 && match_at(d, (const uint8_t *)content, clen, p, p, m);
 }
 
 int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p, uint32_t *end)
 {
     const Database &d = db->db;
     MatchAt m;
-    if (d.minlen <= 0 || p < subject_start || !match_at(d, (const uint8_t *)content, clen, p, p == subject_start, m)) return 0;
+    if (d.minlen <= 0 || p < subject_start || !match_at(d, (const uint8_t *)content, clen, p, subject_start, m)) return 0;
     if (end) *end = m.end;
     return m.captures ? 2 : 1;
 }
@@ -491,7 +564,7 @@ uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, u
 {
     const Database &d = db->db;
     MatchAt m;
-    return d.minlen > 0 && match_at(d, (const uint8_t *)content, clen, start, true, m) ? m.end : start; // start itself: not a match start
+    return d.minlen > 0 && match_at(d, (const uint8_t *)content, clen, start, start, m) ? m.end : start; // start itself: not a match start
 }
 
 uint64_t gscan_resource_errors(void) { return g_given_up.load(std::memory_order_relaxed); }
@@ -538,7 +611,7 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
         const size_t best = leftmost(d, content, clen, starts, n, li, cur, s, x, any_plain);
         if (best == Walk::kEnd) return 0;
         MatchAt m;
-        if (match_at(d, content, clen, best, best == (size_t)s, m)) {
+        if (match_at(d, content, clen, best, (size_t)s, m)) {
             *m0 = (uint32_t)best;
             *m1 = m.end;
             return m.captures ? 2 : 1;

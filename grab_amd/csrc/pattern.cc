@@ -138,7 +138,23 @@ struct Parser {
     int rc = 0; // 0 ok, 1 unsupported, -1 malformed
     // inline options in force (PCRE: a change made inside a group lasts to the end of that
     // group, and carries into the alternatives that follow it there)
-    bool caseless = false, dotall = false, multiline = false;
+    bool caseless = false, dotall = false, multiline = false, extended = false;
+
+    // (?x): white space and #-comments between the items of a pattern mean nothing (not inside [...] or \Q..\E)
+    void skip_extended()
+    {
+        while (extended && !quoting && !eof()) {
+            const int c = p[i];
+            if (c == ' ' || (c >= 9 && c <= 13)) {
+                i++;
+            } else if (c == '#') {
+                while (!eof() && p[i] != '\n') i++;
+                if (!eof()) i++;
+            } else {
+                break;
+            }
+        }
+    }
     bool quoting = false; // inside \Q...\E
     int depth = 0;
 
@@ -399,10 +415,49 @@ struct Parser {
     // "(?" just consumed.  Either an option setting "(?i)" (returns with is_group = false), or the
     // opening of a non-capturing group "(?:" / "(?i:" (is_group = true; options already applied,
     // the caller restores them at the closing parenthesis).
+    int special = 0; // set by group_head: 1 (?=  2 (?!  3 (?<=  4 (?<!  5 (?>
+
+    // the length of everything the node can match, -1 if it varies (look-behind bodies must not: PCRE's rule -- the
+    // top-level alternatives of the body may differ from each other, nested ones may not)
+    static long fixed_len(const Node &nd)
+    {
+        switch (nd.kind) {
+        case Node::SET: return 1;
+        case Node::ASSERT:
+        case Node::LOOK: return 0;
+        case Node::ATOMIC: return fixed_len(nd.kids[0]);
+        case Node::CAT: {
+            long t = 0;
+            for (const Node &k : nd.kids) {
+                const long l = fixed_len(k);
+                if (l < 0) return -1;
+                t += l;
+            }
+            return t;
+        }
+        case Node::ALT: {
+            long t = -2;
+            for (const Node &k : nd.kids) {
+                const long l = fixed_len(k);
+                if (l < 0 || (t != -2 && l != t)) return -1;
+                t = l;
+            }
+            return t;
+        }
+        case Node::REP: {
+            if (nd.min != nd.max) return -1;
+            const long l = fixed_len(nd.kids[0]);
+            return l < 0 ? -1 : l * (long)nd.min;
+        }
+        }
+        return -1;
+    }
+
     bool group_head(bool &is_group, bool &named)
     {
         is_group = false;
         named = false;
+        special = 0;
         if (eof()) return fail(-1, "unrecognized character after (?");
         int c = p[i];
         if (c == '#') { // comment
@@ -416,8 +471,19 @@ struct Parser {
             is_group = true;
             return true;
         }
-        if (c == '=' || c == '!') return fail(1, "look-ahead");
-        if (c == '<' && i + 1 < n && (p[i + 1] == '=' || p[i + 1] == '!')) return fail(1, "look-behind");
+        special = 0;
+        if (c == '=' || c == '!') { // look-ahead
+            special = c == '=' ? 1 : 2;
+            i++;
+            is_group = true;
+            return true;
+        }
+        if (c == '<' && i + 1 < n && (p[i + 1] == '=' || p[i + 1] == '!')) { // look-behind
+            special = p[i + 1] == '=' ? 3 : 4;
+            i += 2;
+            is_group = true;
+            return true;
+        }
         if (c == '<' || c == '\'' || (c == 'P' && i + 1 < n && p[i + 1] == '<')) { // (?<name>  (?'name'  (?P<name> : capturing
             if (c == 'P') i++;
             const int close = p[i] == '<' ? '>' : '\'';
@@ -430,11 +496,16 @@ struct Parser {
             named = true;
             return true;
         }
-        if (c == '>') return fail(1, "atomic group");
+        if (c == '>') {
+            special = 5;
+            i++;
+            is_group = true;
+            return true;
+        }
         if (c == '|') return fail(1, "branch-reset group");
         if (c == 'P' || c == 'R' || c == '&' || c == '(' || c == 'C' || c == '+' || (c >= '0' && c <= '9'))
             return fail(1, "recursion / conditional / callout / named reference");
-        bool on = true, ci = caseless, da = dotall, ml = multiline;
+        bool on = true, ci = caseless, da = dotall, ml = multiline, ex = extended;
         for (;; i++) {
             if (eof()) return fail(-1, "missing ) after option setting");
             c = p[i];
@@ -447,7 +518,9 @@ struct Parser {
                 da = on;
             } else if (c == 'm') {
                 ml = on;
-            } else if (c == 'x' || c == 'J' || c == 'U' || c == 'X') {
+            } else if (c == 'x') {
+                ex = on;
+            } else if (c == 'J' || c == 'U' || c == 'X') {
                 return fail(1, "inline option outside the engine's subset");
             } else if (c == ')' || c == ':') {
                 break;
@@ -458,6 +531,7 @@ struct Parser {
         caseless = ci;
         dotall = da;
         multiline = ml;
+        extended = ex;
         is_group = (p[i] == ':');
         i++;
         return true;
@@ -488,9 +562,12 @@ struct Parser {
     {
         out = Node();
         out.kind = Node::CAT;
-        while (!eof()) {
+        for (;;) {
+            skip_extended();
+            if (eof()) break;
             int c = p[i];
             Node a;
+            bool look_quant = false;
             if (quoting) {
                 if (c == '\\' && i + 1 < n && p[i + 1] == 'E') {
                     quoting = false;
@@ -524,6 +601,7 @@ struct Parser {
                 }
                 if (acode) {
                     i += (c == '\\') ? 2 : 1;
+                    skip_extended();
                     if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?')) return fail(1, "quantified assertion");
                     uint32_t mn, mx;
                     size_t end;
@@ -543,6 +621,20 @@ struct Parser {
                     if (i + 1 < n && p[i + 1] == 'E') { // stray \E is ignored by PCRE
                         i += 2;
                         continue;
+                    }
+                    if (i + 1 < n && p[i + 1] == 'R') { // any newline sequence: (?>\r\n|\n|\x0b|\f|\r|\x85), 8-bit mode
+                        i += 2;
+                        Node crlf, cr, lf, one, alt;
+                        cr.set.set('\r');
+                        lf.set.set('\n');
+                        crlf.kind = Node::CAT;
+                        crlf.kids = {cr, lf};
+                        for (unsigned b : {0x0au, 0x0bu, 0x0cu, 0x0du, 0x85u}) one.set.set(b);
+                        alt.kind = Node::ALT;
+                        alt.kids = {crlf, one};
+                        a.kind = Node::ATOMIC;
+                        a.kids = {alt};
+                        break;
                     }
                     i++;
                     {
@@ -564,7 +656,7 @@ struct Parser {
                     i++;
                     if (eof()) return fail(-1, "missing )");
                     if (p[i] == '*') return fail(1, "backtracking control verb");
-                    const bool ci = caseless, da = dotall, ml = multiline;
+                    const bool ci = caseless, da = dotall, ml = multiline, ex = extended;
                     bool capture = true;
                     if (p[i] == '?') {
                         i++;
@@ -576,6 +668,8 @@ struct Parser {
                         }
                         capture = named;
                     }
+                    const int sp = special;
+                    special = 0;
                     depth++;
                     if (!parse_alt(a)) return false;
                     depth--;
@@ -584,6 +678,25 @@ struct Parser {
                     caseless = ci;
                     dotall = da;
                     multiline = ml;
+                    extended = ex;
+                    if (sp) { // look-around / atomic group: a wrapper node around the body
+                        if (sp == 3 || sp == 4) {
+                            bool fixed = true;
+                            if (a.kind == Node::ALT)
+                                for (const Node &k : a.kids) fixed = fixed && fixed_len(k) >= 0;
+                            else
+                                fixed = fixed_len(a) >= 0;
+                            if (!fixed) return fail(-1, "lookbehind assertion is not fixed length");
+                        }
+                        Node w;
+                        w.kind = sp == 5 ? Node::ATOMIC : Node::LOOK;
+                        w.behind = sp == 3 || sp == 4;
+                        w.neg = sp == 2 || sp == 4;
+                        w.kids.push_back(std::move(a));
+                        a = std::move(w);
+                        look_quant = sp != 5; // a quantifier behind an assertion only says whether it may be skipped (below)
+                        capture = false;
+                    }
                     if (capture) { // wrap: the body keeps its own kind, the wrapper carries the flag
                         Node w;
                         w.kind = Node::CAT;
@@ -612,6 +725,7 @@ struct Parser {
             }
             // quantifier (a quoted \Q..\E char may be quantified once the quote ended; PCRE
             // applies a quantifier after \E to the last quoted char -- same thing here)
+            skip_extended();
             if (!quoting && !eof()) {
                 int q = p[i];
                 bool have = false;
@@ -635,6 +749,16 @@ struct Parser {
                     int mode = 0;
                     if (!eof() && p[i] == '?') { mode = 1; i++; }
                     else if (!eof() && p[i] == '+') { mode = 2; i++; }
+                    if (look_quant) { // PCRE: {0} drops the assertion, a minimum of 0 makes it optional, anything else means once
+                        if (qmax == 0) {
+                            a = Node();
+                            a.kind = Node::CAT;
+                        }
+                        qmax = qmax == 0 ? 0 : 1;
+                        qmin = qmin == 0 ? 0 : 1;
+                        if (mode == 2) mode = 0;
+                    }
+                    skip_extended();
                     if (!eof()) {
                         int r = p[i];
                         uint32_t mn, mx;
@@ -882,6 +1006,16 @@ struct Unfold {
             out.push_back(std::move(s));
             return true;
         }
+        case Node::LOOK: { // consumes nothing; what it demands of the text is the matcher's business
+            Seq s;
+            s.inexact = true;
+            out.push_back(std::move(s));
+            return true;
+        }
+        case Node::ATOMIC: // the paths of the body, minus PCRE's "no way back into the group": necessary conditions
+            if (!run(nd.kids[0], out)) return false;
+            for (Seq &s : out) s.inexact = true;
+            return true;
         case Node::CAT: {
             out.push_back(Seq());
             for (const Node &k : nd.kids) {
@@ -1176,6 +1310,14 @@ std::atomic<uint64_t> g_next_id{1};
 
 uint64_t node_minlen(const Node &n);
 
+bool has_optional_group(const Node &n)
+{
+    if (n.kind == Node::REP && n.kids[0].kind != Node::SET && n.min == 0) return true;
+    for (const Node &k : n.kids)
+        if (has_optional_group(k)) return true;
+    return false;
+}
+
 // libpcre quirk (8.39 and 8.45 alike): a greedy repeat of a single class that is followed -- directly, or across group
 // brackets and items that may match "" -- by a possessive group repeat with a variable count ((?:0)?+, (..){1,2}+: compiled
 // as an atomic group whose last item is optional) is made possessive by pcre_compile's auto-possessification whenever
@@ -1187,6 +1329,14 @@ bool ends_in_greedy_repeat(const Node &n, bool prev, bool &quirk)
     switch (n.kind) {
     case Node::SET: return false;
     case Node::ASSERT: return prev;
+    case Node::LOOK: { // an assertion opcode stops auto-possessification's look-ahead; its body is a pattern of its own
+        ends_in_greedy_repeat(n.kids[0], false, quirk);
+        return false;
+    }
+    case Node::ATOMIC: { // (?>..) is what a possessive group repeat compiles to: the same quirk when an optional group ends it
+        if (prev && has_optional_group(n.kids[0])) quirk = true;
+        return ends_in_greedy_repeat(n.kids[0], prev, quirk);
+    }
     case Node::CAT: {
         bool f = prev;
         for (const Node &k : n.kids) f = ends_in_greedy_repeat(k, f, quirk);
@@ -1220,7 +1370,9 @@ uint64_t node_minlen(const Node &n)
     constexpr uint64_t cap = 1u << 30;
     switch (n.kind) {
     case Node::SET: return 1;
-    case Node::ASSERT: return 0;
+    case Node::ASSERT:
+    case Node::LOOK: return 0;
+    case Node::ATOMIC: return node_minlen(n.kids[0]);
     case Node::CAT: {
         uint64_t t = 0;
         for (const Node &k : n.kids) t = std::min(cap, t + node_minlen(k));

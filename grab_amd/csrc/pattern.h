@@ -75,8 +75,10 @@ enum { A_BOS = 1, // ^ without (?m), \A, \G: the subject start (the restart posi
        A_NWB };   // \B
 
 // Parse tree.  SET = one byte drawn from a class; REP repeats its single child (max == UINT32_MAX: unbounded).
+// LOOK = (?=..) (?!..) (?<=..) (?<!..) around its single child; ATOMIC = (?>..).
 struct Node {
-    enum Kind { SET, CAT, ALT, REP, ASSERT } kind = SET;
+    enum Kind { SET, CAT, ALT, REP, ASSERT, LOOK, ATOMIC } kind = SET;
+    bool behind = false, neg = false; // LOOK
     int acode = 0;             // ASSERT: one of the A_* codes
     ByteSet set;
     std::vector<Node> kids;

@@ -168,6 +168,26 @@ CASES = [
     dict(name="big_caret_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "^\\.{10}NEE|^\\.{4090}|DLE\\B", "big.txt"], big=True),
     dict(name="big_gap_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "\\.+NEEDLE", "big.txt"], big=True),   # runs of dots reach back across lines? no: up to the newline
     dict(name="big2_gap_L5", inputs={"big2.txt": {"kind": "big2"}}, args=L5 + ["-O", "-l", "a+\\.|\\.+N", "big2.txt"], big=True),
+    # ---- patterns the kernels can only pre-filter (gscan_info.exact == 0): the host's backtracking matcher confirms every offset ----
+    dict(name="inx_two_repeats", inputs={"f": lit("a@b.com x@y.org zz@ww.com.\nfoo@bar.comx @a.com a@.com\n")}, args=["-O", "\\w+@\\w+\\.com", "f"]),
+    dict(name="inx_two_repeats_Ol", inputs={"f": lit("a@b.com x@y.org zz@ww.com.\nfoo@bar.comx @a.com a@.com\n")}, args=["-O", "-l", "\\w+@\\w+\\.com", "f"]),
+    dict(name="inx_group_plus", inputs={"f": lit("foobaz foobarbaz barbar baz bazfoo foofoobaz\n")}, args=["-O", "-l", "(?:foo|bar)+baz", "f"]),
+    dict(name="inx_group_star_cap", inputs={"f": lit("abab ab c abc x\n")}, args=["-O", "-l", "(ab)*c|x", "f"]),
+    dict(name="inx_three_gaps", inputs={"f": lit("a1b2c\nabc\na b\nc a..b..c..a.b.c\n")}, args=["-O", "a.*b.*c", "f"]),
+    dict(name="inx_possessive", inputs={"f": lit("aaab aab ab b aaa\n")}, args=["-O", "-l", "a++b|a{1,40}$", "f"]),
+    dict(name="inx_lazy_group", inputs={"f": lit("abcd ababd cd abcabd\n")}, args=["-O", "-l", "(?:ab|c)+?d", "f"]),
+    dict(name="inx_many_alts", inputs={"f": lit("w001 w064 w065 xw03 w0640\n")}, args=["-O", "-l", "|".join("w%03d" % i for i in range(65)), "f"]),
+    dict(name="look_ahead", inputs={"f": lit("foobar foobaz foo\nfoobar")}, args=["-O", "-l", "foo(?=bar)", "f"]),
+    dict(name="look_ahead_neg", inputs={"f": lit("foobar foobaz foo\nfoobar")}, args=["-O", "-l", "foo(?!bar)", "f"]),
+    dict(name="look_behind", inputs={"f": lit("xfoo foo yfoo\nfoo xfoofoo")}, args=["-O", "-l", "(?<=x)foo", "f"]),
+    dict(name="look_behind_neg", inputs={"f": lit("xfoo foo yfoo\nfoo xfoofoo")}, args=["-O", "-l", "(?<!x)foo", "f"]),  # Q4: nothing lies before a restart position
+    dict(name="look_behind_alt", inputs={"f": lit("abd cd xd abcd\n")}, args=["-O", "-l", "(?<=ab|c)d", "f"]),
+    dict(name="look_atomic", inputs={"f": lit("aaab aaa ab\n")}, args=["-O", "-l", "(?>a+)b|(?>a+)a", "f"]),
+    dict(name="look_capture", inputs={"f": lit("xab ab\n")}, args=["-O", "-l", "x(?=(a))ab|ab", "f"]),
+    dict(name="syn8_inx_call", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 5}}, args=["-O", "[a-z]+\\([a-z0-9, ]*\\);", "syn"]),
+    dict(name="syn8_inx_member", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 5}}, args=["-O", "-l", "[a-z]+_[0-9]+\\.[a-z]+", "syn"]),
+    dict(name="syn8_inx_look", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 5}}, args=["-O", "-l", "(?<![a-z_])[a-z]{3}(?=\\()|(?<=;)\\n(?!\\n)", "syn"]),
+    dict(name="big_inx_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-O", "-l", "\\.+N+E+DLE|(?<=\\n)\\.{3}N", "big.txt"], big=True),
     dict(name="big_s_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-s", "-O", "-l", "NEEDLE", "big.txt"], big=True),
     dict(name="big_l_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-l", "NEEDLE", "big.txt"], big=True),
 ]

@@ -1,7 +1,7 @@
 """Grammar-based differential fuzz of the pattern compiler + host match rule against libpcre.
 
 Random patterns are drawn from the grammar the engine claims to take (byte classes, greedy / lazy / possessive repeats,
-alternation, plain / capturing / option-scoped groups, ^ $ \\b \\B \\A \\z \\Z, (?i) (?m) (?s)).  For every pattern PCRE
+alternation, plain / capturing / option-scoped / atomic groups, look-ahead and look-behind, ^ $ \\b \\B \\A \\z \\Z, (?i) (?m) (?s)).  For every pattern PCRE
 accepts and the engine does not refuse, the product's chunk walk (grab_report_chunk -> gscan_next_match) -- fed with
 exactly what the kernels are specified to report for the text (device windows: tests/inputs.py:db_candidates) -- must
 print what the reference's loop prints; the oracle runs pcre_exec the way /root/reference/src/grab.cc:175-213 does, with
@@ -34,9 +34,15 @@ def gen(rng):
             return rng.choice(ATOMS)
         if r < 0.85:
             return "(?:" + alt(d + 1) + ")"
-        if r < 0.93:
+        if r < 0.91:
             return "(" + alt(d + 1) + ")"
-        return "(?i:" + alt(d + 1) + ")"
+        if r < 0.94:
+            return "(?i:" + alt(d + 1) + ")"
+        if r < 0.955:
+            return rng.choice(["(?=", "(?!"]) + alt(d + 1) + ")"
+        if r < 0.975:  # look-behind: fixed-length alternatives
+            return rng.choice(["(?<=", "(?<!"]) + "|".join("".join(rng.choice(ATOMS) for _ in range(rng.choice([1, 1, 2, 3]))) for _ in range(rng.choice([1, 1, 2]))) + ")"
+        return "(?>" + alt(d + 1) + ")"
 
     def piece(d):
         a = atom(d)
@@ -57,7 +63,7 @@ def gen(rng):
 
     p = alt(0)
     if rng.random() < 0.25:
-        p = rng.choice(["(?i)", "(?m)", "(?s)", "(?im)", "(?ms)"]) + p
+        p = rng.choice(["(?i)", "(?m)", "(?s)", "(?im)", "(?ms)", "(?x)", "(?xi)", "(?x) # c\n"]) + p
     return p
 
 

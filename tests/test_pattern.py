@@ -88,12 +88,12 @@ SUPPORTED = [
 NULL_TIER = ["a?", "x*", "", "a{0}", "[a-z]{0,3}", "x{0}", "a|", "(?:foo|b?)", "a??", "(?:ab)?", "x*?y{0}"]
 
 UNSUPPORTED = [r"\1", r"\pL",
-               r"\Rfoo", "a{2}{3}", "x" * 300, "(?=foo)", "(?<!a)b", "(?>ab)c", "(?x)a b",
-               "(?|a|b)", r"(a)\1", "(?P=n)", "(?<=a)b", "(*UTF8)a", r"x*(?:ab)?+x", r"b[x.]{0,2}(?:0)?+[x.]{1,3} ", "(?i)[[:^upper:]]a", "a(?R)?b"]
+               r"\Xfoo", "a{2}{3}", "x" * 300, "(?x)a + ?b",
+               "(?|a|b)", r"(a)\1", "(?P=n)", "(*UTF8)a", r"x*(?>(?:0)?)x", r"x*(?:ab)?+x", r"b[x.]{0,2}(?:0)?+[x.]{1,3} ", "(?i)[[:^upper:]]a", "a(?R)?b"]
 
 # "a(" is reported as unsupported (groups) by the engine alone; FileGrep::prepare asks libpcre first and
 # gives the reference's "pcre_compile error" for it (tests/test_gpu_filegrep.py, golden case bad_regex)
-UNSUPPORTED += [r"\b*a", "(?<=a)b"]
+UNSUPPORTED += [r"\b*a"]
 
 # assertions that contradict each other: pcre_exec never matches, and neither does the engine (nothing is scanned at all)
 NEVER = [r"fo\bo", r"a\Ab", r"x^y|a\zb", r"(?m)a$b"]
@@ -114,9 +114,12 @@ INEXACT = ["a+b+c", "a{1,40}b", "a++b", "(?:ab)+", "(?:a|b)*c", "(?:ab)?+c", "(a
            "fo$o", r"(?:a\b){2}", r"\w+@\w+\.com", r"(?:foo|bar)+baz", r"(\w+\s)+x", r"[a-c]+\d+[x.]", r"(?:ab|c)+?d", r"(?i)(?:li|nu)+s",
            r"(?m)^\w+ \w+$", r"a(?:b|c)*+d", r"x.*y.*z", r"(?s)a.+b.+c", r"(?:a|b)+(?:c|d)+", r"((a|b)+c)+d",
            "(?:a|)+b", "(?:a|b|c|d){4}", r"(?:\.?+a)+b", "(?:a*)+b", "a{0,40}b", "(?:|a){2}b", r"a(?:$cb??|a?+[^a]{0,2}\b){2}",
-           "(?:ab|cd|li|nu|fo|ob|ar|ba){3}", "|".join("w%03d" % i for i in range(65)) + "|foo|linus"]
+           "(?:ab|cd|li|nu|fo|ob|ar|ba){3}", "|".join("w%03d" % i for i in range(65)) + "|foo|linus",
+           # look-around and atomic groups: nothing of them reaches the kernels, the matcher evaluates them
+           "foo(?=bar)", "foo(?!bar)", "(?<=x)y", "(?<!a)b", "(?<=ab|c)d", "(?>a+)b", "(?>ab|a)c", r"\b(?=\w{3}\b)[a-z]+", "(?=(a))ab|b",
+           r"(?<![a-z])li(?=nus)", "a(?=b)?b", "(?!a)*+b" if False else "x(?!y){2}.", "(?<=\n)[a-z]+(?= )", "(?s)a(?=.*z)b", r"\Rfoo", r"a\R+b"]
 
-MALFORMED = ["[abc", "*a", "+", "?x", "a{3,2}", "[z-a]", "\\", "a)", "[[:nope:]]", "(?:a", "(?i", "(?:a|*b)", "a|+", "(?z)a", "(?i)+a"]
+MALFORMED = ["(?<=a+)b", "(?<!ab|c*)d", "[abc", "*a", "+", "?x", "a{3,2}", "[z-a]", "\\", "a)", "[[:nope:]]", "(?:a", "(?i", "(?:a|*b)", "a|+", "(?z)a", "(?i)+a"]
 
 
 def _fix5(p):
@@ -276,6 +279,23 @@ def test_inexact_patterns_match_pcre(pattern, built, liboracle):
     assert got == want
     texts = [buf[o:o + 400] for o in range(0, len(buf), 400)] + [buf]
     assert check(liboracle, pattern, texts) == len(texts)
+
+
+EXTENDED = [("(?x) f o o # the needle\n b a r", "foobar"), ("(?x)a +b", "a+b"), (r"(?x)a\ b", "a b"), ("(?x)[ #]a", "[ #]a"), ("(?x:a b)c d", "abc d"),
+            ("a(?x) b (?-x) c", "ab c"), ("(?x) (?: fo | ba ) {2} r", "(?:fo|ba){2}r"), ("(?xi) li nus", "(?i)linus")]
+
+
+@pytest.mark.parametrize("spaced,plain", EXTENDED)
+def test_extended_mode(spaced, plain, built, liboracle):
+    """(?x): white space and #-comments between items mean nothing -- the compiled form equals the plain spelling's, and
+    libpcre agrees on minlen."""
+    a, b = engine.Database(spaced), engine.Database(plain)
+    ml = C.c_int()
+    assert liboracle.oracle_minlen(spaced.encode(), C.byref(ml)) == 0 and ml.value == a.minlen == b.minlen
+    assert a.info.n_alts == b.info.n_alts and a.info.tier == b.info.tier
+    for i in range(a.info.n_alts):
+        assert a.alt_len(i) == b.alt_len(i)
+        assert all((a.class_table(k, i) == b.class_table(k, i)).all() for k in range(a.alt_len(i)))
 
 
 def test_alternative_order_and_limits(built):
