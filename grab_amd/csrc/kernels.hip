@@ -448,9 +448,36 @@ __device__ __forceinline__ W run_and(uint32_t nruns, uint32_t vrd, const W (&cls
 //   runs under profiles/).  Bank conflicts are possible here (random 16-bit indices) but the LDS
 //   has the cycles to spare; the table is built once per workgroup, so this form runs as a
 //   persistent grid.
-template <int ITER, bool NT, bool WIDE, bool PAIR>
+// (a << SH) | b in one instruction
+template <int SH>
+__device__ __forceinline__ uint32_t lshl_or(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "v"(b));
+    return r;
+}
+
+// one run of the branch-free program (ScanArgs::run_flat): d is wave-uniform, so every field is an s_bfe
+__device__ __forceinline__ uint32_t run_one_flat(uint32_t d, uint32_t w0, uint32_t w1)
+{
+    uint32_t x = (d & 1u) ? w1 : w0;
+    x &= x >> ((d >> 1) & 1u);
+    x &= x >> ((d >> 2) & 3u);
+    x &= x >> ((d >> 4) & 7u);
+    x &= x >> ((d >> 7) & 15u);
+    x &= x >> ((d >> 11) & 31u);
+    return x >> ((d >> 16) & 63u);
+}
+
+// NR: the two-class form with windows of <= 17 bytes runs the branch-free run program (run_one_flat) -- NR = 1..3: the
+// pattern has exactly that many runs and their descriptors are decoded once, before the tile loop; NR = 0: any number,
+// one v_readlane + a handful of s_bfe per run and step; NR = -1 (the other forms): run_and's scalar loops.  Measured on
+// the identifier scan: the scalar loops cost 203 M SALU instructions per 4 GiB against 31 M, and 8 % of the time
+// (profiles/r01_w_k2_opt_sweep.txt, r01_w_k2_pmc.txt).
+template <int ITER, bool NT, bool WIDE, bool PAIR, int NR = -1>
 __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
+    static_assert(NR < 0 || (PAIR && !WIDE), "the flat run program is the two-class, 32-bit form's");
     constexpr int kNW = PAIR ? 8 : 4; // waves per workgroup
     __shared__ uint32_t tbl[PAIR ? 65536 / 4 : 256 * 32];
     __shared__ __attribute__((aligned(8))) uint16_t s_xp[kNW * ITER * 64]; // epilogue transposition strip, 2 bytes per (step, lane)
@@ -466,6 +493,10 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
     // would put a scalar load + s_waitcnt lgkmcnt(0) into every step, and that wait also drains
     // the LDS lookups already in flight for the next step.
     const uint32_t vrd = a.run_desc[lane & (kK2MaxRuns - 1)];
+    const uint32_t vrf = a.run_flat[lane & (kK2MaxRuns - 1)];
+    uint32_t rf[3] = {0, 0, 0}; // NR > 0: the run descriptors, wave-uniform
+    if (NR > 0)
+        for (int r = 0; r < NR; r++) rf[r] = __builtin_amdgcn_readlane(vrf, r);
     const uint8_t *tbl8 = reinterpret_cast<const uint8_t *>(tbl);
 
     if (!PAIR) { // stage the class table: entry b replicated into all 32 banks
@@ -512,7 +543,9 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
                     const uint32_t e0 = tbl8[d.x & 0xffffu], e1 = tbl8[d.x >> 16], e2 = tbl8[d.y & 0xffffu], e3 = tbl8[d.y >> 16];
                     const uint32_t e4 = tbl8[d.z & 0xffffu], e5 = tbl8[d.z >> 16], e6 = tbl8[d.w & 0xffffu], e7 = tbl8[d.w >> 16];
                     // byte q of g: low nibble = class 0 of positions 4q..4q+3, high nibble = class 1
-                    const uint32_t g = (e0 | (e1 << 2)) | ((e2 | (e3 << 2)) << 8) | ((e4 | (e5 << 2)) << 16) | ((e6 | (e7 << 2)) << 24);
+                    // (one v_lshl_or_b32 per entry, in the order the look-ups return: the compiler's own choice for this
+                    // expression is 7 shifts + 4 three-way ORs)
+                    const uint32_t g = lshl_or<26>(e7, lshl_or<24>(e6, lshl_or<18>(e5, lshl_or<16>(e4, lshl_or<10>(e3, lshl_or<8>(e2, lshl_or<2>(e1, e0)))))));
                     const uint32_t x = g & 0x0f0f0f0fu, y = (g >> 4) & 0x0f0f0f0fu;
                     const uint32_t tx = x | (x >> 4), ty = y | (y >> 4); // bytes 0 and 2 now hold 8 positions each
                     p01 = (tx & 0xffu) | ((tx >> 8) & 0xff00u) | ((ty & 0xffu) << 16) | ((ty << 8) & 0xff000000u);
@@ -545,7 +578,18 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
                     const uint32_t a23 = more ? down1(p23, __builtin_amdgcn_readfirstlane(p23n)) : 0u;
                     const uint32_t W[4] = {(p01 & 0xffffu) | (a01 << 16), (p01 >> 16) | (a01 & 0xffff0000u),
                                            (p23 & 0xffffu) | (a23 << 16), (p23 >> 16) | (a23 & 0xffff0000u)};
-                    bits = run_and<uint32_t>(nruns, vrd, W) & 0xffffu;
+                    if (NR > 0) {
+                        uint32_t cand = 0xffffu;
+#pragma unroll
+                        for (int r = 0; r < NR; r++) cand &= run_one_flat(rf[r], W[0], W[1]);
+                        bits = cand;
+                    } else if (NR == 0) {
+                        uint32_t cand = 0xffffu;
+                        for (uint32_t r = 0; r < nruns; r++) cand &= run_one_flat(__builtin_amdgcn_readlane(vrf, r), W[0], W[1]);
+                        bits = cand;
+                    } else {
+                        bits = run_and<uint32_t>(nruns, vrd, W) & 0xffffu;
+                    }
                 } else { // look-ahead <= 48 positions: three neighbours
                     const uint32_t s01_0 = __builtin_amdgcn_readlane(p01n, 0), s01_1 = __builtin_amdgcn_readlane(p01n, 1),
                                    s01_2 = __builtin_amdgcn_readlane(p01n, 2);
@@ -934,7 +978,10 @@ static void launch_k2(bool wide, bool pair, const ScanArgs &a, dim3 g, hipStream
     const TileDesc *tiles = a.tiles;
     if (pair) {
         if (wide) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, true, true>), g, dim3(512), 0, st, a, tiles);
-        else hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, true>), g, dim3(512), 0, st, a, tiles);
+        else if (a.nruns == 1) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, true, 1>), g, dim3(512), 0, st, a, tiles);
+        else if (a.nruns == 2) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, true, 2>), g, dim3(512), 0, st, a, tiles);
+        else if (a.nruns == 3) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, true, 3>), g, dim3(512), 0, st, a, tiles);
+        else hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, true, 0>), g, dim3(512), 0, st, a, tiles);
     } else {
         if (wide) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, true, false>), g, dim3(kWG), 0, st, a, tiles);
         else hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, false>), g, dim3(kWG), 0, st, a, tiles);
@@ -975,8 +1022,18 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
     a.k3_exact = pg.n_alts <= (uint32_t)kK3Buckets && pg.k3_off == 0;
     for (uint32_t i = 0; i < pg.n_alts; i++)
         if (pg.alt_len[i] > (uint32_t)kK3Depth) a.k3_exact = 0;
-    for (int r = 0; r < kK2MaxRuns; r++)
+    for (int r = 0; r < kK2MaxRuns; r++) {
         a.run_desc[r] = (uint32_t)pg.run_cls[r] | ((uint32_t)pg.run_len[r] << 8) | ((uint32_t)pg.run_off[r] << 16);
+        const uint32_t n = pg.run_len[r];
+        uint32_t have = 1, f = pg.run_cls[r] & 1u;
+        if (n >= 2) f |= 1u << 1, have = 2;
+        if (n >= 4) f |= 2u << 2, have = 4;
+        if (n >= 8) f |= 4u << 4, have = 8;
+        if (n >= 16) f |= 8u << 7, have = 16;
+        f |= ((n > have ? n - have : 0u) & 31u) << 11;
+        f |= ((uint32_t)pg.run_off[r] & 63u) << 16;
+        a.run_flat[r] = f;
+    }
 }
 
 // does the pattern need the second pass?  (the same condition the scan kernel reads as !k3_confirm_exact)

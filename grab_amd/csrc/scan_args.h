@@ -39,6 +39,10 @@ struct ScanArgs {
     uint32_t k3_off, k3_exact;                            // K3
     uint32_t report_shift;   // reported offset = device window start + this (1 when the windows carry a leading context position)
     uint32_t run_desc[kK2MaxRuns];                        // K2: cls | len<<8 | off<<16
+    // K2, windows of <= 17 bytes: the run's shift program, decoded on the host -- cls @0, then the shift amounts of the
+    // doubling steps (0 = step not taken) 1 @1, 2 @2 (2 bits), 4 @4 (3 bits), 8 @7 (4 bits), the remainder @11 (5 bits),
+    // the run's window offset @16 (6 bits)
+    uint32_t run_flat[kK2MaxRuns];
 };
 
 // variant: bits 0-1 select KiB per wave {0:16, 1:8, 2:12}; bit 2 = nontemporal loads
