@@ -461,11 +461,13 @@ __device__ __forceinline__ uint32_t lshl_or(uint32_t a, uint32_t b)
 __device__ __forceinline__ uint32_t run_one_flat(uint32_t d, uint32_t w0, uint32_t w1)
 {
     uint32_t x = (d & 1u) ? w1 : w0;
-    x &= x >> ((d >> 1) & 1u);
-    x &= x >> ((d >> 2) & 3u);
-    x &= x >> ((d >> 4) & 7u);
-    x &= x >> ((d >> 7) & 15u);
-    x &= x >> ((d >> 11) & 31u);
+    if (d & 0xfffeu) { // (a run of one byte has no steps at all: a uniform branch instead of ten no-ops)
+        x &= x >> ((d >> 1) & 1u);
+        x &= x >> ((d >> 2) & 3u);
+        x &= x >> ((d >> 4) & 7u);
+        x &= x >> ((d >> 7) & 15u);
+        x &= x >> ((d >> 11) & 31u);
+    }
     return x >> ((d >> 16) & 63u);
 }
 
@@ -546,9 +548,11 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
                     // (one v_lshl_or_b32 per entry, in the order the look-ups return: the compiler's own choice for this
                     // expression is 7 shifts + 4 three-way ORs)
                     const uint32_t g = lshl_or<26>(e7, lshl_or<24>(e6, lshl_or<18>(e5, lshl_or<16>(e4, lshl_or<10>(e3, lshl_or<8>(e2, lshl_or<2>(e1, e0)))))));
-                    const uint32_t x = g & 0x0f0f0f0fu, y = (g >> 4) & 0x0f0f0f0fu;
-                    const uint32_t tx = x | (x >> 4), ty = y | (y >> 4); // bytes 0 and 2 now hold 8 positions each
-                    p01 = (tx & 0xffu) | ((tx >> 8) & 0xff00u) | ((ty & 0xffu) << 16) | ((ty << 8) & 0xff000000u);
+                    // nibbles of g: c0 c1 c0 c1 | c0 c1 c0 c1 -> c0 c0 c0 c0 | c1 c1 c1 c1: swap nibbles 1 and 2 of each half
+                    // (xor trick), then bytes 1 and 2 (v_perm): 5 operations
+                    const uint32_t sw = ((g >> 4) ^ g) & 0x00f000f0u;
+                    const uint32_t h = g ^ sw ^ (sw << 4);
+                    p01 = __builtin_amdgcn_perm(h, h, 0x03010200u);
                     p23 = 0;
                 } else {
                     uint32_t lo = 0, hi8 = 0;
@@ -576,8 +580,9 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
                 if (!WIDE) { // look-ahead <= 16 positions: one neighbour
                     const uint32_t a01 = down1(p01, __builtin_amdgcn_readfirstlane(p01n));
                     const uint32_t a23 = more ? down1(p23, __builtin_amdgcn_readfirstlane(p23n)) : 0u;
-                    const uint32_t W[4] = {(p01 & 0xffffu) | (a01 << 16), (p01 >> 16) | (a01 & 0xffff0000u),
-                                           (p23 & 0xffffu) | (a23 << 16), (p23 >> 16) | (a23 & 0xffff0000u)};
+                    // class c's 32 positions: the low (high) halves of this lane's and the next lane's masks -- one v_perm each
+                    const uint32_t W[4] = {__builtin_amdgcn_perm(a01, p01, 0x05040100u), __builtin_amdgcn_perm(a01, p01, 0x07060302u),
+                                           more ? __builtin_amdgcn_perm(a23, p23, 0x05040100u) : 0u, more ? __builtin_amdgcn_perm(a23, p23, 0x07060302u) : 0u};
                     if (NR > 0) {
                         uint32_t cand = 0xffffu;
 #pragma unroll
