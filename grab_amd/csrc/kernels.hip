@@ -57,6 +57,8 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kWG = 256;
 constexpr int kWaves = kWG / kWave;
+constexpr int kK3WG = 512; // K3 and the two-class form of K2: 8 waves share one 64 KiB table
+constexpr int kK3Waves = kK3WG / kWave;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -651,30 +653,35 @@ __device__ __forceinline__ uint32_t and_b2_b3(uint32_t x, uint32_t y)
     return r;
 }
 template <int ITER, bool NT>
-__global__ __launch_bounds__(kWG) void k3_bucket_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
+__global__ __launch_bounds__(kK3WG) void k3_bucket_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
-    __shared__ uint32_t tbl[256 * 32];
+    // The filter table, one copy PER LANE: entry b of lane l lives at byte address b << 8 | l << 2.  Both fields are whole
+    // bytes, so ONE v_perm_b32 turns a text byte into its LDS address (with the 32-copy layout the address took a v_bfe
+    // and a v_lshl_or: 19 look-ups per step made that the kernel's largest single VALU item), and lanes never collide.
+    // 64 KiB per workgroup: 512 threads share it, two workgroups per CU, run as a persistent grid.
+    __shared__ uint32_t tbl[256 * 64];
     __shared__ __attribute__((aligned(16))) uint8_t s_pos[kK3Confirm * 256];
     __shared__ uint8_t s_blen[kK3Buckets];
-    __shared__ uint32_t s_cnt[kWaves];
+    __shared__ uint32_t s_cnt[kK3Waves];
     __shared__ uint32_t s_base;
-    constexpr uint32_t kTile = kWaves * ITER * 1024;
+    constexpr uint32_t kTile = kK3Waves * ITER * 1024;
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x / kWave;
-    const uint32_t bank = lane & 31u;
+    const uint32_t lane4 = lane << 2;
     const uint32_t koff = a.k3_off, m = a.m;
     const bool exact = a.k3_exact != 0;
     const bool confirm_exact = a.prog->k3_confirm_exact != 0; // wave-uniform (scalar load)
+    const uint8_t *tbl8 = reinterpret_cast<const uint8_t *>(tbl);
     {
-        const uint32_t b = threadIdx.x; // 256 threads == 256 entries, each replicated into all 32 banks
+        const uint32_t b = threadIdx.x & 255u, half = threadIdx.x >> 8; // 512 threads: entry b, copies of lanes half*32 .. half*32+31
         const uint32_t v = a.prog->k3_table[b];
 #pragma unroll 8
-        for (uint32_t r = 0; r < 32; r++) tbl[(b << 5) | ((r + lane) & 31u)] = v;
+        for (uint32_t r = 0; r < 32; r++) tbl[(b << 6) | (half << 5) | ((r + lane) & 31u)] = v;
         // confirm tables (cold path only): kK3Confirm window positions x 256 bytes, one copy
         const u32x4 *src = reinterpret_cast<const u32x4 *>(&a.prog->k3_pos[0][0]);
         u32x4 *dst = reinterpret_cast<u32x4 *>(s_pos);
-        for (uint32_t q = b; q < (uint32_t)(kK3Confirm * 256 / 16); q += kWG) dst[q] = src[q];
-        if (b < (uint32_t)kK3Buckets) s_blen[b] = a.prog->k3_blen[b];
+        for (uint32_t q = threadIdx.x; q < (uint32_t)(kK3Confirm * 256 / 16); q += kK3WG) dst[q] = src[q];
+        if (threadIdx.x < (uint32_t)kK3Buckets) s_blen[threadIdx.x] = a.prog->k3_blen[threadIdx.x];
     }
     __syncthreads();
 
@@ -694,21 +701,17 @@ __global__ __launch_bounds__(kWG) void k3_bucket_scan(ScanArgs a, const TileDesc
 #pragma unroll
             for (int k = 0; k < ITER; k++) {
                 const u32x4 d = buf[k];
-                const uint32_t nx = __builtin_amdgcn_readfirstlane(buf[k + 1].x);
+                // the three bytes behind this lane's sixteen: the next lane's first dword (lane 63: the next step's lane 0)
+                const uint32_t nd = down1(d.x, __builtin_amdgcn_readfirstlane(buf[k + 1].x));
                 uint32_t e[19];
-#define GS_E(i_, w_, sh_) e[i_] = tbl[((((w_) >> (sh_)) & 0xffu) << 5) | bank]
-                GS_E(0, d.x, 0);  GS_E(1, d.x, 8);  GS_E(2, d.x, 16);  GS_E(3, d.x, 24);
-                GS_E(4, d.y, 0);  GS_E(5, d.y, 8);  GS_E(6, d.y, 16);  GS_E(7, d.y, 24);
-                GS_E(8, d.z, 0);  GS_E(9, d.z, 8);  GS_E(10, d.z, 16); GS_E(11, d.z, 24);
-                GS_E(12, d.w, 0); GS_E(13, d.w, 8); GS_E(14, d.w, 16); GS_E(15, d.w, 24);
-                uint32_t n0, n1, n2; // entries of the first three bytes of the NEXT step (lane 63 looks into them)
-                n0 = tbl[(((nx >> 0) & 0xffu) << 5) | bank];
-                n1 = tbl[(((nx >> 8) & 0xffu) << 5) | bank];
-                n2 = tbl[(((nx >> 16) & 0xffu) << 5) | bank];
+                // address = [lane << 2, text byte, 0, 0]: selector byte 0 = lane4.b0, byte 1 = w.b(i), 0x0c = constant zero
+#define GS_E(i_, w_, by_) e[i_] = *reinterpret_cast<const uint32_t *>(tbl8 + __builtin_amdgcn_perm((w_), lane4, 0x0c0c0400u | ((uint32_t)(by_) << 8)))
+                GS_E(0, d.x, 0);  GS_E(1, d.x, 1);  GS_E(2, d.x, 2);  GS_E(3, d.x, 3);
+                GS_E(4, d.y, 0);  GS_E(5, d.y, 1);  GS_E(6, d.y, 2);  GS_E(7, d.y, 3);
+                GS_E(8, d.z, 0);  GS_E(9, d.z, 1);  GS_E(10, d.z, 2); GS_E(11, d.z, 3);
+                GS_E(12, d.w, 0); GS_E(13, d.w, 1); GS_E(14, d.w, 2); GS_E(15, d.w, 3);
+                GS_E(16, nd, 0);  GS_E(17, nd, 1);  GS_E(18, nd, 2);
 #undef GS_E
-                e[16] = down1(e[0], n0);
-                e[17] = down1(e[1], n1);
-                e[18] = down1(e[2], n2);
                 // byte selects come for free with SDWA: A_j = e_j.b0 & e_{j+1}.b1, B_j = e_j.b2 & e_{j+1}.b3, h_j = A_j & B_{j+2}
                 // (plain shift + and in place of the byte selects: 4 ops per byte, 14 % slower -- profiles/r01_o_sweep_k3_sdwa.txt)
                 uint32_t h[16], any = 0;
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(kWG) void k3_bucket_scan(ScanArgs a, const TileDesc
                 }
             }
         }
-        emit_tile<ITER, kWaves>(a, t, hits, cnt, sub_off, koff - a.report_shift, lane, wave, s_cnt, &s_base);
+        emit_tile<ITER, kK3Waves>(a, t, hits, cnt, sub_off, koff - a.report_shift, lane, wave, s_cnt, &s_base);
     }
 }
 
@@ -968,14 +971,17 @@ static bool k2_pair(const ScanArgs &a) { return a.n_classes <= 2; }
 
 uint32_t scan_tile_bytes(int tier, int variant, uint32_t n_classes)
 {
-    const int waves = (tier == GSCAN_TIER_CLASSRUN && n_classes <= 2) ? 8 : kWaves;
+    const int waves = ((tier == GSCAN_TIER_CLASSRUN && n_classes <= 2) || tier == GSCAN_TIER_BUCKET) ? 8 : kWaves;
     return (uint32_t)(waves * kIters[variant & 3] * 1024);
 }
 
 uint32_t scan_min_tile_bytes() { return (uint32_t)(kWaves * 8 * 1024); }
 
 // resident workgroups per CU the kernel is designed for when it runs as a persistent grid (0 = no preference)
-uint32_t scan_persistent_blocks(int tier, uint32_t n_classes) { return (tier == GSCAN_TIER_CLASSRUN && n_classes <= 2) ? 2u : 0u; }
+uint32_t scan_persistent_blocks(int tier, uint32_t n_classes)
+{
+    return ((tier == GSCAN_TIER_CLASSRUN && n_classes <= 2) || tier == GSCAN_TIER_BUCKET) ? 2u : 0u; // (64 KiB of table to stage per workgroup)
+}
 
 template <int ITER, bool NT>
 static void launch_k2(bool wide, bool pair, const ScanArgs &a, dim3 g, hipStream_t st)
@@ -999,8 +1005,8 @@ static hipError_t launch_iter(int tier, bool nt, bool wide, const ScanArgs &a, u
     dim3 g(grid);
     const TileDesc *tiles = a.tiles;
     if (tier == GSCAN_TIER_BUCKET) {
-        if (nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true>), g, dim3(kWG), 0, st, a, tiles);
-        else hipLaunchKernelGGL((k3_bucket_scan<ITER, false>), g, dim3(kWG), 0, st, a, tiles);
+        if (nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true>), g, dim3(kK3WG), 0, st, a, tiles);
+        else hipLaunchKernelGGL((k3_bucket_scan<ITER, false>), g, dim3(kK3WG), 0, st, a, tiles);
     } else if (tier == GSCAN_TIER_LITERAL) {
         if (nt) hipLaunchKernelGGL((k1_anchor_scan<ITER, true>), g, dim3(kWG), 0, st, a, tiles);
         else hipLaunchKernelGGL((k1_anchor_scan<ITER, false>), g, dim3(kWG), 0, st, a, tiles);
