@@ -646,13 +646,22 @@ __device__ __forceinline__ uint32_t and_b0_b1(uint32_t x, uint32_t y)
     asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
+__device__ __forceinline__ uint32_t and_dw_b2(uint32_t x, uint32_t y) // x & byte 2 of y (x: a byte value)
+{
+    uint32_t r;
+    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 __device__ __forceinline__ uint32_t and_b2_b3(uint32_t x, uint32_t y)
 {
     uint32_t r;
     asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_3" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
-template <int ITER, bool NT>
+// DEPTH: window positions the filter looks at.  4 by default; 3 when the compiler expects three positions to be selective
+// enough (ScanArgs::k3_depth: literal-like alternatives) -- two SDWA operations per byte instead of three and one look-up
+// less per step, paid for with more trips into the confirm path.
+template <int ITER, bool NT, int DEPTH = 4>
 __global__ __launch_bounds__(kK3WG) void k3_bucket_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     // The filter table, one copy PER LANE: entry b of lane l lives at byte address b << 8 | l << 2.  Both fields are whole
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(kK3WG) void k3_bucket_scan(ScanArgs a, const TileDe
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t lane4 = lane << 2;
     const uint32_t koff = a.k3_off, m = a.m;
-    const bool exact = a.k3_exact != 0;
+    const bool exact = DEPTH == 4 && a.k3_exact != 0; // (the three-position form always confirms)
     const bool confirm_exact = a.prog->k3_confirm_exact != 0; // wave-uniform (scalar load)
     const uint8_t *tbl8 = reinterpret_cast<const uint8_t *>(tbl);
     {
@@ -710,12 +719,19 @@ __global__ __launch_bounds__(kK3WG) void k3_bucket_scan(ScanArgs a, const TileDe
                 GS_E(4, d.y, 0);  GS_E(5, d.y, 1);  GS_E(6, d.y, 2);  GS_E(7, d.y, 3);
                 GS_E(8, d.z, 0);  GS_E(9, d.z, 1);  GS_E(10, d.z, 2); GS_E(11, d.z, 3);
                 GS_E(12, d.w, 0); GS_E(13, d.w, 1); GS_E(14, d.w, 2); GS_E(15, d.w, 3);
-                GS_E(16, nd, 0);  GS_E(17, nd, 1);  GS_E(18, nd, 2);
+                GS_E(16, nd, 0);  GS_E(17, nd, 1);
+                if (DEPTH == 4) GS_E(18, nd, 2);
 #undef GS_E
                 // byte selects come for free with SDWA: A_j = e_j.b0 & e_{j+1}.b1, B_j = e_j.b2 & e_{j+1}.b3, h_j = A_j & B_{j+2}
                 // (plain shift + and in place of the byte selects: 4 ops per byte, 14 % slower -- profiles/r01_o_sweep_k3_sdwa.txt)
                 uint32_t h[16], any = 0;
-                {
+                if (DEPTH == 3) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        h[j] = and_dw_b2(and_b0_b1(e[j], e[j + 1]), e[j + 2]);
+                        any |= h[j];
+                    }
+                } else {
                     uint32_t A[16], B[18];
 #pragma unroll
                     for (int j = 0; j < 16; j++) A[j] = and_b0_b1(e[j], e[j + 1]);
@@ -1005,7 +1021,8 @@ static hipError_t launch_iter(int tier, bool nt, bool wide, const ScanArgs &a, u
     dim3 g(grid);
     const TileDesc *tiles = a.tiles;
     if (tier == GSCAN_TIER_BUCKET) {
-        if (nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true>), g, dim3(kK3WG), 0, st, a, tiles);
+        if (a.k3_depth == 3 && ITER == 12 && nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true, ITER == 12 ? 3 : 4>), g, dim3(kK3WG), 0, st, a, tiles);
+        else if (nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true>), g, dim3(kK3WG), 0, st, a, tiles);
         else hipLaunchKernelGGL((k3_bucket_scan<ITER, false>), g, dim3(kK3WG), 0, st, a, tiles);
     } else if (tier == GSCAN_TIER_LITERAL) {
         if (nt) hipLaunchKernelGGL((k1_anchor_scan<ITER, true>), g, dim3(kWG), 0, st, a, tiles);
@@ -1033,6 +1050,25 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
     a.k3_exact = pg.n_alts <= (uint32_t)kK3Buckets && pg.k3_off == 0;
     for (uint32_t i = 0; i < pg.n_alts; i++)
         if (pg.alt_len[i] > (uint32_t)kK3Depth) a.k3_exact = 0;
+    // Three filter positions are enough when a hit of theirs is rare: expected hits per KiB step of a wave, pricing a
+    // class by its size over the ~64 byte values text is made of, below 2 %.  (GSCAN_K3_DEPTH overrides: measurements.)
+    {
+        double p3 = 0;
+        for (uint32_t i = 0; i < pg.n_alts; i++) {
+            double prod = 1;
+            for (uint32_t k = 0; k < 3; k++) {
+                const uint32_t pos = pg.k3_off + k;
+                if (pos >= pg.alt_len[i]) continue;
+                int members = 0;
+                const uint32_t *bits = pg.cls_bits[pg.alt_window[pg.alt_off[i] + pos]];
+                for (int w = 0; w < 8; w++) members += __builtin_popcount(bits[w]);
+                prod *= std::min(1.0, members / 64.0);
+            }
+            p3 += prod;
+        }
+        a.k3_depth = p3 * 1024.0 < 0.02 ? 3u : 4u;
+        if (const char *e = getenv("GSCAN_K3_DEPTH")) a.k3_depth = (uint32_t)atoi(e);
+    }
     for (int r = 0; r < kK2MaxRuns; r++) {
         a.run_desc[r] = (uint32_t)pg.run_cls[r] | ((uint32_t)pg.run_len[r] << 8) | ((uint32_t)pg.run_off[r] << 16);
         const uint32_t n = pg.run_len[r];

@@ -36,7 +36,7 @@ struct ScanArgs {
     uint32_t m;              // window length
     uint32_t anchor, anchor_mask, anchor_off, anchor_len; // K1
     uint32_t n_classes, nruns;                            // K2
-    uint32_t k3_off, k3_exact;                            // K3
+    uint32_t k3_off, k3_exact, k3_depth;                  // K3 (k3_depth: 3 or 4 filter positions)
     uint32_t report_shift;   // reported offset = device window start + this (1 when the windows carry a leading context position)
     uint32_t run_desc[kK2MaxRuns];                        // K2: cls | len<<8 | off<<16
     // K2, windows of <= 17 bytes: the run's shift program, decoded on the host -- cls @0, then the shift amounts of the
