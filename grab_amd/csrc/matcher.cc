@@ -14,6 +14,9 @@
 #include <cstring>
 #include <vector>
 
+#include <sys/mman.h>
+#include <ucontext.h>
+
 #include "../../include/gscan.h"
 #include "db.h"
 
@@ -129,10 +132,16 @@ struct TreeMatch {
     // thresholds are this matcher's own.
     static uint64_t max_steps()
     {
-        static const uint64_t v = getenv("GSCAN_MATCH_LIMIT") ? strtoull(getenv("GSCAN_MATCH_LIMIT"), nullptr, 10) : (uint64_t)1 << 30;
+        static const uint64_t v = getenv("GSCAN_MATCH_LIMIT") ? strtoull(getenv("GSCAN_MATCH_LIMIT"), nullptr, 10) : (uint64_t)1 << 28;
         return v;
     }
-    static constexpr uint32_t kMaxDepth = 12000; // nested group iterations (each costs a few stack frames)
+    static constexpr uint32_t kMaxDepth = 12000; // nested group iterations (each costs a few stack frames) ...
+    // ... and the stack the recursion may use, whichever is hit first: the matcher runs on the CALLER's stack -- a worker of
+    // grab_cli, a Python thread, a JNI / cgo thread with far less than 8 MiB
+    static constexpr size_t kCallerStack = 192 * 1024;
+    size_t max_stack = kCallerStack;
+    bool out_of_stack = false; // gave up for THIS reason: tree_match_at repeats the attempt on a stack of its own
+    const char *stack_base = (const char *)__builtin_frame_address(0);
     uint64_t steps = 0;
     uint32_t depth = 0;
     bool gave_up = false;
@@ -246,6 +255,7 @@ struct TreeMatch {
     bool m(const Node *n, size_t pos, bool cap, const Cont *k)
     {
         if (++steps > max_steps()) gave_up = true;
+        if ((size_t)(stack_base - (const char *)__builtin_frame_address(0)) > max_stack) gave_up = out_of_stack = true;
         if (gave_up) return false;
         switch (n->kind) {
         case Node::SET:
@@ -263,9 +273,14 @@ struct TreeMatch {
                 TreeMatch inner{c, clen, s0};
                 inner.steps = steps;
                 inner.depth = depth;
+                inner.stack_base = stack_base;
+            inner.max_stack = max_stack;
+                inner.max_stack = max_stack;
                 const bool got = inner.m(alt, at, cap, &stop);
                 steps = inner.steps;
                 gave_up = gave_up || inner.gave_up;
+            out_of_stack = out_of_stack || inner.out_of_stack;
+                out_of_stack = out_of_stack || inner.out_of_stack;
                 if (got && !gave_up && (!n->behind || inner.end == pos)) {
                     ok = true;
                     inner_cap = inner.captured;
@@ -292,9 +307,12 @@ struct TreeMatch {
             TreeMatch inner{c, clen, s0};
             inner.steps = steps;
             inner.depth = depth;
+            inner.stack_base = stack_base;
+            inner.max_stack = max_stack;
             const bool got = inner.m(&n->kids[0], pos, cap, &stop);
             steps = inner.steps;
             gave_up = gave_up || inner.gave_up;
+            out_of_stack = out_of_stack || inner.out_of_stack;
             if (!got || gave_up) return false;
             return run(k, inner.end, inner.captured);
         }
@@ -330,9 +348,14 @@ struct TreeMatch {
                 TreeMatch inner{c, clen, s0};
                 inner.steps = steps;
                 inner.depth = depth;
+                inner.stack_base = stack_base;
+            inner.max_stack = max_stack;
+                inner.max_stack = max_stack;
                 const bool got = inner.rep_group(&greedy, 0, pos, cap, &stop);
                 steps = inner.steps;
                 gave_up = gave_up || inner.gave_up;
+            out_of_stack = out_of_stack || inner.out_of_stack;
+                out_of_stack = out_of_stack || inner.out_of_stack;
                 if (!got || gave_up) return false;
                 return run(k, inner.end, inner.captured);
             }
@@ -343,11 +366,63 @@ struct TreeMatch {
     }
 };
 
+// A match attempt that ran out of the caller's stack budget (hundreds of nested group iterations: (?:ab)+ over a long
+// run) is repeated on a stack of the matcher's own -- 16 MiB per thread, mapped on first use, entered with
+// makecontext / swapcontext.  kMaxDepth (12 000 nested iterations) is what ends an attempt there; libpcre's JIT gives up
+// between ~1 400 and ~4 100 iterations of such a group on its 32 KiB stack.
+constexpr size_t kOwnStack = 16u << 20;
+struct OwnStack {
+    void *mem = nullptr;
+    ucontext_t caller, callee;
+    ~OwnStack()
+    {
+        if (mem) munmap(mem, kOwnStack);
+    }
+};
+struct OwnCall {
+    TreeMatch *t;
+    const Node *root;
+    size_t p;
+    bool hit;
+};
+void own_stack_entry(unsigned lo, unsigned hi)
+{
+    OwnCall *c = reinterpret_cast<OwnCall *>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    c->t->stack_base = (const char *)__builtin_frame_address(0);
+    c->hit = c->t->m(c->root, c->p, false, nullptr);
+}
+bool run_on_own_stack(TreeMatch &t, const Node *root, size_t p)
+{
+    static thread_local OwnStack st;
+    if (!st.mem) {
+        void *m = mmap(nullptr, kOwnStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_STACK, -1, 0);
+        if (m == MAP_FAILED) {
+            t.gave_up = true;
+            return false;
+        }
+        st.mem = m;
+    }
+    OwnCall call{&t, root, p, false};
+    getcontext(&st.callee);
+    st.callee.uc_stack.ss_sp = st.mem;
+    st.callee.uc_stack.ss_size = kOwnStack;
+    st.callee.uc_link = &st.caller;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(&call);
+    makecontext(&st.callee, reinterpret_cast<void (*)()>(own_stack_entry), 2, (unsigned)(a & 0xffffffffu), (unsigned)(a >> 32));
+    swapcontext(&st.caller, &st.callee);
+    return call.hit;
+}
+
 bool tree_match_at(const Database &d, const uint8_t *content, size_t clen, size_t p, size_t subject_start, MatchAt &out)
 {
     if (!d.tree) return false;
     TreeMatch t{content, clen, subject_start};
-    const bool hit = t.m(d.tree.get(), p, false, nullptr);
+    bool hit = t.m(d.tree.get(), p, false, nullptr);
+    if (t.out_of_stack) { // again, with room
+        t = TreeMatch{content, clen, subject_start};
+        t.max_stack = kOwnStack - (256u << 10);
+        hit = run_on_own_stack(t, d.tree.get(), p);
+    }
     out.gave_up = t.gave_up;
     if (t.gave_up) g_given_up.fetch_add(1, std::memory_order_relaxed);
     if (!hit || t.gave_up) return false;

@@ -147,7 +147,8 @@ int gscan_next_match(const gscan_db *db, const void *content, size_t clen, const
  * PCRE_ERROR_JIT_STACKLIMIT): gscan_next_match then answers 0, which ends the chunk exactly as every pcre_exec error
  * does in the reference (rc <= 0: break, src/grab.cc:179).  WHERE an engine gives up is its own business -- libpcre's
  * interpreter, its JIT and this matcher all differ -- so differential tests skip inputs on which either side did.
- * Limit: 2^30 matcher steps per attempt (GSCAN_MATCH_LIMIT in the environment overrides it), 12000 nested group iterations. */
+ * Limit: 2^28 matcher steps per attempt (GSCAN_MATCH_LIMIT in the environment overrides it), 12000 nested group iterations (an attempt that outgrows 192 KiB of the caller's stack is repeated on a
+ * 16 MiB stack of the matcher's own). */
 uint64_t gscan_resource_errors(void);
 /* the offsets gscan_next_match tests itself because a window there would end with the chunk (patterns with
  * look-ahead context only: foo\b, foo$ ...); exported for tests.  Returns how many there are; fills at most cap. */

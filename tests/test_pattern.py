@@ -403,3 +403,36 @@ def test_assertions_match_reference_loop(pattern, built, liboracle):
                 liboracle.oracle_free(out)
             got = filegrep.report_chunk(db, f, b"", data, 0, starts) if 0 <= db.minlen <= len(text) else b""
             assert got == want, (pattern, text, f)
+
+
+def test_deep_group_repeats_and_small_stacks(built, liboracle):
+    """Thousands of nested group iterations: the matcher leaves the caller's stack alone (192 KiB budget, then a stack of
+    its own), so a thread with a 1 MiB stack survives what would otherwise be megabytes of recursion; up to libpcre-JIT's own
+    depth (4095 iterations of (?:ab)+ on its 32 KiB stack) the two agree, beyond it only the matcher still answers."""
+    import threading
+
+    results = {}
+
+    def work():
+        db = engine.Database(r"(?:ab)+x")
+        for n in (10, 369, 371, 4000, 11000, 13000):
+            text = np.frombuffer(b"ab" * n + b"x", np.uint8)
+            results[n] = db.match_info(text, 0)
+        db2 = engine.Database(r"(?:a|b)+c")
+        results["long"] = db2.match_info(np.frombuffer(b"a" * 1000000 + b"bc", np.uint8), 0)
+
+    threading.stack_size(1 << 20)
+    try:
+        t = threading.Thread(target=work)
+        t.start()
+        t.join()
+    finally:
+        threading.stack_size(0)
+    for n in (10, 369, 371, 4000, 11000):
+        assert results[n] == (1, 2 * n + 1), n
+    assert results[13000][0] == 0 and results["long"][0] == 0  # beyond 12000 nested iterations: given up, like a pcre_exec error
+    s = np.zeros(4, np.uint32)
+    e = np.zeros(4, np.uint32)
+    text = b"ab" * 4000 + b"x"
+    assert liboracle.oracle_all_starts(b"(?:ab)+x", text, len(text), s.ctypes.data, e.ctypes.data, 4) >= 1 and (s[0], e[0]) == (0, 8001)
+
