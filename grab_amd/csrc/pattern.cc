@@ -1531,10 +1531,6 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
 
     bool exact = true;
     for (const Seq &s : seqs) exact = exact && !s.inexact && !s.frozen;
-    if (getenv("GSCAN_DUMP"))
-        for (const Seq &s : seqs)
-            fprintf(stderr, "seq: win %zu pwin %zu gapped %d tail %d frozen %d inexact %d cap %d\n", s.win.size(), s.pwin.size(), (int)s.gapped,
-                    (int)s.has_tail, (int)s.frozen, (int)s.inexact, (int)s.cap);
     for (const Seq &s : seqs)
         if (s.win.empty() && !s.gapped) {
             why = "nothing fixed to look for in front of a repeated group";
