@@ -145,6 +145,9 @@ struct TreeMatch {
     uint64_t steps = 0;
     uint32_t depth = 0;
     bool gave_up = false;
+    // What the groups captured: kept only for patterns with back references ([2g], [2g+1] = start, end; SIZE_MAX = unset).
+    // Shared with the matchers of look-arounds / atomic groups; every setter restores the old value when what follows fails.
+    std::vector<size_t> *caps = nullptr;
 
     // what is still to be matched after the current node
     struct Cont {
@@ -162,6 +165,7 @@ struct TreeMatch {
         case Node::SET: return 1;
         case Node::ASSERT:
         case Node::LOOK: return 0;
+        case Node::BACKREF: return -1;
         case Node::ATOMIC: return look_len(nd.kids[0]);
         case Node::CAT: {
             long t = 0;
@@ -181,6 +185,7 @@ struct TreeMatch {
         return -1;
     }
 
+    static uint8_t lower(uint8_t b) { return b >= 'A' && b <= 'Z' ? (uint8_t)(b + 32) : b; }
     static bool is_word(uint8_t b) { return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_'; }
 
     bool holds(int code, size_t pos) const
@@ -209,9 +214,22 @@ struct TreeMatch {
         }
         switch (k->kind) {
         case Cont::SEQ:
-            if (k->i == k->n->kids.size()) return run(k->next, pos, cap || k->n->cap); // a capturing group closes here
+            if (k->i == k->n->kids.size()) { // a capturing group closes here
+                if (caps && k->n->cap && k->n->group > 0) {
+                    size_t *slot = caps->data() + 2 * (size_t)k->n->group;
+                    const size_t o0 = slot[0], o1 = slot[1];
+                    slot[0] = k->start;
+                    slot[1] = pos;
+                    if (run(k->next, pos, true)) return true;
+                    slot = caps->data() + 2 * (size_t)k->n->group;
+                    slot[0] = o0;
+                    slot[1] = o1;
+                    return false;
+                }
+                return run(k->next, pos, cap || k->n->cap);
+            }
             {
-                const Cont f{Cont::SEQ, k->n, k->i + 1, 0, k->next};
+                const Cont f{Cont::SEQ, k->n, k->i + 1, k->start, k->next};
                 return m(&k->n->kids[k->i], pos, cap, &f);
             }
         case Cont::REPG:
@@ -252,6 +270,27 @@ struct TreeMatch {
         return can_stop && run(k, pos, cap);
     }
 
+    // `what` matched on its own with a matcher of its own (same limits, same captures), to its first success: the end of
+    // that match and whether its path closed a capturing group.  as_repeat: `what` is a REP node entered at count 0.
+    bool atomic_run(const Node *what, bool as_repeat, size_t at, bool cap, size_t &end_out, bool &cap_out)
+    {
+        const Cont stop{Cont::ATOMIC_END, nullptr, 0, 0, nullptr};
+        TreeMatch inner{c, clen, s0};
+        inner.steps = steps;
+        inner.depth = depth;
+        inner.stack_base = stack_base;
+        inner.max_stack = max_stack;
+        inner.caps = caps;
+        const bool got = as_repeat ? inner.rep_group(what, 0, at, cap, &stop) : inner.m(what, at, cap, &stop);
+        steps = inner.steps;
+        gave_up = gave_up || inner.gave_up;
+        out_of_stack = out_of_stack || inner.out_of_stack;
+        if (!got || gave_up) return false;
+        end_out = inner.end;
+        cap_out = inner.captured;
+        return true;
+    }
+
     bool m(const Node *n, size_t pos, bool cap, const Cont *k)
     {
         if (++steps > max_steps()) gave_up = true;
@@ -267,58 +306,55 @@ struct TreeMatch {
             // fixed length per top-level alternative and may not reach back over the subject start (the restart
             // position: src/grab.cc:178 hands pcre_exec the subject FROM there).
             const Node *body = &n->kids[0];
+            const std::vector<size_t> saved = caps ? *caps : std::vector<size_t>();
             bool ok = false, inner_cap = cap;
-            auto attempt = [&](const Node *alt, size_t at) {
-                const Cont stop{Cont::ATOMIC_END, nullptr, 0, 0, nullptr};
-                TreeMatch inner{c, clen, s0};
-                inner.steps = steps;
-                inner.depth = depth;
-                inner.stack_base = stack_base;
-            inner.max_stack = max_stack;
-                inner.max_stack = max_stack;
-                const bool got = inner.m(alt, at, cap, &stop);
-                steps = inner.steps;
-                gave_up = gave_up || inner.gave_up;
-            out_of_stack = out_of_stack || inner.out_of_stack;
-                out_of_stack = out_of_stack || inner.out_of_stack;
-                if (got && !gave_up && (!n->behind || inner.end == pos)) {
-                    ok = true;
-                    inner_cap = inner.captured;
-                }
-            };
+            size_t e = 0;
             if (!n->behind) {
-                attempt(body, pos);
+                ok = atomic_run(body, false, pos, cap, e, inner_cap);
             } else if (body->kind == Node::ALT) {
                 for (const Node &alt : body->kids) {
                     const long len = look_len(alt);
-                    if (len >= 0 && pos >= s0 + (size_t)len) attempt(&alt, pos - (size_t)len);
+                    if (len >= 0 && pos >= s0 + (size_t)len) ok = atomic_run(&alt, false, pos - (size_t)len, cap, e, inner_cap) && e == pos;
                     if (ok || gave_up) break;
                 }
             } else {
                 const long len = look_len(*body);
-                if (len >= 0 && pos >= s0 + (size_t)len) attempt(body, pos - (size_t)len);
+                if (len >= 0 && pos >= s0 + (size_t)len) ok = atomic_run(body, false, pos - (size_t)len, cap, e, inner_cap) && e == pos;
             }
             if (gave_up) return false;
-            if (n->neg) return !ok && run(k, pos, cap); // (groups set inside a failed assertion are unset again)
-            return ok && run(k, pos, inner_cap);
+            if (n->neg) { // (groups set inside a failed -- or a negative -- assertion are unset again)
+                if (caps) *caps = saved;
+                return !ok && run(k, pos, cap);
+            }
+            if (ok && run(k, pos, inner_cap)) return true;
+            if (caps) *caps = saved;
+            return false;
         }
         case Node::ATOMIC: { // matched on its own to its first success; no way back into it
-            const Cont stop{Cont::ATOMIC_END, nullptr, 0, 0, nullptr};
-            TreeMatch inner{c, clen, s0};
-            inner.steps = steps;
-            inner.depth = depth;
-            inner.stack_base = stack_base;
-            inner.max_stack = max_stack;
-            const bool got = inner.m(&n->kids[0], pos, cap, &stop);
-            steps = inner.steps;
-            gave_up = gave_up || inner.gave_up;
-            out_of_stack = out_of_stack || inner.out_of_stack;
-            if (!got || gave_up) return false;
-            return run(k, inner.end, inner.captured);
+            const std::vector<size_t> saved = caps ? *caps : std::vector<size_t>();
+            size_t e = 0;
+            bool inner_cap = cap;
+            if (atomic_run(&n->kids[0], false, pos, cap, e, inner_cap) && run(k, e, inner_cap)) return true;
+            if (caps) *caps = saved;
+            return false;
         }
         case Node::CAT: {
-            const Cont f{Cont::SEQ, n, 0, 0, k};
+            const Cont f{Cont::SEQ, n, 0, pos, k}; // (start: where the group begins -- what a capturing group records)
             return run(&f, pos, cap);
+        }
+        case Node::BACKREF: {
+            if (!caps) return false;
+            const size_t lo = (*caps)[2 * (size_t)n->group], hi = (*caps)[2 * (size_t)n->group + 1];
+            if (lo == SIZE_MAX) return false; // a reference to a group that has not been set fails
+            const size_t len = hi - lo;
+            if (pos + len > clen) return false;
+            if (n->icase) {
+                for (size_t q = 0; q < len; q++)
+                    if (lower(c[lo + q]) != lower(c[pos + q])) return false;
+            } else if (memcmp(c + lo, c + pos, len) != 0) {
+                return false;
+            }
+            return run(k, pos + len, cap);
         }
         case Node::ALT:
             for (const Node &kid : n->kids)
@@ -344,20 +380,12 @@ struct TreeMatch {
             if (n->mode == 2) { // possessive group repeat: match the repeat on its own (greedily), then never re-enter it
                 Node greedy = *n;
                 greedy.mode = 0;
-                const Cont stop{Cont::ATOMIC_END, nullptr, 0, 0, nullptr};
-                TreeMatch inner{c, clen, s0};
-                inner.steps = steps;
-                inner.depth = depth;
-                inner.stack_base = stack_base;
-            inner.max_stack = max_stack;
-                inner.max_stack = max_stack;
-                const bool got = inner.rep_group(&greedy, 0, pos, cap, &stop);
-                steps = inner.steps;
-                gave_up = gave_up || inner.gave_up;
-            out_of_stack = out_of_stack || inner.out_of_stack;
-                out_of_stack = out_of_stack || inner.out_of_stack;
-                if (!got || gave_up) return false;
-                return run(k, inner.end, inner.captured);
+                const std::vector<size_t> saved = caps ? *caps : std::vector<size_t>();
+                size_t e = 0;
+                bool inner_cap = cap;
+                if (atomic_run(&greedy, true, pos, cap, e, inner_cap) && run(k, e, inner_cap)) return true;
+                if (caps) *caps = saved;
+                return false;
             }
             return rep_group(n, 0, pos, cap, k);
         }
@@ -416,10 +444,15 @@ bool run_on_own_stack(TreeMatch &t, const Node *root, size_t p)
 bool tree_match_at(const Database &d, const uint8_t *content, size_t clen, size_t p, size_t subject_start, MatchAt &out)
 {
     if (!d.tree) return false;
+    std::vector<size_t> caps;
+    if (d.has_backref) caps.assign(2 * (size_t)d.n_groups + 2, SIZE_MAX);
     TreeMatch t{content, clen, subject_start};
+    t.caps = d.has_backref ? &caps : nullptr;
     bool hit = t.m(d.tree.get(), p, false, nullptr);
     if (t.out_of_stack) { // again, with room
         t = TreeMatch{content, clen, subject_start};
+        if (d.has_backref) caps.assign(2 * (size_t)d.n_groups + 2, SIZE_MAX);
+        t.caps = d.has_backref ? &caps : nullptr;
         t.max_stack = kOwnStack - (256u << 10);
         hit = run_on_own_stack(t, d.tree.get(), p);
     }

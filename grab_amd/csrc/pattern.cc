@@ -48,6 +48,8 @@ struct Seq {
                                 // The path is then a necessary condition only ("inexact"): the host confirms candidates
                                 // with the backtracking matcher (matcher.cc)
     bool inexact = false;       // frozen, or an assertion of the path was left to the matcher
+    bool needs_cap = false;     // the path BEGINS with a back reference and has not closed any group before it: if that is
+                                // still so when the whole pattern is unfolded, the reference is to an unset group and fails
     bool settled = false;       // assertions behind the tail were dropped because they hold wherever the greedy repeat stops:
                                 // true only as long as NOTHING follows (with more pattern behind, PCRE backtracks into the repeat)
     bool empty() const { return win.empty() && !has_tail && !cap && asserts.empty() && !gapped && !frozen && !inexact; }
@@ -415,7 +417,109 @@ struct Parser {
     // "(?" just consumed.  Either an option setting "(?i)" (returns with is_group = false), or the
     // opening of a non-capturing group "(?:" / "(?i:" (is_group = true; options already applied,
     // the caller restores them at the closing parenthesis).
-    int special = 0; // set by group_head: 1 (?=  2 (?!  3 (?<=  4 (?<!  5 (?>
+    int special = 0; // set by group_head: 1 (?=  2 (?!  3 (?<=  4 (?<!  5 (?>  6 (?P=name) (a back reference, not a group)
+    int ngroups = 0; // capturing groups opened so far
+    // capturing groups whose closing parenthesis has not been seen yet, with "a back reference inside it refers to it":
+    // pcre_compile wraps such a group in atomic brackets (the value \N repeats must not change under it), and so does
+    // parse_cat
+    std::vector<std::pair<int, bool>> open_groups;
+    void note_reference(int num)
+    {
+        for (auto &og : open_groups)
+            if (og.first == num) og.second = true;
+    }
+    bool has_backref = false;
+    std::vector<std::pair<std::string, int>> names; // named groups
+    std::string group_name, ref_name;              // set by group_head
+
+    int named_group(const std::string &nm) const
+    {
+        for (const auto &kv : names)
+            if (kv.first == nm) return kv.second;
+        return 0;
+    }
+
+    // "\" consumed, i at the character behind it.  A back reference?  (\1-\9, \10.. when that many groups are open,
+    // \g1 \g{1} \g{-1} \g{name}, \k<name> \k'name' \k{name}.)  Returns 0 no, 1 yes (node filled), -1 error.
+    int backref(Node &a)
+    {
+        if (eof()) return 0;
+        const int c = p[i];
+        auto name_until = [&](size_t from, int close, std::string &out) -> size_t { // index behind the close, 0 if malformed
+            size_t j = from;
+            while (j < n && (isalnum(p[j]) || p[j] == '_')) j++;
+            if (j == from || j >= n || p[j] != close) return 0;
+            out.assign((const char *)p + from, j - from);
+            return j + 1;
+        };
+        int num = 0;
+        std::string nm;
+        if (c >= '1' && c <= '9') {
+            size_t j = i;
+            long v = 0;
+            while (j < n && isdigit(p[j]) && v < 100000) v = v * 10 + (p[j++] - '0');
+            if (v >= 10 && v > ngroups) return 0; // an octal escape (or \8 \9): escape() deals with it
+            num = (int)v;
+            i = j;
+        } else if (c == 'g') {
+            size_t j = i + 1;
+            if (j < n && (p[j] == '<' || p[j] == '\'')) return fail(1, "subroutine call") ? 0 : -1;
+            const bool braced = j < n && p[j] == '{';
+            if (braced) j++;
+            bool neg = false;
+            if (j < n && p[j] == '-') neg = true, j++;
+            if (j < n && isdigit(p[j])) {
+                long v = 0;
+                while (j < n && isdigit(p[j]) && v < 100000) v = v * 10 + (p[j++] - '0');
+                if (braced) {
+                    if (j >= n || p[j] != '}') return fail(-1, "\\g is not followed by a braced, angle-bracketed, or quoted name/number or by a plain number") ? 0 : -1;
+                    j++;
+                }
+                if (v == 0) return fail(-1, "a numbered reference must not be zero") ? 0 : -1;
+                num = neg ? ngroups - (int)v + 1 : (int)v;
+                if (num <= 0) return fail(-1, "reference to non-existent subpattern") ? 0 : -1;
+                i = j;
+            } else if (braced && !neg) {
+                const size_t e = name_until(j, '}', nm);
+                if (!e) return fail(-1, "\\g is not followed by a braced, angle-bracketed, or quoted name/number or by a plain number") ? 0 : -1;
+                i = e;
+            } else {
+                return fail(-1, "\\g is not followed by a braced, angle-bracketed, or quoted name/number or by a plain number") ? 0 : -1;
+            }
+        } else if (c == 'k') {
+            const size_t j = i + 1;
+            if (j >= n || (p[j] != '<' && p[j] != '\'' && p[j] != '{')) return fail(-1, "\\k is not followed by a braced, angle-bracketed, or quoted name") ? 0 : -1;
+            const size_t e = name_until(j + 1, p[j] == '<' ? '>' : p[j] == '{' ? '}' : '\'', nm);
+            if (!e) return fail(-1, "\\k is not followed by a braced, angle-bracketed, or quoted name") ? 0 : -1;
+            i = e;
+        } else {
+            return 0;
+        }
+        a = Node();
+        a.kind = Node::BACKREF;
+        a.group = num;
+        a.refname = nm;
+        a.icase = caseless;
+        has_backref = true;
+        note_reference(nm.empty() ? num : named_group(nm));
+        return 1;
+    }
+
+    // names -> numbers, and every reference must name a group of the pattern (forward references are fine)
+    bool resolve_refs(Node &nd)
+    {
+        if (nd.kind == Node::BACKREF) {
+            if (!nd.refname.empty()) {
+                nd.group = named_group(nd.refname);
+                nd.refname.clear();
+                if (!nd.group) return fail(-1, "reference to non-existent subpattern");
+            }
+            if (nd.group > ngroups) return fail(-1, "reference to non-existent subpattern");
+        }
+        for (Node &k : nd.kids)
+            if (!resolve_refs(k)) return false;
+        return true;
+    }
 
     // the length of everything the node can match, -1 if it varies (look-behind bodies must not: PCRE's rule -- the
     // top-level alternatives of the body may differ from each other, nested ones may not)
@@ -425,6 +529,7 @@ struct Parser {
         case Node::SET: return 1;
         case Node::ASSERT:
         case Node::LOOK: return 0;
+        case Node::BACKREF: return -1;
         case Node::ATOMIC: return fixed_len(nd.kids[0]);
         case Node::CAT: {
             long t = 0;
@@ -491,6 +596,8 @@ struct Parser {
             if (j < n && isdigit(p[j])) return fail(-1, "group name must not start with a digit");
             while (j < n && (isalnum(p[j]) || p[j] == '_')) j++;
             if (j == i + 1 || j >= n || p[j] != close) return fail(-1, "syntax error in group name");
+            group_name.assign((const char *)p + i + 1, j - i - 1);
+            if (named_group(group_name)) return fail(-1, "two named subpatterns have the same name");
             i = j + 1;
             is_group = true;
             named = true;
@@ -503,6 +610,15 @@ struct Parser {
             return true;
         }
         if (c == '|') return fail(1, "branch-reset group");
+        if (c == 'P' && i + 1 < n && p[i + 1] == '=') { // (?P=name): a back reference in group clothing
+            size_t j = i + 2;
+            while (j < n && (isalnum(p[j]) || p[j] == '_')) j++;
+            if (j == i + 2 || j >= n || p[j] != ')') return fail(-1, "syntax error in subpattern name (missing terminator)");
+            ref_name.assign((const char *)p + i + 2, j - i - 2);
+            i = j + 1;
+            special = 6;
+            return true;
+        }
         if (c == 'P' || c == 'R' || c == '&' || c == '(' || c == 'C' || c == '+' || (c >= '0' && c <= '9'))
             return fail(1, "recursion / conditional / callout / named reference");
         bool on = true, ci = caseless, da = dotall, ml = multiline, ex = extended;
@@ -622,6 +738,15 @@ struct Parser {
                         i += 2;
                         continue;
                     }
+                    {
+                        const size_t save = i;
+                        i++;
+                        const int br = backref(a);
+                        if (br < 0) return false;
+                        if (br > 0) break;
+                        if (rc) return false; // (a refusal raised on the way)
+                        i = save;
+                    }
                     if (i + 1 < n && p[i + 1] == 'R') { // any newline sequence: (?>\r\n|\n|\x0b|\f|\r|\x85), 8-bit mode
                         i += 2;
                         Node crlf, cr, lf, one, alt;
@@ -657,11 +782,22 @@ struct Parser {
                     if (eof()) return fail(-1, "missing )");
                     if (p[i] == '*') return fail(1, "backtracking control verb");
                     const bool ci = caseless, da = dotall, ml = multiline, ex = extended;
-                    bool capture = true;
+                    bool capture = true, named = false;
                     if (p[i] == '?') {
                         i++;
-                        bool is_group, named;
+                        bool is_group;
                         if (!group_head(is_group, named)) return false;
+                        if (special == 6) { // (?P=name)
+                            special = 0;
+                            a = Node();
+                            a.kind = Node::BACKREF;
+                            a.refname = ref_name;
+                            a.icase = caseless;
+                            has_backref = true;
+                            note_reference(named_group(ref_name));
+                            caseless = ci, dotall = da, multiline = ml;
+                            break;
+                        }
                         if (!is_group) { // "(?i)": stays in force to the end of the enclosing group
                             if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?')) return fail(-1, "nothing to repeat");
                             continue;
@@ -670,6 +806,12 @@ struct Parser {
                     }
                     const int sp = special;
                     special = 0;
+                    int gno = 0;
+                    if (capture) { // groups are numbered by their opening parenthesis
+                        gno = ++ngroups;
+                        if (named) names.emplace_back(group_name, gno);
+                        open_groups.emplace_back(gno, false);
+                    }
                     depth++;
                     if (!parse_alt(a)) return false;
                     depth--;
@@ -701,8 +843,17 @@ struct Parser {
                         Node w;
                         w.kind = Node::CAT;
                         w.cap = true;
+                        w.group = gno;
                         w.kids.push_back(std::move(a));
                         a = std::move(w);
+                        const bool self_ref = open_groups.back().second;
+                        open_groups.pop_back();
+                        if (self_ref) { // see open_groups
+                            Node at;
+                            at.kind = Node::ATOMIC;
+                            at.kids.push_back(std::move(a));
+                            a = std::move(at);
+                        }
                     }
                     break;
                 }
@@ -783,7 +934,7 @@ struct Parser {
     {
         if (!parse_alt(root)) return false;
         if (!eof()) return fail(-1, "unmatched parentheses"); // a ')' at depth 0
-        return true;
+        return resolve_refs(root);
     }
 };
 
@@ -816,7 +967,7 @@ struct Unfold {
     {
         Seq f = freeze(a);
         for (const Seq &o : out)
-            if (o.frozen && o.gapped == f.gapped && o.win.size() == f.win.size() && o.pwin.size() == f.pwin.size() && o.asserts == f.asserts &&
+            if (o.frozen && o.needs_cap == f.needs_cap && o.cap == f.cap && o.gapped == f.gapped && o.win.size() == f.win.size() && o.pwin.size() == f.pwin.size() && o.asserts == f.asserts &&
                 o.p_asserts == f.p_asserts && (!f.gapped || o.gap == f.gap) && std::equal(o.win.begin(), o.win.end(), f.win.begin()) &&
                 std::equal(o.pwin.begin(), o.pwin.end(), f.pwin.begin()))
                 return true;
@@ -945,6 +1096,8 @@ struct Unfold {
                     s.settled = b.settled;
                     s.frozen = b.frozen;
                     s.inexact = h.inexact || b.inexact;
+                    // (still nothing in front of the back reference: see compile_pattern)
+                    s.needs_cap = h.needs_cap || (b.needs_cap && h.win.empty() && !h.gapped && !h.cap && b.win.empty() && !b.gapped);
                     s.cap = a.cap || b.cap;
                     if (b.gapped) { // the unbounded repeat sits in b: everything of h goes in front of it
                         bool stop = h.gapped || (!b.p_asserts.empty() && !h.win.empty());
@@ -1012,6 +1165,14 @@ struct Unfold {
             out.push_back(std::move(s));
             return true;
         }
+        case Node::BACKREF: { // what it repeats is known at match time only: the path stops here
+            Seq s;
+            s.frozen = true;
+            s.inexact = true;
+            s.needs_cap = true;
+            out.push_back(std::move(s));
+            return true;
+        }
         case Node::ATOMIC: // the paths of the body, minus PCRE's "no way back into the group": necessary conditions
             if (!run(nd.kids[0], out)) return false;
             for (Seq &s : out) s.inexact = true;
@@ -1024,8 +1185,9 @@ struct Unfold {
                 if (!concat(out, kid, joined)) return false;
                 out.swap(joined);
             }
-            if (nd.cap) // every path through a capturing group sets it, even an empty one
-                for (Seq &s : out) s.cap = true;
+            if (nd.cap) // every path through a capturing group sets it, even an empty one (a frozen path never got to its end)
+                for (Seq &s : out)
+                    if (!s.frozen) s.cap = true;
             return true;
         }
         case Node::ALT:
@@ -1071,7 +1233,7 @@ struct Unfold {
             // iteration (same paths) or from what follows the group -- the path that skips the group stands for that.
             bool skip = nd.min == 0;
             for (const Seq &e : E) {
-                if (!e.win.empty() || e.gapped) {
+                if (!e.win.empty() || e.gapped || e.needs_cap) { // (an iteration that is a back reference: unknown bytes)
                     if (!push_frozen(out, e)) return false;
                     continue;
                 }
@@ -1329,6 +1491,7 @@ bool ends_in_greedy_repeat(const Node &n, bool prev, bool &quirk)
     switch (n.kind) {
     case Node::SET: return false;
     case Node::ASSERT: return prev;
+    case Node::BACKREF: return false; // (not an opcode auto-possessification looks through)
     case Node::LOOK: { // an assertion opcode stops auto-possessification's look-ahead; its body is a pattern of its own
         ends_in_greedy_repeat(n.kids[0], false, quirk);
         return false;
@@ -1365,27 +1528,129 @@ bool ends_in_greedy_repeat(const Node &n, bool prev, bool &quirk)
 
 // The shortest subject a match needs, the way pcre_study's find_minlength() counts it: alternatives take the minimum,
 // repeats multiply, assertions count nothing (and are not checked for consistency).
-uint64_t node_minlen(const Node &n)
+// A back reference counts what its group counts (find_minlength: OP_REF), nothing when it stands inside that group or the
+// groups refer to each other in a circle.
+struct MinCtx {
+    const Node *root;
+    std::vector<int> active;
+    std::vector<std::pair<int, uint64_t>> fixed; // group -> the length a reference to it counts (later copies of a counted repeat)
+    bool plain = false; // the true lower bound instead of find_minlength's: a reference may repeat "", every branch counts
+};
+const Node *find_group(const Node &n, int g)
+{
+    if (n.kind == Node::CAT && n.cap && n.group == g) return &n;
+    for (const Node &k : n.kids)
+        if (const Node *f = find_group(k, g)) return f;
+    return nullptr;
+}
+bool contains(const Node &n, const Node *x)
+{
+    if (&n == x) return true;
+    for (const Node &k : n.kids)
+        if (contains(k, x)) return true;
+    return false;
+}
+bool has_kind(const Node &n, Node::Kind kind)
+{
+    if (n.kind == kind) return true;
+    for (const Node &k : n.kids)
+        if (has_kind(k, kind)) return true;
+    return false;
+}
+void collect_groups(const Node &n, std::vector<const Node *> &out)
+{
+    if (n.kind == Node::CAT && n.cap) out.push_back(&n);
+    for (const Node &k : n.kids) collect_groups(k, out);
+}
+// is the item a back reference (possibly quantified) to a group it stands in, or to one whose length is being computed?
+bool recursive_ref(const Node &item, const MinCtx &cx)
+{
+    const Node *r = &item;
+    if (r->kind == Node::REP && r->kids[0].kind == Node::BACKREF) {
+        if (r->mode == 2) return false; // \1?+ is compiled as (?>\1?): a group of its own, whose recursion flag stays inside it
+        r = &r->kids[0];
+    }
+    if (r->kind != Node::BACKREF) return false;
+    if (cx.plain) return false;
+    for (const auto &fx : cx.fixed)
+        if (fx.first == r->group) return false;
+    for (int a : cx.active)
+        if (a == r->group) return true;
+    const Node *grp = find_group(*cx.root, r->group);
+    return grp && contains(*grp, r);
+}
+uint64_t node_minlen(const Node &n, MinCtx &cx)
 {
     constexpr uint64_t cap = 1u << 30;
     switch (n.kind) {
     case Node::SET: return 1;
     case Node::ASSERT:
     case Node::LOOK: return 0;
-    case Node::ATOMIC: return node_minlen(n.kids[0]);
+    case Node::BACKREF: {
+        if (cx.plain) return 0;
+        for (const auto &fx : cx.fixed)
+            if (fx.first == n.group) return fx.second;
+        const Node *grp = find_group(*cx.root, n.group);
+        if (!grp || contains(*grp, &n)) return 0;
+        for (int a : cx.active)
+            if (a == n.group) return 0;
+        cx.active.push_back(n.group);
+        const uint64_t d = node_minlen(*grp, cx);
+        cx.active.pop_back();
+        return d;
+    }
+    case Node::ATOMIC: return node_minlen(n.kids[0], cx);
     case Node::CAT: {
         uint64_t t = 0;
-        for (const Node &k : n.kids) t = std::min(cap, t + node_minlen(k));
+        for (const Node &k : n.kids) t = std::min(cap, t + node_minlen(k, cx));
         return t;
     }
     case Node::ALT: {
+        // find_minlength's rule for a branch that holds a recursive reference at its own level: it sets the length only
+        // when it is the first branch -- ((ab|\1?)c) counts 3, (a|\1b) counts 1
+        bool first = true;
         uint64_t t = cap;
-        for (const Node &k : n.kids) t = std::min(t, node_minlen(k));
+        for (const Node &k : n.kids) {
+            const uint64_t bl = node_minlen(k, cx);
+            bool rec = recursive_ref(k, cx);
+            if (k.kind == Node::CAT && !k.cap)
+                for (const Node &item : k.kids) rec = rec || recursive_ref(item, cx);
+            if (first || (!rec && bl < t)) t = bl;
+            first = false;
+        }
         return t;
     }
-    case Node::REP: return std::min(cap, (uint64_t)n.min * node_minlen(n.kids[0]));
+    case Node::REP: {
+        const Node &k = n.kids[0];
+        const uint64_t m1 = node_minlen(k, cx);
+        // A counted repeat is compiled into copies; a group that refers to itself finds, from its second copy on, the
+        // FIRST copy's bracket: there the reference counts what that copy counts (and is no recursion any more).
+        // (every capturing group inside the repeated item, whether the reference stands inside that group or next to it)
+        if (n.min >= 2 && !cx.plain && has_kind(k, Node::BACKREF)) {
+            std::vector<const Node *> groups;
+            collect_groups(k, groups);
+            const size_t keep = cx.fixed.size();
+            std::vector<std::pair<int, uint64_t>> add;
+            for (const Node *g : groups) add.emplace_back(g->group, node_minlen(*g, cx));
+            cx.fixed.insert(cx.fixed.end(), add.begin(), add.end());
+            const uint64_t m2 = node_minlen(k, cx);
+            cx.fixed.resize(keep);
+            return std::min(cap, m1 + (uint64_t)(n.min - 1) * m2);
+        }
+        return std::min(cap, (uint64_t)n.min * m1);
+    }
     }
     return 0;
+}
+uint64_t node_minlen(const Node &n)
+{
+    MinCtx cx{&n, {}, {}, false};
+    return node_minlen(n, cx);
+}
+uint64_t node_true_minlen(const Node &n)
+{
+    MinCtx cx{&n, {}, {}, true};
+    return node_minlen(n, cx);
 }
 
 } // namespace
@@ -1395,6 +1660,8 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     std::vector<Seq> seqs;
     Seq literal_seq;
     Node root;
+    int n_groups = 0;
+    bool has_backref = false;
     if (flags & GSCAN_LITERAL) {
         Seq &s = literal_seq;
         root.kind = Node::CAT;
@@ -1416,6 +1683,8 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             why = ps.why;
             return ps.rc;
         }
+        n_groups = ps.ngroups;
+        has_backref = ps.has_backref;
         bool quirk = false;
         ends_in_greedy_repeat(root, false, quirk);
         if (quirk) {
@@ -1428,6 +1697,13 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     // it comes from the parse tree, not from the unfolded paths -- the reference's loop bound and file-skip rule use it
     // (grab.cc:133,175).
     const size_t pcre_min = (size_t)node_minlen(root);
+    if (pcre_min > 0 && has_backref && node_true_minlen(root) == 0) {
+        // find_minlength skips branches that hold a recursive back reference, so PCRE_INFO_MINLENGTH can be positive for a
+        // pattern that does match "" -- (a|\1?)b*: files are not skipped (Q2 does not apply), and the reference's loop either
+        // stops at its first pcre_exec (the empty match has set a group: rc == 0) or never advances
+        why = "the pattern can match the empty string although PCRE_INFO_MINLENGTH is positive (a recursive back reference)";
+        return 1;
+    }
     if (pcre_min == 0) { // can match the empty string: PCRE_INFO_MINLENGTH == -1 and every file is skipped
         db = Database();
         db.tree = std::make_shared<Node>(std::move(root));
@@ -1531,14 +1807,23 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
 
     bool exact = true;
     for (const Seq &s : seqs) exact = exact && !s.inexact && !s.frozen;
+    {
+        // a path that starts with a back reference, no group closed before it: the reference fails (unset group), the path is dead
+        std::vector<Seq> alive;
+        for (Seq &s : seqs)
+            if (!(s.needs_cap && !s.cap && s.win.empty() && !s.gapped)) alive.push_back(std::move(s));
+        seqs.swap(alive);
+    }
     for (const Seq &s : seqs)
         if (s.win.empty() && !s.gapped) {
-            why = "nothing fixed to look for in front of a repeated group";
+            why = "nothing fixed to look for in front of a repeated group or a back reference";
             return 1;
         }
 
     db = Database();
     db.exact = exact;
+    db.n_groups = n_groups;
+    db.has_backref = has_backref;
     db.tree = std::make_shared<Node>(std::move(root));
     db.id = g_next_id.fetch_add(1);
     memset(&db.prog, 0, sizeof db.prog);

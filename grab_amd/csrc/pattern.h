@@ -75,10 +75,13 @@ enum { A_BOS = 1, // ^ without (?m), \A, \G: the subject start (the restart posi
        A_NWB };   // \B
 
 // Parse tree.  SET = one byte drawn from a class; REP repeats its single child (max == UINT32_MAX: unbounded).
-// LOOK = (?=..) (?!..) (?<=..) (?<!..) around its single child; ATOMIC = (?>..).
+// LOOK = (?=..) (?!..) (?<=..) (?<!..) around its single child; ATOMIC = (?>..); BACKREF = \1 \g{2} \k<name> (?P=name).
 struct Node {
-    enum Kind { SET, CAT, ALT, REP, ASSERT, LOOK, ATOMIC } kind = SET;
+    enum Kind { SET, CAT, ALT, REP, ASSERT, LOOK, ATOMIC, BACKREF } kind = SET;
     bool behind = false, neg = false; // LOOK
+    int group = 0;                    // capturing CAT: its number (1..);  BACKREF: the group referred to
+    bool icase = false;               // BACKREF under (?i)
+    std::string refname;              // BACKREF by name, until the parser has resolved it
     int acode = 0;             // ASSERT: one of the A_* codes
     ByteSet set;
     std::vector<Node> kids;
@@ -179,6 +182,8 @@ struct Database {
                                  // unbounded repeat, a repeated group, ...).  The alternatives then only say where a match
                                  // MAY start; matcher.cc's backtracking matcher confirms every such offset
     std::shared_ptr<Node> tree;  // the parse tree: matcher.cc's backtracking matcher walks it (match end, capturing groups)
+    int n_groups = 0;            // capturing groups in the pattern
+    bool has_backref = false;    // the matcher has to remember what the groups captured
     // What the kernels scan: when some alternative looks at the byte before (after) its window, EVERY alternative's
     // device window gets a leading (trailing) context position -- its own condition, or "any byte".  A device hit at q
     // is reported as q + dev_pre.  Matches at the restart position and windows ending at the chunk end have no such

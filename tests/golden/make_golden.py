@@ -184,6 +184,12 @@ CASES = [
     dict(name="look_behind_alt", inputs={"f": lit("abd cd xd abcd\n")}, args=["-O", "-l", "(?<=ab|c)d", "f"]),
     dict(name="look_atomic", inputs={"f": lit("aaab aaa ab\n")}, args=["-O", "-l", "(?>a+)b|(?>a+)a", "f"]),
     dict(name="look_capture", inputs={"f": lit("xab ab\n")}, args=["-O", "-l", "x(?=(a))ab|ab", "f"]),
+    # back references: a match that used one has set a group -> rc == 0 -> the chunk ends there (Q5); before that, the
+    # alternatives without groups print
+    dict(name="bref_ends_chunk", inputs={"f": lit("li nus li ab aa li\nli\n")}, args=["-O", "-l", "(a|b)\\1|li", "f"]),
+    dict(name="bref_never_set", inputs={"f": lit("li nus li ab ba li\nli\n")}, args=["-O", "-l", "(a|b)\\1|li", "f"]),
+    dict(name="bref_named_lines", inputs={"f": lit("x nus\nnus abab nus\nnus\n")}, args=["-O", "(?P<q>ab)(?P=q)|nus", "f"]),
+    dict(name="bref_self", inputs={"f": lit("z abbc z ac z\n")}, args=["-O", "-l", "(a|b\\1)+c|z", "f"]),
     dict(name="syn8_inx_call", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 5}}, args=["-O", "[a-z]+\\([a-z0-9, ]*\\);", "syn"]),
     dict(name="syn8_inx_member", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 5}}, args=["-O", "-l", "[a-z]+_[0-9]+\\.[a-z]+", "syn"]),
     dict(name="syn8_inx_look", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 5}}, args=["-O", "-l", "(?<![a-z_])[a-z]{3}(?=\\()|(?<=;)\\n(?!\\n)", "syn"]),

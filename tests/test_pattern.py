@@ -87,9 +87,9 @@ SUPPORTED = [
 
 NULL_TIER = ["a?", "x*", "", "a{0}", "[a-z]{0,3}", "x{0}", "a|", "(?:foo|b?)", "a??", "(?:ab)?", "x*?y{0}"]
 
-UNSUPPORTED = [r"\1", r"\pL",
+UNSUPPORTED = [r"(a|\1?)b*", r"\pL",
                r"\Xfoo", "a{2}{3}", "x" * 300, "(?x)a + ?b",
-               "(?|a|b)", r"(a)\1", "(?P=n)", "(*UTF8)a", r"x*(?>(?:0)?)x", r"x*(?:ab)?+x", r"b[x.]{0,2}(?:0)?+[x.]{1,3} ", "(?i)[[:^upper:]]a", "a(?R)?b"]
+               "(?|a|b)", r"\g<1>(a)", "(*UTF8)a", r"x*(?>(?:0)?)x", r"x*(?:ab)?+x", r"b[x.]{0,2}(?:0)?+[x.]{1,3} ", "(?i)[[:^upper:]]a", "a(?R)?b"]
 
 # "a(" is reported as unsupported (groups) by the engine alone; FileGrep::prepare asks libpcre first and
 # gives the reference's "pcre_compile error" for it (tests/test_gpu_filegrep.py, golden case bad_regex)
@@ -117,9 +117,13 @@ INEXACT = ["a+b+c", "a{1,40}b", "a++b", "(?:ab)+", "(?:a|b)*c", "(?:ab)?+c", "(a
            "(?:ab|cd|li|nu|fo|ob|ar|ba){3}", "|".join("w%03d" % i for i in range(65)) + "|foo|linus",
            # look-around and atomic groups: nothing of them reaches the kernels, the matcher evaluates them
            "foo(?=bar)", "foo(?!bar)", "(?<=x)y", "(?<!a)b", "(?<=ab|c)d", "(?>a+)b", "(?>ab|a)c", r"\b(?=\w{3}\b)[a-z]+", "(?=(a))ab|b",
-           r"(?<![a-z])li(?=nus)", "a(?=b)?b", "x(?!y){2}.", "(?<=\n)[a-z]+(?= )", "(?s)a(?=.*z)b", r"\Rfoo", r"a\R+b"]
+           r"(?<![a-z])li(?=nus)", "a(?=b)?b", "x(?!y){2}.", "(?<=\n)[a-z]+(?= )", "(?s)a(?=.*z)b", r"\Rfoo", r"a\R+b",
+           # back references: the matcher remembers what the groups captured; with the reference's ovector[3] a match that used
+           # one has set a group and ends the chunk (Q5) -- what prints are the matches of the alternatives without groups
+           r"(a|b)\1|li", r"(\w)\1+x|foo", r"(?P<q>ab)(?P=q)|nus", r"(?i)(ab)\1|c", r"(a)(b)\2\1|x", r"(?:(a)|b)\1?c", r"(a|b\1)+c|z",
+           r"(\w+) \1\b|ab", r"(ab)\g{-1}|(?<n>l)\k<n>|f", r"((\2a|b){2}c){2}|li"]
 
-MALFORMED = ["(?<=a+)b", "(?<!ab|c*)d", "[abc", "*a", "+", "?x", "a{3,2}", "[z-a]", "\\", "a)", "[[:nope:]]", "(?:a", "(?i", "(?:a|*b)", "a|+", "(?z)a", "(?i)+a"]
+MALFORMED = [r"\1", r"(a)\2", "(?P=n)", r"(?<n>a)(?<n>b)", r"(a)(?<=\1)b", "(?<=a+)b", "(?<!ab|c*)d", "[abc", "*a", "+", "?x", "a{3,2}", "[z-a]", "\\", "a)", "[[:nope:]]", "(?:a", "(?i", "(?:a|*b)", "a|+", "(?z)a", "(?i)+a"]
 
 
 def _fix5(p):
