@@ -441,6 +441,11 @@ struct Parser {
 
     // "\" consumed, i at the character behind it.  A back reference?  (\1-\9, \10.. when that many groups are open,
     // \g1 \g{1} \g{-1} \g{name}, \k<name> \k'name' \k{name}.)  Returns 0 no, 1 yes (node filled), -1 error.
+    int bad(int code, const char *msg)
+    {
+        fail(code, msg);
+        return -1;
+    }
     int backref(Node &a)
     {
         if (eof()) return 0;
@@ -463,7 +468,7 @@ struct Parser {
             i = j;
         } else if (c == 'g') {
             size_t j = i + 1;
-            if (j < n && (p[j] == '<' || p[j] == '\'')) return fail(1, "subroutine call") ? 0 : -1;
+            if (j < n && (p[j] == '<' || p[j] == '\'')) return bad(1, "subroutine call");
             const bool braced = j < n && p[j] == '{';
             if (braced) j++;
             bool neg = false;
@@ -472,25 +477,25 @@ struct Parser {
                 long v = 0;
                 while (j < n && isdigit(p[j]) && v < 100000) v = v * 10 + (p[j++] - '0');
                 if (braced) {
-                    if (j >= n || p[j] != '}') return fail(-1, "\\g is not followed by a braced, angle-bracketed, or quoted name/number or by a plain number") ? 0 : -1;
+                    if (j >= n || p[j] != '}') return bad(-1, "\\g is not followed by a braced, angle-bracketed, or quoted name/number or by a plain number");
                     j++;
                 }
-                if (v == 0) return fail(-1, "a numbered reference must not be zero") ? 0 : -1;
+                if (v == 0) return bad(-1, "a numbered reference must not be zero");
                 num = neg ? ngroups - (int)v + 1 : (int)v;
-                if (num <= 0) return fail(-1, "reference to non-existent subpattern") ? 0 : -1;
+                if (num <= 0) return bad(-1, "reference to non-existent subpattern");
                 i = j;
             } else if (braced && !neg) {
                 const size_t e = name_until(j, '}', nm);
-                if (!e) return fail(-1, "\\g is not followed by a braced, angle-bracketed, or quoted name/number or by a plain number") ? 0 : -1;
+                if (!e) return bad(-1, "\\g is not followed by a braced, angle-bracketed, or quoted name/number or by a plain number");
                 i = e;
             } else {
-                return fail(-1, "\\g is not followed by a braced, angle-bracketed, or quoted name/number or by a plain number") ? 0 : -1;
+                return bad(-1, "\\g is not followed by a braced, angle-bracketed, or quoted name/number or by a plain number");
             }
         } else if (c == 'k') {
             const size_t j = i + 1;
-            if (j >= n || (p[j] != '<' && p[j] != '\'' && p[j] != '{')) return fail(-1, "\\k is not followed by a braced, angle-bracketed, or quoted name") ? 0 : -1;
+            if (j >= n || (p[j] != '<' && p[j] != '\'' && p[j] != '{')) return bad(-1, "\\k is not followed by a braced, angle-bracketed, or quoted name");
             const size_t e = name_until(j + 1, p[j] == '<' ? '>' : p[j] == '{' ? '}' : '\'', nm);
-            if (!e) return fail(-1, "\\k is not followed by a braced, angle-bracketed, or quoted name") ? 0 : -1;
+            if (!e) return bad(-1, "\\k is not followed by a braced, angle-bracketed, or quoted name");
             i = e;
         } else {
             return 0;
@@ -744,7 +749,6 @@ struct Parser {
                         const int br = backref(a);
                         if (br < 0) return false;
                         if (br > 0) break;
-                        if (rc) return false; // (a refusal raised on the way)
                         i = save;
                     }
                     if (i + 1 < n && p[i + 1] == 'R') { // any newline sequence: (?>\r\n|\n|\x0b|\f|\r|\x85), 8-bit mode
@@ -1231,13 +1235,20 @@ struct Unfold {
             // iterations are allowed, the path that skips the group.
             // An iteration that consumes nothing contributes no bytes: the first byte a match takes then comes from a later
             // iteration (same paths) or from what follows the group -- the path that skips the group stands for that.
-            bool skip = nd.min == 0;
+            bool skip = nd.min == 0, skip_cap = false;
+            // an iteration that consumes nothing can still close a group: behind it, an iteration that begins with a back
+            // reference is no longer dead
+            bool empty_iteration = false;
+            for (const Seq &e : E) empty_iteration = empty_iteration || (e.win.empty() && !e.gapped && !e.needs_cap);
+            if (empty_iteration && nd.max > 1)
+                for (Seq &e : E) e.needs_cap = false;
             for (const Seq &e : E) {
-                if (!e.win.empty() || e.gapped || e.needs_cap) { // (an iteration that is a back reference: unknown bytes)
+                if (!e.win.empty() || e.gapped || (e.frozen && e.win.empty())) { // (an iteration that is a back reference: unknown bytes)
                     if (!push_frozen(out, e)) return false;
                     continue;
                 }
                 skip = true;
+                skip_cap = skip_cap || e.cap;
                 if (e.has_tail) { // (?:a*)+ : an iteration that does consume begins with a byte of the repeat
                     Seq one = e;
                     one.win.push_back(e.tail);
@@ -1247,6 +1258,7 @@ struct Unfold {
             if (skip) {
                 Seq none;
                 none.inexact = true;
+                none.cap = skip_cap; // (iterations that consumed nothing may have closed a group: a back reference behind them is alive)
                 out.push_back(none);
             }
             return room(out.size());
@@ -1472,6 +1484,40 @@ std::atomic<uint64_t> g_next_id{1};
 
 uint64_t node_minlen(const Node &n);
 
+// libpcre quirk no. 2 (8.39 and 8.45, interpreter and JIT): a group whose first item is a positive look-ahead that begins
+// with a literal byte -- (?:(?=x))x\B -- gives pcre_exec both a "first byte" and a "required byte" that are the same
+// occurrence; the start-up optimisation then looks for a SECOND one further on and reports "no match" when there is none.
+// Refused rather than imitated.
+const Node *first_item(const Node &n)
+{
+    if (n.kind == Node::CAT) return n.kids.empty() ? nullptr : first_item(n.kids[0]);
+    return &n;
+}
+bool lookahead_first_in_group(const Node &n, bool top)
+{
+    if (!top && (n.kind == Node::CAT || n.kind == Node::ALT)) {
+        const Node *branches = n.kind == Node::ALT ? n.kids.data() : &n;
+        const size_t nb = n.kind == Node::ALT ? n.kids.size() : 1;
+        for (size_t b = 0; b < nb; b++) {
+            const Node *f = first_item(branches[b]);
+            if (f && f->kind == Node::LOOK && !f->neg && !f->behind) {
+                const Node *g = first_item(f->kids[0]);
+                if (g && g->kind == Node::SET && g->set.count() <= 2) return true;
+            }
+        }
+    }
+    for (const Node &k : n.kids) {
+        // a CAT directly under the top-level CAT/ALT is a branch of the pattern itself, not a group
+        const bool kid_top = top && (n.kind == Node::ALT) && k.kind == Node::CAT && !k.cap;
+        if (k.kind == Node::LOOK) {
+            if (lookahead_first_in_group(k.kids[0], true)) return true;
+            continue;
+        }
+        if (lookahead_first_in_group(k, kid_top)) return true;
+    }
+    return false;
+}
+
 bool has_optional_group(const Node &n)
 {
     if (n.kind == Node::REP && n.kids[0].kind != Node::SET && n.min == 0) return true;
@@ -1496,8 +1542,8 @@ bool ends_in_greedy_repeat(const Node &n, bool prev, bool &quirk)
         ends_in_greedy_repeat(n.kids[0], false, quirk);
         return false;
     }
-    case Node::ATOMIC: { // (?>..) is what a possessive group repeat compiles to: the same quirk when an optional group ends it
-        if (prev && has_optional_group(n.kids[0])) quirk = true;
+    case Node::ATOMIC: { // (?>..) is what a possessive group repeat compiles to: the same quirk when a branch of it can match ""
+        if (prev && node_minlen(n.kids[0]) == 0) quirk = true;
         return ends_in_greedy_repeat(n.kids[0], prev, quirk);
     }
     case Node::CAT: {
@@ -1689,6 +1735,10 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         ends_in_greedy_repeat(root, false, quirk);
         if (quirk) {
             why = "possessive group repeat behind a greedy repeat (libpcre's auto-possessification treats it inconsistently)";
+            return 1;
+        }
+        if (lookahead_first_in_group(root, true)) {
+            why = "a group that begins with a look-ahead for a literal byte (libpcre's first-byte / required-byte start-up check misfires on it)";
             return 1;
         }
     }
