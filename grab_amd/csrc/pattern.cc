@@ -204,10 +204,22 @@ struct Parser {
         case 'w': out = set_word(); is_set_escape = true; return true;
         case 'W': out = set_not(set_word()); is_set_escape = true; return true;
         case 's': out = set_space(); is_set_escape = true; return true;
-        case 'S': out = set_not(set_space()); is_set_escape = true; return true;
-        case 'h': out = set_hspace(); is_set_escape = true; return true;
+        case 'S':
+            out = set_not(set_space());
+            is_set_escape = true;
+            saw_bare_S = saw_bare_S || !in_class;
+            return true;
+        case 'h':
+            out = set_hspace();
+            is_set_escape = true;
+            saw_bare_hv = saw_bare_hv || !in_class;
+            return true;
         case 'H': out = set_not(set_hspace()); is_set_escape = true; return true;
-        case 'v': out = set_vspace(); is_set_escape = true; return true;
+        case 'v':
+            out = set_vspace();
+            is_set_escape = true;
+            saw_bare_hv = saw_bare_hv || !in_class;
+            return true;
         case 'V': out = set_not(set_vspace()); is_set_escape = true; return true;
         case 'N':
             if (in_class) return fail(-1, "\\N in class");
@@ -418,6 +430,10 @@ struct Parser {
     // opening of a non-capturing group "(?:" / "(?i:" (is_group = true; options already applied,
     // the caller restores them at the closing parenthesis).
     int special = 0; // set by group_head: 1 (?=  2 (?!  3 (?<=  4 (?<!  5 (?>  6 (?P=name) (a back reference, not a group)
+    // libpcre's auto-possessification table calls \S disjoint from \h and from \v; in the C locale it is not (0xa0 is \h
+    // and 0x85 is \v, neither is isspace()): \S+\h and \v*\S keep bytes they would have to give back.  A pattern that
+    // uses both kinds of escape outside classes is refused.
+    bool saw_bare_S = false, saw_bare_hv = false;
     int ngroups = 0; // capturing groups opened so far
     // capturing groups whose closing parenthesis has not been seen yet, with "a back reference inside it refers to it":
     // pcre_compile wraps such a group in atomic brackets (the value \N repeats must not change under it), and so does
@@ -751,20 +767,8 @@ struct Parser {
                         if (br > 0) break;
                         i = save;
                     }
-                    if (i + 1 < n && p[i + 1] == 'R') { // any newline sequence: (?>\r\n|\n|\x0b|\f|\r|\x85), 8-bit mode
-                        i += 2;
-                        Node crlf, cr, lf, one, alt;
-                        cr.set.set('\r');
-                        lf.set.set('\n');
-                        crlf.kind = Node::CAT;
-                        crlf.kids = {cr, lf};
-                        for (unsigned b : {0x0au, 0x0bu, 0x0cu, 0x0du, 0x85u}) one.set.set(b);
-                        alt.kind = Node::ALT;
-                        alt.kids = {crlf, one};
-                        a.kind = Node::ATOMIC;
-                        a.kids = {alt};
-                        break;
-                    }
+                    // (\R is refused: libpcre's auto-possessification treats \R as disjoint from \s and from ".", which it is not
+                    // under the LF newline convention -- \R?\s misses "\n", \N+\R never ends in \r, VT, FF or NEL)
                     i++;
                     {
                         bool is_set;
@@ -938,6 +942,7 @@ struct Parser {
     {
         if (!parse_alt(root)) return false;
         if (!eof()) return fail(-1, "unmatched parentheses"); // a ')' at depth 0
+        if (saw_bare_S && saw_bare_hv) return fail(1, "\\S next to \\h or \\v (libpcre's auto-possessification treats them as disjoint; 0xa0 and 0x85 are in both)");
         return resolve_refs(root);
     }
 };

@@ -23,17 +23,22 @@ from inputs import db_candidates
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import scan_oracle as so  # noqa: E402
 
+# a second vocabulary for texts with control characters and high bytes: the escapes whose C-locale meaning is easy to get wrong
+BIN_ATOMS = ["\\S", "\\D", "\\s", "\\h", "\\x00", "\\xff", "[\\x80-\\xff]", "\\v", "\\N", "[[:alpha:]]", "\\H", "[[:^space:]]", "\\V", "[[:punct:]]", "\\x85",
+             "a", "b", "Z", " ", "\\n", ".", "0", "[ab]", "[^a]", "\\w", "\\W", "_"]
 ATOMS = ["a", "b", "c", "x", " ", "\\n", ".", "0", "1", "[ab]", "[^a]", "[a-c]", "\\w", "\\d", "\\s", "\\W", "[b0 ]", "\\.", "[^\\n]", "A", "[x.]"]
 QUANTS = ["?", "*", "+", "{2}", "{1,2}", "{0,2}", "{2,}", "{1,3}", "??", "+?", "*?", "{1,2}?", "?+", "?"]
 
 
-def gen(rng):
+def gen(rng, atoms=None):
+    atoms = atoms or ATOMS
+
     def atom(d):
         r = rng.random()
         if r < 0.04:  # back references (most draws refer to a group that does not exist: PCRE rejects those)
             return rng.choice(["\\1", "\\2", "\\1", "\\g{-1}", "\\3"])
         if r < 0.70 or d > 2:
-            return rng.choice(ATOMS)
+            return rng.choice(atoms)
         if r < 0.85:
             return "(?:" + alt(d + 1) + ")"
         if r < 0.91:
@@ -43,7 +48,7 @@ def gen(rng):
         if r < 0.955:
             return rng.choice(["(?=", "(?!"]) + alt(d + 1) + ")"
         if r < 0.975:  # look-behind: fixed-length alternatives
-            return rng.choice(["(?<=", "(?<!"]) + "|".join("".join(rng.choice(ATOMS) for _ in range(rng.choice([1, 1, 2, 3]))) for _ in range(rng.choice([1, 1, 2]))) + ")"
+            return rng.choice(["(?<=", "(?<!"]) + "|".join("".join(rng.choice(atoms) for _ in range(rng.choice([1, 1, 2, 3]))) for _ in range(rng.choice([1, 1, 2]))) + ")"
         return "(?>" + alt(d + 1) + ")"
 
     def piece(d):
@@ -119,6 +124,20 @@ def test_random_patterns_match_pcre(seed, built, liboracle):
     for _ in range(1000):
         tested += check(liboracle, gen(rng), texts) is not None
     assert tested > 450  # (the rest: rejected by PCRE -- references to groups that do not exist --, patterns that can match "" -- every file is skipped, Q2 -- and a few per cent refused)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_patterns_on_binary_text(seed, built, liboracle):
+    """The same comparison over texts with NUL, VT, FF, CR, NEL (0x85), NBSP (0xa0) and other high bytes, patterns drawn from
+    the escapes whose C-locale sets are easy to get wrong (\\s \\S \\h \\v \\N [[:classes:]] \\xhh)."""
+    rng = random.Random(seed)
+    nrng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"abZ01 .\n\nab  \x00\xff\x85\x0b\r\t\x0c\xa0\xe9_", np.uint8)
+    texts = [alpha[nrng.integers(0, alpha.size, int(nrng.integers(1, 120)))].tobytes() for _ in range(14)] + [b"\x85", b"\xa0 \x0b", b"a\r\n\x00b"]
+    tested = 0
+    for _ in range(700):
+        tested += check(liboracle, gen(rng, BIN_ATOMS), texts) is not None
+    assert tested > 250
 
 
 # found by the campaign (each one printed something else than the reference before its fix)
