@@ -338,7 +338,8 @@ struct Parser {
                     }
                     ByteSet ps;
                     if (!posix_class(name, ps)) return fail(-1, "unknown POSIX class name");
-                    if (pneg && caseless) return fail(1, "negated POSIX class under (?i)");
+                    // (pcre_compile: "if matching is caseless, upper and lower are converted to alpha" -- before the negation)
+                    if (caseless && (name == "upper" || name == "lower")) posix_class("alpha", ps);
                     if (pneg) ps.negate();
                     s.merge(ps);
                     i = j + 2;
@@ -739,10 +740,10 @@ struct Parser {
                 if (acode) {
                     i += (c == '\\') ? 2 : 1;
                     skip_extended();
-                    if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?')) return fail(1, "quantified assertion");
+                    if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?')) return fail(-1, "nothing to repeat");
                     uint32_t mn, mx;
                     size_t end;
-                    if (!eof() && p[i] == '{' && counted(mn, mx, end)) return fail(1, "quantified assertion");
+                    if (!eof() && p[i] == '{' && counted(mn, mx, end)) return fail(-1, "nothing to repeat");
                     a.kind = Node::ASSERT;
                     a.acode = acode;
                     out.kids.push_back(std::move(a));
@@ -906,6 +907,7 @@ struct Parser {
                 }
                 if (have) {
                     int mode = 0;
+                    skip_extended(); // (?x): white space and comments may stand between a quantifier and its ? / + suffix
                     if (!eof() && p[i] == '?') { mode = 1; i++; }
                     else if (!eof() && p[i] == '+') { mode = 2; i++; }
                     if (look_quant) { // PCRE: {0} drops the assertion, a minimum of 0 makes it optional, anything else means once
@@ -922,7 +924,7 @@ struct Parser {
                         int r = p[i];
                         uint32_t mn, mx;
                         size_t end;
-                        if (r == '*' || r == '+' || r == '?' || (r == '{' && counted(mn, mx, end))) return fail(1, "stacked quantifiers");
+                        if (r == '*' || r == '+' || r == '?' || (r == '{' && counted(mn, mx, end))) return fail(-1, "nothing to repeat");
                     }
                     Node rep;
                     rep.kind = Node::REP;

@@ -27,7 +27,7 @@ import scan_oracle as so  # noqa: E402
 BIN_ATOMS = ["\\S", "\\D", "\\s", "\\h", "\\x00", "\\xff", "[\\x80-\\xff]", "\\v", "\\N", "[[:alpha:]]", "\\H", "[[:^space:]]", "\\V", "[[:punct:]]", "\\x85",
              "a", "b", "Z", " ", "\\n", ".", "0", "[ab]", "[^a]", "\\w", "\\W", "_"]
 ATOMS = ["a", "b", "c", "x", " ", "\\n", ".", "0", "1", "[ab]", "[^a]", "[a-c]", "\\w", "\\d", "\\s", "\\W", "[b0 ]", "\\.", "[^\\n]", "A", "[x.]"]
-QUANTS = ["?", "*", "+", "{2}", "{1,2}", "{0,2}", "{2,}", "{1,3}", "??", "+?", "*?", "{1,2}?", "?+", "?"]
+QUANTS = ["?", "*", "+", "{2}", "{1,2}", "{0,2}", "{2,}", "{1,3}", "??", "+?", "*?", "{1,2}?", "?+", "?", "+ ?", "* +", "{1,2} ?"]
 
 
 def gen(rng, atoms=None):
