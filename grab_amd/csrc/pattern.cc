@@ -221,6 +221,11 @@ struct Parser {
             saw_bare_hv = saw_bare_hv || !in_class;
             return true;
         case 'V': out = set_not(set_vspace()); is_set_escape = true; return true;
+        case 'C': // one data unit: any byte, newline included (no UTF here)
+            if (in_class) return fail(-1, "\\C in class");
+            out = set_all();
+            is_set_escape = true;
+            return true;
         case 'N':
             if (in_class) return fail(-1, "\\N in class");
             out = set_dot();
@@ -926,6 +931,12 @@ struct Parser {
                         size_t end;
                         if (r == '*' || r == '+' || r == '?' || (r == '{' && counted(mn, mx, end))) return fail(-1, "nothing to repeat");
                     }
+                    // (x)*+ : libpcre's JIT (the reference's timing build) leaves the group set when an attempt that went through
+                    // it fails, so a later group-free match of the same pcre_exec call comes back as 0 -- x|(a)*+b on "a x".
+                    // Only this form does ((a)++, ((a))*+, (?:(a))*+ do not); what it depends on -- every start offset
+                    // pcre_exec tries, candidate or not -- is not something the engine looks at.  Refused.
+                    if (mode == 2 && qmin == 0 && qmax == kInf && a.kind == Node::CAT && a.cap)
+                        return fail(1, "possessive * directly on a capturing group (libpcre's JIT reports the group as set after failed attempts)");
                     Node rep;
                     rep.kind = Node::REP;
                     rep.min = qmin;
