@@ -222,7 +222,10 @@ struct Parser {
             return true;
         case 'V': out = set_not(set_vspace()); is_set_escape = true; return true;
         case 'C': // one data unit: any byte, newline included (no UTF here)
-            if (in_class) return fail(-1, "\\C in class");
+            if (in_class) { // (libpcre: inside a class \C, like \R \X \B, is the letter)
+                s.set('C');
+                break;
+            }
             out = set_all();
             is_set_escape = true;
             return true;
