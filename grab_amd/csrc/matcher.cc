@@ -80,6 +80,7 @@ struct MatchAt {
     uint32_t end;
     bool captures;
     bool gave_up = false; // the attempt ran into the matcher's resource limits
+    uint32_t start = UINT32_MAX; // where the match is reported to start when the pattern says so (\K); UINT32_MAX: at the offset tried
 };
 bool match_at_alts(const Database &d, const uint8_t *content, size_t clen, size_t p, bool at_start, MatchAt &out)
 {
@@ -148,6 +149,7 @@ struct TreeMatch {
     // What the groups captured: kept only for patterns with back references ([2g], [2g+1] = start, end; SIZE_MAX = unset).
     // Shared with the matchers of look-arounds / atomic groups; every setter restores the old value when what follows fails.
     std::vector<size_t> *caps = nullptr;
+    size_t keep = SIZE_MAX; // \K: the reported start of the match (restored when what follows fails)
 
     // what is still to be matched after the current node
     struct Cont {
@@ -281,6 +283,7 @@ struct TreeMatch {
         inner.stack_base = stack_base;
         inner.max_stack = max_stack;
         inner.caps = caps;
+        inner.keep = keep;
         const bool got = as_repeat ? inner.rep_group(what, 0, at, cap, &stop) : inner.m(what, at, cap, &stop);
         steps = inner.steps;
         gave_up = gave_up || inner.gave_up;
@@ -288,6 +291,7 @@ struct TreeMatch {
         if (!got || gave_up) return false;
         end_out = inner.end;
         cap_out = inner.captured;
+        keep = inner.keep; // (the callers put the old value back when what follows the atomic part fails)
         return true;
     }
 
@@ -300,6 +304,13 @@ struct TreeMatch {
         case Node::SET:
             return pos < clen && n->set.test(c[pos]) && run(k, pos + 1, cap);
         case Node::ASSERT:
+            if (n->acode == gscan::A_KEEP) {
+                const size_t old = keep;
+                keep = pos;
+                if (run(k, pos, cap)) return true;
+                keep = old;
+                return false;
+            }
             return holds(n->acode, pos) && run(k, pos, cap);
         case Node::LOOK: {
             // The body is matched on its own, to its first success (assertions are atomic).  A look-behind body has a
@@ -332,10 +343,12 @@ struct TreeMatch {
         }
         case Node::ATOMIC: { // matched on its own to its first success; no way back into it
             const std::vector<size_t> saved = caps ? *caps : std::vector<size_t>();
+            const size_t saved_keep = keep;
             size_t e = 0;
             bool inner_cap = cap;
             if (atomic_run(&n->kids[0], false, pos, cap, e, inner_cap) && run(k, e, inner_cap)) return true;
             if (caps) *caps = saved;
+            keep = saved_keep;
             return false;
         }
         case Node::CAT: {
@@ -381,10 +394,12 @@ struct TreeMatch {
                 Node greedy = *n;
                 greedy.mode = 0;
                 const std::vector<size_t> saved = caps ? *caps : std::vector<size_t>();
+                const size_t saved_keep = keep;
                 size_t e = 0;
                 bool inner_cap = cap;
                 if (atomic_run(&greedy, true, pos, cap, e, inner_cap) && run(k, e, inner_cap)) return true;
                 if (caps) *caps = saved;
+                keep = saved_keep;
                 return false;
             }
             return rep_group(n, 0, pos, cap, k);
@@ -460,7 +475,7 @@ bool tree_match_at(const Database &d, const uint8_t *content, size_t clen, size_
     if (t.gave_up) g_given_up.fetch_add(1, std::memory_order_relaxed);
     if (!hit || t.gave_up) return false;
     if (t.end == p) return false; // (patterns that can match "" never get here: minlen -1, every file skipped)
-    out = {(uint32_t)t.end, t.captured, false};
+    out = {(uint32_t)t.end, t.captured, false, t.keep == SIZE_MAX ? UINT32_MAX : (uint32_t)t.keep};
     return true;
 }
 
@@ -720,7 +735,7 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
         if (best == Walk::kEnd) return 0;
         MatchAt m;
         if (match_at(d, content, clen, best, (size_t)s, m)) {
-            *m0 = (uint32_t)best;
+            *m0 = m.start == UINT32_MAX ? (uint32_t)best : m.start;
             *m1 = m.end;
             return m.captures ? 2 : 1;
         }

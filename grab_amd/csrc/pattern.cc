@@ -438,6 +438,7 @@ struct Parser {
     // "(?" just consumed.  Either an option setting "(?i)" (returns with is_group = false), or the
     // opening of a non-capturing group "(?:" / "(?i:" (is_group = true; options already applied,
     // the caller restores them at the closing parenthesis).
+    int look_depth = 0; // nesting depth of look-arounds at the current position
     int special = 0; // set by group_head: 1 (?=  2 (?!  3 (?<=  4 (?<!  5 (?>  6 (?P=name) (a back reference, not a group)
     // libpcre's auto-possessification table calls \S disjoint from \h and from \v; in the C locale it is not (0xa0 is \h
     // and 0x85 is \v, neither is isspace()): \S+\h and \v*\S keep bytes they would have to give back.  A pattern that
@@ -743,6 +744,10 @@ struct Parser {
                     case 'A': case 'G': acode = A_BOS; break;
                     case 'Z': acode = A_EOL; break;
                     case 'z': acode = A_EOS; break;
+                    case 'K':
+                        if (look_depth > 0) return fail(1, "\\K inside a look-around");
+                        acode = A_KEEP;
+                        break;
                     }
                 }
                 if (acode) {
@@ -830,7 +835,10 @@ struct Parser {
                         open_groups.emplace_back(gno, false);
                     }
                     depth++;
-                    if (!parse_alt(a)) return false;
+                    if (sp >= 1 && sp <= 4) look_depth++;
+                    const bool body_ok = parse_alt(a);
+                    if (sp >= 1 && sp <= 4) look_depth--;
+                    if (!body_ok) return false;
                     depth--;
                     if (eof() || p[i] != ')') return fail(-1, "missing )");
                     i++;
@@ -1180,7 +1188,8 @@ struct Unfold {
         }
         case Node::ASSERT: {
             Seq s;
-            s.asserts.emplace_back(0u, nd.acode);
+            if (nd.acode == A_KEEP) s.inexact = true; // no condition on the text; where the match is REPORTED to start is the matcher's to say
+            else s.asserts.emplace_back(0u, nd.acode);
             out.push_back(std::move(s));
             return true;
         }
@@ -1557,7 +1566,7 @@ bool ends_in_greedy_repeat(const Node &n, bool prev, bool &quirk)
 {
     switch (n.kind) {
     case Node::SET: return false;
-    case Node::ASSERT: return prev;
+    case Node::ASSERT: return n.acode == A_KEEP ? false : prev; // (\K is an opcode of its own: the look-ahead stops there)
     case Node::BACKREF: return false; // (not an opcode auto-possessification looks through)
     case Node::LOOK: { // an assertion opcode stops auto-possessification's look-ahead; its body is a pattern of its own
         ends_in_greedy_repeat(n.kids[0], false, quirk);

@@ -72,7 +72,8 @@ enum { A_BOS = 1, // ^ without (?m), \A, \G: the subject start (the restart posi
        A_MEOL,    // (?m)$: the very end, or just before any newline
        A_EOS,     // \z: the very end only
        A_WB,      // \b
-       A_NWB };   // \B
+       A_NWB,     // \B
+       A_KEEP };  // \K: always holds; the reported match starts here (ovector[0])
 
 // Parse tree.  SET = one byte drawn from a class; REP repeats its single child (max == UINT32_MAX: unbounded).
 // LOOK = (?=..) (?!..) (?<=..) (?<!..) around its single child; ATOMIC = (?>..); BACKREF = \1 \g{2} \k<name> (?P=name).

@@ -190,6 +190,9 @@ CASES = [
     dict(name="bref_never_set", inputs={"f": lit("li nus li ab ba li\nli\n")}, args=["-O", "-l", "(a|b)\\1|li", "f"]),
     dict(name="bref_named_lines", inputs={"f": lit("x nus\nnus abab nus\nnus\n")}, args=["-O", "(?P<q>ab)(?P=q)|nus", "f"]),
     dict(name="bref_self", inputs={"f": lit("z abbc z ac z\n")}, args=["-O", "-l", "(a|b\\1)+c|z", "f"]),
+    # \K: ovector[0] moves -- the offset printed, the highlighted part and the "before" context follow it
+    dict(name="keep_offsets", inputs={"f": lit("foobar foo bar foobar\nxfoobar")}, args=["-O", "-l", "foo\\Kbar", "f"]),
+    dict(name="keep_lines", inputs={"f": lit("foobar foo bar foobar\nxfoobar\nfoo\nbar\n")}, args=["-O", "foo\\K(?:bar)?", "f"]),
     dict(name="syn8_inx_call", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 5}}, args=["-O", "[a-z]+\\([a-z0-9, ]*\\);", "syn"]),
     dict(name="syn8_inx_member", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 5}}, args=["-O", "-l", "[a-z]+_[0-9]+\\.[a-z]+", "syn"]),
     dict(name="syn8_inx_look", inputs={"syn": {"kind": "synth", "nbytes": 8 << 20, "k": 5}}, args=["-O", "-l", "(?<![a-z_])[a-z]{3}(?=\\()|(?<=;)\\n(?!\\n)", "syn"]),

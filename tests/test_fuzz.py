@@ -59,7 +59,7 @@ def gen(rng, atoms=None):
         parts = []
         for _ in range(rng.choice([1, 1, 2, 2, 3, 4])):
             if rng.random() < 0.12:
-                parts.append(rng.choice(["\\b", "\\B", "^", "$", "\\A", "\\z", "\\Z"]))
+                parts.append(rng.choice(["\\b", "\\B", "^", "$", "\\A", "\\z", "\\Z", "\\K"]))
             parts.append(piece(d))
         if rng.random() < 0.10:
             parts.append(rng.choice(["\\b", "$", "\\B", "\\z"]))

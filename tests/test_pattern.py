@@ -93,7 +93,7 @@ UNSUPPORTED = [r"(a|\1?)b*", r"\pL",
 
 # "a(" is reported as unsupported (groups) by the engine alone; FileGrep::prepare asks libpcre first and
 # gives the reference's "pcre_compile error" for it (tests/test_gpu_filegrep.py, golden case bad_regex)
-UNSUPPORTED += [r"\Ka"]
+UNSUPPORTED += [r"(?=a\K)b"]
 
 # assertions that contradict each other: pcre_exec never matches, and neither does the engine (nothing is scanned at all)
 NEVER = [r"fo\bo", r"a\Ab", r"x^y|a\zb", r"(?m)a$b"]
@@ -121,7 +121,9 @@ INEXACT = ["a+b+c", "a{1,40}b", "a++b", "(?:ab)+", "(?:a|b)*c", "(?:ab)?+c", "(a
            # back references: the matcher remembers what the groups captured; with the reference's ovector[3] a match that used
            # one has set a group and ends the chunk (Q5) -- what prints are the matches of the alternatives without groups
            r"(a|b)\1|li", r"(\w)\1+x|foo", r"(?P<q>ab)(?P=q)|nus", r"(?i)(ab)\1|c", r"(a)(b)\2\1|x", r"(?:(a)|b)\1?c", r"(a|b\1)+c|z",
-           r"(\w+) \1\b|ab", r"(ab)\g{-1}|(?<n>l)\k<n>|f", r"((\2a|b){2}c){2}|li"]
+           r"(\w+) \1\b|ab", r"(ab)\g{-1}|(?<n>l)\k<n>|f", r"((\2a|b){2}c){2}|li",
+           # \K: the reported start moves (ovector[0]); where the match is FOUND does not
+           r"foo\Kbar|li", r"\w+\K\d", r"a\Kb|b\Kc|c", r"(?:a\K)+b|nus"]
 
 MALFORMED = ["a{2}{3}", "a**", "(?x)a + ? *b", r"\b*a", r"\1", r"(a)\2", "(?P=n)", r"(?<n>a)(?<n>b)", r"(a)(?<=\1)b", "(?<=a+)b", "(?<!ab|c*)d", "[abc", "*a", "+", "?x", "a{3,2}", "[z-a]", "\\", "a)", "[[:nope:]]", "(?:a", "(?i", "(?:a|*b)", "a|+", "(?z)a", "(?i)+a"]
 
