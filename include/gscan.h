@@ -9,13 +9,17 @@
  *       -> gscan_compile()      (pattern -> database, minlen with PCRE's meaning)
  *   pcre_exec(h, extra, start, end-start, 0, 0, ovector, 3)          src/grab.cc:178
  *       -> gscan_submit()/gscan_wait()   (one call per CHUNK instead of one per match:
- *          the engine scans for every offset p of the chunk at which pcre_exec would
- *          report a match if asked to start at p -- the "candidates" -- and returns the
- *          start of every group of consecutive candidates; the restart orbit of
- *          src/grab.cc:175-213 is then a host walk over that list, see grab_host.h /
- *          DESIGN.md)
- *       -> gscan_match_at()     (is offset p a candidate: the window test, on the host)
- *       -> gscan_match_end()    (ovector[1] for one selected start, computed lazily)
+ *          the kernels scan for every offset p of the chunk at which a match may start --
+ *          the "candidates": exactly the offsets at which pcre_exec would report a match if
+ *          asked to start there when gscan_info.exact is set, a superset of them (what a
+ *          match must begin with) otherwise -- and return the start of every group of
+ *          consecutive candidates)
+ *       -> gscan_next_match()   (one pcre_exec call of the reference's loop: the leftmost
+ *          match at or after the restart position, found by walking that list and asking the
+ *          host matcher AT the offsets it yields; src/grab.cc:175-213 stays as it is around it)
+ *       -> gscan_match_at() / gscan_match_info() / gscan_match_end()   (the matcher's answer
+ *          for one offset: is it a match start, where does the match end (ovector[1]), did
+ *          its path set a capturing group)
  *   pcre_free_study                                                   src/grab.cc:79
  *       -> gscan_free()
  *
