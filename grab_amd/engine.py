@@ -33,6 +33,12 @@ class Info(C.Structure):
                 ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int), ("lines_ok", C.c_int), ("exact", C.c_int)]
 
 
+class Cursor(C.Structure):
+    """gscan_cursor (include/gscan.h): per-chunk state of gscan_next_match; `ready = 0` before the first call."""
+    _fields_ = [("li", C.c_size_t), ("ntails", C.c_uint32), ("ready", C.c_uint32), ("tails", C.c_uint32 * 132),
+                ("next_at", C.c_uint32 * 65), ("next_known", C.c_uint8 * 65)]
+
+
 class Seg(C.Structure):
     _fields_ = [("offset", C.c_uint64), ("len", C.c_uint32), ("_pad", C.c_uint32)]
 
@@ -73,6 +79,8 @@ def lib():
         L.gscan_match_end.restype = C.c_uint32
         L.gscan_match_info.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.gscan_tail_positions.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.gscan_next_match.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
+                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.gscan_tail_positions.restype = C.c_size_t
         L.gscan_db_dev_window.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gscan_open.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -164,6 +172,16 @@ class Database:
         e = C.c_uint32()
         s0 = p if subject_start is None else subject_start
         return int(lib().gscan_match_info(self._h, buf.ctypes.data, buf.size, s0, p, C.byref(e))), e.value
+
+    def next_match(self, content, starts, cursor, s):
+        """gscan_next_match: one pcre_exec call of the reference's loop -- (rc, m0, m1), rc 0 none / 1 match / 2 match that set a
+        capturing group.  `starts`: the uint32 list the engine returned for the chunk; `cursor`: a Cursor() kept across the
+        calls for one chunk (s may only grow)."""
+        buf = np.frombuffer(content, np.uint8)
+        st = np.ascontiguousarray(starts, np.uint32)
+        m0, m1 = C.c_uint32(), C.c_uint32()
+        rc = lib().gscan_next_match(self._h, buf.ctypes.data, buf.size, st.ctypes.data, st.size, C.byref(cursor), s, C.byref(m0), C.byref(m1))
+        return int(rc), m0.value, m1.value
 
     def dev_window(self, alt):
         """What the kernels scan for alternative `alt`: ([membership table per device window position], shift)."""

@@ -91,3 +91,36 @@ def test_report_matches_python_oracle_random(built):
                 want = so.grab_file(pattern, data.tobytes(), f, 1 << 30)
                 assert host_find(db, data, f, 1 << 30) == want, (pattern, n, f)
                 assert host_find(db, data, f, 1 << 30, minimal=False) == want, (pattern, n, f)
+
+
+def test_next_match_any_restart_sequence(built):
+    """gscan_next_match keeps per-alternative answers in its cursor from call to call.  Whatever increasing sequence of
+    restart positions it is asked for -- not only the ones the reference's loop would produce -- its answer must be the
+    leftmost offset >= s at which the matcher reports a match with the subject starting at s."""
+    rng = np.random.default_rng(77)
+    alphabet = np.frombuffer(b"abcfoo01_ AZ.\n\n", np.uint8)
+    patterns = ["foo", "a|ab", r"\bfoo", r"o\b", "(?m)^f", "e$|o$", "a+b", r"[a-z]+\b", r"\w+@?\w+\.[a-c]+", "(?:fo|ab)+c", "a.*b.*c",
+                "(?<=o)o|b(?=c)", r"(a|b)\1|c", r"fo\Ko|ab", r"(?>a+)b|o", "[a-c]{1,20}0", "(?:a|b|c|f|o|0|1|_){3}"]
+    for pattern in patterns:
+        db = engine.Database(pattern)
+        for trial in range(4):
+            n = int(rng.integers(1, 600))
+            data = alphabet[rng.integers(0, alphabet.size, n)]
+            starts = np.zeros(0, np.uint32) if db.info.tier == engine.TIER_ANCHORED else so.group_starts(db_candidates(db, data)).astype(np.uint32)
+            cur = engine.Cursor()
+            s = 0
+            while s < n:
+                rc, m0, m1 = db.next_match(data, starts, cur, s)
+                want = (0, 0, 0)
+                for p in range(s, n):
+                    kind, end = db.match_info(data, p, s)
+                    if kind:
+                        want = (kind, p, end)
+                        break
+                got = (rc, m0, m1) if rc else (0, 0, 0)
+                if r"\K" not in pattern:  # (with \K the reported start is not the offset the match was found at)
+                    assert got == want, (pattern, data.tobytes(), s, got, want)
+                else:
+                    assert (got[0], got[2]) == (want[0], want[2]), (pattern, data.tobytes(), s, got, want)
+                s += int(rng.integers(1, 40))
+
