@@ -1,25 +1,28 @@
 // pattern.h -- PCRE-subset pattern compiler for the gfx950 scan engine.
 //
 // Replaces the reference's pcre_compile/pcre_study/pcre_fullinfo(MINLENGTH) step
-// (/root/reference/src/grab.cc:101-123) for the patterns the GPU engine can scan.
-// Accepted: single-byte atoms (literal, '.', escape class, [...] class), repeats,
-// alternation, groups and the inline options i / s / m -- as long as the
-// pattern unfolds into a short, PRIORITY-ORDERED list of alternatives, each of which is
-// a fixed class window optionally ending in ONE variable repeat of a single class
-// ("tail": * + ? {n,} {n,m}, greedy/lazy/possessive).  Optional and bounded repeats
-// in the middle of the pattern (colou?r, [ab]{1,3}c, (?:foo|bar)?baz) unfold into
-// alternatives in the order PCRE's backtracking tries them, so "the first alternative
-// whose window matches at p" is exactly pcre_exec's match at p, and its end is the
-// window end plus the tail's extension.  For that shape "pcre_exec reports a match
-// starting at p" is a pure function of the bytes at p (and of the chunk end), which
-// is what makes the "GPU emits all candidate starts, host walks the restart orbit"
-// split exact.  Capturing groups are taken too: the reference gives
-// pcre_exec room for one offset pair only (int ovector[3], src/grab.cc:171), so a match whose
-// path closes a group comes back as rc == 0 and ENDS the chunk silently, while a match that
-// bypasses every group prints as usual (both libpcre builds agree) -- each
-// alternative simply remembers whether it runs through a group.  Everything else -- anchors,
-// \b, look-around, back references, an unbounded repeat before the end of an alternative --
-// is reported as GSCAN_UNSUPPORTED.
+// (/root/reference/src/grab.cc:101-123).  The pattern is parsed into a tree (Node) -- single-byte
+// atoms (literal, '.', escape classes, [...]), repeats (greedy / lazy / possessive), alternation,
+// groups (plain, capturing, named, atomic), assertions (^ $ \b \B \A \z \Z, look-ahead, look-behind),
+// back references, \K, the inline options i s m x -- and the tree serves two readers:
+//
+// * matcher.cc walks it: a backtracking matcher with PCRE's semantics decides "the match pcre_exec
+//   reports AT offset p" (its end, the reported start, whether its path set a capturing group: the
+//   reference gives pcre_exec room for one offset pair only -- int ovector[3], src/grab.cc:171 -- so
+//   such a match comes back as rc == 0 and ENDS the chunk).
+// * the unfolder (pattern.cc) turns it into what the KERNELS look for: a short, priority-ordered list
+//   of alternatives, each a fixed window of byte classes, optionally ending in ONE variable repeat of a
+//   single class ("tail"), optionally with one unbounded repeat in the middle ("gapped"), and one byte
+//   of context at either end for the assertions.  Optional and bounded repeats in the middle of the
+//   pattern (colou?r, [ab]{1,3}c, (?:foo|bar)?baz) unfold into alternatives in the order PCRE's
+//   backtracking tries them.  When that list IS the pattern (Database::exact) "a match starts at p" is a
+//   function of the bytes at p; where the unfolder has to stop -- a second unbounded repeat, a repeated
+//   group, a look-around, a back reference -- the list says what every match must BEGIN with, and the
+//   matcher confirms each such offset.  Either way the split "GPU lists candidate starts, host walks the
+//   restart orbit" is exact.
+//
+// What stays outside (recursion, conditionals, Unicode properties, a few constructs libpcre itself
+// treats inconsistently) is reported as GSCAN_UNSUPPORTED with the reason.
 #pragma once
 #include <cstdint>
 #include <memory>
