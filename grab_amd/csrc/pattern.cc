@@ -972,6 +972,10 @@ struct Parser {
 };
 
 // ---- unfolding the tree into priority-ordered alternatives ----
+// window bytes a path may carry: the device window adds up to three positions (context before / after, the repeat byte
+// of a gapped path) and has to stay within kMaxWindow
+constexpr size_t kWinCap = (size_t)kMaxWindow - 3;
+
 struct Unfold {
     std::string why;
     int rc = 0;
@@ -1147,7 +1151,12 @@ struct Unfold {
                         s.inexact = h.inexact || b.inexact;
                         if (s.pwin.size() > (size_t)kMaxWindow) return fail("window longer than the engine supports");
                     }
-                    if (s.win.size() > (size_t)kMaxWindow) return fail("window longer than the engine supports");
+                    if (s.win.size() > kWinCap) { // longer than the kernels' windows go: its first kWinCap bytes, the matcher for the rest
+                        s.win.resize(kWinCap);
+                        s.asserts.erase(std::remove_if(s.asserts.begin(), s.asserts.end(), [](const std::pair<uint32_t, int> &as) { return as.first > kWinCap; }),
+                                        s.asserts.end());
+                        s = freeze(s);
+                    }
                     out.push_back(std::move(s));
                     if (!room(out.size())) return false;
                 }
@@ -1239,8 +1248,12 @@ struct Unfold {
                 return true;
             }
             if (k.kind == Node::SET) {
-                if (nd.min > (uint32_t)kMaxWindow) return fail("window longer than the engine supports");
                 Seq s;
+                if (nd.min > kWinCap) { // x{300}: the kernels look for its first kWinCap bytes
+                    s.win.assign(kWinCap, k.set);
+                    out.push_back(freeze(s));
+                    return true;
+                }
                 s.win.assign(nd.min, k.set);
                 if (nd.max > nd.min) {
                     s.has_tail = true;
@@ -1749,9 +1762,9 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             leaf.set = b;
             root.kids.push_back(leaf);
         }
-        if (s.win.size() > (size_t)kMaxWindow) {
-            why = "window longer than the engine supports";
-            return 1;
+        if (s.win.size() > kWinCap) { // a long literal: the kernels look for its first kWinCap bytes, the matcher compares the rest
+            s.win.resize(kWinCap);
+            s.frozen = s.inexact = true;
         }
     } else {
         Parser ps{(const unsigned char *)pat, len};
