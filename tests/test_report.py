@@ -124,3 +124,30 @@ def test_next_match_any_restart_sequence(built):
                     assert (got[0], got[2]) == (want[0], want[2]), (pattern, data.tobytes(), s, got, want)
                 s += int(rng.integers(1, 40))
 
+
+def test_long_lines_all_modes_match_libpcre(built, liboracle):
+    """Lines of ~800 bytes (the 511-byte context caps of grab.cc:173,190-197 bite), every output mode incl. -s, patterns of every
+    kind the host matcher serves: the product's chunk walk == libpcre under the reference's loop (oracle_scan_chunk)."""
+    import ctypes as C
+
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"abcxyz01 ._@()=;" + b"\n", np.uint8)
+    w = np.ones(alpha.size)
+    w[-1] = 0.02
+    w /= w.sum()
+    patterns = [r"\w+@\w+\.\w+", r"(?:ab|xy)+z", r"a.*b.*c", r"(\w)\1\1", r"ab\Kc+", r"(?<=\()\w+(?=\))", r"[a-c]+\([a-z0-9, ]*\);", r"(?>a+)b",
+                r"x{2,}y{2,}z*0", r"(?m)^\w+ = \w+;$", r"\b(?:[a-c]+_)+[a-c]+\b", "ab", "[a-c]{3,}"]
+    for trial in range(5):
+        text = alpha[rng.choice(alpha.size, 20000, p=w)].tobytes()
+        data = np.frombuffer(text, np.uint8)
+        for pattern in patterns:
+            db = engine.Database(pattern)
+            starts = so.group_starts(db_candidates(db, data)).astype(np.uint32)
+            for f in (0, 1, 3, 2, 4, 5):
+                out = C.c_void_p()
+                n = C.c_size_t()
+                assert liboracle.oracle_scan_chunk(pattern.encode(), b"", text, len(text), 0, f, C.byref(out), C.byref(n)) == 0
+                want = C.string_at(out, n.value) if n.value else b""
+                liboracle.oracle_free(out)
+                assert filegrep.report_chunk(db, f, b"", data, 0, starts) == want, (pattern, trial, f)
+
