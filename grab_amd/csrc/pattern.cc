@@ -976,6 +976,15 @@ struct Parser {
 // of a gapped path) and has to stay within kMaxWindow
 constexpr size_t kWinCap = (size_t)kMaxWindow - 3;
 
+// does the subtree hold a capturing group?
+bool has_cap_group(const Node &n)
+{
+    if (n.kind == Node::CAT && n.cap) return true;
+    for (const Node &k : n.kids)
+        if (has_cap_group(k)) return true;
+    return false;
+}
+
 struct Unfold {
     std::string why;
     int rc = 0;
@@ -1205,6 +1214,10 @@ struct Unfold {
         case Node::LOOK: { // consumes nothing; what it demands of the text is the matcher's business
             Seq s;
             s.inexact = true;
+            // a positive assertion keeps what its body captured ((?=(x))\1x matches "xx"): a back reference behind it is
+            // alive, so the path must not be dropped as "reference to a group that cannot be set" (needs_cap && !cap).
+            // Whether the match really closed a group is the matcher's to say (the path is inexact).
+            if (!nd.neg && has_cap_group(nd)) s.cap = true;
             out.push_back(std::move(s));
             return true;
         }

@@ -140,6 +140,24 @@ def test_random_patterns_on_binary_text(seed, built, liboracle):
     assert tested > 250
 
 
+@pytest.mark.parametrize("seed", [31, 32])
+def test_backrefs_to_groups_closed_inside_assertions(seed, built, liboracle):
+    """Capturing groups inside positive / negative look-arounds with a back reference to them behind the assertion
+    (the unfolder had dropped such paths as dead)."""
+    rng = random.Random(seed)
+    texts = make_texts(seed) + [b"xx xa", b"abab aab", b"a1a1 0a0a"]
+    tested = 0
+    for _ in range(400):
+        body = "|".join(rng.choice(ATOMS) + rng.choice(["", "", "?", "+"]) for _ in range(rng.choice([1, 1, 2])))
+        look = rng.choice(["(?=", "(?=", "(?!", "(?<="]) + ("(" + rng.choice(ATOMS) + ")" if rng.random() < 0.3 else "(" + body + ")") + ")"
+        if look.startswith("(?<="):
+            look = "(?<=(" + rng.choice(ATOMS) + "))"
+        tail = rng.choice(["\\1", "\\1x", "\\1" + rng.choice(QUANTS), rng.choice(ATOMS) + "\\1", "\\1|" + rng.choice(ATOMS) + rng.choice(ATOMS)])
+        pat = rng.choice(["", "", rng.choice(ATOMS), rng.choice(ATOMS) + "|"]) + look + tail + rng.choice(["", "| xa", "|" + rng.choice(ATOMS) + "{2}"])
+        tested += check(liboracle, pat, texts) is not None
+    assert tested > 60
+
+
 # found by the campaign (each one printed something else than the reference before its fix)
 REGRESSIONS = [
     (r"\W*?0|\b\n", b"  \n0a c A0x0c\n 0\nbaAacA11 c  a"),                      # a group of hits starting AT the restart position (list cursor)
@@ -152,6 +170,18 @@ REGRESSIONS = [
     (r"(?i:0?? *?\b[b0 ]?[^a])|x|0a", b".bx0a \nac 0ac0ac0  a\n 1ca.."),
     (r"\A[^a]\n|x\d", b"c\n. cba .  x1 c \nb1.ab1c 1b \n"),
 ]
+
+# a group closed inside a positive assertion keeps its capture, so a back reference behind it is alive: the unfolder had dropped
+# such a path as dead and printed matches the reference does not.  Now the path survives; with nothing fixed in
+# front of the reference the pattern is refused loudly.  Either way: never a different output.
+ASSERTION_CAPTURES = [(r"(?=(x))\1x| xa", b"xx xa"), (r"(?=(x))\1x", b"xx xa xx"), (r"(?<=(a))\1b|c", b"aab c ab"), (r"a(?=(x))\1x| xa", b"axx xa"),
+                      (r"x(?=(x))\1| xa", b"xxx xa xx")]
+
+
+@pytest.mark.parametrize("pattern,text", ASSERTION_CAPTURES)
+def test_fuzz_assertion_captures(pattern, text, built, liboracle):
+    check(liboracle, pattern, [text] + make_texts(7))  # (None = refused: fine; a difference asserts)
+
 
 # ... and patterns that were accepted wrongly: an assertion that always holds where a greedy repeat stops (\w+\b, (?m).*$)
 # had been dropped although more pattern followed the repeat (PCRE then backtracks into it and the assertion decides).
