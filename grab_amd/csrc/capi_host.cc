@@ -1,4 +1,5 @@
 // capi_host.cc -- extern "C" facade declared in include/grab_host.h.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -6,6 +7,7 @@
 
 #include "../../include/grab_host.h"
 #include "filegrep.h"
+#include "walk.h"
 
 struct grab_filegrep {
     FileGrep g;
@@ -26,6 +28,8 @@ void grab_filegrep_config(grab_filegrep *g, const char *key, size_t value)
 }
 int grab_filegrep_prepare(grab_filegrep *g, const char *regex, size_t len) { return g->g.prepare(std::string(regex, len)); }
 int grab_filegrep_find(grab_filegrep *g, const char *path) { return g->g.find(std::string(path)); }
+int grab_filegrep_find3(grab_filegrep *g, const char *path, const struct stat *st, int typeflag) { return g->g.find(path, st, typeflag); }
+int grab_filegrep_flush(grab_filegrep *g) { return g->g.flush(); }
 int grab_filegrep_find_recursive(grab_filegrep *g, const char *path) { return g->g.find_recursive(std::string(path)); }
 int grab_filegrep_engine_option(grab_filegrep *g, const char *name, long value) { return g->g.engine_option(name, value); }
 
@@ -47,5 +51,19 @@ int grab_report_chunk_c(const gscan_db *db, unsigned flags, const char *path, co
 }
 
 void grab_free(void *p) { free(p); }
+
+long grab_walk_parallel(const char *root, int threads, grab_walk_fn fn, void *arg)
+{
+    if (!root || !fn) return -1;
+    return (long)grab_walk(root, threads, [&](std::string &&path, const struct stat &st) { fn(path.c_str(), &st, arg); });
+}
+
+int grab_validate(const char *regex, size_t len, int literal, char *why, size_t whycap)
+{
+    std::string w;
+    const int rc = FileGrep::validate(std::string(regex, len), literal != 0, w);
+    if (why && whycap) snprintf(why, whycap, "%s", w.c_str());
+    return rc;
+}
 
 } // extern "C"

@@ -9,15 +9,16 @@
 //        ──compute stream: async D2H of counter + descriptors + first records──► event `done`
 //   gscan_wait: sync `done`, fetch the rest if needed, stitch runs in tile order.
 //
-// With GSCAN_SLOTS = 2 the copy of chunk k+1 overlaps the scan and report of chunk k.
+// With GSCAN_SLOTS = 3 the read + copy of chunk k+2 overlaps the scan of chunk k+1 and the report of chunk k.
 //
 // How the bytes get to the copy stream (measured on the MI355X box, profiles/r01_g_host_probe.txt:
 // hipHostMalloc 0.22 s/GiB, page cache -> pinned 8-10 GB/s per thread and linear in threads,
 // H2D 57 GB/s, register + unregister + munmap of a mapping ~55 ms/GiB per thread and slower with
 // more threads):
-//   gscan_submit_fd   a file range: the process-wide reader threads pread(2) it piecewise into a
-//                     small pool of 8 MiB pinned blocks and DMA each piece as soon as it is read;
-//                     nothing is pinned per chunk
+//   gscan_submit_fd   a file range: the device's reader threads pread(2) it piecewise into a small pool
+//                     of pinned blocks and DMA each piece as soon as it is read, spread over the
+//                     context's copy streams; the thread that finishes the last piece launches the
+//                     scan, the submitting thread does not wait; nothing is pinned per chunk
 //   gscan_submit_segs many small files packed by the caller into the slot's pinned block: one
 //                     H2D, one launch over a segment table
 //   gscan_submit      a caller buffer: registered and DMA'd in place (>= 1 MiB) or staged
@@ -37,6 +38,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -61,7 +63,39 @@ constexpr size_t kCounterWords = gscan::kShards + 2; // per-shard counts + overf
 constexpr size_t kCopyPiece = 32u << 20; // memcpy/H2D pipelining granule for foreign host buffers
 constexpr size_t kMaxChunk = (1ull << 30) + 4096;
 
-constexpr size_t kBlock = 8u << 20; // pinned pool block == read piece == batch buffer
+// ---- ingest configuration (environment, read once) ----
+//   GSCAN_BLOCK_MIB     pinned pool block == read piece == one hipMemcpyAsync == batch buffer        (default 16)
+//   GSCAN_READERS       reader threads per device                                                   (default 12)
+//   GSCAN_COPY_STREAMS  copy streams per context the pieces of a file range are spread over         (default 2)
+//   GSCAN_NUMA          0: readers inherit the opener's CPU mask; else the CPUs local to the device  (default 1)
+// Why these: a hipMemcpyAsync carries a fixed cost that 8 MiB pieces on one stream do not hide (39 GB/s against 56 GB/s
+// for 32 MiB pieces, profiles/r01_g_host_probe.txt); the sweep behind the defaults is profiles/r02_*e2e_sweep*.
+struct IngestCfg {
+    size_t block;
+    int readers;
+    int copy_streams;
+    bool numa;
+};
+const IngestCfg &ingest_cfg()
+{
+    static const IngestCfg c = [] {
+        IngestCfg v;
+        auto env = [](const char *n, long def, long lo, long hi) {
+            const char *e = getenv(n);
+            long x = e && *e ? atol(e) : def;
+            return std::max(lo, std::min(hi, x));
+        };
+        v.block = (size_t)env("GSCAN_BLOCK_MIB", 16, 1, 64) << 20;
+        v.readers = (int)env("GSCAN_READERS", 12, 1, 64);
+        const long hw = (long)std::thread::hardware_concurrency();
+        if (hw > 0 && v.readers > hw) v.readers = (int)hw;
+        v.copy_streams = (int)env("GSCAN_COPY_STREAMS", 2, 1, 4);
+        v.numa = env("GSCAN_NUMA", 1, 0, 1) != 0;
+        return v;
+    }();
+    return c;
+}
+inline size_t block_bytes() { return ingest_cfg().block; }
 
 // A pinned block of the process-wide pool.  ev is recorded after the last DMA out of the block.
 struct PinBlock {
@@ -69,37 +103,97 @@ struct PinBlock {
     hipEvent_t ev = nullptr;
 };
 
-// One piece of a file range on its way to HBM.
+// One file range on its way to HBM (gscan_submit_fd): its pieces are read by the reader threads; whoever finishes the
+// last piece runs `finish` (records the copy events and launches the scan), so the submitting thread never waits.
 struct ReadGroup {
     std::mutex m;
     std::condition_variable cv;
     size_t pending = 0;
     int err = 0; // errno of the first failed read, -1 for a short file, -2 for a HIP failure
+    bool finished = true;
+    void (*finish)(ReadGroup *) = nullptr;
+    void *ctx = nullptr, *slot = nullptr; // for `finish`
+    int rc = 0;                           // what `finish` came to (a GSCAN_* code) ...
+    std::string msg;                      // ... and its text
 };
 struct ReadTask {
     int fd;
     off_t off;
     size_t n;
     uint8_t *dst;       // device
-    hipStream_t stream; // the submitting context's copy stream
+    hipStream_t stream; // one of the submitting context's copy streams
     ReadGroup *grp;
 };
 
-// Process-wide, one per device: pinned blocks + the reader threads that fill them.
-// Two block pools so that readers can never be starved by blocks parked in contexts' slots:
+// "0-31,64-95" -> CPU numbers (the format of sysfs cpulist files)
+size_t parse_cpulist(const char *list, std::vector<int> &out)
+{
+    out.clear();
+    for (const char *q = list; q && *q;) {
+        while (*q == ',' || *q == ' ' || *q == '\n' || *q == '\t') q++;
+        if (*q < '0' || *q > '9') break;
+        char *e = nullptr;
+        long a = strtol(q, &e, 10), b = a;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        if (b < a || b - a > 65536) break;
+        for (long c = a; c <= b; c++) out.push_back((int)c);
+        q = e;
+    }
+    return out.size();
+}
+
+int pci_cpulist(const char *root, const char *busid, char *buf, size_t cap)
+{
+    if (!root || !busid || !buf || cap < 2) return GSCAN_EINVAL;
+    std::string id(busid);
+    for (char &ch : id) ch = (char)tolower((unsigned char)ch);
+    const std::string path = std::string(root) + "/" + id + "/local_cpulist";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return GSCAN_EIO;
+    size_t n = fread(buf, 1, cap - 1, f);
+    fclose(f);
+    while (n && (buf[n - 1] == '\n' || buf[n - 1] == ' ')) n--;
+    buf[n] = 0;
+    return (int)n;
+}
+
+int device_cpulist(int device, char *buf, size_t cap)
+{
+    char id[64] = {0};
+    if (hipDeviceGetPCIBusId(id, (int)sizeof id, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return GSCAN_EHIP;
+    }
+    const char *root = getenv("GSCAN_SYSFS_PCI");
+    return pci_cpulist(root && *root ? root : "/sys/bus/pci/devices", id, buf, cap);
+}
+
+// Process-wide, one per device while any context on that device is open: pinned blocks + the reader threads that fill
+// them.  Two block pools so that readers can never be starved by blocks parked in contexts' slots:
 //   reader blocks (at most 2 per reader thread) cycle  free -> read -> DMA in flight -> free;
 //   slot blocks back gscan_acquire and are cached here between contexts.
+// Reference-counted by the contexts: the last gscan_close on a device joins the threads and frees the blocks.
 class Ingest {
 public:
-    static Ingest *get(int device)
+    static Ingest *acquire(int device)
     {
-        static std::mutex gm;
-        static std::vector<Ingest *> all;
-        std::lock_guard<std::mutex> lk(gm);
-        for (Ingest *i : all)
-            if (i->device_ == device) return i;
-        all.push_back(new Ingest(device)); // lives as long as the process: its threads are never joined
-        return all.back();
+        std::lock_guard<std::mutex> lk(gm());
+        for (Ingest *i : all())
+            if (i->device_ == device) {
+                i->refs_++;
+                return i;
+            }
+        all().push_back(new Ingest(device));
+        return all().back();
+    }
+    static void release(Ingest *g)
+    {
+        {
+            std::lock_guard<std::mutex> lk(gm());
+            if (--g->refs_ > 0) return;
+            all().erase(std::find(all().begin(), all().end(), g));
+        }
+        delete g;
     }
 
     PinBlock *take_slot_block()
@@ -120,47 +214,91 @@ public:
         slot_free_.push_back(b);
     }
 
-    void read(const ReadTask &t)
+    void read(const ReadTask *t, size_t n)
     {
         std::lock_guard<std::mutex> lk(m_);
         if (!started_) {
             started_ = true;
-            for (int i = 0; i < readers_; i++) std::thread([this] { reader_main(); }).detach();
+            for (int i = 0; i < readers_; i++) threads_.emplace_back([this] { reader_main(); });
         }
-        tasks_.push_back(t);
-        cv_tasks_.notify_one();
+        tasks_.insert(tasks_.end(), t, t + n);
+        if (n == 1) cv_tasks_.notify_one();
+        else cv_tasks_.notify_all();
     }
     int readers() const { return readers_; }
-
-private:
-    explicit Ingest(int device) : device_(device)
-    {
-        const char *e = getenv("GSCAN_READERS");
-        long r = e ? atol(e) : 8; // 8 threads x 8.4 GB/s of pread cover one PCIe Gen5 x16 link
-        const long hw = (long)std::thread::hardware_concurrency();
-        if (hw > 0 && r > hw) r = hw;
-        readers_ = (int)std::max<long>(1, std::min<long>(r, 64));
-        cap_ = (size_t)readers_ * 2;
-        // the readers are started later, possibly from a worker thread that is pinned to one CPU (grab -n pins
-        // worker i to CPU i like the reference): they run with the affinity of the thread that opened the first context
-        have_mask_ = sched_getaffinity(0, sizeof mask_, &mask_) == 0;
-        timing_ = getenv("GSCAN_TIMING") != nullptr;
-    }
-
-public:
     void report_if_timing()
     {
         if (timing_ && n_pieces_) report();
     }
 
 private:
+    static std::mutex &gm()
+    {
+        static std::mutex m;
+        return m;
+    }
+    static std::vector<Ingest *> &all()
+    {
+        static std::vector<Ingest *> v;
+        return v;
+    }
+
+    explicit Ingest(int device) : device_(device)
+    {
+        readers_ = ingest_cfg().readers;
+        cap_ = (size_t)readers_ * 2;
+        // Where the readers run: on the CPUs of the device's NUMA node (the pinned blocks are first touched by them, and the
+        // page cache -> pinned copy is the host's share of every byte), as far as the process is allowed there.  Without
+        // that information: the mask of the thread that opened the first context.
+        have_mask_ = sched_getaffinity(0, sizeof mask_, &mask_) == 0;
+        if (ingest_cfg().numa) {
+            char list[1024];
+            std::vector<int> cpus;
+            cpu_set_t allowed, local;
+            if (device_cpulist(device, list, sizeof list) > 0 && parse_cpulist(list, cpus) && sched_getaffinity(getpid(), sizeof allowed, &allowed) == 0) {
+                CPU_ZERO(&local);
+                int n = 0;
+                for (int c : cpus)
+                    if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) {
+                        CPU_SET(c, &local);
+                        n++;
+                    }
+                if (n > 0) {
+                    mask_ = local;
+                    have_mask_ = true;
+                    numa_cpus_ = n;
+                }
+            }
+        }
+        timing_ = getenv("GSCAN_TIMING") != nullptr;
+    }
+    ~Ingest()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            cv_tasks_.notify_all();
+        }
+        for (std::thread &t : threads_) t.join();
+        (void)hipSetDevice(device_);
+        for (PinBlock *b : busy_) free_block(b, true);
+        for (PinBlock *b : free_) free_block(b, false);
+        for (PinBlock *b : slot_free_) free_block(b, false);
+    }
+    void free_block(PinBlock *b, bool wait)
+    {
+        if (wait) (void)hipEventSynchronize(b->ev);
+        if (b->ev) (void)hipEventDestroy(b->ev);
+        if (b->p) (void)hipHostFree(b->p);
+        delete b;
+    }
 
     PinBlock *alloc_block()
     {
         PinBlock *b = new (std::nothrow) PinBlock();
         if (!b) return nullptr;
         (void)hipSetDevice(device_);
-        if (hipHostMalloc(&b->p, kBlock + kPad, hipHostMallocDefault) != hipSuccess ||
+        if (hipHostMalloc(&b->p, block_bytes() + kPad, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             if (b->p) hipHostFree(b->p);
@@ -216,7 +354,8 @@ private:
             double t0 = timing_ ? now() : 0;
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_tasks_.wait(lk, [&] { return !tasks_.empty(); });
+                cv_tasks_.wait(lk, [&] { return !tasks_.empty() || stop_; });
+                if (tasks_.empty()) return; // stop_: every context on the device is closed, nothing can be queued any more
                 t = tasks_.front();
                 tasks_.pop_front();
             }
@@ -257,9 +396,13 @@ private:
                 n_pieces_++;
                 n_bytes_ += t.n;
             }
-            std::lock_guard<std::mutex> lk(t.grp->m);
-            if (err && !t.grp->err) t.grp->err = err;
-            if (--t.grp->pending == 0) t.grp->cv.notify_all();
+            bool last;
+            {
+                std::lock_guard<std::mutex> lk(t.grp->m);
+                if (err && !t.grp->err) t.grp->err = err;
+                last = --t.grp->pending == 0;
+            }
+            if (last) t.grp->finish(t.grp); // every piece is on its copy stream: launch the scan behind them
         }
     }
 
@@ -269,21 +412,24 @@ private:
     std::atomic<uint64_t> ns_idle_{0}, ns_block_{0}, ns_read_{0}, ns_hip_{0}, n_pieces_{0}, n_bytes_{0};
     void report()
     {
-        fprintf(stderr, "[gscan timing] device %d readers %d: pieces %llu bytes %llu | per reader: idle %.3f s  wait-for-block %.3f s  pread %.3f s  hip calls %.3f s\n",
-                device_, readers_, (unsigned long long)n_pieces_.load(), (unsigned long long)n_bytes_.load(), ns_idle_ / 1e9 / readers_,
+        fprintf(stderr, "[gscan timing] device %d readers %d (%d local CPUs) block %zu MiB: pieces %llu bytes %llu | per reader: idle %.3f s  wait-for-block %.3f s  pread %.3f s  hip calls %.3f s\n",
+                device_, readers_, numa_cpus_, block_bytes() >> 20, (unsigned long long)n_pieces_.load(), (unsigned long long)n_bytes_.load(), ns_idle_ / 1e9 / readers_,
                 ns_block_ / 1e9 / readers_, ns_read_ / 1e9 / readers_, ns_hip_ / 1e9 / readers_);
     }
     int device_;
+    int refs_ = 1;
     int readers_ = 8;
+    int numa_cpus_ = 0; // CPUs of the device's NUMA node the readers are bound to (0: not bound by NUMA)
     cpu_set_t mask_;
     bool have_mask_ = false;
     size_t cap_ = 16, n_alloc_ = 0;
-    bool started_ = false;
+    bool started_ = false, stop_ = false;
     std::mutex m_;
     std::condition_variable cv_blocks_, cv_tasks_;
     std::vector<PinBlock *> free_, slot_free_;
     std::deque<PinBlock *> busy_;
     std::deque<ReadTask> tasks_;
+    std::vector<std::thread> threads_;
 };
 
 enum SlotState { FREE = 0, ACQUIRED, INFLIGHT };
@@ -312,7 +458,7 @@ struct Slot {
     bool has_ext = false;
     const void *ext = nullptr;  // caller's buffer this chunk was copied from (gscan_wait hands it back as *content)
     void *ext_reg = nullptr;    // ... registered with the runtime for direct DMA until the scan is done
-    PinBlock *blk = nullptr; // pool block serving as this slot's pinned buffer (acquires of <= kBlock bytes)
+    PinBlock *blk = nullptr; // pool block serving as this slot's pinned buffer (acquires of <= block_bytes() bytes)
     bool no_content = false;    // gscan_submit_fd: the bytes never sat in a host buffer of ours
     // multi-segment chunks (gscan_submit_segs)
     std::vector<gscan_seg> segs;
@@ -321,6 +467,8 @@ struct Slot {
     gscan::TileDesc *d_tiles = nullptr, *h_tiles = nullptr;
     size_t seg_tiles_cap = 0;
     hipEvent_t copied = nullptr, done = nullptr;
+    hipEvent_t copied_x[3] = {nullptr, nullptr, nullptr}; // the further copy streams of a file range
+    std::unique_ptr<ReadGroup> grp;                       // gscan_submit_fd: the range's pieces (finished == true when idle)
     uint64_t tag = 0;
     size_t len = 0;
     uint32_t n_tiles = 0;
@@ -339,6 +487,8 @@ struct gscan_ctx {
     int cus = 256;
     size_t max_chunk = 0;
     hipStream_t copy = nullptr, compute = nullptr;
+    hipStream_t copy_x[3] = {nullptr, nullptr, nullptr}; // further copy streams (GSCAN_COPY_STREAMS - 1 of them)
+    int n_copy = 1;
     Ingest *ingest = nullptr;
     Slot slot[GSCAN_SLOTS];
     uint64_t next_seq = 1;
@@ -375,6 +525,10 @@ struct gscan_ctx {
 
 namespace {
 
+// A reader thread that launches a scan on behalf of a context (fd_finish) must not write the context's error text while
+// the owning thread may be reading it: it points this at the read group's own string for the duration.
+thread_local std::string *t_err_sink = nullptr;
+
 int fail(gscan_ctx *c, int code, const char *fmt, ...)
 {
     char buf[512];
@@ -382,7 +536,8 @@ int fail(gscan_ctx *c, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf;
+    if (t_err_sink) *t_err_sink = buf;
+    else if (c) c->err = buf;
     return code;
 }
 
@@ -579,8 +734,48 @@ void free_slot(gscan_ctx *c, Slot &s)
     if (s.d_desc) hipFree(s.d_desc);
     if (s.h_desc) hipHostFree(s.h_desc);
     if (s.copied) hipEventDestroy(s.copied);
+    for (hipEvent_t e : s.copied_x)
+        if (e) hipEventDestroy(e);
     if (s.done) hipEventDestroy(s.done);
     s = Slot();
+}
+
+// gscan_submit_fd, second half: run by the reader thread that finished the range's last piece.  Every piece is on one of
+// the context's copy streams by now; the scan goes behind them.
+void fd_finish(ReadGroup *g)
+{
+    gscan_ctx *c = (gscan_ctx *)g->ctx;
+    Slot &s = *(Slot *)g->slot;
+    t_err_sink = &g->msg;
+    int rc = [&]() -> int {
+        if (g->err) {
+            HIPCHK(c, hipStreamSynchronize(c->copy)); // pieces that did make it must not land after the slot is reused
+            for (int k = 1; k < c->n_copy; k++) HIPCHK(c, hipStreamSynchronize(c->copy_x[k - 1]));
+            if (g->err == -1) return fail(c, GSCAN_EIO, "file shrank while reading");
+            if (g->err == -2) return fail(c, GSCAN_EHIP, "staging block or DMA failed");
+            return fail(c, GSCAN_EIO, "%s", strerror(g->err));
+        }
+        HIPCHK(c, hipEventRecord(s.copied, c->copy));
+        HIPCHK(c, hipStreamWaitEvent(c->compute, s.copied, 0));
+        for (int k = 1; k < c->n_copy; k++) {
+            HIPCHK(c, hipEventRecord(s.copied_x[k - 1], c->copy_x[k - 1]));
+            HIPCHK(c, hipStreamWaitEvent(c->compute, s.copied_x[k - 1], 0));
+        }
+        return slot_launch(c, s);
+    }();
+    t_err_sink = nullptr;
+    std::lock_guard<std::mutex> lk(g->m);
+    g->rc = rc;
+    g->finished = true;
+    g->cv.notify_all();
+}
+
+// the owner waits for a slot's file range to be read and its scan to be launched
+void slot_drain_reads(Slot &s)
+{
+    if (!s.grp) return;
+    std::unique_lock<std::mutex> lk(s.grp->m);
+    s.grp->cv.wait(lk, [&] { return s.grp->finished; });
 }
 
 } // namespace
@@ -681,19 +876,22 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     if (!c) return GSCAN_ENOMEM;
     c->device = hip_device;
     c->max_chunk = max_chunk;
-    c->ingest = Ingest::get(hip_device);
     auto bail = [&](int rc) {
         gscan_close(c);
         return rc;
     };
     if (hipSetDevice(hip_device) != hipSuccess) return bail(GSCAN_EHIP);
     lap("hipSetDevice");
+    c->ingest = Ingest::acquire(hip_device);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && cus > 0) c->cus = cus;
     lap("device attribute");
     if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
     if (hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
-    lap("2 streams");
+    c->n_copy = ingest_cfg().copy_streams;
+    for (int k = 1; k < c->n_copy; k++)
+        if (hipStreamCreateWithFlags(&c->copy_x[k - 1], hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
+    lap("streams");
     // one pinned allocation for every small host-side buffer of the context (each hipHostMalloc costs about a millisecond)
     const size_t per_slot = 64 + kSpecRecs * 4;
     const size_t host_bytes = ((sizeof(DevProgram) + 63) & ~size_t(63)) + GSCAN_SLOTS * per_slot;
@@ -720,6 +918,8 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     for (Slot &s : c->slot) {
         if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
         if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
+        for (int k = 1; k < c->n_copy; k++)
+            if (hipEventCreateWithFlags(&s.copied_x[k - 1], hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
     }
     lap("events");
     *out = c;
@@ -729,6 +929,7 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
 void gscan_close(gscan_ctx *c)
 {
     if (!c) return;
+    for (Slot &s : c->slot) slot_drain_reads(s); // a file range still being read: its last piece launches into this context
     if (c->ingest) c->ingest->report_if_timing();
     hipSetDevice(c->device);
     hipDeviceSynchronize();
@@ -743,7 +944,10 @@ void gscan_close(gscan_ctx *c)
         hipEventDestroy(e.b);
     }
     if (c->copy) hipStreamDestroy(c->copy);
+    for (hipStream_t st : c->copy_x)
+        if (st) hipStreamDestroy(st);
     if (c->compute) hipStreamDestroy(c->compute);
+    if (c->ingest) Ingest::release(c->ingest); // the last context of the device: reader threads joined, pinned pool freed
     delete c;
 }
 
@@ -753,7 +957,7 @@ namespace {
 // the slot's pinned buffer for `len` bytes: a block of the process-wide pool when it fits, else the slot's own allocation
 int slot_pinned_for(gscan_ctx *c, Slot &s, size_t len, void **out)
 {
-    if (len <= kBlock) {
+    if (len <= block_bytes()) {
         if (!s.blk) s.blk = c->ingest->take_slot_block();
         if (!s.blk) return fail(c, GSCAN_ENOMEM, "no pinned memory for a staging block");
         *out = s.blk->p;
@@ -785,7 +989,27 @@ int gscan_acquire(gscan_ctx *c, size_t len, void **pinned)
     return GSCAN_OK;
 }
 
-size_t gscan_block_size(void) { return kBlock; }
+size_t gscan_block_size(void) { return block_bytes(); }
+
+void gscan_ingest_info(size_t *block_bytes_out, int *readers, int *copy_streams)
+{
+    if (block_bytes_out) *block_bytes_out = ingest_cfg().block;
+    if (readers) *readers = ingest_cfg().readers;
+    if (copy_streams) *copy_streams = ingest_cfg().copy_streams;
+}
+
+long gscan_parse_cpulist(const char *list, int *cpus, size_t cap)
+{
+    if (!list) return GSCAN_EINVAL;
+    std::vector<int> v;
+    parse_cpulist(list, v);
+    for (size_t i = 0; i < v.size() && i < cap && cpus; i++) cpus[i] = v[i];
+    return (long)v.size();
+}
+
+int gscan_pci_cpulist(const char *sysfs_pci_root, const char *busid, char *buf, size_t cap) { return pci_cpulist(sysfs_pci_root, busid, buf, cap); }
+
+int gscan_device_cpulist(int hip_device, char *buf, size_t cap) { return device_cpulist(hip_device, buf, cap); }
 
 int gscan_submit(gscan_ctx *c, const gscan_db *db, const void *host_bytes, size_t len, uint64_t tag)
 {
@@ -801,7 +1025,7 @@ int gscan_submit(gscan_ctx *c, const gscan_db *db, const void *host_bytes, size_
         for (Slot &x : c->slot)
             if (x.state == FREE && !s) s = &x;
         if (!s) return fail(c, GSCAN_EBUSY, "all %d slots in flight", GSCAN_SLOTS);
-    } else if (own && len > (host_bytes == s->pinned ? s->pinned_cap : kBlock)) {
+    } else if (own && len > (host_bytes == s->pinned ? s->pinned_cap : block_bytes())) {
         return fail(c, GSCAN_EINVAL, "submitted %zu bytes into a smaller acquired buffer", len);
     }
     int rc = ensure_prog(c, db, c->compute);
@@ -864,7 +1088,7 @@ int gscan_submit_segs(gscan_ctx *c, const gscan_db *db, const void *pinned, cons
     for (Slot &x : c->slot)
         if (x.state == ACQUIRED && slot_owns(x, pinned)) s = &x;
     if (!s) return fail(c, GSCAN_EINVAL, "gscan_submit_segs wants the buffer gscan_acquire handed out");
-    const size_t cap = pinned == s->pinned ? s->pinned_cap : kBlock;
+    const size_t cap = pinned == s->pinned ? s->pinned_cap : block_bytes();
     size_t used = 0;
     for (size_t i = 0; i < nseg; i++) {
         if (segs[i].offset & 15) return fail(c, GSCAN_EINVAL, "segment %zu is not 16-byte aligned", i);
@@ -908,23 +1132,19 @@ int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off
     if (rc) return rc;
     rc = slot_reserve_device(c, *s, len);
     if (rc) return rc;
-    // fan the range out to the reader threads; every piece is DMA'd on this context's copy stream the moment it is read
-    ReadGroup grp;
-    grp.pending = (len + kBlock - 1) / kBlock;
-    for (size_t o = 0; o < len; o += kBlock)
-        c->ingest->read(ReadTask{fd, (off_t)(file_off + (long long)o), std::min(kBlock, len - o), s->d_text + o, c->copy, &grp});
-    {
-        std::unique_lock<std::mutex> lk(grp.m);
-        grp.cv.wait(lk, [&] { return grp.pending == 0; });
-    }
-    if (grp.err) {
-        HIPCHK(c, hipStreamSynchronize(c->copy)); // pieces that did make it must not land after the slot is reused
-        if (grp.err == -1) return fail(c, GSCAN_EIO, "file shrank while reading");
-        if (grp.err == -2) return fail(c, GSCAN_EHIP, "staging block or DMA failed");
-        return fail(c, GSCAN_EIO, "%s", strerror(grp.err));
-    }
-    HIPCHK(c, hipEventRecord(s->copied, c->copy));
-    HIPCHK(c, hipStreamWaitEvent(c->compute, s->copied, 0));
+    // fan the range out to the device's reader threads: every piece is DMA'd on one of this context's copy streams the
+    // moment it is read, and whoever finishes the last piece launches the scan (fd_finish).  This thread goes on.
+    if (!s->grp) s->grp.reset(new (std::nothrow) ReadGroup());
+    if (!s->grp) return fail(c, GSCAN_ENOMEM, "out of memory");
+    ReadGroup &g = *s->grp;
+    const size_t blk = block_bytes();
+    g.pending = (len + blk - 1) / blk;
+    g.err = 0;
+    g.rc = 0;
+    g.msg.clear();
+    g.finish = fd_finish;
+    g.ctx = c;
+    g.slot = s;
     s->ext = nullptr;
     s->no_content = true;
     s->segs.clear();
@@ -932,9 +1152,21 @@ int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off
     s->len = len;
     s->tag = tag;
     s->seq = c->next_seq++;
-    rc = slot_launch(c, *s);
-    if (rc) return rc;
     s->state = INFLIGHT;
+    if (g.pending == 0) { // an empty range: nothing to read, launch right away
+        g.finished = false;
+        fd_finish(&g);
+        return GSCAN_OK;
+    }
+    g.finished = false;
+    std::vector<ReadTask> tasks;
+    tasks.reserve(g.pending);
+    size_t k = 0;
+    for (size_t o = 0; o < len; o += blk, k++) {
+        const int which = (int)(k % (size_t)c->n_copy);
+        tasks.push_back(ReadTask{fd, (off_t)(file_off + (long long)o), std::min(blk, len - o), s->d_text + o, which ? c->copy_x[which - 1] : c->copy, &g});
+    }
+    c->ingest->read(tasks.data(), tasks.size());
     return GSCAN_OK;
 }
 
@@ -945,6 +1177,26 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     for (Slot &x : c->slot)
         if (x.state == INFLIGHT && (!s || x.seq < s->seq)) s = &x;
     if (!s) return fail(c, GSCAN_EEMPTY, "nothing in flight");
+    // Whatever goes wrong from here on, the chunk's result is lost but its slot is free again: one device error does not
+    // leave the context believing a slot is in flight for ever.
+    struct Release {
+        Slot *s;
+        bool ok = false;
+        ~Release()
+        {
+            if (!ok) {
+                slot_unregister(*s);
+                s->state = FREE;
+            }
+        }
+    } release{s};
+    slot_drain_reads(*s);
+    if (s->grp && s->grp->rc) {
+        c->err = s->grp->msg;
+        const int rc = s->grp->rc;
+        s->grp->rc = 0;
+        return rc;
+    }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventSynchronize(s->done));
     slot_unregister(*s); // the DMA out of the caller's buffer is over (the text stays in HBM for a possible rescan)
@@ -1024,6 +1276,7 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     if (content) *content = s->no_content ? nullptr : s->ext;
     c->last_waited = s;
     s->state = FREE;
+    release.ok = true;
     return GSCAN_OK;
 }
 

@@ -163,10 +163,13 @@ FileGrep::FileGrep() : uid_(geteuid()) { timing_ = getenv("GRAB_TIMING") != null
 FileGrep::~FileGrep()
 {
     flush();
-    if (timing_)
+    if (timing_) {
         fprintf(stderr, "[grab timing] device %d: files %zu launches %zu bytes %zu | open %.3f s  read(batch) %.3f s  submit %.3f s  wait %.3f s  map+report %.3f s  close %.3f s\n",
                 device_, t_files_, t_chunks_, t_bytes_, t_map_, t_read_, t_submit_, t_wait_, t_report_, t_unmap_);
-    if (ctx_) gscan_close(ctx_);
+        for (size_t k = 0; k < ctxs_.size(); k++) // what each device was handed: the work queue's balance (bench.py --mode e2e sums these)
+            fprintf(stderr, "[grab bytes] device %d: %zu\n", ctx_dev_[k], ctx_bytes_[k]);
+    }
+    for (gscan_ctx *c : ctxs_) gscan_close(c);
     if (db_) gscan_free(db_);
 }
 
@@ -183,6 +186,7 @@ void FileGrep::config(const std::map<std::string, size_t> &kv)
     if (has("device")) device_ = (int)kv.at("device");
     if (has("out_fd")) out_fd_ = (int)kv.at("out_fd");
     if (has("batch")) batch_max_ = kv.at("batch");
+    if (has("devices")) devices_ = std::max<size_t>(1, kv.at("devices"));
 }
 
 unsigned FileGrep::report_flags() const
@@ -195,23 +199,23 @@ int FileGrep::engine_option(const char *name, long value) { return ctx_ ? gscan_
 
 // Replaces grab.cc:101-123.  Error strings for patterns PCRE itself rejects are the
 // reference's; a valid pattern the engine cannot scan is a distinct, loud error.
-int FileGrep::prepare(const std::string &regex)
+int FileGrep::validate(const std::string &regex, bool literal, std::string &why, int *minlen, gscan_db **db_out)
 {
     int want_minlen = 0;
     bool cross_check = false;
 #ifdef GRAB_PCRE_VALIDATE
-    if (!literal_) {
+    if (!literal) {
         const char *msg = nullptr;
         int at = 0;
         pcre *re = pcre_compile(regex.c_str(), 0, &msg, &at, pcre_maketables());
         if (!re) {
-            err_ = "FileGrep::prepare::pcre_compile error";
+            why = "FileGrep::prepare::pcre_compile error";
             return -1;
         }
         pcre_extra *study = pcre_study(re, PCRE_STUDY_JIT_COMPILE, &msg);
         if (!study) { // no JIT / no study data counts as failure in the reference (Q12)
             pcre_free(re);
-            err_ = "FileGrep::prepare::pcre_study error";
+            why = "FileGrep::prepare::pcre_study error";
             return -1;
         }
         want_minlen = 1;
@@ -221,23 +225,35 @@ int FileGrep::prepare(const std::string &regex)
         pcre_free(re);
     }
 #endif
-    if (db_) gscan_free(db_);
-    db_ = nullptr;
+    gscan_db *db = nullptr;
     char reason[160] = {0};
     int got = 1;
-    const int rc = gscan_compile(regex.data(), regex.size(), literal_ ? GSCAN_LITERAL : 0u, &db_, &got, reason, sizeof reason);
+    const int rc = gscan_compile(regex.data(), regex.size(), literal ? GSCAN_LITERAL : 0u, &db, &got, reason, sizeof reason);
     if (rc == GSCAN_UNSUPPORTED) {
-        err_ = std::string("FileGrep::prepare: pattern is outside the GPU engine's subset (") + reason + ")";
-        return -1;
+        why = std::string("FileGrep::prepare: pattern is outside the GPU engine's subset (") + reason + ")";
+        return -2;
     }
     if (rc != GSCAN_OK) {
-        err_ = "FileGrep::prepare::pcre_compile error";
+        why = "FileGrep::prepare::pcre_compile error";
         return -1;
     }
     if (cross_check && got != want_minlen) {
-        err_ = "FileGrep::prepare: engine minlen " + std::to_string(got) + " disagrees with PCRE's " + std::to_string(want_minlen);
-        return -1;
+        gscan_free(db);
+        why = "FileGrep::prepare: engine minlen " + std::to_string(got) + " disagrees with PCRE's " + std::to_string(want_minlen);
+        return -2;
     }
+    if (minlen) *minlen = got;
+    if (db_out) *db_out = db;
+    else gscan_free(db);
+    return 0;
+}
+
+int FileGrep::prepare(const std::string &regex)
+{
+    if (db_) gscan_free(db_);
+    db_ = nullptr;
+    int got = 1;
+    if (validate(regex, literal_, err_, &got, &db_) != 0) return -1;
     minlen_ = got;
     if (minlen_ < 0) return 0; // can match "": every file is skipped (Q2), nothing to open
     {
@@ -249,17 +265,41 @@ int FileGrep::prepare(const std::string &regex)
         lines_ = info.lines_ok != 0;
     }
 
-    if (ctx_) gscan_close(ctx_);
+    flush();
+    for (gscan_ctx *c : ctxs_) gscan_close(c);
+    ctxs_.clear();
+    inflight_.clear();
+    ctx_dev_.clear();
+    ctx_bytes_.clear();
     ctx_ = nullptr;
-    const int orc = gscan_open(device_, chunk_size_, &ctx_);
-    if (orc != GSCAN_OK) {
-        err_ = "FileGrep::prepare::gscan_open: no usable HIP device " + std::to_string(device_) + " (rc " + std::to_string(orc) + ")";
-        return -1;
+    failed_ = false;
+    return want_contexts(1);
+}
+
+// Contexts 1.. sit on the devices after `device` (mod the number there is): the windows of one multi-window file are
+// dealt out to them round robin (the unit is (file, chunk index); the per-file reorder buffer is flight_,
+// which retires in submission order).  Opened on demand -- a walk over small files never touches a second GPU.
+int FileGrep::want_contexts(size_t n)
+{
+    while (ctxs_.size() < n) {
+        const int ndev = std::max(1, gscan_device_count());
+        const int dev = ctxs_.empty() ? device_ : (device_ + (int)ctxs_.size()) % ndev;
+        gscan_ctx *c = nullptr;
+        const int orc = gscan_open(dev, chunk_size_, &c);
+        if (orc != GSCAN_OK) {
+            err_ = "FileGrep::prepare::gscan_open: no usable HIP device " + std::to_string(dev) + " (rc " + std::to_string(orc) + ")";
+            return -1;
+        }
+        // Line-printing modes: the device can pick the printed matches and find their line extents where the pattern allows it
+        // (k_lines).  Exact, but measured to buy nothing end to end -- the host's share of a printed line is
+        // copying it, not finding it -- so it is opt-in: GRAB_LINE_PASS=1.
+        if (lines_ && !noline_ && getenv("GRAB_LINE_PASS")) gscan_set_option(c, "line_extents", 1);
+        ctxs_.push_back(c);
+        inflight_.push_back(0);
+        ctx_dev_.push_back(dev);
+        ctx_bytes_.push_back(0);
     }
-    // Line-printing modes: the device can pick the printed matches and find their line extents where the pattern allows it
-    // (k_lines).  Exact, but measured to buy nothing end to end -- the host's share of a printed line is
-    // copying it, not finding it -- so it is opt-in: GRAB_LINE_PASS=1.
-    if (lines_ && !noline_ && getenv("GRAB_LINE_PASS")) gscan_set_option(ctx_, "line_extents", 1);
+    ctx_ = ctxs_[0];
     return 0;
 }
 
@@ -314,6 +354,7 @@ struct FileGrep::FileRef { // what the report needs to know about a file after f
 };
 
 struct FileGrep::Job {
+    int ctx = 0; // index into ctxs_
     // big-file window
     std::shared_ptr<FileRef> file;
     off_t off = 0;
@@ -327,15 +368,21 @@ int FileGrep::retire_oldest(bool print)
 {
     Job job = std::move(flight_.front());
     flight_.pop_front();
+    gscan_ctx *const ctx = ctxs_[(size_t)job.ctx];
+    inflight_[(size_t)job.ctx]--;
     const uint32_t *starts = nullptr;
     const size_t *first = nullptr;
     size_t nseg = 0;
     const void *bytes = nullptr;
     double t = timing_ ? now_s() : 0;
-    const int rc = gscan_wait_segs(ctx_, nullptr, &starts, &first, &nseg, &bytes);
+    const int rc = gscan_wait_segs(ctx, nullptr, &starts, &first, &nseg, &bytes);
     if (timing_) t_wait_ += now_s() - t, t = now_s();
     if (rc != GSCAN_OK) {
-        err_ = std::string("FileGrep::find::gscan_wait: ") + gscan_strerror(ctx_);
+        // the error belongs to the file the job came from, which need not be the one find() is busy with: name it.  The
+        // engine has dropped the chunk and freed its slot; a read error leaves the context usable, a device error does not.
+        const std::string &whose = job.file ? job.file->path : (job.files.empty() ? std::string("?") : job.files.front()->path + " (+ the rest of its batch)");
+        err_ = std::string(rc == GSCAN_EIO ? "FileGrep::find::read: " : "FileGrep::find::gscan_wait: ") + gscan_strerror(ctx) + " [" + whose + "]";
+        if (rc != GSCAN_EIO) failed_ = true;
         return -1;
     }
     if (!print) return 0;
@@ -355,7 +402,7 @@ int FileGrep::retire_oldest(bool print)
                 status = -1;
             } else {
                 grab_report_chunk(db_, minlen_, rflags, f.path.c_str(), (const char *)map, job.len, (long long)job.off, starts, first[nseg], text,
-                                  gscan_last_ext(ctx_));
+                                  gscan_last_ext(ctx));
                 munmap(map, job.len); // grab.cc:215
                 if (!text.empty()) {
                     emit(text);
@@ -366,7 +413,7 @@ int FileGrep::retire_oldest(bool print)
     } else { // a batch: every segment is a whole small file, i.e. its one and only chunk
         for (size_t i = 0; i < job.files.size(); i++) {
             if (first[i + 1] == first[i] && !context_) continue;
-            const uint32_t *ext = gscan_last_ext(ctx_);
+            const uint32_t *ext = gscan_last_ext(ctx);
             grab_report_chunk(db_, minlen_, rflags, job.files[i]->path.c_str(), (const char *)bytes + job.segs[i].offset, job.segs[i].len, 0,
                               starts + first[i], first[i + 1] - first[i], text, ext ? ext + 3 * first[i] : nullptr);
         }
@@ -391,8 +438,25 @@ int FileGrep::submit_batch()
         return -1;
     }
     if (timing_) t_submit_ += now_s() - t, t_chunks_++;
+    inflight_[0]++;
     flight_.push_back(std::move(job));
     return 0;
+}
+
+// Jobs retire in submission order, so "a free slot in context k" means: retire from the front until k has one.
+int FileGrep::make_room(int ctx)
+{
+    while (inflight_[(size_t)ctx] >= GSCAN_SLOTS)
+        if (retire_oldest(true) < 0) deferred_error();
+    return failed_ ? -1 : 0;
+}
+
+// A window of an earlier file failed while a later one was being handed over: say so against the file it belongs to (err_
+// names it) and carry on with the current one, as the reference reports per file and keeps walking (grab.cc:267-268).
+void FileGrep::deferred_error()
+{
+    if (recursive_) std::cerr << err_ << std::endl;
+    else deferred_ = err_; // explicit paths: find(path) returns it
 }
 
 // Everything handed over so far is scanned and printed when this returns.
@@ -413,8 +477,8 @@ int FileGrep::batch_add(const char *path, int fd, size_t size)
     const size_t at = (batch_used_ + 15) & ~size_t(15);
     if (batch_buf_ && (at + size > cap || batch_files_.size() >= kBatchMaxFiles) && submit_batch() < 0) return -1;
     if (!batch_buf_) {
-        // a slot has to be free for the new batch: retire the oldest job if both are in flight
-        if (flight_.size() >= GSCAN_SLOTS && retire_oldest(true) < 0) return -1;
+        // a slot has to be free for the new batch
+        if (make_room(0) < 0) return -1;
         void *buf = nullptr;
         if (gscan_acquire(ctx_, cap, &buf) != GSCAN_OK) {
             err_ = std::string("FileGrep::find::gscan_acquire: ") + gscan_strerror(ctx_);
@@ -427,6 +491,7 @@ int FileGrep::batch_add(const char *path, int fd, size_t size)
     double t = timing_ ? now_s() : 0;
     if (read_chunk(fd, (char *)batch_buf_ + off, size, 0) < 0) return -1;
     if (timing_) t_read_ += now_s() - t, t_bytes_ += size;
+    ctx_bytes_[0] += size;
     auto ref = std::make_shared<FileRef>();
     ref->path = path;
     batch_files_.push_back(std::move(ref));
@@ -445,6 +510,7 @@ int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
 {
     const off_t size = st->st_size;
     if ((size_t)minlen_ > (size_t)size) return 0;
+    if (failed_) return -1; // a device error earlier on (why() still says which): nothing can be scanned any more, and no file may pass for clean
 
     double t0 = timing_ ? now_s() : 0;
     int oflags = O_RDONLY | O_NOCTTY;
@@ -491,26 +557,38 @@ int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
         ref->fd = fd;
         keep_fd = true;
         const off_t stride = (off_t)chunk_size_ - kOverlap;
+        // -s needs to know whether a window printed before the next one is worth reading: everything older is retired
+        // first, then one window at a time (grab.cc:232-233)
+        if (single_)
+            while (!flight_.empty())
+                if (retire_oldest(true) < 0) deferred_error();
+        // a file of several windows is dealt out over the configured devices (contexts opened on first need)
+        const size_t nwin = (size_t)((size + stride - 1) / stride);
+        const size_t use = single_ ? 1 : std::min(devices_, nwin);
+        if (status == 0 && use > ctxs_.size() && want_contexts(use) < 0) status = -1;
         for (off_t off = 0; off < size && status == 0 && !ref->done; off += stride) {
             const size_t len = (size_t)std::min<off_t>(size - off, (off_t)chunk_size_);
-            if (flight_.size() >= GSCAN_SLOTS && retire_oldest(true) < 0) {
+            const int k = use > 1 ? (int)(next_ctx_++ % use) : 0;
+            if (make_room(k) < 0) {
                 status = -1;
                 break;
             }
             double t = timing_ ? now_s() : 0;
-            if (gscan_submit_fd(ctx_, db_, fd, (long long)off, len, (uint64_t)off) != GSCAN_OK) {
-                err_ = std::string("FileGrep::find::read: ") + gscan_strerror(ctx_);
+            if (gscan_submit_fd(ctxs_[(size_t)k], db_, fd, (long long)off, len, (uint64_t)off) != GSCAN_OK) {
+                err_ = std::string("FileGrep::find::read: ") + gscan_strerror(ctxs_[(size_t)k]);
                 status = -1;
                 break;
             }
             if (timing_) t_submit_ += now_s() - t, t_chunks_++, t_bytes_ += len;
+            ctx_bytes_[(size_t)k] += len;
             Job job;
+            job.ctx = k;
             job.file = ref;
             job.off = off;
             job.len = len;
+            inflight_[(size_t)k]++;
             flight_.push_back(std::move(job));
-            // -s needs to know whether this window printed before the next one is worth reading
-            if (single_ && retire_oldest(true) < 0) status = -1;
+            if (single_ && retire_oldest(true) < 0) status = -1; // (its own window: the error is this file's)
         }
     }
     t0 = timing_ ? now_s() : 0;
@@ -528,7 +606,13 @@ int FileGrep::find(const std::string &path)
     }
     if (S_ISREG(st.st_mode)) {
         const int rc = find(path.c_str(), &st, FTW_F);
-        return flush() < 0 ? -1 : rc; // an explicit path is done when this returns, like the reference's
+        if (flush() < 0) return -1; // an explicit path is done when this returns, like the reference's
+        if (!deferred_.empty()) { // a window of an earlier explicit path failed while this one was handed over
+            err_.swap(deferred_);
+            deferred_.clear();
+            return -1;
+        }
+        return rc;
     }
     if (S_ISDIR(st.st_mode)) std::cerr << "Clever boy! Want recursion? Add -R!\n"; // grab.cc:253-254, rc stays 0
     return 0;

@@ -45,9 +45,15 @@ public:
 
     // keys the reference understands (grab.cc:83-98): color noline offsets single low_mem
     // chunk_size; extensions: literal (-S), device (HIP device index), out_fd, batch (largest
-    // file size that is batched with others, 0 = none)
+    // file size that is batched with others, 0 = none), devices (how many HIP devices, starting
+    // at `device`, the windows of ONE multi-window file are spread over: contexts on the further
+    // devices are opened when the first such file arrives; output stays in window order)
     void config(const std::map<std::string, size_t> &kv);
     int prepare(const std::string &regex);
+    // prepare() without the device: 0 the pattern is fine; -1 PCRE itself rejects it (why: the reference's message);
+    // -2 valid PCRE outside the engine's subset (why says what).  `grab -n` uses it to tell the two apart before any
+    // worker exists (the reference ignores prepare()'s result there, src/main.cc:198).
+    static int validate(const std::string &regex, bool literal, std::string &why, int *minlen = nullptr, gscan_db **db = nullptr);
     int find(const std::string &path);
     int find(const char *path, const struct stat *st, int typeflag);
     int find_recursive(const std::string &path);
@@ -64,13 +70,16 @@ private:
     struct FileRef;
     struct Job;
     int retire_oldest(bool print);
+    int make_room(int ctx);       // retire until context `ctx` has a free slot
+    int want_contexts(size_t n);  // open contexts on further devices up to n (lazily: a multi-window file asks)
+    void deferred_error();        // a window of an EARLIER file failed while this one was being handed over
     int submit_batch();
     int batch_add(const char *path, int fd, size_t size);
     unsigned report_flags() const;
     int read_chunk(int fd, void *dst, size_t len, off_t at);
     void emit(std::string &text);
 
-    std::string err_;
+    std::string err_, deferred_;
     int minlen_ = 1;               // PCRE_INFO_MINLENGTH of the pattern (grab.h:44)
     size_t chunk_size_ = 1u << 30; // grab.h:48
     bool offsets_ = false, noline_ = false, single_ = false, color_ = false, low_mem_ = false;
@@ -87,6 +96,13 @@ private:
     double t_map_ = 0, t_read_ = 0, t_submit_ = 0, t_wait_ = 0, t_report_ = 0, t_unmap_ = 0;
     // pipeline state
     std::deque<Job> flight_;
+    std::vector<gscan_ctx *> ctxs_;   // [0] == ctx_; further devices for the windows of one big file ("devices")
+    std::vector<size_t> inflight_;    // jobs in flight per context
+    std::vector<int> ctx_dev_;        // HIP device of each context
+    std::vector<size_t> ctx_bytes_;   // bytes handed to each context (GRAB_TIMING prints them per device)
+    size_t devices_ = 1;              // config "devices"
+    size_t next_ctx_ = 0;             // round-robin cursor over the contexts a big file uses
+    bool failed_ = false;             // a device error: every later find() fails at once with why() saying so
     std::string report_buf_;
     size_t batch_max_ = size_t(2) << 20; // files up to this size are batched ("batch" config key; 0 = never)
     void *batch_buf_ = nullptr;          // the engine's pinned block being filled

@@ -9,11 +9,13 @@
 //
 // -n N is organised differently from the reference on purpose: there the tree walk runs
 // to completion on one thread before N pthreads stripe the file list statically
-// (main.cc:175-216); here the walk is a producer that feeds a bounded queue while N
+// (main.cc:175-216); here a multi-threaded walk (walk.h) feeds a bounded queue while N
 // workers are already scanning, each worker owning a FileGrep bound to HIP device
-// (i mod #devices) -- files are independent units, so an 8-GPU node is used with no
-// collective at all.  Output order across files is unspecified, exactly as in the
-// reference's threaded mode (its own check sorts: README:206-216).
+// (i mod #devices) and running on that device's NUMA node -- files are independent units,
+// so an 8-GPU node is used with no collective at all.  Output order across files is
+// unspecified, exactly as in the reference's threaded mode (its own check sorts:
+// README:206-216).  Without -n, the windows of ONE multi-window file are dealt out over
+// all devices (FileGrep "devices"; GRAB_DEVICES overrides the count), printed in order.
 #include <ftw.h>
 #include <pthread.h>
 #include <sched.h>
@@ -25,6 +27,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cerrno>
 #include <cstring>
 #include <deque>
 #include <iostream>
@@ -36,6 +39,7 @@
 #include <vector>
 
 #include "filegrep.h"
+#include "walk.h"
 
 namespace {
 
@@ -93,7 +97,7 @@ Options parse(int argc, char **argv)
     return o;
 }
 
-// ---- walker -> workers queue ----
+// ---- walkers -> workers queue ----
 struct Job {
     std::string path;
     struct stat st;
@@ -104,7 +108,8 @@ public:
     void push(Job &&j)
     {
         std::unique_lock<std::mutex> lk(m_);
-        room_.wait(lk, [&] { return q_.size() < kMax; });
+        room_.wait(lk, [&] { return q_.size() < kMax || abandoned_; });
+        if (abandoned_) return; // no worker is left to take it
         q_.push_back(std::move(j));
         ready_.notify_one();
     }
@@ -118,11 +123,18 @@ public:
         room_.notify_one();
         return true;
     }
-    void close()
+    void close() // the walk is over
     {
         std::lock_guard<std::mutex> lk(m_);
         closed_ = true;
         ready_.notify_all();
+    }
+    void abandon() // the workers cannot run: let the walkers finish into nothing
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        abandoned_ = true;
+        q_.clear();
+        room_.notify_all();
     }
 
 private:
@@ -130,15 +142,33 @@ private:
     std::mutex m_;
     std::condition_variable ready_, room_;
     std::deque<Job> q_;
-    bool closed_ = false;
+    bool closed_ = false, abandoned_ = false;
 };
 
-JobQueue *g_queue = nullptr;
-
-int enqueue_entry(const char *path, const struct stat *st, int type, struct FTW *)
+// The CPUs worker i may run on: those local to its device (i mod #devices), as far as the process is allowed there --
+// the worker's batch reads go into pinned blocks it touches first, and its share of the report walks the page cache, so
+// it belongs next to the PCIe root of its GPU.  The reference pins thread i to CPU i (main.cc:200-215):
+// on a two-socket node that puts the first 8 workers on one socket whatever the devices are.  GRAB_PIN=cpu restores it.
+cpu_set_t worker_cpus(int worker, int device, const cpu_set_t &allowed)
 {
-    if (type == FTW_F && S_ISREG(st->st_mode)) g_queue->push(Job{path, *st});
-    return 0;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    const char *pin = getenv("GRAB_PIN");
+    if (pin && !strcmp(pin, "cpu")) {
+        CPU_SET(worker, &set);
+        return set;
+    }
+    char list[1024];
+    int cpus[1024];
+    long n = 0;
+    if (!(pin && !strcmp(pin, "none")) && gscan_device_cpulist(device, list, sizeof list) > 0) n = gscan_parse_cpulist(list, cpus, 1024);
+    int got = 0;
+    for (long k = 0; k < n && k < 1024; k++)
+        if (cpus[k] < CPU_SETSIZE && CPU_ISSET(cpus[k], &allowed)) {
+            CPU_SET(cpus[k], &set);
+            got++;
+        }
+    return got ? set : allowed;
 }
 
 int run_workers(const Options &o)
@@ -147,46 +177,70 @@ int run_workers(const Options &o)
         std::cerr << "Multicore support only for recursive grabs.\n";
         return -1;
     }
-    const int ndev = std::max(1, gscan_device_count());
-    std::vector<std::unique_ptr<FileGrep>> greps;
-    for (int i = 0; i < o.workers; i++) {
-        auto cfg = o.cfg;
-        cfg["device"] = size_t(i % ndev);
-        greps.emplace_back(new FileGrep);
-        greps.back()->config(cfg);
-        greps.back()->recurse();
-        // The reference ignores prepare()'s result here (main.cc:198) and then silently matches
-        // nothing; a scan that cannot run is reported instead.
-        if (greps.back()->prepare(o.regex) < 0) {
-            std::cerr << greps.back()->why() << std::endl;
+    // What the reference's prepare() would say, before anything is started.  It ignores the result in this mode
+    // (main.cc:198): with a pattern PCRE rejects every pcre_exec fails, nothing is printed and the status is 0 -- same
+    // here.  A pattern that is fine for PCRE and outside this engine is not the reference's case: reported, status 255.
+    {
+        std::string why;
+        const int v = FileGrep::validate(o.regex, o.cfg.count("literal") != 0, why);
+        if (v == -1) return 0;
+        if (v != 0) {
+            std::cerr << why << std::endl;
             return -1;
         }
     }
-    mark("contexts open, pattern compiled");
+    // more threads than CPUs is fatal in the reference (pthread_setaffinity_np on CPU i fails, main.cc:211-215)
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    sched_getaffinity(0, sizeof allowed, &allowed);
+    for (int i = 0; i < o.workers; i++)
+        if (i >= CPU_SETSIZE || !CPU_ISSET(i, &allowed)) {
+            std::cerr << "pthread_setaffinity_np:" << strerror(EINVAL) << " (more threads than cores?)" << std::endl;
+            return -1;
+        }
+
     JobQueue queue;
-    g_queue = &queue;
+    // the walk starts at once, on its own threads; the workers open their devices meanwhile
+    int walkers = 4;
+    if (const char *w = getenv("GRAB_WALKERS")) walkers = std::max(1, atoi(w));
+    std::thread walk([&] {
+        grab_walk(o.paths[0], walkers, [&](std::string &&path, const struct stat &st) { queue.push(Job{std::move(path), st}); });
+        queue.close();
+        mark("walk done");
+    });
+
+    const int ndev = std::max(1, gscan_device_count());
+    mark("runtime up");
+    std::mutex err_lock;
+    std::string first_error;
     std::vector<std::thread> pool;
     for (int i = 0; i < o.workers; i++) {
-        pool.emplace_back([&queue, g = greps[i].get()] {
-            for (Job j; queue.pop(j);) g->find(j.path.c_str(), &j.st, FTW_F); // per-file errors ignored (main.cc:97)
-            g->flush(); // what is still in flight or waiting in a half-filled batch
+        const int device = i % ndev;
+        const cpu_set_t cpus = worker_cpus(i, device, allowed);
+        pool.emplace_back([&, device, cpus] {
+            (void)pthread_setaffinity_np(pthread_self(), sizeof cpus, &cpus);
+            FileGrep g; // one per thread, like the reference (main.cc:195-199); the context is opened by the thread that uses it
+            auto cfg = o.cfg;
+            cfg["device"] = size_t(device);
+            g.config(cfg);
+            g.recurse();
+            if (g.prepare(o.regex) < 0) { // the pattern is fine (checked above): the device could not be opened
+                std::lock_guard<std::mutex> lk(err_lock);
+                if (first_error.empty()) first_error = g.why();
+                queue.abandon();
+                return;
+            }
+            for (Job j; queue.pop(j);) g.find(j.path.c_str(), &j.st, FTW_F); // per-file errors ignored (main.cc:97)
+            g.flush(); // what is still in flight or waiting in a half-filled batch
         });
-        cpu_set_t one;
-        CPU_ZERO(&one);
-        CPU_SET(i, &one); // worker i on CPU i, as main.cc:200-215; more workers than CPUs is fatal there too
-        if (int r = pthread_setaffinity_np(pool.back().native_handle(), sizeof one, &one)) {
-            std::cerr << "pthread_setaffinity_np:" << strerror(r) << " (more threads than cores?)" << std::endl;
-            std::cout.flush();
-            _exit(255);
-        }
     }
-    nftw(o.paths[0].c_str(), enqueue_entry, 1024, FTW_PHYS);
-    queue.close();
-    mark("walk done");
     for (auto &t : pool) t.join();
-    mark("workers joined");
-    greps.clear();
-    mark("contexts closed");
+    mark("workers joined, contexts closed");
+    walk.join();
+    if (!first_error.empty()) {
+        std::cerr << first_error << std::endl;
+        return -1;
+    }
     return 0;
 }
 
@@ -195,6 +249,9 @@ int run_serial(const Options &o)
     FileGrep grep;
     auto cfg = o.cfg;
     if (const char *dev = getenv("GRAB_DEVICE")) cfg["device"] = size_t(atoi(dev));
+    // a file of several windows is spread over the node's GPUs (contexts beyond the first open when such a file turns up)
+    if (const char *n = getenv("GRAB_DEVICES")) cfg["devices"] = size_t(std::max(1, atoi(n)));
+    else cfg["devices"] = size_t(std::max(1, gscan_device_count()));
     grep.config(cfg);
     if (grep.prepare(o.regex) < 0) {
         std::cerr << grep.why() << std::endl;

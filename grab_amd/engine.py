@@ -24,6 +24,7 @@ SYMBOLS = [
     "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs", "gscan_last_ext",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
     "gscan_set_option", "gscan_kernel_time", "gscan_resource_errors",
+    "gscan_ingest_info", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
 ]
 
 
@@ -110,6 +111,12 @@ def lib():
         L.gscan_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.gscan_resource_errors.argtypes = []
         L.gscan_resource_errors.restype = C.c_uint64
+        L.gscan_ingest_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.gscan_ingest_info.restype = None
+        L.gscan_device_cpulist.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+        L.gscan_pci_cpulist.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.gscan_parse_cpulist.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_size_t]
+        L.gscan_parse_cpulist.restype = C.c_long
         _lib = L
     return _lib
 
@@ -346,6 +353,36 @@ class Context:
 
 def device_count():
     return int(lib().gscan_device_count())
+
+
+def ingest_info():
+    """{block_bytes, readers, copy_streams} of the host -> HBM ingest (GSCAN_BLOCK_MIB / GSCAN_READERS / GSCAN_COPY_STREAMS)."""
+    b, r, c = C.c_size_t(), C.c_int(), C.c_int()
+    lib().gscan_ingest_info(C.byref(b), C.byref(r), C.byref(c))
+    return {"block_bytes": b.value, "readers": r.value, "copy_streams": c.value}
+
+
+def parse_cpulist(text):
+    """sysfs cpulist ("0-3,8,10-11") -> [cpu, ...]."""
+    if isinstance(text, str):
+        text = text.encode()
+    n = lib().gscan_parse_cpulist(text, None, 0)
+    buf = (C.c_int * max(n, 1))()
+    lib().gscan_parse_cpulist(text, buf, n)
+    return list(buf[:n])
+
+
+def pci_cpulist(sysfs_root, busid):
+    """local_cpulist of PCI device `busid` under `sysfs_root` (None if unknown): where a GPU's host-side threads belong."""
+    buf = C.create_string_buffer(1024)
+    n = lib().gscan_pci_cpulist(os.fsencode(sysfs_root), busid.encode(), buf, 1024)
+    return buf.value.decode() if n >= 0 else None
+
+
+def device_cpulist(device=0):
+    buf = C.create_string_buffer(1024)
+    n = lib().gscan_device_cpulist(device, buf, 1024)
+    return buf.value.decode() if n >= 0 else None
 
 
 def resource_errors():

@@ -13,7 +13,11 @@ SYMBOLS = [
     "grab_filegrep_new", "grab_filegrep_free", "grab_filegrep_why", "grab_filegrep_recurse",
     "grab_filegrep_show_path", "grab_filegrep_config", "grab_filegrep_prepare", "grab_filegrep_find",
     "grab_filegrep_find_recursive", "grab_filegrep_engine_option", "grab_report_chunk_c", "grab_free",
+    "grab_filegrep_find3", "grab_filegrep_flush", "grab_walk_parallel", "grab_validate",
 ]
+
+FTW_F = 0  # <ftw.h>
+WALK_FN = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p, C.c_void_p)
 
 OFFSETS, NOLINE, SINGLE, PREFIX, COLOR = 1, 2, 4, 8, 16
 
@@ -47,6 +51,11 @@ def lib():
                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.grab_free.argtypes = [C.c_void_p]
         L.grab_free.restype = None
+        L.grab_filegrep_find3.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+        L.grab_filegrep_flush.argtypes = [C.c_void_p]
+        L.grab_walk_parallel.argtypes = [C.c_char_p, C.c_int, WALK_FN, C.c_void_p]
+        L.grab_walk_parallel.restype = C.c_long
+        L.grab_validate.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -77,6 +86,16 @@ class FileGrep:
     def find(self, path):
         return lib().grab_filegrep_find(self._h, os.fsencode(path))
 
+    def find3(self, path, st=None, typeflag=FTW_F):
+        """find(path, st, typeflag) -- the per-file entry the nftw callback and the worker threads use (grab.h:82).
+        `st` is a `struct stat` buffer (c_stat(path) makes one); work may stay in flight until flush()."""
+        if st is None:
+            st = c_stat(path)
+        return lib().grab_filegrep_find3(self._h, os.fsencode(path), st, typeflag)
+
+    def flush(self):
+        return lib().grab_filegrep_flush(self._h)
+
     def find_recursive(self, path):
         return lib().grab_filegrep_find_recursive(self._h, os.fsencode(path))
 
@@ -93,6 +112,41 @@ class FileGrep:
             self.close()
         except Exception:
             pass
+
+
+def c_stat(path):
+    """A C `struct stat` of `path` (stat(2) through libc), as grab_filegrep_find3 wants it."""
+    libc = C.CDLL(None, use_errno=True)
+    buf = C.create_string_buffer(512)  # sizeof(struct stat) is 144 on x86-64 glibc
+    if libc.stat(os.fsencode(path), buf) != 0:
+        raise OSError(C.get_errno(), os.strerror(C.get_errno()), path)
+    return buf
+
+
+def walk_parallel(root, threads=4):
+    """The `grab -n` tree walk: [(path, size)] of every regular file, in no particular order."""
+    import threading
+
+    got, lock = [], threading.Lock()
+
+    def on_file(path, st, _arg):
+        size = C.c_longlong.from_address(st + 48).value  # st_size: offset 48 in x86-64 glibc's struct stat
+        with lock:
+            got.append((path, size))
+
+    fn = WALK_FN(on_file)
+    n = lib().grab_walk_parallel(os.fsencode(root), threads, fn, None)
+    assert n == len(got), (n, len(got))
+    return got
+
+
+def validate(regex, literal=False):
+    """(rc, why): 0 fine, -1 PCRE rejects the pattern (the reference's message), -2 outside the engine's subset."""
+    if isinstance(regex, str):
+        regex = regex.encode("latin-1")
+    why = C.create_string_buffer(512)
+    rc = lib().grab_validate(regex, len(regex), 1 if literal else 0, why, 512)
+    return rc, why.value.decode("latin-1")
 
 
 def report_chunk(db, flags, path, content, off, starts):

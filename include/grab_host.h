@@ -9,6 +9,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <sys/stat.h>
 
 #include "gscan.h"
 
@@ -26,6 +27,12 @@ void grab_filegrep_show_path(grab_filegrep *g, int on);               /* show_pa
 void grab_filegrep_config(grab_filegrep *g, const char *key, size_t value); /* config(map), one key at a time  grab.h:78 */
 int grab_filegrep_prepare(grab_filegrep *g, const char *regex, size_t len); /* prepare(string)  grab.h:76 */
 int grab_filegrep_find(grab_filegrep *g, const char *path);           /* find(string)          grab.h:80 */
+/* find(path, st, typeflag): THE HOT PATH -- what the nftw callback (grab.cc:265-268) and the worker threads (main.cc:85-99)
+ * call per file.  Here the file's windows / its batch may still be in flight when it returns (the next file is read
+ * while this one is on the GPU); grab_filegrep_flush scans and prints whatever is pending -- call it after the last
+ * file.  grab_filegrep_find, _find_recursive and _free flush by themselves.                                  grab.h:82 */
+int grab_filegrep_find3(grab_filegrep *g, const char *path, const struct stat *st, int typeflag);
+int grab_filegrep_flush(grab_filegrep *g);
 int grab_filegrep_find_recursive(grab_filegrep *g, const char *path); /* find_recursive(string) grab.h:84 */
 int grab_filegrep_engine_option(grab_filegrep *g, const char *name, long value);
 
@@ -39,6 +46,18 @@ int grab_report_chunk_c(const gscan_db *db, unsigned flags, const char *path, co
                         size_t clen, long long off, const uint32_t *starts, size_t nstarts,
                         char **out, size_t *outlen);
 void grab_free(void *p);
+
+/*
+ * The tree walk of `grab -n` (grab_amd/csrc/walk.h): `threads` walkers report every regular file nftw(root, fn, 1024,
+ * FTW_PHYS) would report as FTW_F (src/main.cc:74-83,178), in no particular order; fn is called CONCURRENTLY from the
+ * walker threads.  Returns the number of files reported, -1 on bad arguments.
+ */
+typedef void (*grab_walk_fn)(const char *path, const struct stat *st, void *arg);
+long grab_walk_parallel(const char *root, int threads, grab_walk_fn fn, void *arg);
+
+/* FileGrep::prepare's verdict on the pattern text without opening a device: 0 fine; -1 PCRE rejects it (why = the
+ * reference's message, src/grab.cc:108,117); -2 valid PCRE outside the engine's subset. */
+int grab_validate(const char *regex, size_t len, int literal, char *why, size_t whycap);
 
 #ifdef __cplusplus
 }

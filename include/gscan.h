@@ -166,19 +166,35 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out);
 void gscan_close(gscan_ctx *ctx);
 const char *gscan_strerror(const gscan_ctx *ctx);
 int gscan_device_count(void);
+/*
+ * Where a device's host-side work belongs.  The reader threads of a device (gscan_submit_fd) run on the CPUs of the
+ * device's NUMA node -- sysfs <pci root>/<bus id>/local_cpulist, e.g. "0-31,64-95" -- so that the pinned staging blocks
+ * and the page cache -> pinned copy stay local to the PCIe root the GPU hangs off; `grab -n` puts worker i on the CPUs
+ * of device (i mod #devices) the same way (the reference pins thread i to CPU i, src/main.cc:200-215).
+ *   gscan_device_cpulist  the list for a HIP device (bus id from the runtime; root /sys/bus/pci/devices, or
+ *                         $GSCAN_SYSFS_PCI); returns its length, <0 if unknown
+ *   gscan_pci_cpulist     the same for an explicit sysfs root + bus id (no device needed: tests)
+ *   gscan_parse_cpulist   "0-3,8,10-11" -> CPU numbers; returns how many there are, fills at most cap
+ */
+int gscan_device_cpulist(int hip_device, char *buf, size_t cap);
+int gscan_pci_cpulist(const char *sysfs_pci_root, const char *busid, char *buf, size_t cap);
+long gscan_parse_cpulist(const char *list, int *cpus, size_t cap);
 
 /*
  * Host-chunk path (what FileGrep::find uses): three ways to hand over the bytes that the
  * reference mmap()s and gives to pcre_exec (src/grab.cc:161,178).  Each starts H2D (copy stream)
  * + scan (compute stream) of one chunk; up to GSCAN_SLOTS chunks may be in flight and
- * gscan_wait[_segs] returns them in submission order.
+ * gscan_wait[_segs] returns them in submission order.  A gscan_wait that fails (a read error, a
+ * device error) has dropped that chunk and freed its slot: the context stays usable.
  *
- *   gscan_submit_fd    a range of an open file.  The engine's process-wide reader threads
- *                      (GSCAN_READERS, default 8) pread(2) it in 8 MiB pieces into a small pool of
- *                      pinned blocks and DMA every piece as soon as it is read; returns when the
- *                      whole range is on its way (fd may be closed then).  No host copy is kept:
- *                      gscan_wait gives *content = NULL and the caller maps the file itself if it
- *                      has matches to print.
+ *   gscan_submit_fd    a range of an open file.  The device's reader threads (GSCAN_READERS)
+ *                      pread(2) it in pieces of gscan_block_size() bytes into a small pool of pinned
+ *                      blocks and DMA every piece as soon as it is read, spread over the context's
+ *                      copy streams; the reader that finishes the last piece launches the scan.
+ *                      ASYNCHRONOUS: returns once the pieces are queued -- fd must stay open until
+ *                      gscan_wait has returned the chunk; read errors surface there (GSCAN_EIO).
+ *                      No host copy is kept: gscan_wait gives *content = NULL and the caller maps
+ *                      the file itself if it has matches to print.
  *   gscan_acquire +    the caller fills the slot's pinned buffer (gscan_block_size() bytes come
  *   gscan_submit[_segs] from the pinned pool; more is allocated for the slot): one chunk, or MANY
  *                      small files packed at 16-byte aligned offsets and described by a segment
@@ -188,9 +204,11 @@ int gscan_device_count(void);
  *                      in place, less is staged through the slot's pinned buffer.  The buffer must
  *                      stay valid and unchanged until gscan_wait has returned the chunk.
  */
-#define GSCAN_SLOTS 2
+#define GSCAN_SLOTS 3
 int gscan_acquire(gscan_ctx *ctx, size_t len, void **pinned);
 size_t gscan_block_size(void);
+/* the ingest configuration in force (environment: GSCAN_BLOCK_MIB, GSCAN_READERS, GSCAN_COPY_STREAMS); any pointer may be NULL */
+void gscan_ingest_info(size_t *block_bytes, int *readers, int *copy_streams);
 int gscan_submit(gscan_ctx *ctx, const gscan_db *db, const void *host_bytes, size_t len,
                  uint64_t tag);
 int gscan_submit_segs(gscan_ctx *ctx, const gscan_db *db, const void *pinned, const gscan_seg *segs,
