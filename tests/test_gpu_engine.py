@@ -1,6 +1,7 @@
-"""GPU parity, engine level: candidate starts produced by the HIP kernels (through the C ABI,
-include/gscan.h) must equal the oracle's on the same seeded inputs -- bit-exact, every kernel
-variant, ragged sizes, tile/wave boundaries, dense outputs, multi-segment arenas."""
+"""GPU parity, engine level: candidate starts produced by the HIP kernels (through the C ABI, include/gscan.h) on seeded
+inputs -- bit-exact, every kernel variant, ragged sizes, tile/wave boundaries, dense outputs, multi-segment arenas.
+Two checkers: libpcre itself (liboracle.oracle_all_starts: test_kernels_against_libpcre, one case per kernel form) and, for
+the bulk of the size / variant matrix, the candidate set evaluated from the database's class tables (table_candidates)."""
 import os
 import sys
 
@@ -39,9 +40,25 @@ def ctx(built):
     c.close()
 
 
-def oracle_starts(db, data):
-    """Every candidate offset (the oracle's definition)."""
+def table_candidates(db, data):
+    """Every candidate offset according to the DATABASE'S OWN class tables (numpy evaluation of gscan_db_dev_window): what the
+    kernels are asked to find.  This checks the kernels against the compiler's output -- fast enough for every variant and
+    size -- and is blind to a compiler bug by construction; test_kernels_against_libpcre below and the CLI-level tests
+    (reference-generated goldens, liboracle side by side) are what pin the compiler."""
     return db_candidates(db, data)
+
+
+def pcre_starts(liboracle, pattern, data):
+    """Every offset p at which libpcre matches with the subject starting at p (oracle_all_starts: pcre_exec ANCHORED,
+    /root/reference/src/grab.cc:178 semantics) -- the candidate set by the REFERENCE's definition, no product code involved."""
+    import ctypes as C
+
+    buf = np.ascontiguousarray(data)
+    cap = buf.size + 1
+    out = np.zeros(cap, np.uint32)
+    n = liboracle.oracle_all_starts(pattern.encode("latin-1"), buf.ctypes.data, buf.size, out.ctypes.data, None, cap)
+    assert 0 <= n <= cap
+    return out[:n].astype(np.int64)
 
 
 def same(got, want):
@@ -66,6 +83,38 @@ def sample(n, seed):
     return buf
 
 
+# one pattern per kernel form (exact patterns without context or capturing groups: for those the candidate set IS "libpcre
+# matches at p"), checked against libpcre directly
+KERNEL_FORMS = [
+    ("K1 literal", "foobardoesnotexist", engine.TIER_LITERAL),
+    ("K1 class sequence with an anchor", "[Ll]inus", engine.TIER_LITERAL),
+    ("K2 pair form", "[A-Za-z_][A-Za-z0-9_]{15,}", engine.TIER_CLASSRUN),
+    ("K2 pair form, wide", "[0-9a-f]{32}", engine.TIER_CLASSRUN),
+    ("K2 general form, 3 classes", "[a-z][0-9][A-Z]{3}", engine.TIER_CLASSRUN),
+    ("K2 general form, wide", "[ab][cd][ef][gh]{20}", engine.TIER_CLASSRUN),
+    ("K3, tables exact", "foobardoesnotexist|Linus|555-1234", engine.TIER_BUCKET),
+    ("K3, three filter positions", "foo|bar", engine.TIER_BUCKET),
+    ("K3 + settle: shared buckets", "(?:ab|cd|ef|gh|ij|kl|mn|op){2}", engine.TIER_BUCKET),
+    ("K3 + settle: windows beyond the confirm tables", "[0-9a-f]{30}(?:ab|cd)", engine.TIER_BUCKET),
+    ("K3, > 4 classes", "[a-z][0-9][A-Z][.,][;:]", engine.TIER_BUCKET),
+]
+
+
+@pytest.mark.parametrize("name,pattern,tier", KERNEL_FORMS, ids=[k[0] for k in KERNEL_FORMS])
+def test_kernels_against_libpcre(ctx, liboracle, name, pattern, tier):
+    """ctx.scan() -- kernels through the C ABI -- against oracle_all_starts() (libpcre, the reference's engine): no table of
+    the product's compiler sits between the two."""
+    db = engine.Database(pattern)
+    assert db.info.tier == tier and db.info.exact and not db.info.has_context, (name, db.info.tier)
+    for seed, n in ((1, 300_007), (7, 65_536 + 17), (9, 1_200_001)):
+        data = sample(n, seed)
+        want = pcre_starts(liboracle, pattern, data)
+        assert want.size > 0, "the sample holds matches of every form"
+        got = ctx.scan(db, data)
+        assert same(got, want), (name, n, len(got), len(want))
+        assert np.array_equal(want, table_candidates(db, data)), "the compiler's tables and libpcre agree as well"
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_parity_patterns(ctx, variant):
     ctx.set_option("variant", variant)
@@ -73,7 +122,7 @@ def test_parity_patterns(ctx, variant):
     for pattern in PATTERNS:
         db = engine.Database(pattern)
         got = ctx.scan(db, data)
-        want = oracle_starts(db, data)
+        want = table_candidates(db, data)
         assert got.dtype == np.uint32
         assert same(got, want), (pattern, variant, len(got), len(want))
     ctx.set_option("variant", 6)
@@ -100,7 +149,7 @@ def test_ragged_sizes(ctx, variant):
                 # shorter than the window: the host never submits it; the engine must still answer "nothing"
                 pass
             got = ctx.scan(db, data)
-            want = oracle_starts(db, data)
+            want = table_candidates(db, data)
             assert same(got, want), (p, n, variant)
     ctx.set_option("variant", 6)
 
@@ -121,7 +170,7 @@ def test_dense_output_and_regrow(ctx):
     assert np.array_equal(got, np.arange(0, n, 2, dtype=np.uint32))
     data[::7] = ord("\n")
     db = engine.Database("[^\\n]{3}")
-    assert same(ctx.scan(db, data), oracle_starts(db, data))
+    assert same(ctx.scan(db, data), table_candidates(db, data))
 
 
 def test_adversarial_anchor(ctx):
@@ -131,7 +180,7 @@ def test_adversarial_anchor(ctx):
     data[123456:123464] = np.frombuffer(b"abcdabcX", np.uint8)
     for pattern in ["abcdabcX", "bcdabcX", "[ab]bcdabcX"]:
         db = engine.Database(pattern)
-        assert same(ctx.scan(db, data), oracle_starts(db, data)), pattern
+        assert same(ctx.scan(db, data), table_candidates(db, data)), pattern
 
 
 def test_binary_data(ctx):
@@ -140,22 +189,25 @@ def test_binary_data(ctx):
     data[5000:5004] = [0, 255, 0, 255]
     for pattern in [r"\x00\xff\x00\xff", r"[\x80-\xff]{6}", r"\x00[^\x00]{3}\x00", r"[\x00-\x1f][\x7f-\xff]{2,}"]:
         db = engine.Database(pattern)
-        assert same(ctx.scan(db, data), oracle_starts(db, data)), pattern
+        assert same(ctx.scan(db, data), table_candidates(db, data)), pattern
 
 
 def test_pipelined_submits(ctx):
-    """Two chunks in flight come back in submission order with their own results."""
-    a, b = sample(1 << 20, 3), sample((1 << 20) + 77, 4)
+    """GSCAN_SLOTS = 3 chunks in flight come back in submission order with their own results."""
+    a, b, c3 = sample(1 << 20, 3), sample((1 << 20) + 77, 4), sample((1 << 19) + 5, 5)
     db = engine.Database("[a-z]{2,5}")
     ctx.submit(db, a, tag=11)
     ctx.submit(db, b, tag=22)
+    ctx.submit(db, c3, tag=33)
     with pytest.raises(engine.EngineError):
-        ctx.submit(db, a, tag=33)  # GSCAN_EBUSY: both slots in flight
+        ctx.submit(db, a, tag=44)  # GSCAN_EBUSY: every slot in flight
     t1, s1 = ctx.wait()
     t2, s2 = ctx.wait()
-    assert (t1, t2) == (11, 22)
-    assert same(s1, oracle_starts(db, a))
-    assert same(s2, oracle_starts(db, b))
+    t3, s3 = ctx.wait()
+    assert (t1, t2, t3) == (11, 22, 33)
+    assert same(s1, table_candidates(db, a))
+    assert same(s2, table_candidates(db, b))
+    assert same(s3, table_candidates(db, c3))
     with pytest.raises(engine.EngineError):
         ctx.wait()  # GSCAN_EEMPTY
 
@@ -166,7 +218,7 @@ def test_pattern_switch(ctx):
     dbs = [engine.Database(p) for p in ("foo", "[a-z]{2,5}", "foobardoesnotexist", "e+")]
     for _ in range(3):
         for db in dbs:
-            assert same(ctx.scan(db, data), oracle_starts(db, data))
+            assert same(ctx.scan(db, data), table_candidates(db, data))
 
 
 def test_device_resident_segments(ctx):
@@ -193,7 +245,7 @@ def test_device_resident_segments(ctx):
             n = 0
             for i, (o, ln) in enumerate(segs):
                 got = ctx.dev_fetch(res, i)
-                want = oracle_starts(db, host[o:o + ln])
+                want = table_candidates(db, host[o:o + ln])
                 assert same(got, want), (pattern, variant, i)
                 n += len(got)
             assert n == total
@@ -216,7 +268,7 @@ def test_grid_shapes(ctx):
     """One workgroup per tile vs. persistent grid-stride give identical results."""
     data = sample(5_000_000, 8)
     db = engine.Database("[a-z]{2,5}")
-    want = oracle_starts(db, data)
+    want = table_candidates(db, data)
     for bpc in (0, 1, 2, 8, 16):
         ctx.set_option("blocks_per_cu", bpc)
         assert same(ctx.scan(db, data), want), bpc
@@ -224,10 +276,11 @@ def test_grid_shapes(ctx):
 
 
 def test_submit_fd_ranges(ctx, tmp_path):
-    """gscan_submit_fd: file ranges read by the engine's reader threads in 8 MiB pieces -- sizes around the piece
-    boundary, ranges that start inside the file, two ranges in flight, and a range beyond the end of the file."""
+    """gscan_submit_fd: file ranges read by the engine's reader threads piece by piece (asynchronously: the last reader
+    launches the scan) -- sizes around the piece boundary, ranges that start inside the file, three ranges in flight, and
+    a range beyond the end of the file (the error surfaces at gscan_wait and leaves the context usable)."""
     blk = engine.lib().gscan_block_size()
-    assert blk == 8 << 20
+    assert blk == engine.ingest_info()["block_bytes"] and blk % (1 << 20) == 0
     data = sample(2 * blk + 4097 + 77, 21)
     for at in (blk - 9, blk - 2, 2 * blk - 5):  # matches straddling piece boundaries
         data[at:at + 18] = np.frombuffer(b"foobardoesnotexist", np.uint8)
@@ -242,18 +295,30 @@ def test_submit_fd_ranges(ctx, tmp_path):
                 ctx.submit_fd(db, fd, off, ln, tag=off)
                 tag, per_seg, has_content = ctx.wait_segs()
                 assert tag == off and len(per_seg) == 1 and not has_content
-                assert same(per_seg[0], oracle_starts(db, data[off:off + ln])), (pattern, off, ln)
+                assert same(per_seg[0], table_candidates(db, data[off:off + ln])), (pattern, off, ln)
         db = engine.Database("[a-z]{2,5}")
         ctx.submit_fd(db, fd, 0, blk + 123, tag=1)
         ctx.submit_fd(db, fd, 4096, 3 * 4096, tag=2)
         t1, s1, _ = ctx.wait_segs()
         t2, s2, _ = ctx.wait_segs()
         assert (t1, t2) == (1, 2)
-        assert same(s1[0], oracle_starts(db, data[:blk + 123])) and same(s2[0], oracle_starts(db, data[4096:4 * 4096]))
+        assert same(s1[0], table_candidates(db, data[:blk + 123])) and same(s2[0], table_candidates(db, data[4096:4 * 4096]))
+        # GSCAN_SLOTS = 3 ranges in flight, returned in submission order; a fourth is refused until one has been waited for
+        for k in range(3):
+            ctx.submit_fd(db, fd, k * 4096, 2 * blk + 11 - k, tag=10 + k)
+        with pytest.raises(engine.EngineError, match="no free slot"):
+            ctx.submit_fd(db, fd, 0, 100)
+        for k in range(3):
+            t, s_, _ = ctx.wait_segs()
+            assert t == 10 + k and same(s_[0], table_candidates(db, data[k * 4096:k * 4096 + 2 * blk + 11 - k]))
+        ctx.submit_fd(db, fd, data.size - 10, 4096)  # beyond the end of the file: queued ...
+        ctx.submit_fd(db, fd, 0, 5000, tag=77)
         with pytest.raises(engine.EngineError, match="shrank"):
-            ctx.submit_fd(db, fd, data.size - 10, 4096)
+            ctx.wait_segs()  # ... reported when the range is waited for; the chunk is dropped, its slot is free again
+        t, s_, _ = ctx.wait_segs()
+        assert t == 77 and same(s_[0], table_candidates(db, data[:5000]))
         ctx.submit_fd(db, fd, 0, 1000)  # the context is still usable
-        assert same(ctx.wait_segs()[1][0], oracle_starts(db, data[:1000]))
+        assert same(ctx.wait_segs()[1][0], table_candidates(db, data[:1000]))
     finally:
         os.close(fd)
 
@@ -281,7 +346,7 @@ def test_submit_batch_segments(ctx):
             tag, per_seg, has_content = ctx.wait_segs()
             assert tag == 7 and has_content and len(per_seg) == len(parts)
             for i, (part, got) in enumerate(zip(parts, per_seg)):
-                assert same(got, oracle_starts(db, part)), (pattern, variant, i, len(part))
+                assert same(got, table_candidates(db, part)), (pattern, variant, i, len(part))
     ctx.set_option("variant", 6)
     # thousands of tiny segments (more tiles than len / tile size), and an empty batch
     tiny = [base[i * 37:i * 37 + int(rng.integers(0, 37))].copy() for i in range(3000)]
@@ -290,7 +355,7 @@ def test_submit_batch_segments(ctx):
     _, per_seg, _ = ctx.wait_segs()
     assert len(per_seg) == 3000
     for part, got in zip(tiny, per_seg):
-        assert same(got, oracle_starts(db, part))
+        assert same(got, table_candidates(db, part))
     ctx.submit_batch(db, [])
     _, per_seg, _ = ctx.wait_segs()
     assert len(per_seg) == 1 and per_seg[0].size == 0
@@ -317,7 +382,7 @@ def test_shared_buckets_second_pass(ctx):
         w = crosses[i % len(crosses)]
         at = int(rng.integers(0, data.size - 8))
         data[at:at + len(w)] = np.frombuffer(w, np.uint8)
-    want = oracle_starts(db, data)
+    want = table_candidates(db, data)
     got = ctx.scan(db, data)
     assert same(got, want) and len(got) > 500
     # dense: every byte is a hit of some single-letter alternative -> overflow -> regrow -> settle on the rescan
@@ -325,7 +390,7 @@ def test_shared_buckets_second_pass(ctx):
     db2 = engine.Database(dense)
     assert db2.info.n_alts == 13
     got = ctx.scan(db2, data[:700_001])
-    assert same(got, oracle_starts(db2, data[:700_001]))
+    assert same(got, table_candidates(db2, data[:700_001]))
     # device-resident: total counts the survivors only, fetch skips the struck records
     arena = torch.from_numpy(data).cuda()
     ctx.set_capacity(1 << 20)

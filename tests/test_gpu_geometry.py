@@ -1,0 +1,198 @@
+"""GPU parity at BASELINE's real geometry (task 1): the default 1 GiB window with its 4 KiB overlap on a
+file of several windows, a 4096-file three-level tree through the `-n 8` work queue, and the identifier regex over a
+multi-file corpus through `-n 4` -- `grab` and the oracle (oracle/grab_oracle = the reference's loop over libpcre;
+oracle/_ref/grab_jit = the reference binary itself, when it travelled) side by side on the same files.
+
+Rules under test (/root/reference): src/grab.cc:151-159 (stride = chunk - 4096, windows of min(chunk, rest)),
+:175 (strict loop bound), :217-234 (per-chunk flush, -s), src/main.cc:172-173 (chunk >> 2 under -n).
+Sized for the driver's 20-minute budget: about 2.5 GiB + 2 GiB + 1 GiB of input, generated on the device."""
+import hashlib
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from grab_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 1 << 30
+STRIDE = CHUNK - 4096
+NEEDLE = b"NEEDLE"
+
+
+def _scratch(tmp_path, need):
+    """A directory with `need` bytes to spare: /dev/shm (page cache, like the measurements) if it has them, else tmp_path."""
+    for base in ("/dev/shm", str(tmp_path)):
+        try:
+            if os.path.isdir(base) and shutil.disk_usage(base).free > need * 1.15:
+                d = os.path.join(base, "grab_geom_%d" % os.getpid())
+                os.makedirs(d, exist_ok=True)
+                return d
+        except OSError:
+            pass
+    pytest.skip("no scratch space for %d bytes" % need)
+
+
+def _run(binary, argv, cwd, env=None):
+    e = dict(os.environ, GRAB_DIAG="1")
+    e.update(env or {})
+    r = subprocess.run([binary] + argv, cwd=cwd, capture_output=True, env=e)
+    return r.returncode, r.stdout, r.stderr
+
+
+def _oracles(oracle_built):
+    out = [os.path.join(oracle_built, "grab_oracle")]
+    ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
+    if os.path.exists(ref):
+        out.append(ref)
+    return out
+
+
+def boundary_file(size):
+    """`.` lines of 80 bytes with plants wherever the window geometry can go wrong (at the DEFAULT
+    chunk size): inside both overlap windows (printed twice), straddling both chunk ends (found by the next window only),
+    ending exactly at a chunk end, at each chunk start, in the last 18 bytes, at the very end; runs of `a` across chunk
+    starts (the suffix inside the next window is a match of its own there) and across chunk ends."""
+    buf = np.full(size, ord("."), np.uint8)
+    buf[79::80] = 10
+    nd = np.frombuffer(NEEDLE, np.uint8)
+    spots = [100, STRIDE + 1000, 2 * STRIDE + 2000,              # head; inside overlap windows 1 and 2
+             CHUNK - 3, STRIDE + CHUNK - 3,                       # straddling the ends of windows 0 and 1
+             CHUNK - 6, STRIDE + CHUNK - 6,                       # ending exactly at a window end
+             STRIDE, 2 * STRIDE,                                  # at each window start
+             CHUNK - 4096 - 3, CHUNK + 5000,                      # straddling a window START; plain interior of window 1
+             size - 18, size - 6]                                 # the last 18 bytes; the very end
+    for at in spots:
+        buf[at:at + 6] = nd
+    rng = np.random.default_rng(5)
+    for at in rng.integers(1 << 20, size - (1 << 20), 300):      # and a few hundred anywhere
+        buf[int(at):int(at) + 6] = nd
+    for at in (STRIDE - 10, 2 * STRIDE - 10, CHUNK - 20, STRIDE + CHUNK - 20, 77_777):
+        buf[at:at + 40] = ord("a")
+    return buf
+
+
+@pytest.fixture(scope="module")
+def big_file(tmp_path_factory):
+    size = 2 * STRIDE + (CHUNK >> 1) + 12345  # 3 windows at the default chunk: 1 GiB, 1 GiB, 0.5 GiB + 12345 + 8192
+    d = _scratch(tmp_path_factory.mktemp("geom"), size)
+    boundary_file(size).tofile(os.path.join(d, "big.bin"))
+    yield d, size
+    shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.parametrize("pattern", ["NEEDLE", "a{30,}", "NEE?DLE|DLE", r"\.{3}NEEDLE\b|a{39}\."])
+def test_default_chunk_geometry(pattern, big_file, built, oracle_built):
+    """2.5 GiB at the default 1 GiB chunk: 3 windows, all three in flight at once -- every output mode, byte for byte."""
+    d, size = big_file
+    assert size > 2 * STRIDE + 4096 and size < 3 * STRIDE
+    for flags in (["-O", "-l"], ["-O"], [], ["-l"], ["-s", "-O"]):
+        argv = flags + [pattern, "big.bin"]
+        rc, out, err = _run(built.bin_path(), argv, d)
+        assert rc == 0, err
+        for o in _oracles(oracle_built):
+            orc, oout, _ = _run(o, argv, d)
+            assert orc == 0
+            assert out == oout, (pattern, flags, os.path.basename(o), len(out), len(oout))
+        if flags == ["-O", "-l"] and pattern == "NEEDLE":
+            offs = [int(l.split()[-1]) for l in out.splitlines()]
+            assert offs.count(STRIDE + 1000) == 2 and offs.count(2 * STRIDE + 2000) == 2, "overlap windows print twice (Q1)"
+            assert offs.count(CHUNK - 3) == 1 and offs.count(STRIDE) == 2 and offs.count(size - 6) == 1
+    # the same windows dealt out over three contexts (FileGrep "devices": SURVEY.md 8e; on a one-GPU box all three sit
+    # on device 0 -- what is exercised is the per-file reorder buffer): identical bytes
+    for flags in (["-O", "-l"], ["-O"]):
+        argv = flags + [pattern, "big.bin"]
+        _, one, _ = _run(built.bin_path(), argv, d, {"GRAB_DEVICES": "1"})
+        rc, out, err = _run(built.bin_path(), argv, d, {"GRAB_DEVICES": "3", "GRAB_TIMING": "1"})
+        assert rc == 0 and out == one, err
+        assert err.count(b"[grab bytes] device") == 3, err  # three contexts took windows
+
+
+def test_quartered_chunks_two_files(big_file, built, oracle_built):
+    """The -n geometry (chunk >> 2 = 256 MiB, main.cc:172-173) on the same file inside a tree with a second, small-window
+    file: 11 windows through 2 workers, sorted compare."""
+    d, size = big_file
+    tree = os.path.join(d, "tree")
+    os.makedirs(os.path.join(tree, "sub"), exist_ok=True)
+    if not os.path.exists(os.path.join(tree, "big.bin")):
+        os.link(os.path.join(d, "big.bin"), os.path.join(tree, "big.bin"))
+    small = synth.text(3 << 20, 4)
+    small[1000:1006] = np.frombuffer(NEEDLE, np.uint8)
+    small.tofile(os.path.join(tree, "sub", "small.txt"))
+    for flags in (["-n", "2", "-r", "-O", "-l"], ["-n", "2", "-r", "-O"]):
+        argv = flags + ["NEEDLE|a{30,}", "tree"]
+        rc, out, err = _run(built.bin_path(), argv, d)
+        orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), argv, d)
+        assert rc == orc == 0, err
+        if "-l" in flags:
+            assert sorted(out.splitlines()) == sorted(oout.splitlines())
+        else:  # offset line + text line belong together: compare the multiset of 2-line records
+            def recs(b):
+                ls = b.split(b"\n")
+                return sorted(zip(ls[0:-1:2], ls[1::2]))
+            assert recs(out) == recs(oout)
+
+
+def _torch_text(nbytes, k):
+    import torch
+
+    return synth.torch_text(nbytes, k, torch.device("cuda", 0)).cpu().numpy()
+
+
+def test_tree_4096_files_through_the_queue(tmp_path, built, oracle_built):
+    """BASELINE configs[3] in small: 4096 x 512 KiB in a 16 x 16 x 16 tree, one needle per file, `grab -n 8 -r`
+    (parallel walk -> queue -> 8 workers -> batches) against the oracle's `-n 8 -r`, sorted (README.md:206-216)."""
+    files, fbytes = 4096, 512 << 10
+    d = _scratch(tmp_path, files * fbytes)
+    try:
+        nd = np.frombuffer(synth.NEEDLE, np.uint8)
+        block = _torch_text(64 * fbytes, 9000)  # 32 MiB of text, re-cut per file with a per-file rotation: cheap and distinct
+        for i in range(files):
+            sub = os.path.join(d, "t", "a%02d" % (i % 16), "b%02d" % ((i // 16) % 16), "c%02d" % ((i // 256) % 16))
+            os.makedirs(sub, exist_ok=True)
+            buf = np.roll(block[(i % 64) * fbytes:(i % 64 + 1) * fbytes], i * 131)
+            at = (i * 7919) % (fbytes - 64)
+            buf[at:at + nd.size] = nd
+            if i % 512 == 0:
+                buf[fbytes - nd.size:] = nd  # ends with the file
+            buf.tofile(os.path.join(sub, "f%05d.txt" % i))
+        os.symlink(os.path.join(d, "t", "a00"), os.path.join(d, "t", "loop"))  # not followed (FTW_PHYS)
+        for flags in (["-n", "8", "-r", "-O", "-l"], ["-n", "8", "-r"]):
+            argv = flags + [synth.NEEDLE.decode(), "t"]
+            rc, out, err = _run(built.bin_path(), argv, d)
+            orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), argv, d)
+            assert rc == orc == 0, err
+            assert len(out.splitlines()) >= files
+            assert sorted(out.splitlines()) == sorted(oout.splitlines()), flags
+        # one worker per "device" with several walkers and with one: same set of lines
+        argv = ["-n", "3", "-r", "-O", "-l", synth.NEEDLE.decode(), "t"]
+        _, a, _ = _run(built.bin_path(), argv, d, {"GRAB_WALKERS": "1"})
+        _, b, _ = _run(built.bin_path(), argv, d, {"GRAB_WALKERS": "7", "GRAB_PIN": "cpu"})
+        _, o3, _ = _run(os.path.join(oracle_built, "grab_oracle"), argv, d)
+        assert sorted(a.splitlines()) == sorted(b.splitlines()) == sorted(o3.splitlines())
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_identifier_regex_16_files(tmp_path, built, oracle_built):
+    """BASELINE configs[2] in small: 16 x 64 MiB, '[A-Za-z_][A-Za-z0-9_]{15,}' through `-n 4 -r -O -l` (K2 pair kernel,
+    dense records, windows of 64 MiB under the 256 MiB chunk), md5 of the sorted output against the oracle's."""
+    files, fbytes = 16, 64 << 20
+    d = _scratch(tmp_path, files * fbytes)
+    try:
+        os.makedirs(os.path.join(d, "c"))
+        for i in range(files):
+            _torch_text(fbytes, 7000 + i).tofile(os.path.join(d, "c", "f%02d.txt" % i))
+        argv = ["-n", "4", "-r", "-O", "-l", synth.IDENT_RE, "c"]
+        rc, out, err = _run(built.bin_path(), argv, d)
+        orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), argv, d)
+        assert rc == orc == 0, err
+        a, b = sorted(out.splitlines()), sorted(oout.splitlines())
+        assert len(a) == len(b) and len(a) > 2_000_000
+        assert hashlib.md5(b"\n".join(a)).hexdigest() == hashlib.md5(b"\n".join(b)).hexdigest()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
