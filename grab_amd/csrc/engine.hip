@@ -75,6 +75,7 @@ struct IngestCfg {
     int readers;
     int copy_streams;
     bool numa;
+    unsigned pin_flags; // hipHostMalloc flags of the staging blocks (GSCAN_PIN_FLAGS: 0 default, 1 non-coherent, 2 write-combined)
 };
 const IngestCfg &ingest_cfg()
 {
@@ -91,6 +92,8 @@ const IngestCfg &ingest_cfg()
         if (hw > 0 && v.readers > hw) v.readers = (int)hw;
         v.copy_streams = (int)env("GSCAN_COPY_STREAMS", 2, 1, 4);
         v.numa = env("GSCAN_NUMA", 1, 0, 1) != 0;
+        const long pf = env("GSCAN_PIN_FLAGS", 0, 0, 2);
+        v.pin_flags = pf == 1 ? hipHostMallocNonCoherent : pf == 2 ? hipHostMallocWriteCombined : hipHostMallocDefault;
         return v;
     }();
     return c;
@@ -249,8 +252,9 @@ private:
         cap_ = (size_t)readers_ * 2;
         // Where the readers run: on the CPUs of the device's NUMA node (the pinned blocks are first touched by them, and the
         // page cache -> pinned copy is the host's share of every byte), as far as the process is allowed there.  Without
-        // that information: the mask of the thread that opened the first context.
-        have_mask_ = sched_getaffinity(0, sizeof mask_, &mask_) == 0;
+        // that information: the process's own mask.
+        // (the PROCESS's mask, i.e. the main thread's: the opener may be a worker that `grab -n` has bound to a single CPU)
+        have_mask_ = sched_getaffinity(getpid(), sizeof mask_, &mask_) == 0;
         if (ingest_cfg().numa) {
             char list[1024];
             std::vector<int> cpus;
@@ -298,7 +302,7 @@ private:
         PinBlock *b = new (std::nothrow) PinBlock();
         if (!b) return nullptr;
         (void)hipSetDevice(device_);
-        if (hipHostMalloc(&b->p, block_bytes() + kPad, hipHostMallocDefault) != hipSuccess ||
+        if (hipHostMalloc(&b->p, block_bytes() + kPad, ingest_cfg().pin_flags) != hipSuccess ||
             hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             if (b->p) hipHostFree(b->p);
@@ -564,7 +568,7 @@ int ensure_prog(gscan_ctx *c, const gscan_db *db, hipStream_t st)
 uint32_t grid_for(const gscan_ctx *c, const Database &db, uint32_t n_tiles)
 {
     // kernels that stage a big LDS table once per workgroup always run as a persistent grid
-    const uint32_t fixed = gscan::scan_persistent_blocks(db.tier, db.prog.n_classes);
+    const uint32_t fixed = gscan::scan_persistent_blocks(db.tier, c->variant, db.prog.n_classes);
     const uint32_t bpc = fixed ? fixed : (uint32_t)std::max(c->blocks_per_cu, 0);
     if (bpc == 0) return n_tiles;
     uint64_t g = (uint64_t)c->cus * (uint64_t)bpc;
@@ -1307,7 +1311,7 @@ int gscan_set_option(gscan_ctx *c, const char *name, long value)
 {
     if (!c || !name) return GSCAN_EINVAL;
     if (!strcmp(name, "variant")) {
-        if (value < 0 || value > 7 || (value & 3) == 3) return GSCAN_EINVAL; // KiB per wave {16,8,12} | nontemporal<<2
+        if (value != 13 && value != 21 && (value < 0 || value > 7 || (value & 3) == 3)) return GSCAN_EINVAL; // KiB per wave {16,8,12} | nontemporal<<2; 13: 768-thread workgroups for the table kernels
         c->variant = (int)value;
         return GSCAN_OK;
     }

@@ -58,7 +58,6 @@ constexpr int kWave = 64;
 constexpr int kWG = 256;
 constexpr int kWaves = kWG / kWave;
 constexpr int kK3WG = 512; // K3 and the two-class form of K2: 8 waves share one 64 KiB table
-constexpr int kK3Waves = kK3WG / kWave;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -478,13 +477,16 @@ __device__ __forceinline__ uint32_t run_one_flat(uint32_t d, uint32_t w0, uint32
 // one v_readlane + a handful of s_bfe per run and step; NR = -1 (the other forms): run_and's scalar loops.  Measured on
 // the identifier scan: the scalar loops cost 203 M SALU instructions per 4 GiB against 31 M, and 8 % of the time
 // (profiles/r01_w_k2_opt_sweep.txt, r01_w_k2_pmc.txt).
-template <int ITER, bool NT, bool WIDE, bool PAIR, int NR = -1>
-__global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
+// NW (pair form): waves per workgroup -- 8 (512 threads, ITER 12: 4 waves per SIMD), 12 (768 threads, ITER 8, two
+// workgroups per CU = 6 waves per SIMD within 80 VGPRs; same 96 KiB tile) or 16 (1024 threads, ITER 8, two workgroups per
+// CU = 8 waves per SIMD within 64 VGPRs; no room in LDS for the transposition strip next to two 64 KiB tables: plain epilogue).
+template <int ITER, bool NT, bool WIDE, bool PAIR, int NR = -1, int NW = (PAIR ? 8 : 4)>
+__global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : NW == 16 ? 8 : 1) void k2_classrun_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     static_assert(NR < 0 || (PAIR && !WIDE), "the flat run program is the two-class, 32-bit form's");
-    constexpr int kNW = PAIR ? 8 : 4; // waves per workgroup
+    constexpr int kNW = NW; // waves per workgroup
     __shared__ uint32_t tbl[PAIR ? 65536 / 4 : 256 * 32];
-    __shared__ __attribute__((aligned(8))) uint16_t s_xp[kNW * ITER * 64]; // epilogue transposition strip, 2 bytes per (step, lane)
+    __shared__ __attribute__((aligned(8))) uint16_t s_xp[NW == 16 ? 4 : kNW * ITER * 64]; // epilogue transposition strip, 2 bytes per (step, lane)
     __shared__ uint32_t s_cnt[kNW];
     __shared__ uint32_t s_base;
     constexpr uint32_t kTile = kNW * ITER * 1024;
@@ -503,14 +505,11 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
         for (int r = 0; r < NR; r++) rf[r] = __builtin_amdgcn_readlane(vrf, r);
     const uint8_t *tbl8 = reinterpret_cast<const uint8_t *>(tbl);
 
-    if (!PAIR) { // stage the class table: entry b replicated into all 32 banks
-        uint32_t b = threadIdx.x; // 256 threads == 256 entries
-        uint32_t v = a.prog->k2_table[b];
-#pragma unroll 8
-        for (uint32_t r = 0; r < 32; r++) tbl[(b << 5) | ((r + lane) & 31u)] = v;
+    if (!PAIR) { // stage the class table: entry b replicated into all 32 banks (dword q = copy q & 31 of entry q >> 5)
+        for (uint32_t q = threadIdx.x; q < 256u * 32u; q += NW * 64) tbl[q] = a.prog->k2_table[q >> 5];
     } else { // build the pair table from the 256-entry one: index = first byte | second byte << 8
         const uint32_t *base = a.prog->k2_table;
-        for (uint32_t q = threadIdx.x; q < 65536 / 4; q += 512) { // one dword = 4 consecutive first bytes
+        for (uint32_t q = threadIdx.x; q < 65536 / 4; q += NW * 64) { // one dword = 4 consecutive first bytes
             const uint32_t b1 = q >> 6, b0 = (q & 63u) << 2;
             const uint32_t t1 = base[b1];
             const uint32_t hi = (((t1 & 1u) << 1) | ((t1 >> 8 & 1u) << 5)) * 0x01010101u; // second byte's bits, all 4 entries
@@ -629,7 +628,8 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
             }
         }
         // K2's outputs are the dense ones: transposed epilogue (+8 % on the identifier scan, neutral without matches)
-        emit_tile_t<ITER, kNW>(a, t, hits, cnt, sub_off, 0u - a.report_shift, lane, wave, s_cnt, &s_base, s_xp);
+        if (NW == 16) emit_tile<ITER, kNW>(a, t, hits, cnt, sub_off, 0u - a.report_shift, lane, wave, s_cnt, &s_base);
+        else emit_tile_t<ITER, kNW>(a, t, hits, cnt, sub_off, 0u - a.report_shift, lane, wave, s_cnt, &s_base, s_xp);
     }
 }
 #undef GS_LUT
@@ -637,32 +637,34 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k2_classrun_scan(ScanArgs a,
 // ------------------------------------------------------------------------------------
 // K3: bucket filter over 4 window positions (alternations; class sequences with > 4 classes).
 // ------------------------------------------------------------------------------------
-// Table entry of byte b: byte k = buckets that accept b at window position k3_off + k.
-// With e_j the entry of text byte j:   hit(j) = e_j.b0 & e_{j+1}.b1 & e_{j+2}.b2 & e_{j+3}.b3 != 0,
-// three VALU ops per byte: two v_and_b32_sdwa (the byte selects are operand modifiers) and one v_and_b32.
-__device__ __forceinline__ uint32_t and_b0_b1(uint32_t x, uint32_t y)
+// Table entry of byte b (DevProgram::k3_table): byte k = buckets that accept b at window position k3_off + k, P_k(b).
+//   hit(j) = P_0(t_j) & P_1(t_{j+1}) & P_2(t_{j+2}) & P_3(t_{j+3}) != 0.
+// In LDS the entry's middle bytes are swapped -- [P_0, P_2, P_1, P_3] -- so that with e_j the entry of text byte j
+//   Y_j = e_j.WORD_0 & e_{j+1}.WORD_1 = [P_0(t_j) & P_1(t_{j+1}),  P_2(t_j) & P_3(t_{j+1})]     one v_and_b32_sdwa
+//   h_j = Y_j.BYTE_0 & Y_{j+2}.BYTE_1                                                          one v_and_b32_sdwa
+// : TWO VALU operations per text byte for four window positions (the word and byte selects are operand modifiers).  The
+// round-1 form (A_j = e_j.b0 & e_{j+1}.b1, B_j = e_j.b2 & e_{j+1}.b3, h_j = A_j & B_{j+2}) took three, and K3 is bound by
+// VALU issue (profiles/r02_*k3*).
+__device__ __forceinline__ uint32_t and_w0_w1(uint32_t x, uint32_t y) // low half of x & high half of y
+{
+    uint32_t r;
+    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ uint32_t and_b0_b1(uint32_t x, uint32_t y) // byte 0 of x & byte 1 of y
 {
     uint32_t r;
     asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
-__device__ __forceinline__ uint32_t and_dw_b2(uint32_t x, uint32_t y) // x & byte 2 of y (x: a byte value)
-{
-    uint32_t r;
-    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-__device__ __forceinline__ uint32_t and_b2_b3(uint32_t x, uint32_t y)
-{
-    uint32_t r;
-    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_3" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
 // DEPTH: window positions the filter looks at.  4 by default; 3 when the compiler expects three positions to be selective
 // enough (ScanArgs::k3_depth: literal-like alternatives) -- two SDWA operations per byte instead of three and one look-up
 // less per step, paid for with more trips into the confirm path.
-template <int ITER, bool NT, int DEPTH = 4>
-__global__ __launch_bounds__(kK3WG) void k3_bucket_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
+// NW: waves per workgroup.  8 (512 threads, ITER 12: 4 waves per SIMD) or 12 (768 threads, ITER 8, two workgroups per CU
+// = 6 waves per SIMD within 80 VGPRs: the same 96 KiB tile, fewer bytes in flight per wave, more waves to hide the LDS
+// and HBM latency behind).
+template <int ITER, bool NT, int DEPTH = 4, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     // The filter table, one copy PER LANE: entry b of lane l lives at byte address b << 8 | l << 2.  Both fields are whole
     // bytes, so ONE v_perm_b32 turns a text byte into its LDS address (with the 32-copy layout the address took a v_bfe
@@ -671,9 +673,9 @@ __global__ __launch_bounds__(kK3WG) void k3_bucket_scan(ScanArgs a, const TileDe
     __shared__ uint32_t tbl[256 * 64];
     __shared__ __attribute__((aligned(16))) uint8_t s_pos[kK3Confirm * 256];
     __shared__ uint8_t s_blen[kK3Buckets];
-    __shared__ uint32_t s_cnt[kK3Waves];
+    __shared__ uint32_t s_cnt[NW];
     __shared__ uint32_t s_base;
-    constexpr uint32_t kTile = kK3Waves * ITER * 1024;
+    constexpr uint32_t kTile = NW * ITER * 1024;
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t lane4 = lane << 2;
@@ -682,14 +684,16 @@ __global__ __launch_bounds__(kK3WG) void k3_bucket_scan(ScanArgs a, const TileDe
     const bool confirm_exact = a.prog->k3_confirm_exact != 0; // wave-uniform (scalar load)
     const uint8_t *tbl8 = reinterpret_cast<const uint8_t *>(tbl);
     {
-        const uint32_t b = threadIdx.x & 255u, half = threadIdx.x >> 8; // 512 threads: entry b, copies of lanes half*32 .. half*32+31
-        const uint32_t v = a.prog->k3_table[b];
-#pragma unroll 8
-        for (uint32_t r = 0; r < 32; r++) tbl[(b << 6) | (half << 5) | ((r + lane) & 31u)] = v;
+        // dword q of the table = copy (q & 63) of entry (q >> 6), middle bytes swapped (see above); consecutive threads
+        // write consecutive dwords
+        for (uint32_t q = threadIdx.x; q < 256u * 64u; q += NW * 64) {
+            const uint32_t v = a.prog->k3_table[q >> 6];
+            tbl[q] = __builtin_amdgcn_perm(v, v, 0x03010200u);
+        }
         // confirm tables (cold path only): kK3Confirm window positions x 256 bytes, one copy
         const u32x4 *src = reinterpret_cast<const u32x4 *>(&a.prog->k3_pos[0][0]);
         u32x4 *dst = reinterpret_cast<u32x4 *>(s_pos);
-        for (uint32_t q = threadIdx.x; q < (uint32_t)(kK3Confirm * 256 / 16); q += kK3WG) dst[q] = src[q];
+        for (uint32_t q = threadIdx.x; q < (uint32_t)(kK3Confirm * 256 / 16); q += NW * 64) dst[q] = src[q];
         if (threadIdx.x < (uint32_t)kK3Buckets) s_blen[threadIdx.x] = a.prog->k3_blen[threadIdx.x];
     }
     __syncthreads();
@@ -722,26 +726,17 @@ __global__ __launch_bounds__(kK3WG) void k3_bucket_scan(ScanArgs a, const TileDe
                 GS_E(16, nd, 0);  GS_E(17, nd, 1);
                 if (DEPTH == 4) GS_E(18, nd, 2);
 #undef GS_E
-                // byte selects come for free with SDWA: A_j = e_j.b0 & e_{j+1}.b1, B_j = e_j.b2 & e_{j+1}.b3, h_j = A_j & B_{j+2}
-                // (plain shift + and in place of the byte selects: 4 ops per byte, 14 % slower -- profiles/r01_o_sweep_k3_sdwa.txt)
+                // Y_j = [P_0(t_j) & P_1(t_{j+1}), P_2(t_j) & P_3(t_{j+1})]; h_j = Y_j.b0 & Y_{j+2}.b1 (four positions) or
+                // Y_j.b0 & e_{j+2}.b1 = ... & P_2(t_{j+2}) (three): two VALU operations per byte either way
+                // (plain shift + and in place of the selects: twice that -- profiles/r01_o_sweep_k3_sdwa.txt)
                 uint32_t h[16], any = 0;
-                if (DEPTH == 3) {
+                uint32_t Y[18];
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        h[j] = and_dw_b2(and_b0_b1(e[j], e[j + 1]), e[j + 2]);
-                        any |= h[j];
-                    }
-                } else {
-                    uint32_t A[16], B[18];
+                for (int j = 0; j < (DEPTH == 3 ? 16 : 18); j++) Y[j] = and_w0_w1(e[j], e[j + 1]);
 #pragma unroll
-                    for (int j = 0; j < 16; j++) A[j] = and_b0_b1(e[j], e[j + 1]);
-#pragma unroll
-                    for (int j = 2; j < 18; j++) B[j] = and_b2_b3(e[j], e[j + 1]);
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        h[j] = A[j] & B[j + 2];
-                        any |= h[j];
-                    }
+                for (int j = 0; j < 16; j++) {
+                    h[j] = and_b0_b1(Y[j], DEPTH == 3 ? e[j + 2] : Y[j + 2]);
+                    any |= h[j];
                 }
                 if (any) { // cold: which positions, bounds, full windows
                     const int pos0 = sub_off + k * 1024 + (int)lane * 16;
@@ -798,7 +793,7 @@ __global__ __launch_bounds__(kK3WG) void k3_bucket_scan(ScanArgs a, const TileDe
                 }
             }
         }
-        emit_tile<ITER, kK3Waves>(a, t, hits, cnt, sub_off, koff - a.report_shift, lane, wave, s_cnt, &s_base);
+        emit_tile<ITER, NW>(a, t, hits, cnt, sub_off, koff - a.report_shift, lane, wave, s_cnt, &s_base);
     }
 }
 
@@ -985,30 +980,53 @@ static const int kIters[4] = {16, 8, 12, 16};
 // K2 runs its pair-table form whenever the pattern has at most two classes
 static bool k2_pair(const ScanArgs &a) { return a.n_classes <= 2; }
 
+static int variant_wg(int tier, int variant, uint32_t n_classes);
+
 uint32_t scan_tile_bytes(int tier, int variant, uint32_t n_classes)
 {
-    const int waves = ((tier == GSCAN_TIER_CLASSRUN && n_classes <= 2) || tier == GSCAN_TIER_BUCKET) ? 8 : kWaves;
+    const int wg = variant_wg(tier, variant, n_classes);
+    const int waves = wg ? wg : ((tier == GSCAN_TIER_CLASSRUN && n_classes <= 2) || tier == GSCAN_TIER_BUCKET) ? 8 : kWaves;
     return (uint32_t)(waves * kIters[variant & 3] * 1024);
 }
 
 uint32_t scan_min_tile_bytes() { return (uint32_t)(kWaves * 8 * 1024); }
 
 // resident workgroups per CU the kernel is designed for when it runs as a persistent grid (0 = no preference)
-uint32_t scan_persistent_blocks(int tier, uint32_t n_classes)
+uint32_t scan_persistent_blocks(int tier, int variant, uint32_t n_classes)
 {
-    return ((tier == GSCAN_TIER_CLASSRUN && n_classes <= 2) || tier == GSCAN_TIER_BUCKET) ? 2u : 0u; // (64 KiB of table to stage per workgroup)
+    if ((tier == GSCAN_TIER_CLASSRUN && n_classes <= 2) || tier == GSCAN_TIER_BUCKET) return 2u; // (64 KiB of table to stage per workgroup)
+    if (tier == GSCAN_TIER_CLASSRUN && variant_wg(tier, variant, n_classes) == 8) return 3u;    // (32 KiB, 512 threads)
+    return 0u;
 }
 
 template <int ITER, bool NT>
-static void launch_k2(bool wide, bool pair, const ScanArgs &a, dim3 g, hipStream_t st)
+static void launch_k2(bool wide, bool pair, int wg, const ScanArgs &a, dim3 g, hipStream_t st)
 {
     const TileDesc *tiles = a.tiles;
-    if (pair) {
+    const bool w12 = wg == 12;
+    if (pair && wg == 16 && ITER == 8 && NT) { // 1024-thread workgroups, two per CU
+        constexpr int I = 8;
+        if (wide) hipLaunchKernelGGL((k2_classrun_scan<I, true, true, true, -1, 16>), g, dim3(1024), 0, st, a, tiles);
+        else if (a.nruns == 1) hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 1, 16>), g, dim3(1024), 0, st, a, tiles);
+        else if (a.nruns == 2) hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 2, 16>), g, dim3(1024), 0, st, a, tiles);
+        else if (a.nruns == 3) hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 3, 16>), g, dim3(1024), 0, st, a, tiles);
+        else hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 0, 16>), g, dim3(1024), 0, st, a, tiles);
+    } else if (pair && w12 && ITER == 8 && NT) { // 768-thread workgroups, two per CU
+        constexpr int I = 8;
+        if (wide) hipLaunchKernelGGL((k2_classrun_scan<I, true, true, true, -1, 12>), g, dim3(768), 0, st, a, tiles);
+        else if (a.nruns == 1) hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 1, 12>), g, dim3(768), 0, st, a, tiles);
+        else if (a.nruns == 2) hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 2, 12>), g, dim3(768), 0, st, a, tiles);
+        else if (a.nruns == 3) hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 3, 12>), g, dim3(768), 0, st, a, tiles);
+        else hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 0, 12>), g, dim3(768), 0, st, a, tiles);
+    } else if (pair) {
         if (wide) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, true, true>), g, dim3(512), 0, st, a, tiles);
         else if (a.nruns == 1) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, true, 1>), g, dim3(512), 0, st, a, tiles);
         else if (a.nruns == 2) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, true, 2>), g, dim3(512), 0, st, a, tiles);
         else if (a.nruns == 3) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, true, 3>), g, dim3(512), 0, st, a, tiles);
         else hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, true, 0>), g, dim3(512), 0, st, a, tiles);
+    } else if (wg == 8 && ITER == 8 && NT) { // general form, 512-thread workgroups
+        if (wide) hipLaunchKernelGGL((k2_classrun_scan<8, true, true, false, -1, 8>), g, dim3(512), 0, st, a, tiles);
+        else hipLaunchKernelGGL((k2_classrun_scan<8, true, false, false, -1, 8>), g, dim3(512), 0, st, a, tiles);
     } else {
         if (wide) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, true, false>), g, dim3(kWG), 0, st, a, tiles);
         else hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, false>), g, dim3(kWG), 0, st, a, tiles);
@@ -1016,20 +1034,23 @@ static void launch_k2(bool wide, bool pair, const ScanArgs &a, dim3 g, hipStream
 }
 
 template <int ITER>
-static hipError_t launch_iter(int tier, bool nt, bool wide, const ScanArgs &a, uint32_t grid, hipStream_t st)
+static hipError_t launch_iter(int tier, bool nt, bool wide, int wg, const ScanArgs &a, uint32_t grid, hipStream_t st)
 {
     dim3 g(grid);
     const TileDesc *tiles = a.tiles;
     if (tier == GSCAN_TIER_BUCKET) {
-        if (a.k3_depth == 3 && ITER == 12 && nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true, ITER == 12 ? 3 : 4>), g, dim3(kK3WG), 0, st, a, tiles);
+        if (wg == 12 && ITER == 8 && nt) { // 768-thread workgroups, two per CU
+            if (a.k3_depth == 3) hipLaunchKernelGGL((k3_bucket_scan<ITER == 8 ? 8 : 12, true, 3, 12>), g, dim3(768), 0, st, a, tiles);
+            else hipLaunchKernelGGL((k3_bucket_scan<ITER == 8 ? 8 : 12, true, 4, 12>), g, dim3(768), 0, st, a, tiles);
+        } else if (a.k3_depth == 3 && ITER == 12 && nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true, ITER == 12 ? 3 : 4>), g, dim3(kK3WG), 0, st, a, tiles);
         else if (nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true>), g, dim3(kK3WG), 0, st, a, tiles);
         else hipLaunchKernelGGL((k3_bucket_scan<ITER, false>), g, dim3(kK3WG), 0, st, a, tiles);
     } else if (tier == GSCAN_TIER_LITERAL) {
         if (nt) hipLaunchKernelGGL((k1_anchor_scan<ITER, true>), g, dim3(kWG), 0, st, a, tiles);
         else hipLaunchKernelGGL((k1_anchor_scan<ITER, false>), g, dim3(kWG), 0, st, a, tiles);
     } else {
-        if (nt) launch_k2<ITER, true>(wide, k2_pair(a), a, g, st);
-        else launch_k2<ITER, false>(wide, k2_pair(a), a, g, st);
+        if (nt) launch_k2<ITER, true>(wide, k2_pair(a), wg, a, g, st);
+        else launch_k2<ITER, false>(wide, k2_pair(a), 0, a, g, st);
     }
     return hipGetLastError();
 }
@@ -1103,14 +1124,27 @@ hipError_t launch_lines(const ScanArgs &a, uint32_t tile_bytes, uint32_t *ext, h
     return hipGetLastError();
 }
 
+// variant: bits 0-1 KiB per wave {0: 16, 1: 8, 2: 12}; bit 2 nontemporal loads; with 8 KiB per wave + nontemporal, bit 3
+// (variant 13): the table kernels (K3, K2's pair form) run 768-thread workgroups; bit 4 (variant 21): K2's pair form runs
+// 1024-thread workgroups.  K2's general form (3-4 classes): variant 13 = 512-thread workgroups sharing one 32 KiB table,
+// three per CU, as a persistent grid.  Returns the waves per workgroup asked for, 0 = the kernel's own.
+static int variant_wg(int tier, int variant, uint32_t n_classes)
+{
+    const bool pair = tier == GSCAN_TIER_CLASSRUN && n_classes <= 2;
+    if (variant == 13 && (pair || tier == GSCAN_TIER_BUCKET)) return 12;
+    if (variant == 13 && tier == GSCAN_TIER_CLASSRUN) return 8;
+    if (variant == 21 && pair) return 16;
+    return 0;
+}
+
 hipError_t launch_scan(int tier, int variant, const ScanArgs &a, uint32_t grid, hipStream_t st)
 {
     const bool nt = (variant >> 2) & 1;
     const bool wide = a.m > 17; // K2: look-ahead beyond one neighbouring lane
     switch (variant & 3) {
-    case 1: return launch_iter<8>(tier, nt, wide, a, grid, st);
-    case 2: return launch_iter<12>(tier, nt, wide, a, grid, st);
-    default: return launch_iter<16>(tier, nt, wide, a, grid, st);
+    case 1: return launch_iter<8>(tier, nt, wide, variant_wg(tier, variant, a.n_classes), a, grid, st);
+    case 2: return launch_iter<12>(tier, nt, wide, 0, a, grid, st);
+    default: return launch_iter<16>(tier, nt, wide, 0, a, grid, st);
     }
 }
 

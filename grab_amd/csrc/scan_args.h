@@ -45,10 +45,10 @@ struct ScanArgs {
     uint32_t run_flat[kK2MaxRuns];
 };
 
-// variant: bits 0-1 select KiB per wave {0:16, 1:8, 2:12}; bit 2 = nontemporal loads
+// variant: bits 0-1 select KiB per wave {0:16, 1:8, 2:12}; bit 2 = nontemporal loads; 13 / 21: bigger workgroups for the table kernels (kernels.hip, variant_wg)
 uint32_t scan_tile_bytes(int tier, int variant, uint32_t n_classes);
 uint32_t scan_min_tile_bytes();
-uint32_t scan_persistent_blocks(int tier, uint32_t n_classes);
+uint32_t scan_persistent_blocks(int tier, int variant, uint32_t n_classes);
 void fill_program(ScanArgs &a, const DevProgram &pg);
 hipError_t launch_scan(int tier, int variant, const ScanArgs &a, uint32_t grid, hipStream_t st);
 bool scan_needs_settle(int tier, const DevProgram &pg);

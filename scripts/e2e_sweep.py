@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--streams", default="1,2")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--extra-env", default="", help="';'-separated sets of K=V,K=V run at the first combination in addition (cfg2 only)")
     a = ap.parse_args()
     combos = [(b, r, c, {}) for b, r, c in itertools.product([int(x) for x in a.blocks.split(",")], [int(x) for x in a.readers.split(",")], [int(x) for x in a.streams.split(",")])]
     cores = ref_cores()
@@ -122,6 +123,9 @@ def main():
             mid = combos[len(combos) // 2][:3]
             sweep("cfg2", d, files * (64 << 20), [bin_path(), "-n", str(a.workers), "-r", needle, d], [REF, "-n", str(cores), "-r", needle, d],
                   [mid + ({"GSCAN_NUMA": "0", "GRAB_PIN": "cpu"},), mid + ({"GRAB_PIN": "none", "GSCAN_NUMA": "0"},), mid + ({"GRAB_WALKERS": "1"},)], a.reps)
+            for spec in [x for x in a.extra_env.split(";") if x]:
+                extra = dict(kv.split("=", 1) for kv in spec.split(","))
+                sweep("cfg2", d, files * (64 << 20), [bin_path(), "-n", str(a.workers), "-r", needle, d], [REF, "-n", str(cores), "-r", needle, d], [combos[0][:3] + (extra,)], a.reps)
             sweep("cfg2-n16", d, files * (64 << 20), [bin_path(), "-n", "16", "-r", needle, d], [REF, "-n", str(cores), "-r", needle, d], [mid + ({},)], a.reps)
             shutil.rmtree(d, ignore_errors=True)
         if a.small_gib:

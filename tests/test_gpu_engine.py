@@ -73,7 +73,8 @@ def sample(n, seed):
     buf = synth.text(n, seed % 1000)
     plants = [b"foobardoesnotexist", b"foo", b"Linus", b"linus", b"555-1234", b"abc0123456789", b"a\nc", b"axc",
               b"0123456789abcdef0123456789abcdef", b"ABCDEF012x", b"a 1 b 2 c", b"k7Q,;q", b"acegggggggggggggggggggggggg",
-              b"12345678901234567890", b"abcdefghijklmnopqrstuvwxyz_abcdefghijklmnopqrstuvwxyz", b"eeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeee"]
+              b"12345678901234567890", b"abcdefghijklmnopqrstuvwxyz_abcdefghijklmnopqrstuvwxyz", b"eeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeee",
+              b"0123456789abcdef0123456789abcdabcd", b"a7Q.;x5R,:", b"abefghghghghghghghghghghghghgh", b"ijopabklmn"]
     if n > 400:
         spots = list(rng.integers(0, n - 64, 40)) + [b - d for b in (1024, 4096, 16384, 32768, 65536, 131072) for d in (1, 3, 9, 17, 30) if b < n - 64]
         for i, at in enumerate(spots):
