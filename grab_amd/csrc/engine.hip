@@ -76,6 +76,8 @@ struct IngestCfg {
     int copy_streams;
     bool numa;
     unsigned pin_flags; // hipHostMalloc flags of the staging blocks (GSCAN_PIN_FLAGS: 0 default, 1 non-coherent, 2 write-combined)
+    int shared_copy;    // GSCAN_SHARED_COPY: 0 = every context has copy streams of its own; N = the contexts of a device share N
+    bool slab;          // GSCAN_SLAB: the reader blocks of a device are carved from ONE pinned allocation instead of one each
 };
 const IngestCfg &ingest_cfg()
 {
@@ -92,6 +94,8 @@ const IngestCfg &ingest_cfg()
         if (hw > 0 && v.readers > hw) v.readers = (int)hw;
         v.copy_streams = (int)env("GSCAN_COPY_STREAMS", 2, 1, 4);
         v.numa = env("GSCAN_NUMA", 1, 0, 1) != 0;
+        v.shared_copy = (int)env("GSCAN_SHARED_COPY", 0, 0, 4);
+        v.slab = env("GSCAN_SLAB", 0, 0, 1) != 0;
         const long pf = env("GSCAN_PIN_FLAGS", 0, 0, 2);
         v.pin_flags = pf == 1 ? hipHostMallocNonCoherent : pf == 2 ? hipHostMallocWriteCombined : hipHostMallocDefault;
         return v;
@@ -104,6 +108,7 @@ inline size_t block_bytes() { return ingest_cfg().block; }
 struct PinBlock {
     void *p = nullptr;
     hipEvent_t ev = nullptr;
+    bool from_slab = false;
 };
 
 // One file range on its way to HBM (gscan_submit_fd): its pieces are read by the reader threads; whoever finishes the
@@ -229,6 +234,18 @@ public:
         else cv_tasks_.notify_all();
     }
     int readers() const { return readers_; }
+    // device-wide copy streams (GSCAN_SHARED_COPY): created on first use, destroyed with the pool
+    hipStream_t shared_stream(int k)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        while ((int)shared_.size() <= k) {
+            hipStream_t st = nullptr;
+            (void)hipSetDevice(device_);
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+            shared_.push_back(st);
+        }
+        return shared_[(size_t)k];
+    }
     void report_if_timing()
     {
         if (timing_ && n_pieces_) report();
@@ -288,12 +305,14 @@ private:
         for (PinBlock *b : busy_) free_block(b, true);
         for (PinBlock *b : free_) free_block(b, false);
         for (PinBlock *b : slot_free_) free_block(b, false);
+        for (hipStream_t st : shared_) (void)hipStreamDestroy(st);
+        if (slab_) (void)hipHostFree(slab_);
     }
     void free_block(PinBlock *b, bool wait)
     {
         if (wait) (void)hipEventSynchronize(b->ev);
         if (b->ev) (void)hipEventDestroy(b->ev);
-        if (b->p) (void)hipHostFree(b->p);
+        if (b->p && !b->from_slab) (void)hipHostFree(b->p);
         delete b;
     }
 
@@ -302,6 +321,23 @@ private:
         PinBlock *b = new (std::nothrow) PinBlock();
         if (!b) return nullptr;
         (void)hipSetDevice(device_);
+        if (ingest_cfg().slab) { // one pinned allocation for all the blocks of the device (big pages under the DMA)
+            std::lock_guard<std::mutex> lk(slab_m_);
+            const size_t each = block_bytes() + kPad, total = each * (cap_ + 8);
+            if (!slab_ && hipHostMalloc(&slab_, total, ingest_cfg().pin_flags) != hipSuccess) {
+                (void)hipGetLastError();
+                slab_ = nullptr;
+            }
+            if (slab_ && slab_used_ + each <= total) {
+                b->p = (char *)slab_ + slab_used_;
+                slab_used_ += each;
+                b->from_slab = true;
+                if (hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) == hipSuccess) return b;
+                (void)hipGetLastError();
+                delete b;
+                return nullptr;
+            }
+        }
         if (hipHostMalloc(&b->p, block_bytes() + kPad, ingest_cfg().pin_flags) != hipSuccess ||
             hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
@@ -434,6 +470,10 @@ private:
     std::deque<PinBlock *> busy_;
     std::deque<ReadTask> tasks_;
     std::vector<std::thread> threads_;
+    std::vector<hipStream_t> shared_;
+    std::mutex slab_m_;
+    void *slab_ = nullptr;
+    size_t slab_used_ = 0;
 };
 
 enum SlotState { FREE = 0, ACQUIRED, INFLIGHT };
@@ -493,6 +533,7 @@ struct gscan_ctx {
     hipStream_t copy = nullptr, compute = nullptr;
     hipStream_t copy_x[3] = {nullptr, nullptr, nullptr}; // further copy streams (GSCAN_COPY_STREAMS - 1 of them)
     int n_copy = 1;
+    bool copy_shared = false; // the copy streams belong to the device's Ingest (GSCAN_SHARED_COPY), not to this context
     Ingest *ingest = nullptr;
     Slot slot[GSCAN_SLOTS];
     uint64_t next_seq = 1;
@@ -681,7 +722,7 @@ int slot_build_tiles(gscan_ctx *c, Slot &s, uint32_t tile_bytes)
 int slot_launch(gscan_ctx *c, Slot &s)
 {
     const Database &db = s.db->db;
-    const uint32_t tile_bytes = gscan::scan_tile_bytes(db.tier, c->variant, db.prog.n_classes);
+    const uint32_t tile_bytes = (db.prog.vm_filter ? gscan::scan_tile_bytes_vm() : gscan::scan_tile_bytes(db.tier, c->variant, db.prog.n_classes));
     const bool multi = !s.segs.empty();
     s.n_tiles = multi ? s.tile_first.back() : (uint32_t)((s.len + tile_bytes - 1) / tile_bytes);
     HIPCHK(c, hipMemsetAsync(s.d_counter, 0, kCounterWords * 4, c->compute));
@@ -826,6 +867,7 @@ int gscan_db_info(const gscan_db *db, gscan_info *info)
     info->has_context = (d.dev_pre ? 1 : 0) | (d.dev_post ? 2 : 0);
     info->lines_ok = (int)d.prog.lines_ok;
     info->exact = d.exact ? 1 : 0;
+    info->vm = d.prog.vm_filter ? 1 : 0;
     return GSCAN_OK;
 }
 
@@ -890,11 +932,19 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && cus > 0) c->cus = cus;
     lap("device attribute");
-    if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
     if (hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
-    c->n_copy = ingest_cfg().copy_streams;
-    for (int k = 1; k < c->n_copy; k++)
-        if (hipStreamCreateWithFlags(&c->copy_x[k - 1], hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
+    if (ingest_cfg().shared_copy > 0) {
+        c->copy_shared = true;
+        c->n_copy = ingest_cfg().shared_copy;
+        if (!(c->copy = c->ingest->shared_stream(0))) return bail(GSCAN_EHIP);
+        for (int k = 1; k < c->n_copy; k++)
+            if (!(c->copy_x[k - 1] = c->ingest->shared_stream(k))) return bail(GSCAN_EHIP);
+    } else {
+        if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
+        c->n_copy = ingest_cfg().copy_streams;
+        for (int k = 1; k < c->n_copy; k++)
+            if (hipStreamCreateWithFlags(&c->copy_x[k - 1], hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
+    }
     lap("streams");
     // one pinned allocation for every small host-side buffer of the context (each hipHostMalloc costs about a millisecond)
     const size_t per_slot = 64 + kSpecRecs * 4;
@@ -947,9 +997,11 @@ void gscan_close(gscan_ctx *c)
         hipEventDestroy(e.a);
         hipEventDestroy(e.b);
     }
-    if (c->copy) hipStreamDestroy(c->copy);
-    for (hipStream_t st : c->copy_x)
-        if (st) hipStreamDestroy(st);
+    if (!c->copy_shared) {
+        if (c->copy) hipStreamDestroy(c->copy);
+        for (hipStream_t st : c->copy_x)
+            if (st) hipStreamDestroy(st);
+    }
     if (c->compute) hipStreamDestroy(c->compute);
     if (c->ingest) Ingest::release(c->ingest); // the last context of the device: reader threads joined, pinned pool freed
     delete c;
@@ -1107,7 +1159,7 @@ int gscan_submit_segs(gscan_ctx *c, const gscan_db *db, const void *pinned, cons
     s->no_content = false;
     s->segs.assign(segs, segs + nseg);
     if (nseg == 0) s->segs.push_back({0, 0, 0}); // keeps the chunk on the multi-segment path with one empty segment
-    rc = slot_build_tiles(c, *s, gscan::scan_tile_bytes(db->db.tier, c->variant, db->db.prog.n_classes));
+    rc = slot_build_tiles(c, *s, (db->db.prog.vm_filter ? gscan::scan_tile_bytes_vm() : gscan::scan_tile_bytes(db->db.tier, c->variant, db->db.prog.n_classes)));
     if (rc) return rc;
     if (used) HIPCHK(c, hipMemcpyAsync(s->d_text, pinned, used, hipMemcpyHostToDevice, c->copy));
     HIPCHK(c, hipEventRecord(s->copied, c->copy));
@@ -1342,7 +1394,7 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
     c->dv_stream = st;
     int rc = ensure_prog(c, db, st);
     if (rc) return rc;
-    const uint32_t tile_bytes = gscan::scan_tile_bytes(db->db.tier, c->variant, db->db.prog.n_classes);
+    const uint32_t tile_bytes = (db->db.prog.vm_filter ? gscan::scan_tile_bytes_vm() : gscan::scan_tile_bytes(db->db.tier, c->variant, db->db.prog.n_classes));
     const size_t K = gscan::kShards;
 
     // tile table: rebuilt only when the segment table or the tile size changed

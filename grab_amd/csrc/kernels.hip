@@ -663,7 +663,16 @@ __device__ __forceinline__ uint32_t and_b0_b1(uint32_t x, uint32_t y) // byte 0 
 // NW: waves per workgroup.  8 (512 threads, ITER 12: 4 waves per SIMD) or 12 (768 threads, ITER 8, two workgroups per CU
 // = 6 waves per SIMD within 80 VGPRs: the same 96 KiB tile, fewer bytes in flight per wave, more waves to hide the LDS
 // and HBM latency behind).
-template <int ITER, bool NT, int DEPTH = 4, int NW = 8>
+// VM: the pattern is inexact (its alternatives only say what a match must begin with) and never looks behind the match
+// start: every filter hit is put to the pattern's backtracking VM (vm.h, program in LDS) right here, and a hit at which no
+// match can start is dropped instead of being recorded for the host's matcher (DevProgram::vm_filter).  The text is read with
+// the default cache policy in this form: the VM comes back to it.
+__device__ __noinline__ bool vm_keep_hit_dev(const DevProgram *pg, const VmProg *vm, const uint8_t *seg, uint32_t slen, uint32_t q)
+{
+    return vm_keep_hit(pg, vm, seg, slen, q);
+}
+
+template <int ITER, bool NT, int DEPTH = 4, int NW = 8, bool VM = false>
 __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     // The filter table, one copy PER LANE: entry b of lane l lives at byte address b << 8 | l << 2.  Both fields are whole
@@ -675,6 +684,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
     __shared__ uint8_t s_blen[kK3Buckets];
     __shared__ uint32_t s_cnt[NW];
     __shared__ uint32_t s_base;
+    __shared__ __attribute__((aligned(16))) uint32_t s_vm[VM ? sizeof(VmProg) / 4 : 1];
     constexpr uint32_t kTile = NW * ITER * 1024;
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x / kWave;
@@ -695,6 +705,10 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
         u32x4 *dst = reinterpret_cast<u32x4 *>(s_pos);
         for (uint32_t q = threadIdx.x; q < (uint32_t)(kK3Confirm * 256 / 16); q += NW * 64) dst[q] = src[q];
         if (threadIdx.x < (uint32_t)kK3Buckets) s_blen[threadIdx.x] = a.prog->k3_blen[threadIdx.x];
+        if (VM) {
+            const uint32_t *vsrc = reinterpret_cast<const uint32_t *>(&a.prog->vm);
+            for (uint32_t q = threadIdx.x; q < (uint32_t)(sizeof(VmProg) / 4); q += NW * 64) s_vm[q] = vsrc[q];
+        }
     }
     __syncthreads();
 
@@ -741,7 +755,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                 if (any) { // cold: which positions, bounds, full windows
                     const int pos0 = sub_off + k * 1024 + (int)lane * 16;
                     const uint32_t vm = valid16(pos0, lo, hi);
-                    const bool direct = exact && pos0 + 16 + kK3Depth <= c.slen; // filter == pattern, windows in bounds
+                    const bool direct = !VM && exact && pos0 + 16 + kK3Depth <= c.slen; // filter == pattern, windows in bounds
                     uint32_t hm = 0;
 #pragma unroll
                     for (int j = 0; j < 16; j++) hm |= h[j] ? 1u << j : 0u;
@@ -782,12 +796,15 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                                     ok = p + m <= (uint32_t)c.slen;
                                 }
                             }
+                            // the device's own confirmation: can a match start here (or, for a gapped alternative, along the run
+                            // of repeat bytes that ends here) at all?
+                            if (VM && ok) ok = vm_keep_hit_dev(a.prog, reinterpret_cast<const VmProg *>(s_vm), c.seg, (uint32_t)c.slen, p);
                             if (ok) bits |= 1u << j;
                         }
                     }
                     // keep group starts (within the lane; a superset of them is fine) -- unless hits may still be struck
-                    // out by k3_settle: a real hit must not be dropped for following a false one
-                    if (direct || confirm_exact) bits &= ~(bits << 1);
+                    // out by k3_settle, or have been by the VM: a real hit must not be dropped for following a false one
+                    if (!VM && (direct || confirm_exact)) bits &= ~(bits << 1);
                     hits[k >> 1] |= bits << (16 * (k & 1));
                     cnt += (uint32_t)__popc(bits);
                 }
@@ -982,6 +999,8 @@ static bool k2_pair(const ScanArgs &a) { return a.n_classes <= 2; }
 
 static int variant_wg(int tier, int variant, uint32_t n_classes);
 
+uint32_t scan_tile_bytes_vm() { return 8u * 8u * 1024u; } // K3 with the VM: 8 waves x 8 KiB whatever the variant
+
 uint32_t scan_tile_bytes(int tier, int variant, uint32_t n_classes)
 {
     const int wg = variant_wg(tier, variant, n_classes);
@@ -1039,7 +1058,9 @@ static hipError_t launch_iter(int tier, bool nt, bool wide, int wg, const ScanAr
     dim3 g(grid);
     const TileDesc *tiles = a.tiles;
     if (tier == GSCAN_TIER_BUCKET) {
-        if (wg == 12 && ITER == 8 && nt) { // 768-thread workgroups, two per CU
+        if (a.vm_filter) { // candidates confirmed on the device: one form, whatever the variant
+            hipLaunchKernelGGL((k3_bucket_scan<8, false, 4, 8, true>), g, dim3(kK3WG), 0, st, a, tiles);
+        } else if (wg == 12 && ITER == 8 && nt) { // 768-thread workgroups, two per CU
             if (a.k3_depth == 3) hipLaunchKernelGGL((k3_bucket_scan<ITER == 8 ? 8 : 12, true, 3, 12>), g, dim3(768), 0, st, a, tiles);
             else hipLaunchKernelGGL((k3_bucket_scan<ITER == 8 ? 8 : 12, true, 4, 12>), g, dim3(768), 0, st, a, tiles);
         } else if (a.k3_depth == 3 && ITER == 12 && nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true, ITER == 12 ? 3 : 4>), g, dim3(kK3WG), 0, st, a, tiles);
@@ -1066,6 +1087,7 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
     a.n_classes = pg.n_classes;
     a.nruns = pg.nruns;
     a.k3_off = pg.k3_off;
+    a.vm_filter = pg.vm_filter;
     a.report_shift = pg.report_shift;
     // the filter IS the pattern when every alternative has its own bucket and lies inside the filtered positions
     a.k3_exact = pg.n_alts <= (uint32_t)kK3Buckets && pg.k3_off == 0;
@@ -1107,7 +1129,7 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
 // does the pattern need the second pass?  (the same condition the scan kernel reads as !k3_confirm_exact)
 bool scan_needs_settle(int tier, const DevProgram &pg)
 {
-    return tier == GSCAN_TIER_BUCKET && !pg.k3_confirm_exact;
+    return tier == GSCAN_TIER_BUCKET && !pg.k3_confirm_exact && !pg.vm_filter; // (the VM has already decided every hit)
 }
 
 hipError_t launch_settle(const ScanArgs &a, uint32_t tile_bytes, hipStream_t st)

@@ -528,13 +528,17 @@ struct Walk {
     size_t x;      // next offset to look at
     bool in_group; // x - 1 was a device hit: x may belong to the same group without being listed
     bool first0;   // offset 0 is still to be handed out (see the constructor)
+    bool probe;    // look for unlisted members of a listed hit's group
 
     static constexpr size_t kEnd = SIZE_MAX;
 
     Walk(const Database &db, const uint8_t *c, size_t cl, const uint32_t *st, size_t nst, size_t li0, const uint32_t *tl, size_t ntl, size_t from)
         : d(db), content(c), clen(cl), starts(st), n(nst), li(li0), tails(tl), nt(ntl), ti(0), x(from)
     {
-        in_group = from > 0 && dev_hit(d, content, clen, from - 1);
+        // (a database whose candidates the device has confirmed itself lists EVERY hit it kept -- no group-start compression --
+        // so there is nothing to find between the listed offsets; probing would only dig up what the device has dropped)
+        probe = !d.prog.vm_filter;
+        in_group = probe && from > 0 && dev_hit(d, content, clen, from - 1);
         // device windows with a leading context position start one byte before the offset they report: offset 0 can
         // never be listed.  A walk that starts there has to look at it itself.
         first0 = from == 0 && d.dev_pre;
@@ -559,7 +563,7 @@ struct Walk {
             const size_t c = std::min(a, b);
             if (c == kEnd) return kEnd;
             x = c + 1;
-            in_group = c == a; // a listed offset is a device hit
+            in_group = probe && c == a; // a listed offset is a device hit
             return c;
         }
     }
@@ -744,6 +748,24 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
         if (x >= clen) return 0;
         while (li < n && (size_t)starts[li] < x) li++;
     }
+}
+
+int gscan_vm_verdict(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p)
+{
+    if (!db || !db->db.vm_ok || p < subject_start || (size_t)p > clen || clen > 0xfffffff0u) return -1;
+    return gscan::vm_run(&db->db.prog.vm, (const uint8_t *)content, (uint32_t)clen, p, subject_start);
+}
+
+long gscan_vm_filter(const gscan_db *db, const void *content, size_t clen, const uint32_t *hits, size_t n, uint32_t *kept)
+{
+    if (!db || !db->db.prog.vm_filter || (!hits && n) || clen > 0xfffffff0u) return -1;
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++)
+        if (gscan::vm_keep_hit(&db->db.prog, &db->db.prog.vm, (const uint8_t *)content, (uint32_t)clen, hits[i])) {
+            if (kept) kept[k] = hits[i];
+            k++;
+        }
+    return (long)k;
 }
 
 int gscan_db_dev_window(const gscan_db *db, int alt, int pos, uint8_t table[256], int *len, int *shift)

@@ -1933,6 +1933,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     db.tree = std::make_shared<Node>(std::move(root));
     db.id = g_next_id.fetch_add(1);
     memset(&db.prog, 0, sizeof db.prog);
+    db.vm_ok = vm_compile(*db.tree, db.n_groups, db.has_backref, db.prog.vm); // the tree as a program for the device's VM (vm.h)
 
     const size_t minm = pcre_min;
     if (seqs.empty()) { // no path can ever match (a\\Ab, x^y ...): pcre_exec finds nothing, and neither is there anything to scan for
@@ -2057,6 +2058,10 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             pg.alt_bucket[i] = (uint8_t)(i % kK3Buckets);
             memcpy(pg.alt_window + at, w.data(), w.size());
             at += w.size();
+            // (a gapped alternative's device window begins with its repeat byte, behind a context position if there is one)
+            const AltSeq &alt = db.alts[i];
+            pg.alt_gap_cls[i] = alt.gapped && !db.dev_pre && !w.empty() ? w[0] : (uint8_t)0xff;
+            pg.alt_plen[i] = (uint16_t)alt.pwindow.size();
         }
     }
     if (!can_hit) { // ^foo, foo$ and the like: a match can only sit at the subject start / chunk end, which is the host's job
@@ -2127,8 +2132,13 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         }
     }
 
+    // Inexact patterns: the device confirms its own candidates with the VM (vm.h) where one verdict per offset serves every
+    // restart position, i.e. the pattern never looks behind the match start.  That is K3's cold path.
+    const bool vm_dev = !db.exact && db.vm_ok && !db.dev_pre && vm_independent_of_subject_start(*db.tree) && !getenv("GSCAN_NO_VM");
+
     if (db.alts.size() > 1) { // several alternatives: the bucket filter is the one kernel that takes them
         db.tier = GSCAN_TIER_BUCKET;
+        pg.vm_filter = vm_dev;
         return 0;
     }
 
@@ -2201,6 +2211,12 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         db.tier = GSCAN_TIER_CLASSRUN;
     else
         db.tier = GSCAN_TIER_BUCKET;
+    // (a single-alternative pattern that would have gone to K2 goes to K3 for the VM; a literal anchor of 3+ bytes hits
+    // rarely enough for the host: K1 stays)
+    if (vm_dev && db.tier != GSCAN_TIER_LITERAL) {
+        pg.vm_filter = 1;
+        db.tier = GSCAN_TIER_BUCKET;
+    }
     return 0;
 }
 

@@ -29,6 +29,8 @@
 #include <string>
 #include <vector>
 
+#include "vm.h"
+
 namespace gscan {
 
 struct ByteSet {
@@ -139,6 +141,13 @@ struct DevProgram {
     uint32_t tail_bits[8];
     uint32_t tail_extra;                 // 0: no tail
     uint32_t lines_ok;                   // one plain alternative, no context, and no class of it contains a newline
+    // Candidates confirmed on the device (vm.h): K3 runs the pattern's VM program at every filter hit and drops the hits at
+    // which no match can start.  For a gapped alternative the hit is the LAST byte of its unbounded repeat (device window =
+    // repeat byte + the rest): the possible starts are walked back along the run of repeat bytes.
+    uint32_t vm_filter;                  // 1: on
+    uint8_t alt_gap_cls[kMaxAlts];       // class id of a gapped alternative's repeat byte; 0xff: a plain alternative
+    uint16_t alt_plen[kMaxAlts];         // gapped: length of the fixed part in front of the repeat
+    VmProg vm;
 };
 
 // One alternative: a fixed class window + an optional variable repeat of one class at its end.
@@ -196,7 +205,49 @@ struct Database {
     std::vector<std::vector<uint8_t>> dev_windows; // class ids, per alternative
     DevProgram prog;
     uint64_t id = 0; // unique per compile; contexts key their device copy on it
+    bool vm_ok = false; // prog.vm holds the tree as a VM program (vm.h): gscan_vm_verdict works; prog.vm_filter says whether the device uses it
 };
+
+// vm_compile.cc
+bool vm_compile(const Node &root, int n_groups, bool has_backref, VmProg &out);
+bool vm_independent_of_subject_start(const Node &root);
+
+// Keep the device hit at q (the start of some alternative's device window)?  false only if NO match can start there: at q
+// itself for the plain alternatives, anywhere along the run of repeat bytes that ends at q for a gapped one.  Shared by
+// the K3 kernel and the host (gscan_vm_filter, tests).
+GSCAN_HD inline bool vm_keep_hit(const DevProgram *pg, const VmProg *vm, const uint8_t *seg, uint32_t slen, uint32_t q)
+{
+    if (vm_run(vm, seg, slen, q, 0) != 0) return true;
+    const uint32_t n = pg->n_alts;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t gc = pg->alt_gap_cls[i];
+        if (gc == 0xffu) continue;
+        const uint32_t m = pg->alt_len[i];
+        if (q + m > slen) continue;
+        const uint8_t *w = pg->alt_window + pg->alt_off[i];
+        uint32_t k = 0;
+        for (; k < m; k++) {
+            const uint32_t b = seg[q + k];
+            if (!((pg->cls_bits[w[k]][b >> 5] >> (b & 31)) & 1u)) break;
+        }
+        if (k < m) continue;
+        // the run of repeat bytes that ends at q reaches back to r0; a match of this alternative starts plen bytes in
+        // front of a position of that run
+        uint32_t r0 = q, walked = 0;
+        while (r0 > 0) {
+            const uint32_t b = seg[r0 - 1];
+            if (!((pg->cls_bits[gc][b >> 5] >> (b & 31)) & 1u)) break;
+            r0--;
+            if (++walked > 255u) return true; // a long run: the host looks at it
+        }
+        const uint32_t plen = pg->alt_plen[i];
+        for (uint32_t g = r0; g <= q; g++) {
+            if (g < plen || g - plen == q) continue;
+            if (vm_run(vm, seg, slen, g - plen, 0) != 0) return true;
+        }
+    }
+    return false;
+}
 
 // rc: 0 ok, 1 unsupported, -1 malformed.  `why` gets a short reason.
 int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, std::string &why);

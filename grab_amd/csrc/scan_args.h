@@ -37,6 +37,7 @@ struct ScanArgs {
     uint32_t anchor, anchor_mask, anchor_off, anchor_len; // K1
     uint32_t n_classes, nruns;                            // K2
     uint32_t k3_off, k3_exact, k3_depth;                  // K3 (k3_depth: 3 or 4 filter positions)
+    uint32_t vm_filter;                                   // K3: every filter hit is put to the VM (DevProgram::vm_filter)
     uint32_t report_shift;   // reported offset = device window start + this (1 when the windows carry a leading context position)
     uint32_t run_desc[kK2MaxRuns];                        // K2: cls | len<<8 | off<<16
     // K2, windows of <= 17 bytes: the run's shift program, decoded on the host -- cls @0, then the shift amounts of the
@@ -47,6 +48,7 @@ struct ScanArgs {
 
 // variant: bits 0-1 select KiB per wave {0:16, 1:8, 2:12}; bit 2 = nontemporal loads; 13 / 21: bigger workgroups for the table kernels (kernels.hip, variant_wg)
 uint32_t scan_tile_bytes(int tier, int variant, uint32_t n_classes);
+uint32_t scan_tile_bytes_vm();
 uint32_t scan_min_tile_bytes();
 uint32_t scan_persistent_blocks(int tier, int variant, uint32_t n_classes);
 void fill_program(ScanArgs &a, const DevProgram &pg);

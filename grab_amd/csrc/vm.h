@@ -1,0 +1,336 @@
+// vm.h -- a small backtracking regex VM that runs on the DEVICE (and, same source, on the host for its tests).
+//
+// What it is for (task 7; DESIGN.md 2 "Beyond the unfoldable subset"): for patterns whose alternatives only
+// say what a match must BEGIN with (gscan_info.exact == 0) the kernels used to list every such offset and the host's
+// backtracking matcher (matcher.cc, TreeMatch) was asked at each of them -- one CPU thread per worker in front of a
+// common prefix.  With this VM the scan kernel asks the question itself, per candidate, before it writes the record:
+// the parse tree is compiled into a short program (vm_compile, pattern.cc) and run AT the candidate offset; a candidate
+// at which the program finds no match is dropped on the device and never reaches the host.
+//
+// The VM is a FILTER, not the judge: it answers  0 = no match starts at p,  1 = a match starts at p,  2 = gave up
+// (step or stack limit, anything it is not sure about) -- and only 0 drops a candidate.  For everything that is kept the
+// host's matcher still decides the match end, the reported start (\K) and the one-pair ovector rule (src/grab.cc:171,179)
+// as before.  So the VM has to be SOUND in one direction only: never say 0 where TreeMatch finds a match.  It follows
+// TreeMatch's order of exploration construct by construct (alternatives left to right, greedy longest first, lazy shortest
+// first, possessive / atomic / look-around bodies matched once and cut, the empty-iteration rule of unbounded group
+// repeats, captures restored on backtracking), which is PCRE's; tests/test_vm.py checks verdict against TreeMatch and
+// libpcre offset by offset on random patterns.
+//
+// Device use is limited to patterns that never look BEHIND the match start (no ^ \A \b \B (?m)^ look-behind): then "a
+// match starts at p" does not depend on where the reference restarted pcre_exec and one verdict per
+// offset serves every restart position.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GSCAN_HD __host__ __device__
+#else
+#define GSCAN_HD
+#endif
+
+namespace gscan {
+
+constexpr int kVmMaxIns = 192;   // instructions per program
+constexpr int kVmMaxCls = 32;    // byte classes per program
+constexpr int kVmMaxSlots = 40;  // capture offsets (3 per group) + repeat counters and iteration marks
+constexpr int kVmStack = 80;     // backtrack entries (2 words each) per attempt
+constexpr uint32_t kVmMaxSteps = 1536;
+constexpr uint32_t kVmUnset = 0xffffffffu;
+constexpr uint32_t kVmInf = 0xffffffffu;
+
+enum : uint32_t {
+    V_SET = 1,     // a: class                                   one byte of the class
+    V_REPSET,      // a: class, b: min, c: max; op bits 8-9: mode  a repeat of one class (0 greedy, 1 lazy, 2 possessive)
+    V_JMP,         // a: pc
+    V_SPLIT,       // a: pc tried first, b: pc tried second
+    V_SAVE,        // a: slot                                    slot = pos (undone on backtracking)
+    V_CLOSE,       // a: first capture slot of the group, b: slot holding its start   a capturing group closes
+    V_REP_ENTER,   // a: counter slot                            a repeated group is entered: counter = 0
+    V_REP_TOP,     // a: counter slot, b: min, c: max; op bits 8-9: mode, bits 16-31: exit pc; the body starts at pc + 1
+    V_REP_END,     // a: counter slot, b: mark slot, c: min; op bit 8: unbounded, bits 16-31: pc of the REP_TOP
+    V_ASSERT,      // a: A_* code
+    V_BACKREF,     // a: first capture slot of the group; op bit 8: caseless
+    V_BAR_BEGIN,   // op bits 8-9: 0 atomic group, 1 positive look-around, 2 negative; bits 16-31: pc behind the matching BAR_END
+    V_BAR_END,     // op bits 8-9: the same
+    V_BACK,        // a: length                                  look-behind: step back (fails in front of the subject start)
+    V_MATCH,
+    V_FAIL,
+};
+
+struct VmIns {
+    uint32_t op, a, b, c;
+};
+
+struct VmProg {
+    uint32_t n_ins, n_slots, n_cls, ok; // ok: the pattern compiled into a program within the limits
+    VmIns ins[kVmMaxIns];
+    uint32_t cls[kVmMaxCls][8];
+};
+
+// backtrack stack entry kinds (low 4 bits of word 0; the rest of word 0 is the payload, word 1 a value)
+enum : uint32_t {
+    VK_CHOICE = 1, // payload: pc, value: pos
+    VK_UNDO,       // payload: slot, value: old content
+    VK_RANGE_DN,   // header of a 2-entry frame; payload: pc to continue at; the entry below holds {lo, cur}: give back one byte at a time
+    VK_RANGE_UP,   // the same, taking one more byte at a time: {hi, cur}
+    VK_BAR,        // payload: kind (2 bits) | pc behind the group << 2, value: pos where the group began
+    VK_DEAD,       // a choice point that an atomic group / look-around has cut
+    VK_DEAD2,      // ... a 2-entry one
+};
+
+GSCAN_HD inline bool vm_is_word(uint32_t b) { return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_'; }
+GSCAN_HD inline uint32_t vm_lower(uint32_t b) { return b >= 'A' && b <= 'Z' ? b + 32 : b; }
+
+// Assertion codes: pattern.h (A_BOS = 1 ... A_KEEP = 8).  s0: the subject start -- nothing lies before it.
+GSCAN_HD inline bool vm_holds(uint32_t code, const uint8_t *c, uint32_t clen, uint32_t s0, uint32_t pos)
+{
+    switch (code) {
+    case 1: return pos == s0;                                                        // A_BOS
+    case 2: return pos == s0 || (pos > s0 && c[pos - 1] == '\n' && pos < clen);      // A_MBOL
+    case 3: return pos == clen || (c[pos] == '\n' && pos + 1 == clen);               // A_EOL
+    case 4: return pos == clen || c[pos] == '\n';                                    // A_MEOL
+    case 5: return pos == clen;                                                      // A_EOS
+    case 6:
+    case 7: {                                                                        // A_WB, A_NWB
+        const bool l = pos > s0 && vm_is_word(c[pos - 1]), r = pos < clen && vm_is_word(c[pos]);
+        return (l != r) == (code == 6);
+    }
+    case 8: return true;                                                             // A_KEEP: where the match is REPORTED to start is the host's business
+    }
+    return false;
+}
+
+// 0: no match starts at p;  1: a match starts at p;  2: gave up.  c[0..clen) is the chunk (segment), s0 its subject start.
+GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, uint32_t p, uint32_t s0)
+{
+    uint32_t slots[kVmMaxSlots];
+    uint32_t stk[2 * kVmStack];
+    const uint32_t n_slots = pg->n_slots;
+    for (uint32_t i = 0; i < n_slots; i++) slots[i] = kVmUnset;
+    uint32_t sp = 0, pc = 0, pos = p, steps = 0;
+
+#define VM_PUSH(w0_, w1_)                      \
+    do {                                       \
+        if (sp >= (uint32_t)kVmStack) return 2; \
+        stk[2 * sp] = (w0_);                   \
+        stk[2 * sp + 1] = (w1_);               \
+        sp++;                                  \
+    } while (0)
+#define VM_TEST(cls_, b_) ((pg->cls[(cls_)][(b_) >> 5] >> ((b_) & 31)) & 1u)
+
+    for (;;) {
+        bool fail = false;
+        if (++steps > kVmMaxSteps) return 2;
+        const VmIns in = pg->ins[pc];
+        switch (in.op & 0xffu) {
+        case V_SET:
+            if (pos < clen && VM_TEST(in.a, (uint32_t)c[pos])) pos++, pc++;
+            else fail = true;
+            break;
+        case V_REPSET: {
+            const uint32_t mode = (in.op >> 8) & 3u;
+            uint32_t k = 0;
+            while (k < in.c && pos + k < clen && VM_TEST(in.a, (uint32_t)c[pos + k])) k++;
+            steps += k >> 3;
+            if (k < in.b) {
+                fail = true;
+                break;
+            }
+            if (mode == 0) { // greedy: all of it, give back one at a time
+                if (k > in.b) {
+                    VM_PUSH(pos + in.b, pos + k);
+                    VM_PUSH(VK_RANGE_DN | ((pc + 1) << 4), 0u);
+                }
+                pos += k;
+            } else if (mode == 1) { // lazy: the minimum, take one more at a time
+                if (k > in.b) {
+                    VM_PUSH(pos + k, pos + in.b);
+                    VM_PUSH(VK_RANGE_UP | ((pc + 1) << 4), 0u);
+                }
+                pos += in.b;
+            } else {
+                pos += k;
+            }
+            pc++;
+            break;
+        }
+        case V_JMP: pc = in.a; break;
+        case V_SPLIT:
+            VM_PUSH(VK_CHOICE | (in.b << 4), pos);
+            pc = in.a;
+            break;
+        case V_SAVE:
+            VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
+            slots[in.a] = pos;
+            pc++;
+            break;
+        case V_CLOSE:
+            VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
+            VM_PUSH(VK_UNDO | ((in.a + 1) << 4), slots[in.a + 1]);
+            slots[in.a] = slots[in.b];
+            slots[in.a + 1] = pos;
+            pc++;
+            break;
+        case V_REP_ENTER:
+            VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
+            slots[in.a] = 0;
+            pc++;
+            break;
+        case V_REP_TOP: {
+            const uint32_t mode = (in.op >> 8) & 3u, exit_pc = in.op >> 16, count = slots[in.a];
+            const bool can_more = count < in.c, can_stop = count >= in.b;
+            if (mode == 1) { // lazy: stop first
+                if (can_stop) {
+                    if (can_more) VM_PUSH(VK_CHOICE | ((pc + 1) << 4), pos);
+                    pc = exit_pc;
+                } else if (can_more) {
+                    pc++;
+                } else {
+                    fail = true;
+                }
+            } else {
+                if (can_more) {
+                    if (can_stop) VM_PUSH(VK_CHOICE | (exit_pc << 4), pos);
+                    pc++;
+                } else if (can_stop) {
+                    pc = exit_pc;
+                } else {
+                    fail = true;
+                }
+            }
+            break;
+        }
+        case V_REP_END: {
+            const uint32_t top = in.op >> 16, count = slots[in.a] + 1;
+            VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
+            slots[in.a] = count;
+            // an iteration of the UNBOUNDED part that matched "" leaves the loop (PCRE's OP_KETRMAX rule; TreeMatch, Cont::REPG)
+            if (pos == slots[in.b] && ((in.op >> 8) & 1u) && count >= in.c) pc = pg->ins[top].op >> 16;
+            else pc = top;
+            break;
+        }
+        case V_ASSERT:
+            if (vm_holds(in.a, c, clen, s0, pos)) pc++;
+            else fail = true;
+            break;
+        case V_BACKREF: {
+            const uint32_t lo = slots[in.a], hi = slots[in.a + 1];
+            if (lo == kVmUnset || hi == kVmUnset || hi < lo) { // a reference to a group that has not been set fails
+                fail = true;
+                break;
+            }
+            const uint32_t len = hi - lo;
+            if (pos + len > clen) {
+                fail = true;
+                break;
+            }
+            steps += len >> 2;
+            const bool icase = (in.op >> 8) & 1u;
+            for (uint32_t q = 0; q < len; q++) {
+                const uint32_t x = c[lo + q], y = c[pos + q];
+                if (icase ? vm_lower(x) != vm_lower(y) : x != y) {
+                    fail = true;
+                    break;
+                }
+            }
+            if (!fail) pos += len, pc++;
+            break;
+        }
+        case V_BAR_BEGIN:
+            VM_PUSH(VK_BAR | (((in.op >> 8) & 3u) << 4) | ((in.op >> 16) << 6), pos);
+            pc++;
+            break;
+        case V_BAR_END: {
+            const uint32_t kind = (in.op >> 8) & 3u;
+            if (kind == 2) { // the body of a NEGATIVE look-around matched: the assertion fails; what the body captured is undone
+                for (;;) {
+                    if (sp == 0) return 2;
+                    sp--;
+                    const uint32_t w0 = stk[2 * sp], k = w0 & 15u;
+                    if (k == VK_UNDO) slots[w0 >> 4] = stk[2 * sp + 1];
+                    else if (k == VK_RANGE_DN || k == VK_RANGE_UP || k == VK_DEAD2) sp--;
+                    else if (k == VK_BAR) break;
+                }
+                fail = true;
+                break;
+            }
+            // atomic group / positive look-around matched: no way back into it -- its choice points die, its undo records stay
+            uint32_t i = sp;
+            for (;;) {
+                if (i == 0) return 2;
+                i--;
+                const uint32_t w0 = stk[2 * i], k = w0 & 15u;
+                if (k == VK_CHOICE) stk[2 * i] = VK_DEAD;
+                else if (k == VK_RANGE_DN || k == VK_RANGE_UP) {
+                    stk[2 * i] = VK_DEAD2;
+                    i--;
+                } else if (k == VK_DEAD2) {
+                    i--;
+                } else if (k == VK_BAR) {
+                    if (kind == 1) pos = stk[2 * i + 1]; // an assertion consumes nothing
+                    stk[2 * i] = VK_DEAD;
+                    break;
+                }
+            }
+            pc++;
+            break;
+        }
+        case V_BACK:
+            if (pos >= s0 + in.a) pos -= in.a, pc++;
+            else fail = true;
+            break;
+        case V_MATCH:
+            return 1; // (an empty match AT p is "no match" for tree_match_at; such a candidate is simply kept)
+        default: // V_FAIL and anything unknown
+            fail = true;
+            break;
+        }
+        while (fail) { // backtrack
+            if (sp == 0) return 0;
+            sp--;
+            const uint32_t w0 = stk[2 * sp], w1 = stk[2 * sp + 1], k = w0 & 15u;
+            if (k == VK_CHOICE) {
+                pc = w0 >> 4;
+                pos = w1;
+                fail = false;
+            } else if (k == VK_UNDO) {
+                slots[w0 >> 4] = w1;
+            } else if (k == VK_RANGE_DN) { // the entry below: {lo, cur}
+                const uint32_t lo = stk[2 * (sp - 1)], cur = stk[2 * (sp - 1) + 1] - 1;
+                pos = cur;
+                pc = w0 >> 4;
+                if (cur > lo) {
+                    stk[2 * (sp - 1) + 1] = cur;
+                    sp++; // the frame stays
+                } else {
+                    sp--;
+                }
+                fail = false;
+            } else if (k == VK_RANGE_UP) { // {hi, cur}
+                const uint32_t hi = stk[2 * (sp - 1)], cur = stk[2 * (sp - 1) + 1] + 1;
+                pos = cur;
+                pc = w0 >> 4;
+                if (cur < hi) {
+                    stk[2 * (sp - 1) + 1] = cur;
+                    sp++;
+                } else {
+                    sp--;
+                }
+                fail = false;
+            } else if (k == VK_BAR) {
+                if (((w0 >> 4) & 3u) == 2) { // the body of a negative look-around found no match: the assertion holds
+                    pos = w1;
+                    pc = w0 >> 6;
+                    fail = false;
+                } // else: an atomic group / positive look-around that cannot match -- keep failing
+            } else if (k == VK_DEAD2) {
+                sp--;
+            } // VK_DEAD: skip
+            if (!fail && ++steps > kVmMaxSteps) return 2;
+        }
+    }
+#undef VM_PUSH
+#undef VM_TEST
+}
+
+} // namespace gscan

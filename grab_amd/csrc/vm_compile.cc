@@ -1,0 +1,240 @@
+// vm_compile.cc -- the parse tree (pattern.h, Node) as a program for the backtracking VM of vm.h.
+//
+// Construct by construct this mirrors TreeMatch (matcher.cc), the host's authority on "the match AT an offset", so that
+// the VM explores the same paths in the same order:
+//   CAT            its items in sequence; a capturing group records its span when it CLOSES (start kept in a temporary slot)
+//   ALT            SPLIT chain, left to right
+//   REP of a class one V_REPSET (a loop over counts: longest first when greedy, shortest first when lazy, all of it when
+//                  possessive)
+//   REP of a group counter + iteration mark in slots; V_REP_TOP decides "one more or leave" the way rep_group does, V_REP_END
+//                  applies the empty-iteration rule of the unbounded part; a possessive one is the greedy one inside an
+//                  atomic bracket
+//   LOOK / ATOMIC  a barrier on the backtrack stack: the body is matched to its first success, then its choice points are
+//                  cut; a look-behind steps back by the fixed length of each of its top-level alternatives
+//   BACKREF        compares with what the group captured (fails while the group is unset)
+//   \K             nothing: where the match is reported to start is the host's business
+#include <cstring>
+#include <vector>
+
+#include "pattern.h"
+#include "vm.h"
+
+namespace gscan {
+
+namespace {
+
+struct Builder {
+    VmProg &pg;
+    bool ok = true;
+    bool use_caps;
+    int n_groups;
+    uint32_t next_slot;
+
+    Builder(VmProg &p, int groups, bool caps) : pg(p), use_caps(caps), n_groups(groups)
+    {
+        memset(&pg, 0, sizeof pg);
+        // slots: [2g, 2g+1] what group g captured (g = 1 ..), [2 (n+1) + g] where it was entered
+        next_slot = caps ? (uint32_t)(3 * (groups + 1)) : 0u;
+        if (next_slot > (uint32_t)kVmMaxSlots) ok = false;
+    }
+    uint32_t cap_slot(int g) const { return 2u * (uint32_t)g; }
+    uint32_t tmp_slot(int g) const { return 2u * (uint32_t)(n_groups + 1) + (uint32_t)g; }
+    uint32_t new_slot()
+    {
+        if (next_slot >= (uint32_t)kVmMaxSlots) {
+            ok = false;
+            return 0;
+        }
+        return next_slot++;
+    }
+    uint32_t emit(uint32_t op, uint32_t a = 0, uint32_t b = 0, uint32_t c = 0)
+    {
+        if (pg.n_ins >= (uint32_t)kVmMaxIns) {
+            ok = false;
+            return 0;
+        }
+        pg.ins[pg.n_ins] = {op, a, b, c};
+        return pg.n_ins++;
+    }
+    uint32_t here() const { return pg.n_ins; }
+    uint32_t cls_id(const ByteSet &s)
+    {
+        for (uint32_t i = 0; i < pg.n_cls; i++)
+            if (!memcmp(pg.cls[i], s.w, sizeof s.w)) return i;
+        if (pg.n_cls >= (uint32_t)kVmMaxCls) {
+            ok = false;
+            return 0;
+        }
+        memcpy(pg.cls[pg.n_cls], s.w, sizeof s.w);
+        return pg.n_cls++;
+    }
+
+    // the fixed length of a look-behind alternative (TreeMatch::look_len)
+    static long look_len(const Node &nd)
+    {
+        switch (nd.kind) {
+        case Node::SET: return 1;
+        case Node::ASSERT:
+        case Node::LOOK: return 0;
+        case Node::BACKREF: return -1;
+        case Node::ATOMIC: return look_len(nd.kids[0]);
+        case Node::CAT: {
+            long t = 0;
+            for (const Node &k : nd.kids) {
+                const long l = look_len(k);
+                if (l < 0) return -1;
+                t += l;
+            }
+            return t;
+        }
+        case Node::ALT: return nd.kids.empty() ? 0 : look_len(nd.kids[0]);
+        case Node::REP: {
+            const long l = look_len(nd.kids[0]);
+            return l < 0 || nd.min != nd.max ? -1 : l * (long)nd.min;
+        }
+        }
+        return -1;
+    }
+
+    void group_repeat(const Node &n, int mode)
+    {
+        const uint32_t cnt = new_slot(), mark = new_slot();
+        emit(V_REP_ENTER, cnt);
+        const uint32_t top = emit(V_REP_TOP | ((uint32_t)mode << 8), cnt, n.min, n.max);
+        emit(V_SAVE, mark);
+        gen(n.kids[0]);
+        emit(V_REP_END | ((n.max == kVmInf ? 1u : 0u) << 8) | (top << 16), cnt, mark, n.min);
+        if (here() > 0xffffu) ok = false;
+        if (ok) pg.ins[top].op |= here() << 16; // the exit
+    }
+
+    void behind_alt(const Node &alt)
+    {
+        const long len = look_len(alt);
+        if (len < 0) {
+            emit(V_FAIL);
+            return;
+        }
+        if (len > 0) emit(V_BACK, (uint32_t)len);
+        gen(alt);
+    }
+
+    void alternatives(const std::vector<const Node *> &kids, bool behind)
+    {
+        std::vector<uint32_t> jumps;
+        for (size_t i = 0; i < kids.size(); i++) {
+            uint32_t split = 0;
+            const bool last = i + 1 == kids.size();
+            if (!last) split = emit(V_SPLIT, here() + 1, 0);
+            if (behind) behind_alt(*kids[i]);
+            else gen(*kids[i]);
+            if (!last) {
+                jumps.push_back(emit(V_JMP, 0));
+                if (ok) pg.ins[split].b = here();
+            }
+        }
+        for (uint32_t j : jumps)
+            if (ok) pg.ins[j].a = here();
+    }
+
+    void gen(const Node &n)
+    {
+        if (!ok) return;
+        switch (n.kind) {
+        case Node::SET: emit(V_SET, cls_id(n.set)); break;
+        case Node::CAT: {
+            const bool cap = use_caps && n.cap && n.group > 0 && n.group <= n_groups;
+            if (cap) emit(V_SAVE, tmp_slot(n.group));
+            for (const Node &k : n.kids) gen(k);
+            if (cap) emit(V_CLOSE, cap_slot(n.group), tmp_slot(n.group));
+            break;
+        }
+        case Node::ALT: {
+            std::vector<const Node *> kids;
+            for (const Node &k : n.kids) kids.push_back(&k);
+            if (kids.empty()) break;
+            alternatives(kids, false);
+            break;
+        }
+        case Node::REP: {
+            if (n.max == 0) break;
+            const Node &kid = n.kids[0];
+            if (kid.kind == Node::SET) {
+                emit(V_REPSET | ((uint32_t)n.mode << 8), cls_id(kid.set), n.min, n.max);
+                break;
+            }
+            if (n.mode == 2) { // possessive: the greedy repeat matched on its own, never re-entered
+                const uint32_t b = emit(V_BAR_BEGIN | (0u << 8));
+                group_repeat(n, 0);
+                emit(V_BAR_END | (0u << 8));
+                if (ok) pg.ins[b].op |= here() << 16;
+                break;
+            }
+            group_repeat(n, n.mode);
+            break;
+        }
+        case Node::ASSERT:
+            if (n.acode != A_KEEP) emit(V_ASSERT, (uint32_t)n.acode);
+            break;
+        case Node::LOOK: {
+            const uint32_t kind = n.neg ? 2u : 1u;
+            const uint32_t b = emit(V_BAR_BEGIN | (kind << 8));
+            const Node &body = n.kids[0];
+            if (!n.behind) {
+                gen(body);
+            } else if (body.kind == Node::ALT) {
+                std::vector<const Node *> kids;
+                for (const Node &k : body.kids) kids.push_back(&k);
+                alternatives(kids, true);
+            } else {
+                behind_alt(body);
+            }
+            emit(V_BAR_END | (kind << 8));
+            if (here() > 0xffffu) ok = false;
+            if (ok) pg.ins[b].op |= here() << 16; // where a NEGATIVE assertion goes on when its body finds no match
+            break;
+        }
+        case Node::ATOMIC: {
+            const uint32_t b = emit(V_BAR_BEGIN | (0u << 8));
+            gen(n.kids[0]);
+            emit(V_BAR_END | (0u << 8));
+            if (ok) pg.ins[b].op |= here() << 16;
+            break;
+        }
+        case Node::BACKREF:
+            if (!use_caps || n.group <= 0 || n.group > n_groups) {
+                emit(V_FAIL); // (a reference with no captures kept can only fail: TreeMatch, `if (!caps) return false`)
+                break;
+            }
+            emit(V_BACKREF | ((n.icase ? 1u : 0u) << 8), cap_slot(n.group));
+            break;
+        }
+    }
+};
+
+bool looks_behind(const Node &n)
+{
+    if (n.kind == Node::ASSERT && (n.acode == A_BOS || n.acode == A_MBOL || n.acode == A_WB || n.acode == A_NWB)) return true;
+    if (n.kind == Node::LOOK && n.behind) return true;
+    for (const Node &k : n.kids)
+        if (looks_behind(k)) return true;
+    return false;
+}
+
+} // namespace
+
+// The tree as a VM program; false if it does not fit the VM's limits (the pattern then stays with the host matcher).
+bool vm_compile(const Node &root, int n_groups, bool has_backref, VmProg &out)
+{
+    Builder b(out, n_groups, has_backref);
+    b.gen(root);
+    b.emit(V_MATCH);
+    out.n_slots = b.next_slot;
+    out.ok = b.ok ? 1u : 0u;
+    return b.ok;
+}
+
+// May the device drop candidates on the VM's verdict?  Only if "a match starts at p" does not depend on the restart position.
+bool vm_independent_of_subject_start(const Node &root) { return !looks_behind(root); }
+
+} // namespace gscan

@@ -25,13 +25,14 @@ SYMBOLS = [
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
     "gscan_set_option", "gscan_kernel_time", "gscan_resource_errors",
     "gscan_ingest_info", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
+    "gscan_vm_verdict", "gscan_vm_filter",
 ]
 
 
 class Info(C.Structure):
     _fields_ = [("tier", C.c_int), ("minlen", C.c_int), ("n_classes", C.c_int), ("has_tail", C.c_int),
                 ("tail_extra", C.c_uint32), ("anchor_off", C.c_int), ("anchor_len", C.c_int),
-                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int), ("lines_ok", C.c_int), ("exact", C.c_int)]
+                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int), ("lines_ok", C.c_int), ("exact", C.c_int), ("vm", C.c_int)]
 
 
 class Cursor(C.Structure):
@@ -117,6 +118,9 @@ def lib():
         L.gscan_pci_cpulist.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
         L.gscan_parse_cpulist.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_size_t]
         L.gscan_parse_cpulist.restype = C.c_long
+        L.gscan_vm_verdict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]
+        L.gscan_vm_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gscan_vm_filter.restype = C.c_long
         _lib = L
     return _lib
 
@@ -189,6 +193,21 @@ class Database:
         m0, m1 = C.c_uint32(), C.c_uint32()
         rc = lib().gscan_next_match(self._h, buf.ctypes.data, buf.size, st.ctypes.data, st.size, C.byref(cursor), s, C.byref(m0), C.byref(m1))
         return int(rc), m0.value, m1.value
+
+    def vm_verdict(self, content, p, subject_start=0):
+        """The device VM's answer AT p, run on the host: 0 no match starts at p, 1 one does, 2 gave up, -1 no VM program."""
+        buf = np.frombuffer(content, np.uint8)
+        return int(lib().gscan_vm_verdict(self._h, buf.ctypes.data, buf.size, subject_start, p))
+
+    def vm_filter(self, content, hits):
+        """What K3 does with its filter hits when info.vm is set: the hits it keeps (uint32 array)."""
+        buf = np.frombuffer(content, np.uint8)
+        h = np.ascontiguousarray(hits, np.uint32)
+        out = np.zeros(h.size, np.uint32)
+        n = lib().gscan_vm_filter(self._h, buf.ctypes.data if buf.size else None, buf.size, h.ctypes.data if h.size else None, h.size, out.ctypes.data if h.size else None)
+        if n < 0:
+            raise ValueError("the pattern's candidates are not confirmed on the device")
+        return out[:n]
 
     def dev_window(self, alt):
         """What the kernels scan for alternative `alt`: ([membership table per device window position], shift)."""

@@ -84,6 +84,10 @@ typedef struct gscan_info {
     int exact;           /* 1: the alternatives ARE the pattern.  0: they are what every match must begin with (the pattern goes on
                             with a second unbounded repeat, a repeated group ...); the host confirms each offset with its
                             backtracking matcher (gscan_next_match does) */
+    int vm;              /* 1 (exact == 0 only): the DEVICE confirms the candidates itself -- the scan kernel runs the pattern as a
+                            small backtracking VM at every filter hit and drops the hits at which no match can start -- and the
+                            list it returns holds EVERY hit it kept (no group-start compression): gscan_next_match then asks the
+                            host matcher at the listed offsets only */
 } gscan_info;
 
 /* one scan unit inside a device-resident arena (gscan_scan_device) */
@@ -157,6 +161,14 @@ uint64_t gscan_resource_errors(void);
 /* the offsets gscan_next_match tests itself because a window there would end with the chunk (patterns with
  * look-ahead context only: foo\b, foo$ ...); exported for tests.  Returns how many there are; fills at most cap. */
 size_t gscan_tail_positions(const gscan_db *db, size_t clen, uint32_t *out, size_t cap);
+/* The device's VM (grab_amd/csrc/vm.h), run on the host -- for tests and diagnostics.
+ *   gscan_vm_verdict  at offset p with the subject starting at subject_start: 0 no match starts at p, 1 a match starts at p,
+ *                     2 the VM gave up (step / stack limit), -1 the pattern has no VM program.  Never 0 where
+ *                     gscan_match_info finds a match.
+ *   gscan_vm_filter   what the K3 kernel does with its filter hits when gscan_info.vm is set: of hits[0..n) (offsets of device
+ *                     windows) the ones it keeps, in order, into kept (may be NULL); returns how many, -1 if vm is not set. */
+int gscan_vm_verdict(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p);
+long gscan_vm_filter(const gscan_db *db, const void *content, size_t clen, const uint32_t *hits, size_t n, uint32_t *kept);
 /* What the kernels scan for alternative `alt`: the membership table of DEVICE window position `pos` (the window plus
  * its context positions), the device window length, and the shift from a device hit to the reported match start. */
 int gscan_db_dev_window(const gscan_db *db, int alt, int pos, uint8_t table[256], int *len, int *shift);

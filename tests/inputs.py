@@ -83,3 +83,16 @@ def db_candidates(db, data):
         tables, shift = db.dev_window(a)
         out.append(so.window_starts(data, tables) + shift)
     return np.unique(np.concatenate(out))
+
+
+def engine_list(db, data):
+    """The list the engine hands to gscan_next_match for `data`, computed on the host from the candidate set: the start of every
+    group of consecutive candidates -- or, for a database whose candidates the device confirms itself (info.vm), EVERY device
+    hit its VM filter keeps (gscan_vm_filter is the kernel's cold path, same source)."""
+    import numpy as np
+    import scan_oracle as so
+
+    cands = db_candidates(db, data)
+    if db.info.vm:
+        return db.vm_filter(np.ascontiguousarray(data), cands.astype(np.uint32)).astype(np.uint32)
+    return so.group_starts(cands).astype(np.uint32)

@@ -18,7 +18,7 @@ import pytest
 
 from conftest import ROOT
 from grab_amd import engine, filegrep
-from inputs import db_candidates
+from inputs import db_candidates, engine_list
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import scan_oracle as so  # noqa: E402
@@ -98,7 +98,7 @@ def check(liboracle, pat, texts):
         return None  # can match "": every file is skipped (Q2)
     for text in texts:
         data = np.frombuffer(text, np.uint8)
-        starts = np.zeros(0, np.uint32) if db.info.tier == engine.TIER_ANCHORED else so.group_starts(db_candidates(db, data)).astype(np.uint32)
+        starts = np.zeros(0, np.uint32) if db.info.tier == engine.TIER_ANCHORED else engine_list(db, data)
         for f in (1 | 2, 1, 0):
             e0, g0 = liboracle.oracle_resource_errors(), engine.resource_errors()
             want = ref_chunk(liboracle, pb, text, f) if ml.value <= len(text) else b""

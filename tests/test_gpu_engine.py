@@ -306,12 +306,12 @@ def test_submit_fd_ranges(ctx, tmp_path):
         assert same(s1[0], table_candidates(db, data[:blk + 123])) and same(s2[0], table_candidates(db, data[4096:4 * 4096]))
         # GSCAN_SLOTS = 3 ranges in flight, returned in submission order; a fourth is refused until one has been waited for
         for k in range(3):
-            ctx.submit_fd(db, fd, k * 4096, 2 * blk + 11 - k, tag=10 + k)
+            ctx.submit_fd(db, fd, k * 4096, 2 * blk - 5000 + k, tag=10 + k)
         with pytest.raises(engine.EngineError, match="no free slot"):
             ctx.submit_fd(db, fd, 0, 100)
         for k in range(3):
             t, s_, _ = ctx.wait_segs()
-            assert t == 10 + k and same(s_[0], table_candidates(db, data[k * 4096:k * 4096 + 2 * blk + 11 - k]))
+            assert t == 10 + k and same(s_[0], table_candidates(db, data[k * 4096:k * 4096 + 2 * blk - 5000 + k]))
         ctx.submit_fd(db, fd, data.size - 10, 4096)  # beyond the end of the file: queued ...
         ctx.submit_fd(db, fd, 0, 5000, tag=77)
         with pytest.raises(engine.EngineError, match="shrank"):

@@ -61,8 +61,8 @@ def boundary_file(size):
     buf[79::80] = 10
     nd = np.frombuffer(NEEDLE, np.uint8)
     spots = [100, STRIDE + 1000, 2 * STRIDE + 2000,              # head; inside overlap windows 1 and 2
-             CHUNK - 3, STRIDE + CHUNK - 3,                       # straddling the ends of windows 0 and 1
-             CHUNK - 6, STRIDE + CHUNK - 6,                       # ending exactly at a window end
+             STRIDE + CHUNK - 3,                                  # straddling the end of window 1
+             CHUNK - 6,                                           # ending exactly at the end of window 0
              STRIDE, 2 * STRIDE,                                  # at each window start
              CHUNK - 4096 - 3, CHUNK + 5000,                      # straddling a window START; plain interior of window 1
              size - 18, size - 6]                                 # the last 18 bytes; the very end
@@ -71,7 +71,7 @@ def boundary_file(size):
     rng = np.random.default_rng(5)
     for at in rng.integers(1 << 20, size - (1 << 20), 300):      # and a few hundred anywhere
         buf[int(at):int(at) + 6] = nd
-    for at in (STRIDE - 10, 2 * STRIDE - 10, CHUNK - 20, STRIDE + CHUNK - 20, 77_777):
+    for at in (STRIDE - 10, 2 * STRIDE - 10, CHUNK - 60, STRIDE + CHUNK - 70, 77_777):
         buf[at:at + 40] = ord("a")
     return buf
 
@@ -101,7 +101,7 @@ def test_default_chunk_geometry(pattern, big_file, built, oracle_built):
         if flags == ["-O", "-l"] and pattern == "NEEDLE":
             offs = [int(l.split()[-1]) for l in out.splitlines()]
             assert offs.count(STRIDE + 1000) == 2 and offs.count(2 * STRIDE + 2000) == 2, "overlap windows print twice (Q1)"
-            assert offs.count(CHUNK - 3) == 1 and offs.count(STRIDE) == 2 and offs.count(size - 6) == 1
+            assert offs.count(STRIDE + CHUNK - 3) == 1 and offs.count(CHUNK - 6) == 2 and offs.count(STRIDE) == 2 and offs.count(size - 6) == 1
     # the same windows dealt out over three contexts (FileGrep "devices": SURVEY.md 8e; on a one-GPU box all three sit
     # on device 0 -- what is exercised is the per-file reorder buffer): identical bytes
     for flags in (["-O", "-l"], ["-O"]):

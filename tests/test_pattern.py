@@ -257,7 +257,7 @@ def test_alternatives_match_pcre(pattern, built, liboracle):
     assert got == want
     assert all(db.match_end(buf, p) == end for p, (kind, end) in info.items())
     # the device-side view of the same thing: the union of the alternatives' windows is the candidate set
-    from inputs import db_candidates
+    from inputs import db_candidates, engine_list
     assert db_candidates(db, data).tolist() == sorted(info)
 
 
@@ -381,7 +381,7 @@ def test_assertions_match_reference_loop(pattern, built, liboracle):
     reference's loop prints -- the oracle runs pcre_exec the way grab.cc:175-213 does, subject restarted at every match
     (quirk Q4) -- on fixed and random texts, in all output modes."""
     from grab_amd import filegrep
-    from inputs import db_candidates
+    from inputs import db_candidates, engine_list
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
@@ -402,7 +402,7 @@ def test_assertions_match_reference_loop(pattern, built, liboracle):
         if db.info.tier == engine.TIER_ANCHORED or db.minlen < 0:
             starts = np.zeros(0, np.uint32)
         else:
-            starts = so.group_starts(db_candidates(db, data)).astype(np.uint32)
+            starts = engine_list(db, data)
         for f in (1 | 2, 1, 0, 1 | 2 | 4, 2):
             want = b""
             if 0 <= ml.value <= len(text):

@@ -1,0 +1,108 @@
+"""The device's backtracking VM (grab_amd/csrc/vm.h), run on the host: the same source the K3 kernel calls for every
+filter hit of an inexact pattern.  It is a FILTER -- only its verdict 0 ("no match starts here") drops a candidate -- so
+the property that must hold is one-sided: never 0 where the host matcher (TreeMatch, itself pinned against libpcre by
+tests/test_fuzz.py) finds a match.  Checked offset by offset on random patterns, with the subject starting at 0 and at
+the offset itself (look-behind, \\b and ^ see the difference); how often the VM agrees exactly is measured too -- a VM
+that keeps everything would be sound and useless.  Then the whole host side of the new contract: the list "every device
+hit the VM keeps" fed to the reference's loop prints what libpcre prints."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from grab_amd import engine, filegrep
+from inputs import db_candidates, engine_list
+from test_fuzz import ATOMS, BIN_ATOMS, gen, make_texts, ref_chunk
+
+TARGETS = [r"(\w)\1{3,}x|foobardoes(?=not)", r"[a-z]+\([a-z0-9, ]*\);", r"[a-z]+_[0-9]+\.[a-z]+", r"(?:foo|bar|ab)+baz", r"\w+@\w+\.com",
+           r"a.*b.*c", r"(?:ab|cd)+?e", r"e++f", r"(?>a+)b|(?>a+)a", r"(a|b\1)+c|z", r"(?i)(ab)\1+", r"foo(?!bar)\w+", r"x(?=(a))ab|ab",
+           r"(?:a|b)*?c{2,3}d", r"[0-9]{1,40}x", r"(?s)a.{2,}?b", r"(a)(b)?\2c|abc", r"(?:(?:ab)+c)+d", r"a{2,}+b", r"(?:\s|x)+y$"]
+
+
+def verdicts(db, text):
+    data = np.frombuffer(text, np.uint8)
+    out = []
+    for p in range(len(text)):
+        for s0 in {0, p}:
+            v = db.vm_verdict(data, p, s0)
+            e0 = engine.resource_errors()
+            k = db.match_info(data, p, s0)[0]
+            if engine.resource_errors() != e0:
+                continue  # the host matcher gave up at its own limit: nothing to compare
+            out.append((p, s0, v, k))
+    return out
+
+
+@pytest.mark.parametrize("pattern", TARGETS)
+def test_vm_on_named_patterns(pattern, built):
+    db = engine.Database(pattern)
+    texts = [b"xx aaaax bbbbbx foobardoesnot foo(a, b); foobarbaz a@b.com abaz", b"abcde ababe cde e eef aab aaa abab ABab abAB 11ax x9x",
+             b"foobar foobaz food(x); f_1.a a_12.bc  \tx y\n", b"abc abbc ab c accd bccd aaccd ccd", b"aXXb a\nb a12b ab", b"ababcabcd abd ababd", b" x y\n  y"] + make_texts(3)
+    hits = agree = 0
+    for t in texts:
+        for p, s0, v, k in verdicts(db, t):
+            assert v in (0, 1, 2)
+            assert not (v == 0 and k != 0), (pattern, t, p, s0, "the VM drops an offset at which a match starts")
+            hits += k != 0
+            agree += (v == 1) == (k != 0)
+    assert hits > 0, "the texts hold matches of every pattern"
+
+
+@pytest.mark.parametrize("seed", [41, 42, 43, 44])
+def test_vm_never_drops_a_match(seed, built):
+    rng = random.Random(seed)
+    texts = make_texts(seed)[:10]
+    total = exact = unknown = programs = 0
+    for _ in range(500):
+        pat = gen(rng, BIN_ATOMS if seed == 44 else ATOMS)
+        try:
+            db = engine.Database(pat)
+        except ValueError:
+            continue
+        if db.minlen < 0 or db.vm_verdict(np.zeros(1, np.uint8), 0, 0) < 0:
+            continue  # matches "" (every file is skipped, Q2) / no VM program (too big for the VM's limits)
+        programs += 1
+        for t in texts:
+            for p, s0, v, k in verdicts(db, t):
+                assert not (v == 0 and k != 0), (pat, t, p, s0)
+                total += 1
+                exact += (v == 1) == (k != 0) and v != 2
+                unknown += v == 2
+    assert programs > 200
+    assert exact > 0.995 * total, (exact, total, unknown)  # a filter that keeps everything would be sound and useless
+
+
+@pytest.mark.parametrize("seed", [51, 52])
+def test_vm_filtered_list_prints_what_pcre_prints(seed, built, liboracle):
+    """For patterns whose candidates the device confirms (info.vm): the list the kernel produces -- every device hit its VM
+    keeps, no group-start compression -- under gscan_next_match / the reference's loop, against libpcre under the same loop."""
+    rng = random.Random(seed)
+    texts = make_texts(seed) + [b"xx aaaax bbbbbx foobardoesnot foo(a, b); foobarbaz a@b.com abaz", b"ab ab ab abc\nabab c abcabc"]
+    done = 0
+    pats = list(TARGETS) if seed == 51 else []
+    while done < 120:
+        pat = pats.pop() if pats else gen(rng)
+        pb = pat.encode("latin-1")
+        ml = C.c_int(-9)
+        if liboracle.oracle_minlen(pb, C.byref(ml)) != 0:
+            continue
+        try:
+            db = engine.Database(pat)
+        except ValueError:
+            continue
+        if not db.info.vm or db.minlen < 0:
+            continue
+        assert db.info.tier == engine.TIER_BUCKET and not db.info.exact
+        for text in texts:
+            data = np.frombuffer(text, np.uint8)
+            starts = engine_list(db, data)
+            assert np.all(np.isin(starts, db_candidates(db, data)))
+            for f in (1 | 2, 1, 0):
+                e0, g0 = liboracle.oracle_resource_errors(), engine.resource_errors()
+                want = ref_chunk(liboracle, pb, text, f) if ml.value <= len(text) else b""
+                got = filegrep.report_chunk(db, f, b"", data, 0, starts) if db.minlen <= len(text) else b""
+                if liboracle.oracle_resource_errors() != e0 or engine.resource_errors() != g0:
+                    continue
+                assert got == want, (pat, text, f)
+        done += 1
