@@ -26,6 +26,8 @@
 
 #include <pthread.h>
 #include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -47,6 +49,10 @@
 
 #include "scan_args.h"
 
+
+namespace gscan {
+void nt_copy(void *dst, const void *src, size_t n); // hostcopy.cc
+}
 
 using gscan::Database;
 using gscan::DevProgram;
@@ -78,6 +84,7 @@ struct IngestCfg {
     unsigned pin_flags; // hipHostMalloc flags of the staging blocks (GSCAN_PIN_FLAGS: 0 default, 1 non-coherent, 2 write-combined)
     int shared_copy;    // GSCAN_SHARED_COPY: 0 = every context has copy streams of its own; N = the contexts of a device share N
     bool slab;          // GSCAN_SLAB: the reader blocks of a device are carved from ONE pinned allocation instead of one each
+    int read_mode;      // GSCAN_READ_MODE: 0 pread(2) into the block; 1 map the piece and copy it with non-temporal stores (hostcopy.cc)
 };
 const IngestCfg &ingest_cfg()
 {
@@ -96,6 +103,7 @@ const IngestCfg &ingest_cfg()
         v.numa = env("GSCAN_NUMA", 1, 0, 1) != 0;
         v.shared_copy = (int)env("GSCAN_SHARED_COPY", 0, 0, 4);
         v.slab = env("GSCAN_SLAB", 0, 0, 1) != 0;
+        v.read_mode = (int)env("GSCAN_READ_MODE", 1, 0, 1);
         const long pf = env("GSCAN_PIN_FLAGS", 0, 0, 2);
         v.pin_flags = pf == 1 ? hipHostMallocNonCoherent : pf == 2 ? hipHostMallocWriteCombined : hipHostMallocDefault;
         return v;
@@ -407,6 +415,19 @@ private:
                 err = -2;
             } else {
                 size_t got = 0;
+                if (ingest_cfg().read_mode == 1 && (t.off & 4095) == 0 && t.n >= (1u << 20)) {
+                    // the piece through a mapping, copied with non-temporal stores (hostcopy.cc).  A file that is shorter
+                    // than the range (it shrank) would fault beyond its end: checked first; anything odd falls back to pread
+                    struct stat st;
+                    if (fstat(t.fd, &st) == 0 && (off_t)(t.off + (off_t)t.n) <= st.st_size) {
+                        void *map = mmap(nullptr, t.n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, t.fd, t.off);
+                        if (map != MAP_FAILED) {
+                            gscan::nt_copy(b->p, map, t.n);
+                            munmap(map, t.n);
+                            got = t.n;
+                        }
+                    }
+                }
                 while (got < t.n && !err) {
                     const ssize_t r = pread(t.fd, (char *)b->p + got, t.n - got, t.off + (off_t)got);
                     if (r > 0) got += (size_t)r;
@@ -516,6 +537,7 @@ struct Slot {
     uint64_t tag = 0;
     size_t len = 0;
     uint32_t n_tiles = 0;
+    uint32_t nw = 1; // waves per workgroup of the launch: descriptors per tile
     const gscan_db *db = nullptr;
     uint64_t seq = 0;
 };
@@ -562,6 +584,7 @@ struct gscan_ctx {
     std::vector<gscan_seg> dv_last_segs;
     std::vector<uint32_t> dv_tile_first_h;
     uint32_t dv_last_tile_bytes = 0;
+    uint32_t dv_last_nw = 1;
     hipStream_t dv_stream = nullptr;
     // kernel timing
     std::vector<EvPair> ev_pool;
@@ -639,8 +662,8 @@ int slot_reserve_device(gscan_ctx *c, Slot &s, size_t len)
         HIPCHK(c, hipMalloc((void **)&s.d_text, cap));
         s.d_text_cap = cap - kPad;
     }
-    // tiles at the smallest tile size any variant uses
-    size_t tiles = len / gscan::scan_min_tile_bytes() + 2;
+    // descriptors: one per wave sub-tile, at the smallest sub-tile any variant uses (+ the padding of a last, partial tile)
+    size_t tiles = len / gscan::kMinSubTileBytes + 2 * gscan::kMaxWavesPerTile;
     if (tiles > s.tiles_cap) {
         if (s.d_desc) hipFree(s.d_desc);
         if (s.h_desc) hipHostFree(s.h_desc);
@@ -704,14 +727,15 @@ int slot_build_tiles(gscan_ctx *c, Slot &s, uint32_t tile_bytes)
         for (uint32_t t = s.tile_first[i]; t < s.tile_first[i + 1]; t++)
             s.h_tiles[t] = {s.segs[i].offset, s.segs[i].len, (t - s.tile_first[i]) * tile_bytes};
     if (nt) HIPCHK(c, hipMemcpyAsync(s.d_tiles, s.h_tiles, (size_t)nt * sizeof(gscan::TileDesc), hipMemcpyHostToDevice, c->copy));
-    // descriptors: one per tile; make room (a batch of tiny files has far more tiles than len / tile size)
-    if ((size_t)nt + 2 > s.tiles_cap) {
+    // descriptors: one per wave of every tile; make room (a batch of tiny files has far more tiles than len / tile size)
+    const size_t nd = ((size_t)nt + 2) * gscan::kMaxWavesPerTile;
+    if (nd > s.tiles_cap) {
         if (s.d_desc) hipFree(s.d_desc);
         if (s.h_desc) hipHostFree(s.h_desc);
         s.d_desc = nullptr;
         s.h_desc = nullptr;
         s.tiles_cap = 0;
-        const size_t cap = (size_t)nt + nt / 2 + 64;
+        const size_t cap = nd + nd / 2 + 64;
         HIPCHK(c, hipMalloc((void **)&s.d_desc, cap * 8));
         HIPCHK(c, hipHostMalloc((void **)&s.h_desc, cap * 8, hipHostMallocDefault));
         s.tiles_cap = cap;
@@ -722,9 +746,12 @@ int slot_build_tiles(gscan_ctx *c, Slot &s, uint32_t tile_bytes)
 int slot_launch(gscan_ctx *c, Slot &s)
 {
     const Database &db = s.db->db;
-    const uint32_t tile_bytes = (db.prog.vm_filter ? gscan::scan_tile_bytes_vm() : gscan::scan_tile_bytes(db.tier, c->variant, db.prog.n_classes));
+    uint32_t tile_bytes = 0, nw = 1;
+    gscan::scan_geometry(db.tier, c->variant, db.prog, &tile_bytes, &nw);
     const bool multi = !s.segs.empty();
     s.n_tiles = multi ? s.tile_first.back() : (uint32_t)((s.len + tile_bytes - 1) / tile_bytes);
+    s.nw = nw;
+    if ((size_t)s.n_tiles * nw > s.tiles_cap) return fail(c, GSCAN_EHIP, "descriptor buffer too small (%u tiles x %u waves)", s.n_tiles, nw);
     HIPCHK(c, hipMemsetAsync(s.d_counter, 0, kCounterWords * 4, c->compute));
     ScanArgs a;
     memset(&a, 0, sizeof a);
@@ -740,7 +767,7 @@ int slot_launch(gscan_ctx *c, Slot &s)
     a.prog = c->d_prog;
     gscan::fill_program(a, db.prog);
     if (s.n_tiles) HIPCHK(c, gscan::launch_scan(db.tier, c->variant, a, grid_for(c, db, s.n_tiles), c->compute));
-    if (s.n_tiles && gscan::scan_needs_settle(db.tier, db.prog)) HIPCHK(c, gscan::launch_settle(a, tile_bytes, c->compute));
+    if (s.n_tiles && gscan::scan_needs_settle(db.tier, db.prog)) HIPCHK(c, gscan::launch_settle(a, nw, c->compute));
     s.has_ext = c->line_extents && db.prog.lines_ok && s.n_tiles;
     if (s.has_ext) {
         if (s.ext_cap < s.rec_cap) {
@@ -751,13 +778,13 @@ int slot_launch(gscan_ctx *c, Slot &s)
             s.ext_cap = s.rec_cap;
         }
         if (!s.h_ext_spec) HIPCHK(c, hipHostMalloc((void **)&s.h_ext_spec, kSpecRecs * 12, hipHostMallocDefault));
-        HIPCHK(c, gscan::launch_lines(a, tile_bytes, s.d_ext, c->compute));
+        HIPCHK(c, gscan::launch_lines(a, nw, tile_bytes / nw, s.d_ext, c->compute));
         HIPCHK(c, hipMemcpy2DAsync(s.h_ext_spec, kSpecPer * 12, s.d_ext, (size_t)a.cap_shard * 12, kSpecPer * 12, gscan::kShards,
                                    hipMemcpyDeviceToHost, c->compute));
     }
     HIPCHK(c, hipMemcpyAsync(s.h_counter, s.d_counter, kCounterWords * 4, hipMemcpyDeviceToHost, c->compute));
     if (s.n_tiles)
-        HIPCHK(c, hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)s.n_tiles * 8, hipMemcpyDeviceToHost, c->compute));
+        HIPCHK(c, hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)s.n_tiles * nw * 8, hipMemcpyDeviceToHost, c->compute));
     // the head of every shard region in one strided copy: enough for any sparse result
     HIPCHK(c, hipMemcpy2DAsync(s.h_spec, kSpecPer * 4, s.d_recs, (size_t)a.cap_shard * 4, kSpecPer * 4, gscan::kShards,
                                hipMemcpyDeviceToHost, c->compute));
@@ -1159,7 +1186,11 @@ int gscan_submit_segs(gscan_ctx *c, const gscan_db *db, const void *pinned, cons
     s->no_content = false;
     s->segs.assign(segs, segs + nseg);
     if (nseg == 0) s->segs.push_back({0, 0, 0}); // keeps the chunk on the multi-segment path with one empty segment
-    rc = slot_build_tiles(c, *s, (db->db.prog.vm_filter ? gscan::scan_tile_bytes_vm() : gscan::scan_tile_bytes(db->db.tier, c->variant, db->db.prog.n_classes)));
+    {
+        uint32_t tb = 0, nw = 1;
+        gscan::scan_geometry(db->db.tier, c->variant, db->db.prog, &tb, &nw);
+        rc = slot_build_tiles(c, *s, tb);
+    }
     if (rc) return rc;
     if (used) HIPCHK(c, hipMemcpyAsync(s->d_text, pinned, used, hipMemcpyHostToDevice, c->copy));
     HIPCHK(c, hipEventRecord(s->copied, c->copy));
@@ -1304,10 +1335,12 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     const size_t ns = multi ? s->segs.size() : 1;
     s->seg_first.assign(ns + 1, 0);
     size_t seg = 0;
-    for (uint32_t t = 0; t < s->n_tiles; t++) { // tiles are in (segment, text) order: concatenating their runs sorts the list
+    const size_t n_desc = (size_t)s->n_tiles * s->nw;
+    for (size_t di = 0; di < n_desc; di++) { // descriptors are in (segment, text) order: concatenating their runs sorts the list
+        const uint32_t t = (uint32_t)(di / s->nw);
         if (multi)
             while (seg + 1 <= ns && t >= s->tile_first[seg + 1]) s->seg_first[++seg] = s->sorted.size();
-        unsigned long long d = s->h_desc[t];
+        unsigned long long d = s->h_desc[di];
         uint32_t cnt = (uint32_t)d;
         size_t base = (size_t)(d >> 32);
         if (!cnt) continue;
@@ -1394,7 +1427,9 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
     c->dv_stream = st;
     int rc = ensure_prog(c, db, st);
     if (rc) return rc;
-    const uint32_t tile_bytes = (db->db.prog.vm_filter ? gscan::scan_tile_bytes_vm() : gscan::scan_tile_bytes(db->db.tier, c->variant, db->db.prog.n_classes));
+    uint32_t tile_bytes = 0, nw = 1;
+    gscan::scan_geometry(db->db.tier, c->variant, db->db.prog, &tile_bytes, &nw);
+    c->dv_last_nw = nw;
     const size_t K = gscan::kShards;
 
     // tile table: rebuilt only when the segment table or the tile size changed
@@ -1422,7 +1457,7 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
             c->dv_desc = nullptr;
             c->dv_tiles = nullptr;
             c->dv_tiles_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->dv_desc, (size_t)(nt + 1) * 8));
+            HIPCHK(c, hipMalloc((void **)&c->dv_desc, (size_t)(nt + 1) * gscan::kMaxWavesPerTile * 8));
             HIPCHK(c, hipMalloc((void **)&c->dv_tiles, (size_t)(nt + 1) * sizeof(gscan::TileDesc)));
             c->dv_tiles_cap = (size_t)nt + 1;
         }
@@ -1467,15 +1502,15 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
     bool timed = c->ev_used < c->ev_pool.size();
     if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used].a, st));
     if (n_tiles) HIPCHK(c, gscan::launch_scan(db->db.tier, c->variant, a, grid_for(c, db->db, n_tiles), st));
-    if (n_tiles && gscan::scan_needs_settle(db->db.tier, db->db.prog)) HIPCHK(c, gscan::launch_settle(a, tile_bytes, st)); // inside the timed region
+    if (n_tiles && gscan::scan_needs_settle(db->db.tier, db->db.prog)) HIPCHK(c, gscan::launch_settle(a, nw, st)); // inside the timed region
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used].b, st));
         c->ev_used++;
     }
     res->recs = c->dv_recs;
     res->desc = (const uint64_t *)c->dv_desc;
-    res->n_tiles = n_tiles;
-    res->tile_bytes = tile_bytes;
+    res->n_tiles = (uint64_t)n_tiles * nw; // descriptors: one per wave sub-tile
+    res->tile_bytes = tile_bytes / nw;
     res->total = 0;
     res->overflow = 0;
     return GSCAN_OK;
@@ -1503,7 +1538,7 @@ long gscan_dev_fetch(gscan_ctx *c, const gscan_dev_result *res, size_t seg, uint
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->dv_stream ? c->dv_stream : c->compute;
     HIPCHK(c, hipStreamSynchronize(st));
-    uint32_t t0 = c->dv_tile_first_h[seg], t1 = c->dv_tile_first_h[seg + 1];
+    const size_t t0 = (size_t)c->dv_tile_first_h[seg] * c->dv_last_nw, t1 = (size_t)c->dv_tile_first_h[seg + 1] * c->dv_last_nw; // descriptors of the segment
     std::vector<unsigned long long> d(t1 - t0);
     if (t1 > t0) HIPCHK(c, hipMemcpy(d.data(), c->dv_desc + t0, (size_t)(t1 - t0) * 8, hipMemcpyDeviceToHost));
     const size_t cap_shard = c->dv_rec_cap / gscan::kShards;

@@ -24,7 +24,7 @@
 //     t&7, so dense outputs do not serialise on one address); lanes then expand their
 //     masks in text order using a wave prefix sum (K2, whose outputs are the dense
 //     ones, first transposes the masks through LDS so that one scan serves the whole
-//     sub-tile: emit_tile_t), and the tile's descriptor
+//     sub-tile: emit_wave_t), and the sub-tile's descriptor
 //     {count, base} is written at desc[tile].  Tiles are in text order, so walking
 //     desc[] yields ascending offsets with no sort and no second pass over the text.
 //
@@ -206,44 +206,33 @@ __device__ __forceinline__ void load_subtile(u32x4 (&buf)[ITER + 1], const TileC
     buf[ITER] = load16<false>(c.rsrc, lane < (uint32_t)HALO_LANES ? v0 + ITER * 1024 : 0x7ffffff0);
 }
 
-// Tile epilogue shared by both kernels: hits[] holds the per-step 16-bit masks of
-// this lane (two per register), cnt its popcount.  `bias` is subtracted from every
-// position (K1 records window starts, its masks mark anchor positions).
-template <int ITER, int NWAVES>
-__device__ __forceinline__ void emit_tile(const ScanArgs &a, uint32_t t, const uint32_t (&hits)[(ITER + 1) / 2],
-                                          uint32_t cnt, int sub_off, uint32_t bias, uint32_t lane, uint32_t wave,
-                                          uint32_t *s_cnt, uint32_t *s_base)
+// Epilogue of one WAVE's sub-tile: hits[] holds the per-step 16-bit masks of this lane (two per register), cnt its
+// popcount.  `bias` is subtracted from every position (K1 records window starts, its masks mark anchor positions).
+// Every wave reserves its own run in the record buffer and writes its own descriptor, desc[d] (d = tile * waves + wave):
+// no LDS, no workgroup barrier -- a wave that is done with its sub-tile goes straight on to the next tile's loads while
+// its neighbours are still busy.  (Round 1 reserved one run per TILE: wave counts through LDS, a barrier, one atomic by
+// thread 0, its result through LDS, another barrier -- every wave of the workgroup sat through the atomic's round trip
+// once per tile, and the persistent kernels lost the overlap between one tile's tail and the next one's loads.)
+template <int ITER>
+__device__ __forceinline__ void emit_wave(const ScanArgs &a, uint32_t d, const uint32_t (&hits)[(ITER + 1) / 2], uint32_t cnt, int sub_off,
+                                          uint32_t bias, uint32_t lane)
 {
-    // (one wave per workgroup -- no LDS, no barrier here -- was measured too: 4 % slower, the extra dispatches cost
-    // more than the barriers: profiles/r01_n_sweep_k1_solo.txt)
-    uint32_t wtot = wave_sum(cnt);
-    if (lane == 0) s_cnt[wave] = wtot;
-    __syncthreads();
-    uint32_t total = 0, before = 0;
-#pragma unroll
-    for (int w = 0; w < NWAVES; w++) {
-        uint32_t c = s_cnt[w];
-        total += c;
-        if ((uint32_t)w < wave) before += c;
-    }
-    if (total == 0) {
-        if (threadIdx.x == 0) a.desc[t] = 0ull;
-        __syncthreads(); // s_cnt is rewritten by the next tile
+    const uint32_t wtot = wave_sum(cnt);
+    if (wtot == 0) {
+        if (lane == 0) a.desc[d] = 0ull;
         return;
     }
-    const uint32_t shard = t & (kShards - 1);
-    if (threadIdx.x == 0) {
-        uint32_t b = atomicAdd(a.counter + shard, total); // index inside the shard's region
-        *s_base = b;
-        a.desc[t] = (unsigned long long)total | ((unsigned long long)(shard * a.cap_shard + b) << 32);
-        if ((unsigned long long)b + total > (unsigned long long)a.cap_shard) atomicOr(a.counter + kShards, 1u);
+    const uint32_t shard = d & (kShards - 1);
+    uint32_t b = 0;
+    if (lane == 0) b = atomicAdd(a.counter + shard, wtot); // index inside the shard's region
+    const uint32_t base = __builtin_amdgcn_readfirstlane(b);
+    const bool over = (unsigned long long)base + wtot > (unsigned long long)a.cap_shard;
+    if (lane == 0) {
+        a.desc[d] = (unsigned long long)wtot | ((unsigned long long)(shard * a.cap_shard + base) << 32);
+        if (over) atomicOr(a.counter + kShards, 1u);
     }
-    __syncthreads();
-    uint32_t base = *s_base;
-    __syncthreads(); // s_base / s_cnt free for the next tile
-    if ((unsigned long long)base + total > (unsigned long long)a.cap_shard) return; // overflow: host re-runs bigger
-    if (wtot == 0) return;
-    uint32_t run = shard * a.cap_shard + base + before;
+    if (over) return; // overflow: the host re-runs with a bigger buffer
+    uint32_t run = shard * a.cap_shard + base;
 #pragma unroll
     for (int k = 0; k < ITER; k++) {
         uint32_t bits = (hits[k >> 1] >> (16 * (k & 1))) & 0xffffu;
@@ -269,44 +258,29 @@ __device__ __forceinline__ void emit_tile(const ScanArgs &a, uint32_t t, const u
     }
 }
 
-// Dense-output epilogue: the same reservation protocol as emit_tile, but the per-step masks are first
-// transposed through a wave-private strip of LDS so that lane L owns ITER consecutive (step, lane) cells,
-// i.e. a contiguous piece of text.  One wave scan then places every lane's records; emit_tile pays a
-// ballot + rank + branch for each of the ITER steps instead, which is what limits the kernels when most
-// steps carry records (identifier regex: 3.6 records per KiB).
-template <int ITER, int NWAVES>
-__device__ __forceinline__ void emit_tile_t(const ScanArgs &a, uint32_t t, const uint32_t (&hits)[(ITER + 1) / 2], uint32_t cnt,
-                                            int sub_off, uint32_t bias, uint32_t lane, uint32_t wave, uint32_t *s_cnt,
-                                            uint32_t *s_base, uint16_t *s_xp)
+// Dense-output epilogue: the same reservation, but the per-step masks are first transposed through a wave-private strip of
+// LDS so that lane L owns ITER consecutive (step, lane) cells, i.e. a contiguous piece of text.  One wave scan then places
+// every lane's records; emit_wave pays a ballot + rank + branch for each of the ITER steps instead, which is what limits the
+// kernels when most steps carry records (identifier regex: 3.6 records per KiB).  The strip is the wave's own: the only
+// ordering needed is between the wave's LDS writes and its reads (no workgroup barrier).
+template <int ITER>
+__device__ __forceinline__ void emit_wave_t(const ScanArgs &a, uint32_t d, const uint32_t (&hits)[(ITER + 1) / 2], uint32_t cnt, int sub_off,
+                                            uint32_t bias, uint32_t lane, uint16_t *xp)
 {
     static_assert(ITER % 4 == 0, "a lane reads its ITER masks as 64-bit words");
-    uint16_t *xp = s_xp + wave * (ITER * 64);
-#pragma unroll
-    for (int k = 0; k < ITER; k++) xp[k * 64 + lane] = (uint16_t)(hits[k >> 1] >> (16 * (k & 1)));
-    uint32_t wtot = wave_sum(cnt);
-    if (lane == 0) s_cnt[wave] = wtot;
-    __syncthreads(); // also orders the strip's writes before its reads
-    uint32_t total = 0, before = 0;
-#pragma unroll
-    for (int w = 0; w < NWAVES; w++) {
-        uint32_t c = s_cnt[w];
-        total += c;
-        if ((uint32_t)w < wave) before += c;
-    }
-    if (total == 0) {
-        if (threadIdx.x == 0) a.desc[t] = 0ull;
-        __syncthreads();
+    const uint32_t wtot = wave_sum(cnt);
+    if (wtot == 0) {
+        if (lane == 0) a.desc[d] = 0ull;
         return;
     }
-    const uint32_t shard = t & (kShards - 1);
-    if (threadIdx.x == 0) {
-        uint32_t b = atomicAdd(a.counter + shard, total);
-        *s_base = b;
-        a.desc[t] = (unsigned long long)total | ((unsigned long long)(shard * a.cap_shard + b) << 32);
-        if ((unsigned long long)b + total > (unsigned long long)a.cap_shard) atomicOr(a.counter + kShards, 1u);
-    }
-    __syncthreads();
-    uint32_t base = *s_base;
+#pragma unroll
+    for (int k = 0; k < ITER; k++) xp[k * 64 + lane] = (uint16_t)(hits[k >> 1] >> (16 * (k & 1)));
+    const uint32_t shard = d & (kShards - 1);
+    uint32_t b = 0;
+    if (lane == 0) b = atomicAdd(a.counter + shard, wtot);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the strip's writes have landed ...
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // ... before any lane reads its cells
     // cells lane*ITER .. lane*ITER+ITER-1 of the strip, 4 masks per 64-bit word
     unsigned long long w[ITER / 4];
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xp + lane * ITER);
@@ -316,19 +290,24 @@ __device__ __forceinline__ void emit_tile_t(const ScanArgs &a, uint32_t t, const
         w[q] = src[q];
         c += (uint32_t)__popcll(w[q]);
     }
-    __syncthreads(); // s_base / s_cnt / the strip are free for the next tile
-    if ((unsigned long long)base + total > (unsigned long long)a.cap_shard) return; // overflow: host re-runs bigger
-    if (wtot == 0) return;
+    const uint32_t base = __builtin_amdgcn_readfirstlane(b);
+    const bool over = (unsigned long long)base + wtot > (unsigned long long)a.cap_shard;
+    if (lane == 0) {
+        a.desc[d] = (unsigned long long)wtot | ((unsigned long long)(shard * a.cap_shard + base) << 32);
+        if (over) atomicOr(a.counter + kShards, 1u);
+    }
+    __builtin_amdgcn_wave_barrier(); // (the next tile's strip writes stay behind these reads: same wave, program order)
+    if (over) return;
     const uint32_t inc = wave_scan(c);
-    uint32_t idx = shard * a.cap_shard + base + before + inc - c;
+    uint32_t idx = shard * a.cap_shard + base + inc - c;
 #pragma unroll
     for (int q = 0; q < ITER / 4; q++) {
         unsigned long long bitsq = w[q];
         while (bitsq) {
-            const uint32_t b = (uint32_t)__ffsll((long long)bitsq) - 1u;
+            const uint32_t bb = (uint32_t)__ffsll((long long)bitsq) - 1u;
             bitsq &= bitsq - 1ull;
-            const uint32_t cell = lane * ITER + q * 4 + (b >> 4); // = step * 64 + lane of the mask's producer
-            a.recs[idx++] = (uint32_t)sub_off + (cell >> 6) * 1024u + (cell & 63u) * 16u + (b & 15u) - bias;
+            const uint32_t cell = lane * ITER + q * 4 + (bb >> 4); // = step * 64 + lane of the mask's producer
+            a.recs[idx++] = (uint32_t)sub_off + (cell >> 6) * 1024u + (cell & 63u) * 16u + (bb & 15u) - bias;
         }
     }
 }
@@ -339,8 +318,6 @@ __device__ __forceinline__ void emit_tile_t(const ScanArgs &a, uint32_t t, const
 template <int ITER, bool NT>
 __global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
-    __shared__ uint32_t s_cnt[kWaves];
-    __shared__ uint32_t s_base;
     constexpr uint32_t kTile = kWaves * ITER * 1024;
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x / kWave;
@@ -406,7 +383,7 @@ __global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a, const TileDesc
 #undef GS_MIN3
             }
         }
-        emit_tile<ITER, kWaves>(a, t, hits, cnt, sub_off, aoff - a.report_shift, lane, wave, s_cnt, &s_base);
+        emit_wave<ITER>(a, t * kWaves + wave, hits, cnt, sub_off, aoff - a.report_shift, lane);
     }
 }
 
@@ -479,16 +456,14 @@ __device__ __forceinline__ uint32_t run_one_flat(uint32_t d, uint32_t w0, uint32
 // (profiles/r01_w_k2_opt_sweep.txt, r01_w_k2_pmc.txt).
 // NW (pair form): waves per workgroup -- 8 (512 threads, ITER 12: 4 waves per SIMD), 12 (768 threads, ITER 8, two
 // workgroups per CU = 6 waves per SIMD within 80 VGPRs; same 96 KiB tile) or 16 (1024 threads, ITER 8, two workgroups per
-// CU = 8 waves per SIMD within 64 VGPRs; no room in LDS for the transposition strip next to two 64 KiB tables: plain epilogue).
+// CU = 8 waves per SIMD within 64 VGPRs; table + strips = 80 KiB, two of them are the CU's whole LDS).
 template <int ITER, bool NT, bool WIDE, bool PAIR, int NR = -1, int NW = (PAIR ? 8 : 4)>
 __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : NW == 16 ? 8 : 1) void k2_classrun_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     static_assert(NR < 0 || (PAIR && !WIDE), "the flat run program is the two-class, 32-bit form's");
     constexpr int kNW = NW; // waves per workgroup
     __shared__ uint32_t tbl[PAIR ? 65536 / 4 : 256 * 32];
-    __shared__ __attribute__((aligned(8))) uint16_t s_xp[NW == 16 ? 4 : kNW * ITER * 64]; // epilogue transposition strip, 2 bytes per (step, lane)
-    __shared__ uint32_t s_cnt[kNW];
-    __shared__ uint32_t s_base;
+    __shared__ __attribute__((aligned(8))) uint16_t s_xp[kNW * ITER * 64]; // epilogue transposition strips, 2 bytes per (step, lane), one per wave
     constexpr uint32_t kTile = kNW * ITER * 1024;
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x / kWave;
@@ -570,12 +545,32 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : NW ==
                     p23 = ((lo >> 16) & 0xffu) | (((hi8 >> 16) & 0xffu) << 8) | ((lo >> 8) & 0xff0000u) | (hi8 & 0xff000000u);
                 }
             };
+            // The pair form keeps its look-ups one step further ahead: those of step k + 2 are issued before step k is computed
+            // and merged after it, so a wave does not sit out its own LDS latency (random 16-bit indices: bank conflicts make
+            // it long) between issuing eight look-ups and using them.
+            uint32_t ea[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            auto lookups = [&](const u32x4 &d) {
+                ea[0] = tbl8[d.x & 0xffffu], ea[1] = tbl8[d.x >> 16], ea[2] = tbl8[d.y & 0xffffu], ea[3] = tbl8[d.y >> 16];
+                ea[4] = tbl8[d.z & 0xffffu], ea[5] = tbl8[d.z >> 16], ea[6] = tbl8[d.w & 0xffffu], ea[7] = tbl8[d.w >> 16];
+            };
+            auto merge = [&]() -> uint32_t { // (the same five operations as in masks())
+                const uint32_t g = lshl_or<26>(ea[7], lshl_or<24>(ea[6], lshl_or<18>(ea[5], lshl_or<16>(ea[4], lshl_or<10>(ea[3], lshl_or<8>(ea[2], lshl_or<2>(ea[1], ea[0])))))));
+                const uint32_t sw = ((g >> 4) ^ g) & 0x00f000f0u;
+                const uint32_t h = g ^ sw ^ (sw << 4);
+                return __builtin_amdgcn_perm(h, h, 0x03010200u);
+            };
             masks(buf[0], p01n, p23n);
+            if (PAIR) lookups(buf[1]);
             uint32_t last63 = 0; // candidate mask of lane 63 in the previous step (0: unknown at the sub-tile start)
 #pragma unroll
             for (int k = 0; k < ITER; k++) {
                 const uint32_t p01 = p01n, p23 = p23n;
-                masks(buf[k + 1], p01n, p23n); // next step's masks: lanes 61-63 look into them
+                if (PAIR) {
+                    p01n = merge();                          // step k + 1's masks: lanes 61-63 look into them
+                    if (k + 2 <= ITER) lookups(buf[k + 2]); // in flight while step k is computed
+                } else {
+                    masks(buf[k + 1], p01n, p23n); // next step's masks: lanes 61-63 look into them
+                }
                 const bool more = !PAIR && ncls > 2;
                 uint32_t bits;
                 if (!WIDE) { // look-ahead <= 16 positions: one neighbour
@@ -628,8 +623,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : NW ==
             }
         }
         // K2's outputs are the dense ones: transposed epilogue (+8 % on the identifier scan, neutral without matches)
-        if (NW == 16) emit_tile<ITER, kNW>(a, t, hits, cnt, sub_off, 0u - a.report_shift, lane, wave, s_cnt, &s_base);
-        else emit_tile_t<ITER, kNW>(a, t, hits, cnt, sub_off, 0u - a.report_shift, lane, wave, s_cnt, &s_base, s_xp);
+        emit_wave_t<ITER>(a, t * kNW + wave, hits, cnt, sub_off, 0u - a.report_shift, lane, s_xp + wave * (ITER * 64));
     }
 }
 #undef GS_LUT
@@ -682,8 +676,6 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
     __shared__ uint32_t tbl[256 * 64];
     __shared__ __attribute__((aligned(16))) uint8_t s_pos[kK3Confirm * 256];
     __shared__ uint8_t s_blen[kK3Buckets];
-    __shared__ uint32_t s_cnt[NW];
-    __shared__ uint32_t s_base;
     __shared__ __attribute__((aligned(16))) uint32_t s_vm[VM ? sizeof(VmProg) / 4 : 1];
     constexpr uint32_t kTile = NW * ITER * 1024;
     const uint32_t lane = lane_id();
@@ -810,7 +802,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                 }
             }
         }
-        emit_tile<ITER, NW>(a, t, hits, cnt, sub_off, koff - a.report_shift, lane, wave, s_cnt, &s_base);
+        emit_wave<ITER>(a, t * NW + wave, hits, cnt, sub_off, koff - a.report_shift, lane);
     }
 }
 
@@ -821,11 +813,12 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
 // record that is no match is overwritten with kStruck and counted, the readers of the record buffer skip it.
 // Doing this inside the scan kernel costs its hot loop 18 % (registers): profiles/r01_o_sweep_k3_compare_word_confirm_rejected.txt.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k3_settle(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t tile_bytes)
+__global__ __launch_bounds__(256) void k3_settle(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw)
 {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= a.n_tiles) return;
-    const unsigned long long d = a.desc[t];
+    const uint32_t st = blockIdx.x * 256u + threadIdx.x; // one thread per descriptor = per wave sub-tile
+    if (st >= a.n_tiles * nw) return;
+    const uint32_t t = st / nw;
+    const unsigned long long d = a.desc[st];
     const uint32_t cnt = (uint32_t)d;
     if (cnt == 0) return;
     if (a.counter[kShards] != 0) return; // some shard overflowed: the host rescans with a bigger buffer (and settles then)
@@ -884,10 +877,14 @@ __device__ __forceinline__ unsigned long long load8(const uint8_t *q) // any ali
 // One wave per tile, one lane per record (round-robin): whether a record is printed depends only on the record in front
 // of it -- it is the first candidate of its line iff the previous record lies before the line's start -- so nothing is
 // carried from record to record.  Newlines are searched 8 bytes at a time.
-__global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t tile_bytes, uint32_t *__restrict__ ext)
+// (descriptors are per wave sub-tile: st = tile * nw + wave covers sub_bytes bytes; the descriptors of a segment are
+// consecutive, those of a segment's last tile beyond its end are empty)
+__global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t sub_bytes, uint32_t *__restrict__ ext)
 {
-    const uint32_t t = blockIdx.x;
-    const unsigned long long d = a.desc[t];
+    const uint32_t st = blockIdx.x;
+    const uint32_t t = st / nw;
+    const uint32_t tile_bytes = sub_bytes; // (the walk back over earlier descriptors below steps by sub-tiles)
+    const unsigned long long d = a.desc[st];
     const uint32_t cnt = (uint32_t)d;
     if (cnt == 0 || a.counter[kShards] != 0) return; // (overflow: the host rescans with a bigger buffer and this pass runs again)
     const uint32_t base = (uint32_t)(d >> 32);
@@ -896,11 +893,11 @@ __global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__rest
     if (tiles) {
         seg_off = tiles[t].seg_off;
         slen = tiles[t].seg_len;
-        tile_off = tiles[t].tile_off;
+        tile_off = tiles[t].tile_off + (st % nw) * sub_bytes;
     } else {
         seg_off = a.seg0_off;
         slen = a.seg0_len;
-        tile_off = t * tile_bytes;
+        tile_off = st * sub_bytes;
     }
     const uint8_t *seg = a.base + seg_off;
     const DevProgram *pg = a.prog;
@@ -936,8 +933,8 @@ __global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__rest
         if (i > 0) {
             first = a.recs[base + i - 1] < ls;
         } else if (ls < tile_off) {
-            uint32_t u = t, uoff = tile_off;
-            while (uoff > ls) { // tile u - 1 covers [uoff - tile_bytes, uoff)
+            uint32_t u = st, uoff = tile_off;
+            while (uoff > ls) { // descriptor u - 1 covers [uoff - tile_bytes, uoff)
                 u--;
                 uoff -= tile_bytes;
                 const unsigned long long du = a.desc[u];
@@ -1000,6 +997,19 @@ static bool k2_pair(const ScanArgs &a) { return a.n_classes <= 2; }
 static int variant_wg(int tier, int variant, uint32_t n_classes);
 
 uint32_t scan_tile_bytes_vm() { return 8u * 8u * 1024u; } // K3 with the VM: 8 waves x 8 KiB whatever the variant
+
+// The shape of the launch launch_scan() picks: bytes per workgroup tile and waves per workgroup.  Every wave writes one
+// descriptor per tile (desc[tile * waves + wave]) for its sub-tile of tile_bytes / waves bytes.
+void scan_geometry(int tier, int variant, const DevProgram &pg, uint32_t *tile_bytes, uint32_t *waves)
+{
+    if (tier == GSCAN_TIER_BUCKET && pg.vm_filter) {
+        *tile_bytes = scan_tile_bytes_vm();
+        *waves = 8;
+        return;
+    }
+    *tile_bytes = scan_tile_bytes(tier, variant, pg.n_classes);
+    *waves = *tile_bytes / ((uint32_t)kIters[variant & 3] * 1024u);
+}
 
 uint32_t scan_tile_bytes(int tier, int variant, uint32_t n_classes)
 {
@@ -1132,17 +1142,17 @@ bool scan_needs_settle(int tier, const DevProgram &pg)
     return tier == GSCAN_TIER_BUCKET && !pg.k3_confirm_exact && !pg.vm_filter; // (the VM has already decided every hit)
 }
 
-hipError_t launch_settle(const ScanArgs &a, uint32_t tile_bytes, hipStream_t st)
+hipError_t launch_settle(const ScanArgs &a, uint32_t nw, hipStream_t st)
 {
     if (a.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k3_settle, dim3((a.n_tiles + 255u) / 256u), dim3(256), 0, st, a, a.tiles, tile_bytes);
+    hipLaunchKernelGGL(k3_settle, dim3((a.n_tiles * nw + 255u) / 256u), dim3(256), 0, st, a, a.tiles, nw);
     return hipGetLastError();
 }
 
-hipError_t launch_lines(const ScanArgs &a, uint32_t tile_bytes, uint32_t *ext, hipStream_t st)
+hipError_t launch_lines(const ScanArgs &a, uint32_t nw, uint32_t sub_bytes, uint32_t *ext, hipStream_t st)
 {
     if (a.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_lines, dim3(a.n_tiles), dim3(64), 0, st, a, a.tiles, tile_bytes, ext);
+    hipLaunchKernelGGL(k_lines, dim3(a.n_tiles * nw), dim3(64), 0, st, a, a.tiles, nw, sub_bytes, ext);
     return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@ struct ScanArgs {
     uint32_t n_tiles;
     uint32_t cap_shard;      // record capacity of ONE shard region (regions are back to back)
     uint32_t *recs;          // candidate starts, segment-relative
-    unsigned long long *desc; // [n_tiles] count | base<<32 (base = absolute record index)
+    unsigned long long *desc; // [n_tiles * waves per workgroup] one per wave sub-tile: count | base<<32 (base = absolute record index)
     uint32_t *counter;       // [0..kShards) records reserved per shard, [kShards] overflow flag, [kShards+1] records struck out by k3_settle
     const DevProgram *prog;  // cold paths only (K1 verify, K2 table staging)
     // pattern program, hot-loop copy
@@ -49,14 +49,17 @@ struct ScanArgs {
 // variant: bits 0-1 select KiB per wave {0:16, 1:8, 2:12}; bit 2 = nontemporal loads; 13 / 21: bigger workgroups for the table kernels (kernels.hip, variant_wg)
 uint32_t scan_tile_bytes(int tier, int variant, uint32_t n_classes);
 uint32_t scan_tile_bytes_vm();
+void scan_geometry(int tier, int variant, const DevProgram &pg, uint32_t *tile_bytes, uint32_t *waves);
+constexpr uint32_t kMaxWavesPerTile = 16;  // the largest workgroup any variant launches
+constexpr uint32_t kMinSubTileBytes = 8192; // the smallest sub-tile (8 KiB per wave)
 uint32_t scan_min_tile_bytes();
 uint32_t scan_persistent_blocks(int tier, int variant, uint32_t n_classes);
 void fill_program(ScanArgs &a, const DevProgram &pg);
 hipError_t launch_scan(int tier, int variant, const ScanArgs &a, uint32_t grid, hipStream_t st);
 bool scan_needs_settle(int tier, const DevProgram &pg);
-hipError_t launch_settle(const ScanArgs &a, uint32_t tile_bytes, hipStream_t st);
+hipError_t launch_settle(const ScanArgs &a, uint32_t waves, hipStream_t st);
 // line extents + orbit selection for the line-printing modes: ext[3 * record index] = {m1, lb, le} (kernels.hip, k_lines)
-hipError_t launch_lines(const ScanArgs &a, uint32_t tile_bytes, uint32_t *ext, hipStream_t st);
+hipError_t launch_lines(const ScanArgs &a, uint32_t waves, uint32_t sub_bytes, uint32_t *ext, hipStream_t st);
 constexpr uint32_t kLineAskHost = 0xffffffffu;
 
 } // namespace gscan

@@ -101,7 +101,8 @@ typedef struct gscan_seg {
 typedef struct gscan_dev_result {
     const uint32_t *recs;  /* device: candidate group starts (see gscan_wait), segment-relative; runs of ascending offsets */
     const uint64_t *desc;  /* device: per tile {count:u32 | base:u32<<32}, base = index into recs;
-                              tiles are in (segment, text) order, so walking desc yields ascending offsets */
+                              tiles are in (segment, text) order, so walking desc yields ascending offsets.
+                              A "tile" here is what ONE WAVE scans (8-16 KiB): every wave reserves and describes its own run */
     uint64_t n_tiles;
     uint32_t tile_bytes;
     uint64_t total;        /* number of records the scan produced (valid after gscan_dev_sync) */

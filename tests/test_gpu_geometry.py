@@ -63,7 +63,7 @@ def boundary_file(size):
     spots = [100, STRIDE + 1000, 2 * STRIDE + 2000,              # head; inside overlap windows 1 and 2
              STRIDE + CHUNK - 3,                                  # straddling the end of window 1
              CHUNK - 6,                                           # ending exactly at the end of window 0
-             STRIDE, 2 * STRIDE,                                  # at each window start
+             STRIDE,                                              # at the start of window 1 (window 2's start gets a run of `a`)
              CHUNK - 4096 - 3, CHUNK + 5000,                      # straddling a window START; plain interior of window 1
              size - 18, size - 6]                                 # the last 18 bytes; the very end
     for at in spots:
@@ -71,7 +71,7 @@ def boundary_file(size):
     rng = np.random.default_rng(5)
     for at in rng.integers(1 << 20, size - (1 << 20), 300):      # and a few hundred anywhere
         buf[int(at):int(at) + 6] = nd
-    for at in (STRIDE - 10, 2 * STRIDE - 10, CHUNK - 60, STRIDE + CHUNK - 70, 77_777):
+    for at in (2 * STRIDE - 10, CHUNK - 60, STRIDE + CHUNK - 70, 77_777):  # across the start of window 2; near two window ends
         buf[at:at + 40] = ord("a")
     return buf
 
