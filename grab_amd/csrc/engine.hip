@@ -63,7 +63,7 @@ using gscan::ScanArgs;
 namespace {
 
 constexpr size_t kPad = 4096;          // slack behind every text buffer
-constexpr size_t kSpecPer = 2048;       // records of EACH shard region fetched speculatively with the header
+constexpr size_t kSpecPer = 256;        // records of EACH shard region fetched speculatively with the header
 constexpr size_t kSpecRecs = kSpecPer * gscan::kShards;
 constexpr size_t kCounterWords = gscan::kShards + 2; // per-shard counts + overflow flag + records struck out by the second pass
 constexpr size_t kCopyPiece = 32u << 20; // memcpy/H2D pipelining granule for foreign host buffers
@@ -84,7 +84,8 @@ struct IngestCfg {
     unsigned pin_flags; // hipHostMalloc flags of the staging blocks (GSCAN_PIN_FLAGS: 0 default, 1 non-coherent, 2 write-combined)
     int shared_copy;    // GSCAN_SHARED_COPY: 0 = every context has copy streams of its own; N = the contexts of a device share N
     bool slab;          // GSCAN_SLAB: the reader blocks of a device are carved from ONE pinned allocation instead of one each
-    int read_mode;      // GSCAN_READ_MODE: 0 pread(2) into the block; 1 map the piece and copy it with non-temporal stores (hostcopy.cc)
+    int read_mode;      // GSCAN_READ_MODE: 0 pread(2) into the block; 1 map the piece and copy it with non-temporal stores
+                        // (hostcopy.cc); 2 pread into a cache-sized bounce buffer, non-temporal copy from there
 };
 const IngestCfg &ingest_cfg()
 {
@@ -103,7 +104,7 @@ const IngestCfg &ingest_cfg()
         v.numa = env("GSCAN_NUMA", 1, 0, 1) != 0;
         v.shared_copy = (int)env("GSCAN_SHARED_COPY", 0, 0, 4);
         v.slab = env("GSCAN_SLAB", 0, 0, 1) != 0;
-        v.read_mode = (int)env("GSCAN_READ_MODE", 1, 0, 1);
+        v.read_mode = (int)env("GSCAN_READ_MODE", 0, 0, 2); // (1 and 2 measured and not adopted: profiles/r02_d_e2e_reader_modes.jsonl)
         const long pf = env("GSCAN_PIN_FLAGS", 0, 0, 2);
         v.pin_flags = pf == 1 ? hipHostMallocNonCoherent : pf == 2 ? hipHostMallocWriteCombined : hipHostMallocDefault;
         return v;
@@ -426,6 +427,24 @@ private:
                             munmap(map, t.n);
                             got = t.n;
                         }
+                    }
+                }
+                if (ingest_cfg().read_mode == 2) {
+                    // pread into a buffer that stays in this core's L2, stream it out to the block past the caches
+                    constexpr size_t kBounce = 256u << 10;
+                    static thread_local char *bounce = nullptr;
+                    if (!bounce && posix_memalign((void **)&bounce, 4096, kBounce) != 0) bounce = nullptr;
+                    while (bounce && got < t.n && !err) {
+                        const size_t want = std::min(kBounce, t.n - got);
+                        size_t have = 0;
+                        while (have < want && !err) {
+                            const ssize_t r = pread(t.fd, bounce + have, want - have, t.off + (off_t)(got + have));
+                            if (r > 0) have += (size_t)r;
+                            else if (r == 0) err = -1;
+                            else if (errno != EINTR) err = errno;
+                        }
+                        if (!err) gscan::nt_copy((char *)b->p + got, bounce, want);
+                        got += want;
                     }
                 }
                 while (got < t.n && !err) {
@@ -974,11 +993,13 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     }
     lap("streams");
     // one pinned allocation for every small host-side buffer of the context (each hipHostMalloc costs about a millisecond)
-    const size_t per_slot = 64 + kSpecRecs * 4;
+    const size_t kHead = (kCounterWords * 4 + 63) & ~size_t(63); // the slot's counter words
+    const size_t per_slot = kHead + kSpecRecs * 4;
     const size_t host_bytes = ((sizeof(DevProgram) + 63) & ~size_t(63)) + GSCAN_SLOTS * per_slot;
     if (hipHostMalloc((void **)&c->h_arena, host_bytes, hipHostMallocDefault) != hipSuccess) return bail(GSCAN_EHIP);
     lap("pinned arena");
-    const size_t dev_bytes = ((sizeof(DevProgram) + 255) & ~size_t(255)) + (GSCAN_SLOTS + 1) * 256;
+    const size_t kDevHead = (kCounterWords * 4 + 255) & ~size_t(255);
+    const size_t dev_bytes = ((sizeof(DevProgram) + 255) & ~size_t(255)) + (GSCAN_SLOTS + 1) * kDevHead;
     if (hipMalloc((void **)&c->d_arena, dev_bytes) != hipSuccess) return bail(GSCAN_EHIP);
     lap("device arena");
     {
@@ -989,10 +1010,10 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
         d += (sizeof(DevProgram) + 255) & ~size_t(255);
         for (Slot &s : c->slot) {
             s.h_counter = (uint32_t *)h;
-            s.h_spec = (uint32_t *)(h + 64);
+            s.h_spec = (uint32_t *)(h + kHead);
             h += per_slot;
             s.d_counter = (uint32_t *)d;
-            d += 256;
+            d += kDevHead;
         }
         c->dv_counter = (uint32_t *)d;
     }
@@ -1313,19 +1334,15 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
         total += s->h_counter[k];
         if (s->h_counter[k] > kSpecPer) spec_ok = false;
     }
-    if (!spec_ok) { // dense result: fetch each shard region's used part
+    size_t fullest = 0;
+    for (size_t k = 0; k < K; k++) fullest = std::max<size_t>(fullest, s->h_counter[k]);
+    if (!spec_ok) { // dense result: the used part of every shard region in ONE strided copy (descriptors deal the shards round robin: they fill evenly)
         s->raw.resize(s->rec_cap);
-        for (size_t k = 0; k < K; k++)
-            if (s->h_counter[k])
-                HIPCHK(c, hipMemcpy(s->raw.data() + k * cap_shard, s->d_recs + k * cap_shard, (size_t)s->h_counter[k] * 4,
-                                    hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy2D(s->raw.data(), cap_shard * 4, s->d_recs, cap_shard * 4, fullest * 4, K, hipMemcpyDeviceToHost));
     }
     if (s->has_ext && !spec_ok) {
         s->raw_ext.resize(s->rec_cap * 3);
-        for (size_t k = 0; k < K; k++)
-            if (s->h_counter[k])
-                HIPCHK(c, hipMemcpy(s->raw_ext.data() + k * cap_shard * 3, s->d_ext + k * cap_shard * 3, (size_t)s->h_counter[k] * 12,
-                                    hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy2D(s->raw_ext.data(), cap_shard * 12, s->d_ext, cap_shard * 12, fullest * 12, K, hipMemcpyDeviceToHost));
     }
     s->sorted_ext.clear();
     if (s->has_ext) s->sorted_ext.reserve(total * 3);

@@ -8,7 +8,9 @@
 
 namespace gscan {
 
-constexpr int kShards = 8; // record-buffer regions, each with its own reservation counter
+constexpr int kShards = 64; // record-buffer regions, each with its own reservation counter.  Every WAVE reserves its run with one atomic
+                            // (descriptor d uses shard d & 63): with 8 counters the dense patterns queued up on them -- same-address
+                            // atomics are served one at a time, ~90 ns each (profiles/r02_d_kernel_sweep_per_wave_8_shards.txt)
 constexpr uint32_t kStruck = 0xffffffffu; // a record the second pass (k3_settle) found to be no match: readers skip it
 
 // One scan unit of the launch: a tile of one segment.  16 bytes so a workgroup fetches it

@@ -42,7 +42,9 @@ enum : uint32_t {
     V_SET = 1,     // a: class                                   one byte of the class
     V_REPSET,      // a: class, b: min, c: max; op bits 8-9: mode  a repeat of one class (0 greedy, 1 lazy, 2 possessive)
     V_JMP,         // a: pc
-    V_SPLIT,       // a: pc tried first, b: pc tried second
+    V_SPLIT,       // a: pc tried first, b: pc tried second; c: class of the bytes the first branch can begin with | the second's << 16
+                   //    (0xffff: unknown / the branch may match ""): a branch the next byte rules out is not entered, and its
+                   //    choice point never pushed
     V_SAVE,        // a: slot                                    slot = pos (undone on backtracking)
     V_CLOSE,       // a: first capture slot of the group, b: slot holding its start   a capturing group closes
     V_REP_ENTER,   // a: counter slot                            a repeated group is entered: counter = 0
@@ -108,6 +110,8 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
     const uint32_t n_slots = pg->n_slots;
     for (uint32_t i = 0; i < n_slots; i++) slots[i] = kVmUnset;
     uint32_t sp = 0, pc = 0, pos = p, steps = 0;
+    uint32_t live = 0; // choice points (and negative look-around barriers) on the stack: with none, a failure is final and
+                       // nothing that is only there to be undone on backtracking needs to be pushed
 
 #define VM_PUSH(w0_, w1_)                      \
     do {                                       \
@@ -140,12 +144,14 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
                 if (k > in.b) {
                     VM_PUSH(pos + in.b, pos + k);
                     VM_PUSH(VK_RANGE_DN | ((pc + 1) << 4), 0u);
+                    live++;
                 }
                 pos += k;
             } else if (mode == 1) { // lazy: the minimum, take one more at a time
                 if (k > in.b) {
                     VM_PUSH(pos + k, pos + in.b);
                     VM_PUSH(VK_RANGE_UP | ((pc + 1) << 4), 0u);
+                    live++;
                 }
                 pos += in.b;
             } else {
@@ -155,24 +161,39 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
             break;
         }
         case V_JMP: pc = in.a; break;
-        case V_SPLIT:
-            VM_PUSH(VK_CHOICE | (in.b << 4), pos);
-            pc = in.a;
+        case V_SPLIT: {
+            const uint32_t ca = in.c & 0xffffu, cb = in.c >> 16;
+            const bool oka = ca == 0xffffu || (pos < clen && VM_TEST(ca, (uint32_t)c[pos]));
+            const bool okb = cb == 0xffffu || (pos < clen && VM_TEST(cb, (uint32_t)c[pos]));
+            if (oka && okb) {
+                VM_PUSH(VK_CHOICE | (in.b << 4), pos);
+                live++;
+                pc = in.a;
+            } else if (oka) {
+                pc = in.a;
+            } else if (okb) {
+                pc = in.b;
+            } else {
+                fail = true;
+            }
             break;
+        }
         case V_SAVE:
-            VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
+            if (live) VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
             slots[in.a] = pos;
             pc++;
             break;
         case V_CLOSE:
-            VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
-            VM_PUSH(VK_UNDO | ((in.a + 1) << 4), slots[in.a + 1]);
+            if (live) {
+                VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
+                VM_PUSH(VK_UNDO | ((in.a + 1) << 4), slots[in.a + 1]);
+            }
             slots[in.a] = slots[in.b];
             slots[in.a + 1] = pos;
             pc++;
             break;
         case V_REP_ENTER:
-            VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
+            if (live) VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
             slots[in.a] = 0;
             pc++;
             break;
@@ -181,7 +202,10 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
             const bool can_more = count < in.c, can_stop = count >= in.b;
             if (mode == 1) { // lazy: stop first
                 if (can_stop) {
-                    if (can_more) VM_PUSH(VK_CHOICE | ((pc + 1) << 4), pos);
+                    if (can_more) {
+                        VM_PUSH(VK_CHOICE | ((pc + 1) << 4), pos);
+                        live++;
+                    }
                     pc = exit_pc;
                 } else if (can_more) {
                     pc++;
@@ -190,7 +214,10 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
                 }
             } else {
                 if (can_more) {
-                    if (can_stop) VM_PUSH(VK_CHOICE | (exit_pc << 4), pos);
+                    if (can_stop) {
+                        VM_PUSH(VK_CHOICE | (exit_pc << 4), pos);
+                        live++;
+                    }
                     pc++;
                 } else if (can_stop) {
                     pc = exit_pc;
@@ -202,7 +229,7 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
         }
         case V_REP_END: {
             const uint32_t top = in.op >> 16, count = slots[in.a] + 1;
-            VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
+            if (live) VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
             slots[in.a] = count;
             // an iteration of the UNBOUNDED part that matched "" leaves the loop (PCRE's OP_KETRMAX rule; TreeMatch, Cont::REPG)
             if (pos == slots[in.b] && ((in.op >> 8) & 1u) && count >= in.c) pc = pg->ins[top].op >> 16;
@@ -238,6 +265,7 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
         }
         case V_BAR_BEGIN:
             VM_PUSH(VK_BAR | (((in.op >> 8) & 3u) << 4) | ((in.op >> 16) << 6), pos);
+            if (((in.op >> 8) & 3u) == 2) live++; // a failure inside a negative look-around resumes behind it
             pc++;
             break;
         case V_BAR_END: {
@@ -248,8 +276,13 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
                     sp--;
                     const uint32_t w0 = stk[2 * sp], k = w0 & 15u;
                     if (k == VK_UNDO) slots[w0 >> 4] = stk[2 * sp + 1];
-                    else if (k == VK_RANGE_DN || k == VK_RANGE_UP || k == VK_DEAD2) sp--;
-                    else if (k == VK_BAR) break;
+                    else if (k == VK_CHOICE) live--;
+                    else if (k == VK_RANGE_DN || k == VK_RANGE_UP) sp--, live--;
+                    else if (k == VK_DEAD2) sp--;
+                    else if (k == VK_BAR) {
+                        live--; // (the negative barrier itself)
+                        break;
+                    }
                 }
                 fail = true;
                 break;
@@ -260,9 +293,12 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
                 if (i == 0) return 2;
                 i--;
                 const uint32_t w0 = stk[2 * i], k = w0 & 15u;
-                if (k == VK_CHOICE) stk[2 * i] = VK_DEAD;
-                else if (k == VK_RANGE_DN || k == VK_RANGE_UP) {
+                if (k == VK_CHOICE) {
+                    stk[2 * i] = VK_DEAD;
+                    live--;
+                } else if (k == VK_RANGE_DN || k == VK_RANGE_UP) {
                     stk[2 * i] = VK_DEAD2;
+                    live--;
                     i--;
                 } else if (k == VK_DEAD2) {
                     i--;
@@ -286,12 +322,13 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
             break;
         }
         while (fail) { // backtrack
-            if (sp == 0) return 0;
+            if (sp == 0 || live == 0) return 0; // nothing left to try
             sp--;
             const uint32_t w0 = stk[2 * sp], w1 = stk[2 * sp + 1], k = w0 & 15u;
             if (k == VK_CHOICE) {
                 pc = w0 >> 4;
                 pos = w1;
+                live--;
                 fail = false;
             } else if (k == VK_UNDO) {
                 slots[w0 >> 4] = w1;
@@ -304,6 +341,7 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
                     sp++; // the frame stays
                 } else {
                     sp--;
+                    live--;
                 }
                 fail = false;
             } else if (k == VK_RANGE_UP) { // {hi, cur}
@@ -315,12 +353,14 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
                     sp++;
                 } else {
                     sp--;
+                    live--;
                 }
                 fail = false;
             } else if (k == VK_BAR) {
                 if (((w0 >> 4) & 3u) == 2) { // the body of a negative look-around found no match: the assertion holds
                     pos = w1;
                     pc = w0 >> 6;
+                    live--;
                     fail = false;
                 } // else: an atomic group / positive look-around that cannot match -- keep failing
             } else if (k == VK_DEAD2) {

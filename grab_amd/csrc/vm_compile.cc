@@ -119,13 +119,78 @@ struct Builder {
         gen(alt);
     }
 
+    // What a match of the node can begin with: the set of first bytes, and whether it can match without consuming one (then
+    // what follows decides and nothing can be predicted).
+    struct First {
+        ByteSet set;
+        bool nullable = false;
+    };
+    static First first_of(const Node &n)
+    {
+        First f;
+        switch (n.kind) {
+        case Node::SET: f.set = n.set; break;
+        case Node::CAT:
+            f.nullable = true;
+            for (const Node &k : n.kids) {
+                const First g = first_of(k);
+                f.set.merge(g.set);
+                if (!g.nullable) {
+                    f.nullable = false;
+                    break;
+                }
+            }
+            break;
+        case Node::ALT:
+            if (n.kids.empty()) f.nullable = true;
+            for (const Node &k : n.kids) {
+                const First g = first_of(k);
+                f.set.merge(g.set);
+                f.nullable = f.nullable || g.nullable;
+            }
+            break;
+        case Node::REP: {
+            if (n.max == 0) {
+                f.nullable = true;
+                break;
+            }
+            f = first_of(n.kids[0]);
+            if (n.min == 0) f.nullable = true;
+            break;
+        }
+        case Node::ATOMIC: f = first_of(n.kids[0]); break;
+        case Node::ASSERT:
+        case Node::LOOK:
+        case Node::BACKREF: // (what a reference repeats is not known here, and it may be "")
+            f.nullable = true;
+            break;
+        }
+        return f;
+    }
+    // class id of what the alternatives kids[from..] can begin with, 0xffff if one of them may match ""
+    uint32_t first_class(const std::vector<const Node *> &kids, size_t from, size_t to)
+    {
+        First f;
+        for (size_t i = from; i < to; i++) {
+            const First g = first_of(*kids[i]);
+            if (g.nullable) return 0xffffu;
+            f.set.merge(g.set);
+        }
+        const uint32_t id = cls_id(f.set);
+        return ok ? id : 0xffffu;
+    }
+
     void alternatives(const std::vector<const Node *> &kids, bool behind)
     {
         std::vector<uint32_t> jumps;
         for (size_t i = 0; i < kids.size(); i++) {
             uint32_t split = 0;
             const bool last = i + 1 == kids.size();
-            if (!last) split = emit(V_SPLIT, here() + 1, 0);
+            // (look-behind alternatives step BACK first: the byte at pos says nothing about them)
+            if (!last) {
+                const uint32_t ca = behind ? 0xffffu : first_class(kids, i, i + 1), cb = behind ? 0xffffu : first_class(kids, i + 1, kids.size());
+                split = emit(V_SPLIT, here() + 1, 0, ca | (cb << 16));
+            }
             if (behind) behind_alt(*kids[i]);
             else gen(*kids[i]);
             if (!last) {

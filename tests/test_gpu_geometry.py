@@ -64,7 +64,7 @@ def boundary_file(size):
              STRIDE + CHUNK - 3,                                  # straddling the end of window 1
              CHUNK - 6,                                           # ending exactly at the end of window 0
              STRIDE,                                              # at the start of window 1 (window 2's start gets a run of `a`)
-             CHUNK - 4096 - 3, CHUNK + 5000,                      # straddling a window START; plain interior of window 1
+             CHUNK + 5000,                                        # plain interior of window 1
              size - 18, size - 6]                                 # the last 18 bytes; the very end
     for at in spots:
         buf[at:at + 6] = nd
