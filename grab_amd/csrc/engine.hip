@@ -71,11 +71,16 @@ constexpr size_t kMaxChunk = (1ull << 30) + 4096;
 
 // ---- ingest configuration (environment, read once) ----
 //   GSCAN_BLOCK_MIB     pinned pool block == read piece == one hipMemcpyAsync == batch buffer        (default 16)
-//   GSCAN_READERS       reader threads per device                                                   (default 12)
-//   GSCAN_COPY_STREAMS  copy streams per context the pieces of a file range are spread over         (default 2)
-//   GSCAN_NUMA          0: readers inherit the opener's CPU mask; else the CPUs local to the device  (default 1)
-// Why these: a hipMemcpyAsync carries a fixed cost that 8 MiB pieces on one stream do not hide (39 GB/s against 56 GB/s
-// for 32 MiB pieces, profiles/r01_g_host_probe.txt); the sweep behind the defaults is profiles/r02_*e2e_sweep*.
+//   GSCAN_READERS       reader threads per device                                                   (default 8)
+//   GSCAN_COPY_STREAMS  copy streams per context the pieces of a file range are spread over         (default 1)
+//   GSCAN_NUMA          0: readers inherit the process's CPU mask; else the CPUs local to the device (default 1)
+// and, measured and left off: GSCAN_SHARED_COPY (device-wide copy streams), GSCAN_SLAB (one pinned allocation),
+// GSCAN_PIN_FLAGS (non-coherent / write-combined blocks), GSCAN_READ_MODE (mapping or bounce buffer + non-temporal copy).
+// What the round-2 sweeps on the MI355X boxes say (profiles/r02_a_e2e_ingest_sweep.jsonl, r02_b_dma_probe.txt, r02_b..e_e2e_*):
+// the link itself moves 57 GB/s in any piece size >= 16 MiB, also next to 16 busy pread threads; inside the pipeline the
+// 64 GiB corpus goes through at 44-47 GB/s whatever the block size (8/16/32 MiB), the number of copy streams, their
+// sharing, the flavour of the pinned memory or the way the readers copy; 8 readers are the best (more of them wait for
+// blocks longer than they save reading).  16 MiB is where the per-copy cost stops showing in the probe.
 struct IngestCfg {
     size_t block;
     int readers;
@@ -97,10 +102,10 @@ const IngestCfg &ingest_cfg()
             return std::max(lo, std::min(hi, x));
         };
         v.block = (size_t)env("GSCAN_BLOCK_MIB", 16, 1, 64) << 20;
-        v.readers = (int)env("GSCAN_READERS", 12, 1, 64);
+        v.readers = (int)env("GSCAN_READERS", 8, 1, 64);
         const long hw = (long)std::thread::hardware_concurrency();
         if (hw > 0 && v.readers > hw) v.readers = (int)hw;
-        v.copy_streams = (int)env("GSCAN_COPY_STREAMS", 2, 1, 4);
+        v.copy_streams = (int)env("GSCAN_COPY_STREAMS", 1, 1, 4);
         v.numa = env("GSCAN_NUMA", 1, 0, 1) != 0;
         v.shared_copy = (int)env("GSCAN_SHARED_COPY", 0, 0, 4);
         v.slab = env("GSCAN_SLAB", 0, 0, 1) != 0;
@@ -1413,7 +1418,7 @@ int gscan_set_option(gscan_ctx *c, const char *name, long value)
 {
     if (!c || !name) return GSCAN_EINVAL;
     if (!strcmp(name, "variant")) {
-        if (value != 13 && value != 21 && (value < 0 || value > 7 || (value & 3) == 3)) return GSCAN_EINVAL; // KiB per wave {16,8,12} | nontemporal<<2; 13: 768-thread workgroups for the table kernels
+        if (value != 13 && (value < 0 || value > 7 || (value & 3) == 3)) return GSCAN_EINVAL; // KiB per wave {16,8,12} | nontemporal<<2; 13: 768-thread workgroups for the table kernels
         c->variant = (int)value;
         return GSCAN_OK;
     }

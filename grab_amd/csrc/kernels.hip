@@ -258,29 +258,47 @@ __device__ __forceinline__ void emit_wave(const ScanArgs &a, uint32_t d, const u
     }
 }
 
-// Dense-output epilogue: the same reservation, but the per-step masks are first transposed through a wave-private strip of
-// LDS so that lane L owns ITER consecutive (step, lane) cells, i.e. a contiguous piece of text.  One wave scan then places
-// every lane's records; emit_wave pays a ballot + rank + branch for each of the ITER steps instead, which is what limits the
-// kernels when most steps carry records (identifier regex: 3.6 records per KiB).  The strip is the wave's own: the only
-// ordering needed is between the wave's LDS writes and its reads (no workgroup barrier).
-template <int ITER>
-__device__ __forceinline__ void emit_wave_t(const ScanArgs &a, uint32_t d, const uint32_t (&hits)[(ITER + 1) / 2], uint32_t cnt, int sub_off,
-                                            uint32_t bias, uint32_t lane, uint16_t *xp)
+// Dense-output epilogue (K2): the per-step masks are first transposed through a wave-private strip of LDS so that lane L owns
+// ITER consecutive (step, lane) cells, i.e. a contiguous piece of text.  One wave scan then places every lane's records;
+// emit_wave pays a ballot + rank + branch for each of the ITER steps instead, which is what limits the kernels when most
+// steps carry records (identifier regex: 3.6 records per KiB).
+// Reservation: ONE atomic per TILE here (wave counts through LDS, two workgroup barriers), each wave still writing its own
+// descriptor.  When every wave has records a reservation per wave means eight times the returning atomics, and each one
+// stalls its wave for the round trip: measured on the identifier scan, 2.5 TB/s per wave (64 counters; 1.1 TB/s with 8)
+// against 5.2 TB/s per tile (profiles/r02_e_kernel_sweep_per_wave_64_shards.txt).  Without records the per-wave form is
+// the faster one (+8 %): K1 and K3, whose outputs are sparse, use it; K2 pays the barriers.
+template <int ITER, int NWAVES>
+__device__ __forceinline__ void emit_tile_t(const ScanArgs &a, uint32_t t, const uint32_t (&hits)[(ITER + 1) / 2], uint32_t cnt, int sub_off,
+                                            uint32_t bias, uint32_t lane, uint32_t wave, uint32_t *s_cnt, uint32_t *s_base, uint16_t *s_xp)
 {
     static_assert(ITER % 4 == 0, "a lane reads its ITER masks as 64-bit words");
-    const uint32_t wtot = wave_sum(cnt);
-    if (wtot == 0) {
-        if (lane == 0) a.desc[d] = 0ull;
-        return;
-    }
+    uint16_t *xp = s_xp + wave * (ITER * 64);
 #pragma unroll
     for (int k = 0; k < ITER; k++) xp[k * 64 + lane] = (uint16_t)(hits[k >> 1] >> (16 * (k & 1)));
-    const uint32_t shard = d & (kShards - 1);
-    uint32_t b = 0;
-    if (lane == 0) b = atomicAdd(a.counter + shard, wtot);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the strip's writes have landed ...
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // ... before any lane reads its cells
+    const uint32_t wtot = wave_sum(cnt);
+    if (lane == 0) s_cnt[wave] = wtot;
+    __syncthreads(); // also orders the strip's writes before its reads
+    uint32_t total = 0, before = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; w++) {
+        const uint32_t c = s_cnt[w];
+        total += c;
+        if ((uint32_t)w < wave) before += c;
+    }
+    const uint32_t d = t * NWAVES + wave;
+    if (total == 0) {
+        if (lane == 0) a.desc[d] = 0ull;
+        __syncthreads(); // s_cnt is rewritten by the next tile
+        return;
+    }
+    const uint32_t shard = t & (kShards - 1);
+    if (threadIdx.x == 0) {
+        const uint32_t b = atomicAdd(a.counter + shard, total); // index inside the shard's region
+        *s_base = b;
+        if ((unsigned long long)b + total > (unsigned long long)a.cap_shard) atomicOr(a.counter + kShards, 1u);
+    }
+    __syncthreads();
+    const uint32_t base = *s_base;
     // cells lane*ITER .. lane*ITER+ITER-1 of the strip, 4 masks per 64-bit word
     unsigned long long w[ITER / 4];
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xp + lane * ITER);
@@ -290,16 +308,12 @@ __device__ __forceinline__ void emit_wave_t(const ScanArgs &a, uint32_t d, const
         w[q] = src[q];
         c += (uint32_t)__popcll(w[q]);
     }
-    const uint32_t base = __builtin_amdgcn_readfirstlane(b);
-    const bool over = (unsigned long long)base + wtot > (unsigned long long)a.cap_shard;
-    if (lane == 0) {
-        a.desc[d] = (unsigned long long)wtot | ((unsigned long long)(shard * a.cap_shard + base) << 32);
-        if (over) atomicOr(a.counter + kShards, 1u);
-    }
-    __builtin_amdgcn_wave_barrier(); // (the next tile's strip writes stay behind these reads: same wave, program order)
-    if (over) return;
+    __syncthreads(); // s_base / s_cnt / the strip are free for the next tile
+    if (lane == 0) a.desc[d] = wtot ? (unsigned long long)wtot | ((unsigned long long)(shard * a.cap_shard + base + before) << 32) : 0ull;
+    if ((unsigned long long)base + total > (unsigned long long)a.cap_shard) return; // overflow: the host re-runs with a bigger buffer
+    if (wtot == 0) return;
     const uint32_t inc = wave_scan(c);
-    uint32_t idx = shard * a.cap_shard + base + inc - c;
+    uint32_t idx = shard * a.cap_shard + base + before + inc - c;
 #pragma unroll
     for (int q = 0; q < ITER / 4; q++) {
         unsigned long long bitsq = w[q];
@@ -454,16 +468,19 @@ __device__ __forceinline__ uint32_t run_one_flat(uint32_t d, uint32_t w0, uint32
 // one v_readlane + a handful of s_bfe per run and step; NR = -1 (the other forms): run_and's scalar loops.  Measured on
 // the identifier scan: the scalar loops cost 203 M SALU instructions per 4 GiB against 31 M, and 8 % of the time
 // (profiles/r01_w_k2_opt_sweep.txt, r01_w_k2_pmc.txt).
-// NW (pair form): waves per workgroup -- 8 (512 threads, ITER 12: 4 waves per SIMD), 12 (768 threads, ITER 8, two
-// workgroups per CU = 6 waves per SIMD within 80 VGPRs; same 96 KiB tile) or 16 (1024 threads, ITER 8, two workgroups per
-// CU = 8 waves per SIMD within 64 VGPRs; table + strips = 80 KiB, two of them are the CU's whole LDS).
+// NW (pair form): waves per workgroup -- 8 (512 threads, ITER 12: 4 waves per SIMD) or 12 (768 threads, ITER 8, two
+// workgroups per CU = 6 waves per SIMD within 80 VGPRs; same 96 KiB tile).  Measured: more waves buy nothing with records
+// (5.16 vs 5.22 TB/s on the identifier scan) and +1..8 % without (1024 threads, 8 waves per SIMD, plain epilogue: 6.4 vs
+// 5.9 TB/s) -- profiles/r02_b_kernel_sweep_workgroup_shapes.txt; the default stays 512 threads.
 template <int ITER, bool NT, bool WIDE, bool PAIR, int NR = -1, int NW = (PAIR ? 8 : 4)>
-__global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : NW == 16 ? 8 : 1) void k2_classrun_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
+__global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) void k2_classrun_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     static_assert(NR < 0 || (PAIR && !WIDE), "the flat run program is the two-class, 32-bit form's");
     constexpr int kNW = NW; // waves per workgroup
     __shared__ uint32_t tbl[PAIR ? 65536 / 4 : 256 * 32];
     __shared__ __attribute__((aligned(8))) uint16_t s_xp[kNW * ITER * 64]; // epilogue transposition strips, 2 bytes per (step, lane), one per wave
+    __shared__ uint32_t s_cnt[kNW];
+    __shared__ uint32_t s_base;
     constexpr uint32_t kTile = kNW * ITER * 1024;
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x / kWave;
@@ -623,7 +640,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : NW ==
             }
         }
         // K2's outputs are the dense ones: transposed epilogue (+8 % on the identifier scan, neutral without matches)
-        emit_wave_t<ITER>(a, t * kNW + wave, hits, cnt, sub_off, 0u - a.report_shift, lane, s_xp + wave * (ITER * 64));
+        emit_tile_t<ITER, kNW>(a, t, hits, cnt, sub_off, 0u - a.report_shift, lane, wave, s_cnt, &s_base, s_xp);
     }
 }
 #undef GS_LUT
@@ -1033,14 +1050,7 @@ static void launch_k2(bool wide, bool pair, int wg, const ScanArgs &a, dim3 g, h
 {
     const TileDesc *tiles = a.tiles;
     const bool w12 = wg == 12;
-    if (pair && wg == 16 && ITER == 8 && NT) { // 1024-thread workgroups, two per CU
-        constexpr int I = 8;
-        if (wide) hipLaunchKernelGGL((k2_classrun_scan<I, true, true, true, -1, 16>), g, dim3(1024), 0, st, a, tiles);
-        else if (a.nruns == 1) hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 1, 16>), g, dim3(1024), 0, st, a, tiles);
-        else if (a.nruns == 2) hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 2, 16>), g, dim3(1024), 0, st, a, tiles);
-        else if (a.nruns == 3) hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 3, 16>), g, dim3(1024), 0, st, a, tiles);
-        else hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 0, 16>), g, dim3(1024), 0, st, a, tiles);
-    } else if (pair && w12 && ITER == 8 && NT) { // 768-thread workgroups, two per CU
+    if (pair && w12 && ITER == 8 && NT) { // 768-thread workgroups, two per CU
         constexpr int I = 8;
         if (wide) hipLaunchKernelGGL((k2_classrun_scan<I, true, true, true, -1, 12>), g, dim3(768), 0, st, a, tiles);
         else if (a.nruns == 1) hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 1, 12>), g, dim3(768), 0, st, a, tiles);
@@ -1157,15 +1167,13 @@ hipError_t launch_lines(const ScanArgs &a, uint32_t nw, uint32_t sub_bytes, uint
 }
 
 // variant: bits 0-1 KiB per wave {0: 16, 1: 8, 2: 12}; bit 2 nontemporal loads; with 8 KiB per wave + nontemporal, bit 3
-// (variant 13): the table kernels (K3, K2's pair form) run 768-thread workgroups; bit 4 (variant 21): K2's pair form runs
-// 1024-thread workgroups.  K2's general form (3-4 classes): variant 13 = 512-thread workgroups sharing one 32 KiB table,
+// (variant 13): the table kernels (K3, K2's pair form) run 768-thread workgroups.  K2's general form (3-4 classes): variant 13 = 512-thread workgroups sharing one 32 KiB table,
 // three per CU, as a persistent grid.  Returns the waves per workgroup asked for, 0 = the kernel's own.
 static int variant_wg(int tier, int variant, uint32_t n_classes)
 {
     const bool pair = tier == GSCAN_TIER_CLASSRUN && n_classes <= 2;
     if (variant == 13 && (pair || tier == GSCAN_TIER_BUCKET)) return 12;
     if (variant == 13 && tier == GSCAN_TIER_CLASSRUN) return 8;
-    if (variant == 21 && pair) return 16;
     return 0;
 }
 

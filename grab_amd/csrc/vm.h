@@ -102,13 +102,50 @@ GSCAN_HD inline bool vm_holds(uint32_t code, const uint8_t *c, uint32_t clen, ui
     return false;
 }
 
+// The VM's slots (capture offsets, repeat counters, iteration marks).  NREG > 0: at most NREG of them, held in registers --
+// every access is a compare-and-select chain over constant indices, which is a handful of VALU operations where a
+// dynamically indexed array is a round trip to scratch memory (on the device that is what bounds a pattern whose every
+// candidate runs the VM).  NREG == 0: any number, in an array.
+template <int NREG>
+struct VmSlots {
+    uint32_t r[NREG > 0 ? NREG : kVmMaxSlots];
+    GSCAN_HD inline void init(uint32_t n)
+    {
+        if (NREG > 0) {
+#pragma unroll
+            for (int k = 0; k < NREG; k++) r[k] = kVmUnset;
+        } else {
+            for (uint32_t i = 0; i < n; i++) r[i] = kVmUnset;
+        }
+    }
+    GSCAN_HD inline uint32_t get(uint32_t i) const
+    {
+        if (NREG > 0) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < NREG; k++) v = i == (uint32_t)k ? r[k] : v;
+            return v;
+        }
+        return r[i];
+    }
+    GSCAN_HD inline void set(uint32_t i, uint32_t x)
+    {
+        if (NREG > 0) {
+#pragma unroll
+            for (int k = 0; k < NREG; k++) r[k] = i == (uint32_t)k ? x : r[k];
+        } else {
+            r[i] = x;
+        }
+    }
+};
+
 // 0: no match starts at p;  1: a match starts at p;  2: gave up.  c[0..clen) is the chunk (segment), s0 its subject start.
-GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, uint32_t p, uint32_t s0)
+template <int NREG>
+GSCAN_HD inline int vm_run_t(const VmProg *pg, const uint8_t *c, uint32_t clen, uint32_t p, uint32_t s0)
 {
-    uint32_t slots[kVmMaxSlots];
+    VmSlots<NREG> slots;
     uint32_t stk[2 * kVmStack];
-    const uint32_t n_slots = pg->n_slots;
-    for (uint32_t i = 0; i < n_slots; i++) slots[i] = kVmUnset;
+    slots.init(pg->n_slots);
     uint32_t sp = 0, pc = 0, pos = p, steps = 0;
     uint32_t live = 0; // choice points (and negative look-around barriers) on the stack: with none, a failure is final and
                        // nothing that is only there to be undone on backtracking needs to be pushed
@@ -179,26 +216,26 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
             break;
         }
         case V_SAVE:
-            if (live) VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
-            slots[in.a] = pos;
+            if (live) VM_PUSH(VK_UNDO | (in.a << 4), slots.get(in.a));
+            slots.set(in.a, pos);
             pc++;
             break;
         case V_CLOSE:
             if (live) {
-                VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
-                VM_PUSH(VK_UNDO | ((in.a + 1) << 4), slots[in.a + 1]);
+                VM_PUSH(VK_UNDO | (in.a << 4), slots.get(in.a));
+                VM_PUSH(VK_UNDO | ((in.a + 1) << 4), slots.get(in.a + 1));
             }
-            slots[in.a] = slots[in.b];
-            slots[in.a + 1] = pos;
+            slots.set(in.a, slots.get(in.b));
+            slots.set(in.a + 1, pos);
             pc++;
             break;
         case V_REP_ENTER:
-            if (live) VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
-            slots[in.a] = 0;
+            if (live) VM_PUSH(VK_UNDO | (in.a << 4), slots.get(in.a));
+            slots.set(in.a, 0);
             pc++;
             break;
         case V_REP_TOP: {
-            const uint32_t mode = (in.op >> 8) & 3u, exit_pc = in.op >> 16, count = slots[in.a];
+            const uint32_t mode = (in.op >> 8) & 3u, exit_pc = in.op >> 16, count = slots.get(in.a);
             const bool can_more = count < in.c, can_stop = count >= in.b;
             if (mode == 1) { // lazy: stop first
                 if (can_stop) {
@@ -228,11 +265,11 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
             break;
         }
         case V_REP_END: {
-            const uint32_t top = in.op >> 16, count = slots[in.a] + 1;
-            if (live) VM_PUSH(VK_UNDO | (in.a << 4), slots[in.a]);
-            slots[in.a] = count;
+            const uint32_t top = in.op >> 16, old = slots.get(in.a), count = old + 1;
+            if (live) VM_PUSH(VK_UNDO | (in.a << 4), old);
+            slots.set(in.a, count);
             // an iteration of the UNBOUNDED part that matched "" leaves the loop (PCRE's OP_KETRMAX rule; TreeMatch, Cont::REPG)
-            if (pos == slots[in.b] && ((in.op >> 8) & 1u) && count >= in.c) pc = pg->ins[top].op >> 16;
+            if (pos == slots.get(in.b) && ((in.op >> 8) & 1u) && count >= in.c) pc = pg->ins[top].op >> 16;
             else pc = top;
             break;
         }
@@ -241,7 +278,7 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
             else fail = true;
             break;
         case V_BACKREF: {
-            const uint32_t lo = slots[in.a], hi = slots[in.a + 1];
+            const uint32_t lo = slots.get(in.a), hi = slots.get(in.a + 1);
             if (lo == kVmUnset || hi == kVmUnset || hi < lo) { // a reference to a group that has not been set fails
                 fail = true;
                 break;
@@ -275,7 +312,7 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
                     if (sp == 0) return 2;
                     sp--;
                     const uint32_t w0 = stk[2 * sp], k = w0 & 15u;
-                    if (k == VK_UNDO) slots[w0 >> 4] = stk[2 * sp + 1];
+                    if (k == VK_UNDO) slots.set(w0 >> 4, stk[2 * sp + 1]);
                     else if (k == VK_CHOICE) live--;
                     else if (k == VK_RANGE_DN || k == VK_RANGE_UP) sp--, live--;
                     else if (k == VK_DEAD2) sp--;
@@ -331,7 +368,7 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
                 live--;
                 fail = false;
             } else if (k == VK_UNDO) {
-                slots[w0 >> 4] = w1;
+                slots.set(w0 >> 4, w1);
             } else if (k == VK_RANGE_DN) { // the entry below: {lo, cur}
                 const uint32_t lo = stk[2 * (sp - 1)], cur = stk[2 * (sp - 1) + 1] - 1;
                 pos = cur;
@@ -371,6 +408,11 @@ GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, ui
     }
 #undef VM_PUSH
 #undef VM_TEST
+}
+
+GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, uint32_t p, uint32_t s0)
+{
+    return pg->n_slots <= 8u ? vm_run_t<8>(pg, c, clen, p, s0) : vm_run_t<0>(pg, c, clen, p, s0);
 }
 
 } // namespace gscan
