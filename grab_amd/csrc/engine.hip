@@ -65,7 +65,8 @@ namespace {
 constexpr size_t kPad = 4096;          // slack behind every text buffer
 constexpr size_t kSpecPer = 256;        // records of EACH shard region fetched speculatively with the header
 constexpr size_t kSpecRecs = kSpecPer * gscan::kShards;
-constexpr size_t kCounterWords = gscan::kShards + 2; // per-shard counts + overflow flag + records struck out by the second pass
+constexpr size_t kCS = gscan::kCtrStride;                  // the shard counters sit one per 128-byte line (scan_args.h)
+constexpr size_t kCounterWords = gscan::kShards * kCS + 2; // per-shard counts + overflow flag + records struck out by the second pass
 constexpr size_t kCopyPiece = 32u << 20; // memcpy/H2D pipelining granule for foreign host buffers
 constexpr size_t kMaxChunk = (1ull << 30) + 4096;
 
@@ -1315,11 +1316,11 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     slot_unregister(*s); // the DMA out of the caller's buffer is over (the text stays in HBM for a possible rescan)
     const size_t K = gscan::kShards;
     for (int attempt = 0; attempt < 2; attempt++) {
-        if (s->h_counter[K] == 0) break; // no shard overflowed
+        if (s->h_counter[K * kCS] == 0) break; // no shard overflowed
         if (attempt == 1) return fail(c, GSCAN_EHIP, "record buffer overflow persisted after regrow");
         // the text is still in HBM: size every shard for the fullest one (+25%) and rescan
         uint32_t worst = 0;
-        for (size_t k = 0; k < K; k++) worst = std::max(worst, s->h_counter[k]);
+        for (size_t k = 0; k < K; k++) worst = std::max(worst, s->h_counter[k * kCS]);
         size_t want = ((size_t)worst + (size_t)worst / 4 + kSpecPer) * K;
         HIPCHK(c, hipStreamSynchronize(c->compute));
         if (s->d_recs) hipFree(s->d_recs);
@@ -1332,15 +1333,15 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
         HIPCHK(c, hipEventSynchronize(s->done));
     }
     const size_t cap_shard = s->rec_cap / K;
-    const size_t struck = s->h_counter[K + 1]; // records the second pass struck out (kStruck in the buffer)
+    const size_t struck = s->h_counter[K * kCS + 1]; // records the second pass struck out (kStruck in the buffer)
     size_t total = 0;
     bool spec_ok = true;
     for (size_t k = 0; k < K; k++) {
-        total += s->h_counter[k];
-        if (s->h_counter[k] > kSpecPer) spec_ok = false;
+        total += s->h_counter[k * kCS];
+        if (s->h_counter[k * kCS] > kSpecPer) spec_ok = false;
     }
     size_t fullest = 0;
-    for (size_t k = 0; k < K; k++) fullest = std::max<size_t>(fullest, s->h_counter[k]);
+    for (size_t k = 0; k < K; k++) fullest = std::max<size_t>(fullest, s->h_counter[k * kCS]);
     if (!spec_ok) { // dense result: the used part of every shard region in ONE strided copy (descriptors deal the shards round robin: they fill evenly)
         s->raw.resize(s->rec_cap);
         HIPCHK(c, hipMemcpy2D(s->raw.data(), cap_shard * 4, s->d_recs, cap_shard * 4, fullest * 4, K, hipMemcpyDeviceToHost));
@@ -1547,9 +1548,9 @@ int gscan_dev_sync(gscan_ctx *c, gscan_dev_result *res)
     HIPCHK(c, hipMemcpyAsync(h, c->dv_counter, sizeof h, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     res->total = 0;
-    for (size_t k = 0; k < (size_t)gscan::kShards; k++) res->total += h[k];
-    res->overflow = h[gscan::kShards] != 0;
-    if (!res->overflow) res->total -= h[gscan::kShards + 1]; // records struck out by the second pass
+    for (size_t k = 0; k < (size_t)gscan::kShards; k++) res->total += h[k * kCS];
+    res->overflow = h[gscan::kShards * kCS] != 0;
+    if (!res->overflow) res->total -= h[gscan::kShards * kCS + 1]; // records struck out by the second pass
     return GSCAN_OK;
 }
 

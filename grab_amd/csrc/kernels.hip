@@ -224,12 +224,12 @@ __device__ __forceinline__ void emit_wave(const ScanArgs &a, uint32_t d, const u
     }
     const uint32_t shard = d & (kShards - 1);
     uint32_t b = 0;
-    if (lane == 0) b = atomicAdd(a.counter + shard, wtot); // index inside the shard's region
+    if (lane == 0) b = atomicAdd(a.counter + shard * kCtrStride, wtot); // index inside the shard's region
     const uint32_t base = __builtin_amdgcn_readfirstlane(b);
     const bool over = (unsigned long long)base + wtot > (unsigned long long)a.cap_shard;
     if (lane == 0) {
         a.desc[d] = (unsigned long long)wtot | ((unsigned long long)(shard * a.cap_shard + base) << 32);
-        if (over) atomicOr(a.counter + kShards, 1u);
+        if (over) atomicOr(a.counter + kShards * kCtrStride, 1u);
     }
     if (over) return; // overflow: the host re-runs with a bigger buffer
     uint32_t run = shard * a.cap_shard + base;
@@ -255,6 +255,54 @@ __device__ __forceinline__ void emit_wave(const ScanArgs &a, uint32_t d, const u
             a.recs[idx++] = pos0 + j;
         }
         run += __builtin_amdgcn_readlane(inc, 63);
+    }
+}
+
+// The per-wave form of the dense epilogue (experiment switch GSCAN_K2_EMIT_WAVE=1: ScanArgs::k2_emit_wave).
+template <int ITER>
+__device__ __forceinline__ void emit_wave_t(const ScanArgs &a, uint32_t d, const uint32_t (&hits)[(ITER + 1) / 2], uint32_t cnt, int sub_off,
+                                            uint32_t bias, uint32_t lane, uint16_t *xp)
+{
+    const uint32_t wtot = wave_sum(cnt);
+    if (wtot == 0) {
+        if (lane == 0) a.desc[d] = 0ull;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < ITER; k++) xp[k * 64 + lane] = (uint16_t)(hits[k >> 1] >> (16 * (k & 1)));
+    const uint32_t shard = d & (kShards - 1);
+    uint32_t b = 0;
+    if (lane == 0) b = atomicAdd(a.counter + shard * kCtrStride, wtot);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    unsigned long long w[ITER / 4];
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xp + lane * ITER);
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < ITER / 4; q++) {
+        w[q] = src[q];
+        c += (uint32_t)__popcll(w[q]);
+    }
+    const uint32_t base = __builtin_amdgcn_readfirstlane(b);
+    const bool over = (unsigned long long)base + wtot > (unsigned long long)a.cap_shard;
+    if (lane == 0) {
+        a.desc[d] = (unsigned long long)wtot | ((unsigned long long)(shard * a.cap_shard + base) << 32);
+        if (over) atomicOr(a.counter + kShards * kCtrStride, 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (over) return;
+    const uint32_t inc = wave_scan(c);
+    uint32_t idx = shard * a.cap_shard + base + inc - c;
+#pragma unroll
+    for (int q = 0; q < ITER / 4; q++) {
+        unsigned long long bitsq = w[q];
+        while (bitsq) {
+            const uint32_t bb = (uint32_t)__ffsll((long long)bitsq) - 1u;
+            bitsq &= bitsq - 1ull;
+            const uint32_t cell = lane * ITER + q * 4 + (bb >> 4);
+            a.recs[idx++] = (uint32_t)sub_off + (cell >> 6) * 1024u + (cell & 63u) * 16u + (bb & 15u) - bias;
+        }
     }
 }
 
@@ -293,9 +341,9 @@ __device__ __forceinline__ void emit_tile_t(const ScanArgs &a, uint32_t t, const
     }
     const uint32_t shard = t & (kShards - 1);
     if (threadIdx.x == 0) {
-        const uint32_t b = atomicAdd(a.counter + shard, total); // index inside the shard's region
+        const uint32_t b = atomicAdd(a.counter + shard * kCtrStride, total); // index inside the shard's region
         *s_base = b;
-        if ((unsigned long long)b + total > (unsigned long long)a.cap_shard) atomicOr(a.counter + kShards, 1u);
+        if ((unsigned long long)b + total > (unsigned long long)a.cap_shard) atomicOr(a.counter + kShards * kCtrStride, 1u);
     }
     __syncthreads();
     const uint32_t base = *s_base;
@@ -640,7 +688,8 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) vo
             }
         }
         // K2's outputs are the dense ones: transposed epilogue (+8 % on the identifier scan, neutral without matches)
-        emit_tile_t<ITER, kNW>(a, t, hits, cnt, sub_off, 0u - a.report_shift, lane, wave, s_cnt, &s_base, s_xp);
+        if (a.k2_emit_wave) emit_wave_t<ITER>(a, t * kNW + wave, hits, cnt, sub_off, 0u - a.report_shift, lane, s_xp + wave * (ITER * 64));
+        else emit_tile_t<ITER, kNW>(a, t, hits, cnt, sub_off, 0u - a.report_shift, lane, wave, s_cnt, &s_base, s_xp);
     }
 }
 #undef GS_LUT
@@ -838,7 +887,7 @@ __global__ __launch_bounds__(256) void k3_settle(ScanArgs a, const TileDesc *__r
     const unsigned long long d = a.desc[st];
     const uint32_t cnt = (uint32_t)d;
     if (cnt == 0) return;
-    if (a.counter[kShards] != 0) return; // some shard overflowed: the host rescans with a bigger buffer (and settles then)
+    if (a.counter[kShards * kCtrStride] != 0) return; // some shard overflowed: the host rescans with a bigger buffer (and settles then)
     const uint32_t base = (uint32_t)(d >> 32);
     uint64_t seg_off;
     uint32_t slen;
@@ -858,7 +907,7 @@ __global__ __launch_bounds__(256) void k3_settle(ScanArgs a, const TileDesc *__r
             struck++;
         }
     }
-    if (struck) atomicAdd(a.counter + kShards + 1, struck);
+    if (struck) atomicAdd(a.counter + kShards * kCtrStride + 1, struck);
 }
 
 // ------------------------------------------------------------------------------------
@@ -903,7 +952,7 @@ __global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__rest
     const uint32_t tile_bytes = sub_bytes; // (the walk back over earlier descriptors below steps by sub-tiles)
     const unsigned long long d = a.desc[st];
     const uint32_t cnt = (uint32_t)d;
-    if (cnt == 0 || a.counter[kShards] != 0) return; // (overflow: the host rescans with a bigger buffer and this pass runs again)
+    if (cnt == 0 || a.counter[kShards * kCtrStride] != 0) return; // (overflow: the host rescans with a bigger buffer and this pass runs again)
     const uint32_t base = (uint32_t)(d >> 32);
     uint64_t seg_off;
     uint32_t slen, tile_off;
@@ -1108,6 +1157,7 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
     a.nruns = pg.nruns;
     a.k3_off = pg.k3_off;
     a.vm_filter = pg.vm_filter;
+    a.k2_emit_wave = getenv("GSCAN_K2_EMIT_WAVE") ? 1u : 0u;
     a.report_shift = pg.report_shift;
     // the filter IS the pattern when every alternative has its own bucket and lies inside the filtered positions
     a.k3_exact = pg.n_alts <= (uint32_t)kK3Buckets && pg.k3_off == 0;

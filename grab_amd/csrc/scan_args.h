@@ -11,6 +11,9 @@ namespace gscan {
 constexpr int kShards = 64; // record-buffer regions, each with its own reservation counter.  Every WAVE reserves its run with one atomic
                             // (descriptor d uses shard d & 63): with 8 counters the dense patterns queued up on them -- same-address
                             // atomics are served one at a time, ~90 ns each (profiles/r02_d_kernel_sweep_per_wave_8_shards.txt)
+// The counters sit one per 128-byte line: returning atomics on the SAME cache line are served one after the other by that
+// line's L2 channel, whichever dword they name -- 64 adjacent counters were two lines.
+constexpr int kCtrStride = 32; // words between two shard counters
 constexpr uint32_t kStruck = 0xffffffffu; // a record the second pass (k3_settle) found to be no match: readers skip it
 
 // One scan unit of the launch: a tile of one segment.  16 bytes so a workgroup fetches it
@@ -32,7 +35,7 @@ struct ScanArgs {
     uint32_t cap_shard;      // record capacity of ONE shard region (regions are back to back)
     uint32_t *recs;          // candidate starts, segment-relative
     unsigned long long *desc; // [n_tiles * waves per workgroup] one per wave sub-tile: count | base<<32 (base = absolute record index)
-    uint32_t *counter;       // [0..kShards) records reserved per shard, [kShards] overflow flag, [kShards+1] records struck out by k3_settle
+    uint32_t *counter;       // [k * kCtrStride] records reserved in shard k, [kShards * kCtrStride] overflow flag, [.. + 1] records struck out by k3_settle
     const DevProgram *prog;  // cold paths only (K1 verify, K2 table staging)
     // pattern program, hot-loop copy
     uint32_t m;              // window length
@@ -40,6 +43,7 @@ struct ScanArgs {
     uint32_t n_classes, nruns;                            // K2
     uint32_t k3_off, k3_exact, k3_depth;                  // K3 (k3_depth: 3 or 4 filter positions)
     uint32_t vm_filter;                                   // K3: every filter hit is put to the VM (DevProgram::vm_filter)
+    uint32_t k2_emit_wave;                                // K2: reserve per wave instead of per tile (experiment switch)
     uint32_t report_shift;   // reported offset = device window start + this (1 when the windows carry a leading context position)
     uint32_t run_desc[kK2MaxRuns];                        // K2: cls | len<<8 | off<<16
     // K2, windows of <= 17 bytes: the run's shift program, decoded on the host -- cls @0, then the shift amounts of the
