@@ -258,7 +258,19 @@ __device__ __forceinline__ void emit_wave(const ScanArgs &a, uint32_t d, const u
     }
 }
 
-// The per-wave form of the dense epilogue (experiment switch GSCAN_K2_EMIT_WAVE=1: ScanArgs::k2_emit_wave).
+// Dense-output epilogue (K2): the same per-wave reservation, but the per-step masks are first transposed through a
+// wave-private strip of LDS so that lane L owns ITER consecutive (step, lane) cells, i.e. a contiguous piece of text.  One
+// wave scan then places every lane's records; emit_wave pays a ballot + rank + branch for each of the ITER steps instead,
+// which is what limits the kernels when most steps carry records (identifier regex: 3.6 records per KiB).  The strip is
+// the wave's own: the only ordering needed is between the wave's LDS writes and its reads (no workgroup barrier).
+//
+// How the reservation got here (identifier scan / [0-9]{16} without records / [0-9]+\.[0-9]+ on K3, TB/s, same sweep):
+//   round 1, one atomic per TILE behind two workgroup barriers                           5.2 / 5.9 / 4.4
+//   one atomic per WAVE, 8 adjacent counters                                             1.1 / 6.3 / 1.1   (r02_d_...)
+//   ... 64 adjacent counters                                                             2.5 / 6.4 / 2.5   (r02_e_...)
+//   ... 64 counters, one per 128-byte line                                               5.1 / 5.9-6.4 / 4.5 (r02_h_...)
+// Returning atomics on one cache line are served one after the other by that line's L2 channel whichever dword they
+// name: adjacent counters were no counters at all.
 template <int ITER>
 __device__ __forceinline__ void emit_wave_t(const ScanArgs &a, uint32_t d, const uint32_t (&hits)[(ITER + 1) / 2], uint32_t cnt, int sub_off,
                                             uint32_t bias, uint32_t lane, uint16_t *xp)
@@ -301,74 +313,6 @@ __device__ __forceinline__ void emit_wave_t(const ScanArgs &a, uint32_t d, const
             const uint32_t bb = (uint32_t)__ffsll((long long)bitsq) - 1u;
             bitsq &= bitsq - 1ull;
             const uint32_t cell = lane * ITER + q * 4 + (bb >> 4);
-            a.recs[idx++] = (uint32_t)sub_off + (cell >> 6) * 1024u + (cell & 63u) * 16u + (bb & 15u) - bias;
-        }
-    }
-}
-
-// Dense-output epilogue (K2): the per-step masks are first transposed through a wave-private strip of LDS so that lane L owns
-// ITER consecutive (step, lane) cells, i.e. a contiguous piece of text.  One wave scan then places every lane's records;
-// emit_wave pays a ballot + rank + branch for each of the ITER steps instead, which is what limits the kernels when most
-// steps carry records (identifier regex: 3.6 records per KiB).
-// Reservation: ONE atomic per TILE here (wave counts through LDS, two workgroup barriers), each wave still writing its own
-// descriptor.  When every wave has records a reservation per wave means eight times the returning atomics, and each one
-// stalls its wave for the round trip: measured on the identifier scan, 2.5 TB/s per wave (64 counters; 1.1 TB/s with 8)
-// against 5.2 TB/s per tile (profiles/r02_e_kernel_sweep_per_wave_64_shards.txt).  Without records the per-wave form is
-// the faster one (+8 %): K1 and K3, whose outputs are sparse, use it; K2 pays the barriers.
-template <int ITER, int NWAVES>
-__device__ __forceinline__ void emit_tile_t(const ScanArgs &a, uint32_t t, const uint32_t (&hits)[(ITER + 1) / 2], uint32_t cnt, int sub_off,
-                                            uint32_t bias, uint32_t lane, uint32_t wave, uint32_t *s_cnt, uint32_t *s_base, uint16_t *s_xp)
-{
-    static_assert(ITER % 4 == 0, "a lane reads its ITER masks as 64-bit words");
-    uint16_t *xp = s_xp + wave * (ITER * 64);
-#pragma unroll
-    for (int k = 0; k < ITER; k++) xp[k * 64 + lane] = (uint16_t)(hits[k >> 1] >> (16 * (k & 1)));
-    const uint32_t wtot = wave_sum(cnt);
-    if (lane == 0) s_cnt[wave] = wtot;
-    __syncthreads(); // also orders the strip's writes before its reads
-    uint32_t total = 0, before = 0;
-#pragma unroll
-    for (int w = 0; w < NWAVES; w++) {
-        const uint32_t c = s_cnt[w];
-        total += c;
-        if ((uint32_t)w < wave) before += c;
-    }
-    const uint32_t d = t * NWAVES + wave;
-    if (total == 0) {
-        if (lane == 0) a.desc[d] = 0ull;
-        __syncthreads(); // s_cnt is rewritten by the next tile
-        return;
-    }
-    const uint32_t shard = t & (kShards - 1);
-    if (threadIdx.x == 0) {
-        const uint32_t b = atomicAdd(a.counter + shard * kCtrStride, total); // index inside the shard's region
-        *s_base = b;
-        if ((unsigned long long)b + total > (unsigned long long)a.cap_shard) atomicOr(a.counter + kShards * kCtrStride, 1u);
-    }
-    __syncthreads();
-    const uint32_t base = *s_base;
-    // cells lane*ITER .. lane*ITER+ITER-1 of the strip, 4 masks per 64-bit word
-    unsigned long long w[ITER / 4];
-    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xp + lane * ITER);
-    uint32_t c = 0;
-#pragma unroll
-    for (int q = 0; q < ITER / 4; q++) {
-        w[q] = src[q];
-        c += (uint32_t)__popcll(w[q]);
-    }
-    __syncthreads(); // s_base / s_cnt / the strip are free for the next tile
-    if (lane == 0) a.desc[d] = wtot ? (unsigned long long)wtot | ((unsigned long long)(shard * a.cap_shard + base + before) << 32) : 0ull;
-    if ((unsigned long long)base + total > (unsigned long long)a.cap_shard) return; // overflow: the host re-runs with a bigger buffer
-    if (wtot == 0) return;
-    const uint32_t inc = wave_scan(c);
-    uint32_t idx = shard * a.cap_shard + base + before + inc - c;
-#pragma unroll
-    for (int q = 0; q < ITER / 4; q++) {
-        unsigned long long bitsq = w[q];
-        while (bitsq) {
-            const uint32_t bb = (uint32_t)__ffsll((long long)bitsq) - 1u;
-            bitsq &= bitsq - 1ull;
-            const uint32_t cell = lane * ITER + q * 4 + (bb >> 4); // = step * 64 + lane of the mask's producer
             a.recs[idx++] = (uint32_t)sub_off + (cell >> 6) * 1024u + (cell & 63u) * 16u + (bb & 15u) - bias;
         }
     }
@@ -527,8 +471,6 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) vo
     constexpr int kNW = NW; // waves per workgroup
     __shared__ uint32_t tbl[PAIR ? 65536 / 4 : 256 * 32];
     __shared__ __attribute__((aligned(8))) uint16_t s_xp[kNW * ITER * 64]; // epilogue transposition strips, 2 bytes per (step, lane), one per wave
-    __shared__ uint32_t s_cnt[kNW];
-    __shared__ uint32_t s_base;
     constexpr uint32_t kTile = kNW * ITER * 1024;
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x / kWave;
@@ -688,8 +630,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) vo
             }
         }
         // K2's outputs are the dense ones: transposed epilogue (+8 % on the identifier scan, neutral without matches)
-        if (a.k2_emit_wave) emit_wave_t<ITER>(a, t * kNW + wave, hits, cnt, sub_off, 0u - a.report_shift, lane, s_xp + wave * (ITER * 64));
-        else emit_tile_t<ITER, kNW>(a, t, hits, cnt, sub_off, 0u - a.report_shift, lane, wave, s_cnt, &s_base, s_xp);
+        emit_wave_t<ITER>(a, t * kNW + wave, hits, cnt, sub_off, 0u - a.report_shift, lane, s_xp + wave * (ITER * 64));
     }
 }
 #undef GS_LUT
@@ -1157,7 +1098,6 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
     a.nruns = pg.nruns;
     a.k3_off = pg.k3_off;
     a.vm_filter = pg.vm_filter;
-    a.k2_emit_wave = getenv("GSCAN_K2_EMIT_WAVE") ? 1u : 0u;
     a.report_shift = pg.report_shift;
     // the filter IS the pattern when every alternative has its own bucket and lies inside the filtered positions
     a.k3_exact = pg.n_alts <= (uint32_t)kK3Buckets && pg.k3_off == 0;
