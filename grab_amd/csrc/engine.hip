@@ -1419,7 +1419,7 @@ int gscan_set_option(gscan_ctx *c, const char *name, long value)
 {
     if (!c || !name) return GSCAN_EINVAL;
     if (!strcmp(name, "variant")) {
-        if (value != 13 && (value < 0 || value > 7 || (value & 3) == 3)) return GSCAN_EINVAL; // KiB per wave {16,8,12} | nontemporal<<2; 13: 768-thread workgroups for the table kernels
+        if (value != 13 && value != 14 && (value < 0 || value > 7 || (value & 3) == 3)) return GSCAN_EINVAL; // KiB per wave {16,8,12} | nontemporal<<2; 13: 768-thread workgroups for the table kernels
         c->variant = (int)value;
         return GSCAN_OK;
     }

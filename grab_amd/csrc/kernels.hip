@@ -196,6 +196,17 @@ __device__ __forceinline__ TileCtx tile_ctx(const ScanArgs &a, const TileDesc *_
 // segment end come back as zeros (descriptor bounds check); the last partial block is
 // read whole (segment bases are 16-byte aligned, so this stays inside the allocation)
 // and its garbage bytes can only reach windows that valid16() removes.
+// one step of a sub-tile: k < ITER a full KiB, k == ITER the halo (only the first HALO_LANES lanes carry data)
+// (valid == false: the load is issued all the same, far out of range -- zeros, no memory traffic: the prefetching kernels
+// keep the SAME sequence of loads on every path so that the compiler's vmcnt bookkeeping is exact)
+template <int ITER, bool NT, int HALO_LANES>
+__device__ __forceinline__ u32x4 load_step(const TileCtx &c, int sub_off, uint32_t lane, int k, bool valid = true)
+{
+    const int v0 = sub_off + (int)lane * 16;
+    if (k < ITER) return load16<NT>(c.rsrc, valid ? v0 + k * 1024 : 0x7ffffff0);
+    return load16<false>(c.rsrc, valid && lane < (uint32_t)HALO_LANES ? v0 + ITER * 1024 : 0x7ffffff0);
+}
+
 template <int ITER, bool NT, int HALO_LANES>
 __device__ __forceinline__ void load_subtile(u32x4 (&buf)[ITER + 1], const TileCtx &c, int sub_off, uint32_t lane)
 {
@@ -464,9 +475,18 @@ __device__ __forceinline__ uint32_t run_one_flat(uint32_t d, uint32_t w0, uint32
 // workgroups per CU = 6 waves per SIMD within 80 VGPRs; same 96 KiB tile).  Measured: more waves buy nothing with records
 // (5.16 vs 5.22 TB/s on the identifier scan) and +1..8 % without (1024 threads, 8 waves per SIMD, plain epilogue: 6.4 vs
 // 5.9 TB/s) -- profiles/r02_b_kernel_sweep_workgroup_shapes.txt; the default stays 512 threads.
-template <int ITER, bool NT, bool WIDE, bool PAIR, int NR = -1, int NW = (PAIR ? 8 : 4)>
+// PF (persistent forms): the NEXT tile's text is requested while this one is computed, in two bursts -- its first half the
+// moment this tile's first half has been turned into look-up addresses, its second half (and halo) behind this tile's
+// epilogue -- so a wave's loads are in flight through its compute and its epilogue instead of starting behind them (every
+// wave of a persistent workgroup paid one full HBM round trip per tile, hidden only by whatever its three SIMD neighbours
+// happened to be doing).  Two bursts at fixed places, issued on every path (out of range when there is no next tile),
+// first-tile loads in the same order: the compiler's vmcnt counts then come out exact -- with the refills trickling in step
+// by step it merged the loop with its preheader conservatively and made the tail steps of every tile wait for loads issued
+// two steps earlier.
+template <int ITER, bool NT, bool WIDE, bool PAIR, int NR = -1, int NW = (PAIR ? 8 : 4), bool PF = false>
 __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) void k2_classrun_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
+    static_assert(!PF || PAIR, "the prefetching form is the pair form's");
     static_assert(NR < 0 || (PAIR && !WIDE), "the flat run program is the two-class, 32-bit form's");
     constexpr int kNW = NW; // waves per workgroup
     __shared__ uint32_t tbl[PAIR ? 65536 / 4 : 256 * 32];
@@ -506,17 +526,33 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) vo
     }
     __syncthreads();
 
-    for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-        TileCtx c = tile_ctx(a, tiles, t, kTile);
-        const int sub_off = c.tile_off + (int)(wave * ITER * 1024);
+    // The tile loop.  PF: the first pass has no tile of its own (cur == false) and only requests the first one's text --
+    // every load of the kernel is issued inside the loop body, by the same instructions, whatever the path: no preheader
+    // whose pending loads the compiler would have to merge with the steady state's.
+    u32x4 buf[ITER + 1], halo_n = {0, 0, 0, 0};
+    if (blockIdx.x >= a.n_tiles) return;
+    uint32_t t = 0, tn = blockIdx.x;
+    TileCtx c = tile_ctx(a, tiles, tn, kTile);
+    int sub_off = 0;
+    bool have = false, cur = false;
+    for (;;) {
+        // the tile after this one (PF: its loads go out during this tile's steps; out of range -- zeros, no traffic -- if there is none)
+        const bool next = tn < a.n_tiles;
+        TileCtx cn = c;
+        int sub_off_n = 0;
+        bool have_n = false;
+        if (next) {
+            cn = tile_ctx(a, tiles, tn, kTile);
+            sub_off_n = cn.tile_off + (int)(wave * ITER * 1024);
+            have_n = cn.live && sub_off_n < cn.slen;
+        }
         uint32_t hits[(ITER + 1) / 2];
 #pragma unroll
         for (int i = 0; i < (ITER + 1) / 2; i++) hits[i] = 0;
         uint32_t cnt = 0;
 
-        if (c.live && sub_off < c.slen) {
-            u32x4 buf[ITER + 1];
-            load_subtile<ITER, NT, 4>(buf, c, sub_off, lane);
+        if (have) {
+            if (!PF) load_subtile<ITER, NT, 4>(buf, c, sub_off, lane);
             const int hi = c.slen - (int)m;
             const bool interior = sub_off + ITER * 1024 + 64 <= hi;
 
@@ -575,6 +611,14 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) vo
                 if (PAIR) {
                     p01n = merge();                          // step k + 1's masks: lanes 61-63 look into them
                     if (k + 2 <= ITER) lookups(buf[k + 2]); // in flight while step k is computed
+                    if (PF) { // what has just become look-up addresses takes the next tile's text
+                        if (k == 0) {
+                            buf[0] = load_step<ITER, NT, 4>(cn, sub_off_n, lane, 0, have_n);
+                            buf[1] = load_step<ITER, NT, 4>(cn, sub_off_n, lane, 1, have_n);
+                            halo_n = load_step<ITER, NT, 4>(cn, sub_off_n, lane, ITER, have_n); // (this tile's halo is in use until its last step)
+                        }
+                        if (k + 2 < ITER) buf[k + 2] = load_step<ITER, NT, 4>(cn, sub_off_n, lane, k + 2, have_n);
+                    }
                 } else {
                     masks(buf[k + 1], p01n, p23n); // next step's masks: lanes 61-63 look into them
                 }
@@ -628,9 +672,23 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) vo
                 hits[k >> 1] |= bits << (16 * (k & 1));
                 cnt += (uint32_t)__popc(bits);
             }
+        } else if (PF) { // nothing of this tile is this wave's (or there is no tile yet): the same loads all the same
+            buf[0] = load_step<ITER, NT, 4>(cn, sub_off_n, lane, 0, have_n);
+            buf[1] = load_step<ITER, NT, 4>(cn, sub_off_n, lane, 1, have_n);
+            halo_n = load_step<ITER, NT, 4>(cn, sub_off_n, lane, ITER, have_n);
+#pragma unroll
+            for (int j = 2; j < ITER; j++) buf[j] = load_step<ITER, NT, 4>(cn, sub_off_n, lane, j, have_n);
         }
         // K2's outputs are the dense ones: transposed epilogue (+8 % on the identifier scan, neutral without matches)
-        emit_wave_t<ITER>(a, t * kNW + wave, hits, cnt, sub_off, 0u - a.report_shift, lane, s_xp + wave * (ITER * 64));
+        if (cur) emit_wave_t<ITER>(a, t * kNW + wave, hits, cnt, sub_off, 0u - a.report_shift, lane, s_xp + wave * (ITER * 64));
+        if (!next) break;
+        if (PF) buf[ITER] = halo_n;
+        t = tn;
+        tn += gridDim.x;
+        c = cn;
+        sub_off = sub_off_n;
+        have = have_n;
+        cur = true;
     }
 }
 #undef GS_LUT
@@ -673,7 +731,8 @@ __device__ __noinline__ bool vm_keep_hit_dev(const DevProgram *pg, const VmProg 
     return vm_keep_hit(pg, vm, seg, slen, q);
 }
 
-template <int ITER, bool NT, int DEPTH = 4, int NW = 8, bool VM = false>
+// PF: the next tile's text is requested while this one is computed (see k2_classrun_scan).
+template <int ITER, bool NT, int DEPTH = 4, int NW = 8, bool VM = false, bool PF = false>
 __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     // The filter table, one copy PER LANE: entry b of lane l lives at byte address b << 8 | l << 2.  Both fields are whole
@@ -711,17 +770,30 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
     }
     __syncthreads();
 
-    for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-        TileCtx c = tile_ctx(a, tiles, t, kTile);
-        const int sub_off = c.tile_off + (int)(wave * ITER * 1024);
+    // (the tile loop: see k2_classrun_scan)
+    u32x4 buf[ITER + 1], halo_n = {0, 0, 0, 0};
+    if (blockIdx.x >= a.n_tiles) return;
+    uint32_t t = 0, tn = blockIdx.x;
+    TileCtx c = tile_ctx(a, tiles, tn, kTile);
+    int sub_off = 0;
+    bool have = false, cur = false;
+    for (;;) {
+        const bool next = tn < a.n_tiles;
+        TileCtx cn = c;
+        int sub_off_n = 0;
+        bool have_n = false;
+        if (next) {
+            cn = tile_ctx(a, tiles, tn, kTile);
+            sub_off_n = cn.tile_off + (int)(wave * ITER * 1024);
+            have_n = cn.live && sub_off_n < cn.slen;
+        }
         uint32_t hits[(ITER + 1) / 2];
 #pragma unroll
         for (int i = 0; i < (ITER + 1) / 2; i++) hits[i] = 0;
         uint32_t cnt = 0;
 
-        if (c.live && sub_off < c.slen) {
-            u32x4 buf[ITER + 1];
-            load_subtile<ITER, NT, 1>(buf, c, sub_off, lane);
+        if (have) {
+            if (!PF) load_subtile<ITER, NT, 1>(buf, c, sub_off, lane);
             // filter positions q = p + koff of window starts p with 0 <= p and p + m <= slen
             const int lo = (int)koff, hi = c.slen - (int)m + (int)koff;
 #pragma unroll
@@ -739,6 +811,10 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                 GS_E(16, nd, 0);  GS_E(17, nd, 1);
                 if (DEPTH == 4) GS_E(18, nd, 2);
 #undef GS_E
+                if (PF) { // this step's text is look-up addresses now: its registers take the next tile's
+                    buf[k] = load_step<ITER, NT, 1>(cn, sub_off_n, lane, k, have_n);
+                    if (k == 0) halo_n = load_step<ITER, NT, 1>(cn, sub_off_n, lane, ITER, have_n); // (this tile's halo is in use until its last step)
+                }
                 // Y_j = [P_0(t_j) & P_1(t_{j+1}), P_2(t_j) & P_3(t_{j+1})]; h_j = Y_j.b0 & Y_{j+2}.b1 (four positions) or
                 // Y_j.b0 & e_{j+2}.b1 = ... & P_2(t_{j+2}) (three): two VALU operations per byte either way
                 // (plain shift + and in place of the selects: twice that -- profiles/r01_o_sweep_k3_sdwa.txt)
@@ -808,8 +884,21 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                     cnt += (uint32_t)__popc(bits);
                 }
             }
+        } else if (PF) {
+            buf[0] = load_step<ITER, NT, 1>(cn, sub_off_n, lane, 0, have_n);
+            halo_n = load_step<ITER, NT, 1>(cn, sub_off_n, lane, ITER, have_n);
+#pragma unroll
+            for (int j = 1; j < ITER; j++) buf[j] = load_step<ITER, NT, 1>(cn, sub_off_n, lane, j, have_n);
         }
-        emit_wave<ITER>(a, t * NW + wave, hits, cnt, sub_off, koff - a.report_shift, lane);
+        if (cur) emit_wave<ITER>(a, t * NW + wave, hits, cnt, sub_off, koff - a.report_shift, lane);
+        if (!next) break;
+        if (PF) buf[ITER] = halo_n;
+        t = tn;
+        tn += gridDim.x;
+        c = cn;
+        sub_off = sub_off_n;
+        have = have_n;
+        cur = true;
     }
 }
 
@@ -1047,6 +1136,12 @@ static void launch_k2(bool wide, bool pair, int wg, const ScanArgs &a, dim3 g, h
         else if (a.nruns == 2) hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 2, 12>), g, dim3(768), 0, st, a, tiles);
         else if (a.nruns == 3) hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 3, 12>), g, dim3(768), 0, st, a, tiles);
         else hipLaunchKernelGGL((k2_classrun_scan<I, true, false, true, 0, 12>), g, dim3(768), 0, st, a, tiles);
+    } else if (pair && wg == -1 && ITER == 12 && NT) { // the prefetching form
+        if (wide) hipLaunchKernelGGL((k2_classrun_scan<12, true, true, true, -1, 8, true>), g, dim3(512), 0, st, a, tiles);
+        else if (a.nruns == 1) hipLaunchKernelGGL((k2_classrun_scan<12, true, false, true, 1, 8, true>), g, dim3(512), 0, st, a, tiles);
+        else if (a.nruns == 2) hipLaunchKernelGGL((k2_classrun_scan<12, true, false, true, 2, 8, true>), g, dim3(512), 0, st, a, tiles);
+        else if (a.nruns == 3) hipLaunchKernelGGL((k2_classrun_scan<12, true, false, true, 3, 8, true>), g, dim3(512), 0, st, a, tiles);
+        else hipLaunchKernelGGL((k2_classrun_scan<12, true, false, true, 0, 8, true>), g, dim3(512), 0, st, a, tiles);
     } else if (pair) {
         if (wide) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, true, true>), g, dim3(512), 0, st, a, tiles);
         else if (a.nruns == 1) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, true, 1>), g, dim3(512), 0, st, a, tiles);
@@ -1073,6 +1168,9 @@ static hipError_t launch_iter(int tier, bool nt, bool wide, int wg, const ScanAr
         } else if (wg == 12 && ITER == 8 && nt) { // 768-thread workgroups, two per CU
             if (a.k3_depth == 3) hipLaunchKernelGGL((k3_bucket_scan<ITER == 8 ? 8 : 12, true, 3, 12>), g, dim3(768), 0, st, a, tiles);
             else hipLaunchKernelGGL((k3_bucket_scan<ITER == 8 ? 8 : 12, true, 4, 12>), g, dim3(768), 0, st, a, tiles);
+        } else if (wg == -1 && ITER == 12 && nt) { // the prefetching form
+            if (a.k3_depth == 3) hipLaunchKernelGGL((k3_bucket_scan<12, true, 3, 8, false, true>), g, dim3(kK3WG), 0, st, a, tiles);
+            else hipLaunchKernelGGL((k3_bucket_scan<12, true, 4, 8, false, true>), g, dim3(kK3WG), 0, st, a, tiles);
         } else if (a.k3_depth == 3 && ITER == 12 && nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true, ITER == 12 ? 3 : 4>), g, dim3(kK3WG), 0, st, a, tiles);
         else if (nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true>), g, dim3(kK3WG), 0, st, a, tiles);
         else hipLaunchKernelGGL((k3_bucket_scan<ITER, false>), g, dim3(kK3WG), 0, st, a, tiles);
@@ -1173,7 +1271,7 @@ hipError_t launch_scan(int tier, int variant, const ScanArgs &a, uint32_t grid, 
     const bool wide = a.m > 17; // K2: look-ahead beyond one neighbouring lane
     switch (variant & 3) {
     case 1: return launch_iter<8>(tier, nt, wide, variant_wg(tier, variant, a.n_classes), a, grid, st);
-    case 2: return launch_iter<12>(tier, nt, wide, 0, a, grid, st);
+    case 2: return launch_iter<12>(tier, nt, wide, variant == 14 ? -1 : 0, a, grid, st); // 14: the table kernels prefetch the next tile
     default: return launch_iter<16>(tier, nt, wide, 0, a, grid, st);
     }
 }

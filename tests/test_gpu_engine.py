@@ -17,7 +17,7 @@ import scan_oracle as so  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [0, 1, 2, 4, 5, 6]  # KiB per wave {16, 8, 12} x nontemporal loads {off, on}
+VARIANTS = [0, 1, 2, 4, 5, 6, 13, 14]  # KiB per wave {16, 8, 12} x nontemporal loads {off, on}; 13: 768-thread table kernels; 14: table kernels prefetch the next tile
 PATTERNS = ["foobardoesnotexist", "foo", "e", "xy", "[A-Za-z_][A-Za-z0-9_]{15,}", "[a-z]{2,5}", "abc[0-9]*", r"\d{3}-\d{4}",
             "[Ll]inus", "a.c", "[^x]{5,}", "[0-9a-f]{32}", "[0-9A-F]{6}[a-z]", "e+", r"\w\s\w\s\w", "[a-z][0-9][A-Z][.,][;:]q",
             "[ab][cd][ef][gh]{20}", "[0-9]{17}", "[0-9]{18}", "[a-z_]{49}",
