@@ -158,7 +158,12 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
 
 // ------------------------------------------------------------------------------------
 
-FileGrep::FileGrep() : uid_(geteuid()) { timing_ = getenv("GRAB_TIMING") != nullptr; }
+FileGrep::FileGrep() : uid_(geteuid())
+{
+    timing_ = getenv("GRAB_TIMING") != nullptr;
+    const char *ing = getenv("GRAB_INGEST");
+    ingest_register_ = ing && !strcmp(ing, "register");
+}
 
 FileGrep::~FileGrep()
 {
@@ -359,6 +364,7 @@ struct FileGrep::Job {
     std::shared_ptr<FileRef> file;
     off_t off = 0;
     size_t len = 0;
+    void *map = nullptr; // GRAB_INGEST=register: the window's mapping, registered with the runtime and DMA'd in place
     // batch: segment i is file i
     std::vector<std::shared_ptr<FileRef>> files;
     std::vector<gscan_seg> segs;
@@ -383,9 +389,13 @@ int FileGrep::retire_oldest(bool print)
         const std::string &whose = job.file ? job.file->path : (job.files.empty() ? std::string("?") : job.files.front()->path + " (+ the rest of its batch)");
         err_ = std::string(rc == GSCAN_EIO ? "FileGrep::find::read: " : "FileGrep::find::gscan_wait: ") + gscan_strerror(ctx) + " [" + whose + "]";
         if (rc != GSCAN_EIO) failed_ = true;
+        if (job.map) munmap(job.map, job.len);
         return -1;
     }
-    if (!print) return 0;
+    if (!print) {
+        if (job.map) munmap(job.map, job.len);
+        return 0;
+    }
     const unsigned rflags = report_flags();
     std::string &text = report_buf_; // kept across jobs: dense outputs are tens of MB per window, no point in growing it anew each time
     text.clear();
@@ -395,8 +405,9 @@ int FileGrep::retire_oldest(bool print)
         // no candidate start at all -> nothing is printed (a match at s = 0 would head a group and be in the list),
         // and the file's bytes are never touched by the host.  Not so for patterns with context (\b ^ $ ...): a match
         // at offset 0 or at the very end of the window is the host's to find
+        if (job.map && (f.done || !(first[nseg] > 0 || context_))) munmap(job.map, job.len);
         if (!f.done && (first[nseg] > 0 || context_)) {
-            void *map = mmap(nullptr, job.len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, f.fd, job.off); // grab.cc:161 (MAP_POPULATE: no gain, measured)
+            void *map = job.map ? job.map : mmap(nullptr, job.len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, f.fd, job.off); // grab.cc:161 (MAP_POPULATE: no gain, measured)
             if (map == MAP_FAILED) {
                 err_ = std::string("FileGrep::find::mmap: ") + strerror(errno);
                 status = -1;
@@ -574,7 +585,17 @@ int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
                 break;
             }
             double t = timing_ ? now_s() : 0;
-            if (gscan_submit_fd(ctxs_[(size_t)k], db_, fd, (long long)off, len, (uint64_t)off) != GSCAN_OK) {
+            void *reg_map = nullptr;
+            if (ingest_register_) {
+                // experiment (GRAB_INGEST=register): no copy on the host at all -- the window is mapped as the reference maps
+                // it (grab.cc:161), the mapping registered with the runtime and DMA'd straight out of the page cache
+                reg_map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, fd, off);
+                if (reg_map == MAP_FAILED) reg_map = nullptr;
+            }
+            const int src = reg_map ? gscan_submit(ctxs_[(size_t)k], db_, reg_map, len, (uint64_t)off)
+                                    : gscan_submit_fd(ctxs_[(size_t)k], db_, fd, (long long)off, len, (uint64_t)off);
+            if (src != GSCAN_OK) {
+                if (reg_map) munmap(reg_map, len);
                 err_ = std::string("FileGrep::find::read: ") + gscan_strerror(ctxs_[(size_t)k]);
                 status = -1;
                 break;
@@ -583,6 +604,7 @@ int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
             ctx_bytes_[(size_t)k] += len;
             Job job;
             job.ctx = k;
+            job.map = reg_map;
             job.file = ref;
             job.off = off;
             job.len = len;

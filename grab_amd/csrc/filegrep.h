@@ -103,6 +103,7 @@ private:
     size_t devices_ = 1;              // config "devices"
     size_t next_ctx_ = 0;             // round-robin cursor over the contexts a big file uses
     bool failed_ = false;             // a device error: every later find() fails at once with why() saying so
+    bool ingest_register_ = false;    // GRAB_INGEST=register (experiment): windows are mapped, registered and DMA'd in place
     std::string report_buf_;
     size_t batch_max_ = size_t(2) << 20; // files up to this size are batched ("batch" config key; 0 = never)
     void *batch_buf_ = nullptr;          // the engine's pinned block being filled
