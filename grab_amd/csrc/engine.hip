@@ -88,7 +88,12 @@ struct IngestCfg {
     int copy_streams;
     bool numa;
     unsigned pin_flags; // hipHostMalloc flags of the staging blocks (GSCAN_PIN_FLAGS: 0 default, 1 non-coherent, 2 write-combined)
-    int shared_copy;    // GSCAN_SHARED_COPY: 0 = every context has copy streams of its own; N = the contexts of a device share N
+    // A HIP stream is an HSA queue, and on this part a queue comes with ~177 MB of wave-save area that the runtime allocates
+    // AND touches: 7-12 ms to create, ~4 ms of the process's exit, per stream (profiles/r02_r_resident_memory.txt).  Eight
+    // contexts with two streams each were 0.1 s of start-up and 2 GB of resident memory for nothing: a 64 MiB window scans in
+    // 15 us and the copies share one link.  So the contexts of a device share its streams by default.
+    int shared_copy;    // GSCAN_SHARED_COPY (1): N = the contexts of a device share N copy streams; 0 = every context has its own
+    int shared_compute; // GSCAN_SHARED_COMPUTE (2): N = they share N scan streams, dealt round robin; 0 = every context has its own
     bool slab;          // GSCAN_SLAB: the reader blocks of a device are carved from ONE pinned allocation instead of one each
     int read_mode;      // GSCAN_READ_MODE: 0 pread(2) into the block; 1 map the piece and copy it with non-temporal stores
                         // (hostcopy.cc); 2 pread into a cache-sized bounce buffer, non-temporal copy from there
@@ -108,7 +113,8 @@ const IngestCfg &ingest_cfg()
         if (hw > 0 && v.readers > hw) v.readers = (int)hw;
         v.copy_streams = (int)env("GSCAN_COPY_STREAMS", 1, 1, 4);
         v.numa = env("GSCAN_NUMA", 1, 0, 1) != 0;
-        v.shared_copy = (int)env("GSCAN_SHARED_COPY", 0, 0, 4);
+        v.shared_copy = (int)env("GSCAN_SHARED_COPY", 1, 0, 4);
+        v.shared_compute = (int)env("GSCAN_SHARED_COMPUTE", 2, 0, 4);
         v.slab = env("GSCAN_SLAB", 0, 0, 1) != 0;
         v.read_mode = (int)env("GSCAN_READ_MODE", 0, 0, 2); // (1 and 2 measured and not adopted: profiles/r02_d_e2e_reader_modes.jsonl)
         const long pf = env("GSCAN_PIN_FLAGS", 0, 0, 2);
@@ -253,14 +259,14 @@ public:
     hipStream_t shared_stream(int k)
     {
         std::lock_guard<std::mutex> lk(m_);
-        while ((int)shared_.size() <= k) {
-            hipStream_t st = nullptr;
+        if ((int)shared_.size() <= k) shared_.resize((size_t)k + 1, nullptr);
+        if (!shared_[(size_t)k]) {
             (void)hipSetDevice(device_);
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-            shared_.push_back(st);
+            if (hipStreamCreateWithFlags(&shared_[(size_t)k], hipStreamNonBlocking) != hipSuccess) return shared_[(size_t)k] = nullptr;
         }
         return shared_[(size_t)k];
     }
+    int next_compute() { return next_compute_++; }
     void report_if_timing()
     {
         if (timing_ && n_pieces_) report();
@@ -320,7 +326,8 @@ private:
         for (PinBlock *b : busy_) free_block(b, true);
         for (PinBlock *b : free_) free_block(b, false);
         for (PinBlock *b : slot_free_) free_block(b, false);
-        for (hipStream_t st : shared_) (void)hipStreamDestroy(st);
+        for (hipStream_t st : shared_)
+            if (st) (void)hipStreamDestroy(st);
         if (slab_) (void)hipHostFree(slab_);
     }
     void free_block(PinBlock *b, bool wait)
@@ -517,6 +524,7 @@ private:
     std::deque<ReadTask> tasks_;
     std::vector<std::thread> threads_;
     std::vector<hipStream_t> shared_;
+    std::atomic<int> next_compute_{0};
     std::mutex slab_m_;
     void *slab_ = nullptr;
     size_t slab_used_ = 0;
@@ -580,6 +588,7 @@ struct gscan_ctx {
     hipStream_t copy = nullptr, compute = nullptr;
     hipStream_t copy_x[3] = {nullptr, nullptr, nullptr}; // further copy streams (GSCAN_COPY_STREAMS - 1 of them)
     int n_copy = 1;
+    bool compute_shared = false; // the scan stream is one of the device's (GSCAN_SHARED_COMPUTE)
     bool copy_shared = false; // the copy streams belong to the device's Ingest (GSCAN_SHARED_COPY), not to this context
     Ingest *ingest = nullptr;
     Slot slot[GSCAN_SLOTS];
@@ -984,7 +993,18 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && cus > 0) c->cus = cus;
     lap("device attribute");
-    if (hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
+    // Creating a stream takes the runtime ~6 ms and the runtime does them one at a time: eight workers opening their contexts
+    // together would ALL be ready only when the last stream exists (+0.1 s).  One context at a time: the first one is scanning
+    // after two creations while the others queue here.
+    static std::mutex open_order;
+    std::unique_lock<std::mutex> one_at_a_time(open_order, std::defer_lock);
+    if (!getenv("GSCAN_OPEN_UNORDERED")) one_at_a_time.lock(); // (the switch is for measuring the difference)
+    if (ingest_cfg().shared_compute > 0) { // (pool entries 0..3 are the copy streams, 4.. the scan streams)
+        c->compute_shared = true;
+        if (!(c->compute = c->ingest->shared_stream(4 + c->ingest->next_compute() % ingest_cfg().shared_compute))) return bail(GSCAN_EHIP);
+    } else if (hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) != hipSuccess) {
+        return bail(GSCAN_EHIP);
+    }
     if (ingest_cfg().shared_copy > 0) {
         c->copy_shared = true;
         c->n_copy = ingest_cfg().shared_copy;
@@ -997,6 +1017,7 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
         for (int k = 1; k < c->n_copy; k++)
             if (hipStreamCreateWithFlags(&c->copy_x[k - 1], hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
     }
+    if (one_at_a_time.owns_lock()) one_at_a_time.unlock();
     lap("streams");
     // one pinned allocation for every small host-side buffer of the context (each hipHostMalloc costs about a millisecond)
     const size_t kHead = (kCounterWords * 4 + 63) & ~size_t(63); // the slot's counter words
@@ -1056,7 +1077,7 @@ void gscan_close(gscan_ctx *c)
         for (hipStream_t st : c->copy_x)
             if (st) hipStreamDestroy(st);
     }
-    if (c->compute) hipStreamDestroy(c->compute);
+    if (c->compute && !c->compute_shared) hipStreamDestroy(c->compute);
     if (c->ingest) Ingest::release(c->ingest); // the last context of the device: reader threads joined, pinned pool freed
     delete c;
 }
@@ -1105,7 +1126,7 @@ void gscan_ingest_info(size_t *block_bytes_out, int *readers, int *copy_streams)
 {
     if (block_bytes_out) *block_bytes_out = ingest_cfg().block;
     if (readers) *readers = ingest_cfg().readers;
-    if (copy_streams) *copy_streams = ingest_cfg().copy_streams;
+    if (copy_streams) *copy_streams = ingest_cfg().shared_copy > 0 ? ingest_cfg().shared_copy : ingest_cfg().copy_streams;
 }
 
 long gscan_parse_cpulist(const char *list, int *cpus, size_t cap)

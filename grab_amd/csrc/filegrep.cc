@@ -168,14 +168,20 @@ FileGrep::FileGrep() : uid_(geteuid())
 FileGrep::~FileGrep()
 {
     flush();
-    if (timing_) {
+    report_timing();
+    for (gscan_ctx *c : ctxs_) gscan_close(c);
+    if (db_) gscan_free(db_);
+}
+
+void FileGrep::report_timing()
+{
+    if (timing_ && !timing_reported_) {
+        timing_reported_ = true;
         fprintf(stderr, "[grab timing] device %d: files %zu launches %zu bytes %zu | open %.3f s  read(batch) %.3f s  submit %.3f s  wait %.3f s  map+report %.3f s  close %.3f s\n",
                 device_, t_files_, t_chunks_, t_bytes_, t_map_, t_read_, t_submit_, t_wait_, t_report_, t_unmap_);
         for (size_t k = 0; k < ctxs_.size(); k++) // what each device was handed: the work queue's balance (bench.py --mode e2e sums these)
             fprintf(stderr, "[grab bytes] device %d: %zu\n", ctx_dev_[k], ctx_bytes_[k]);
     }
-    for (gscan_ctx *c : ctxs_) gscan_close(c);
-    if (db_) gscan_free(db_);
 }
 
 void FileGrep::config(const std::map<std::string, size_t> &kv)

@@ -62,6 +62,9 @@ public:
     // while this one is on the GPU; small files wait for their batch to fill).  flush() scans and prints
     // whatever is pending; find(string), find_recursive() and the destructor call it themselves.
     int flush();
+    // GRAB_TIMING=1: this instance's time and byte totals on stderr, once (the destructor's job; a caller that leaves
+    // without destroying the instance -- the command line does -- asks for them itself)
+    void report_timing();
 
     // engine knob pass-through (gscan_set_option) for A/B runs
     int engine_option(const char *name, long value);
@@ -91,7 +94,7 @@ private:
     uid_t uid_;
     int device_ = 0, out_fd_ = 1;
     // GRAB_TIMING=1 in the environment: per-instance wall-clock split, printed to stderr by the destructor
-    bool timing_ = false;
+    bool timing_ = false, timing_reported_ = false;
     size_t t_files_ = 0, t_chunks_ = 0, t_bytes_ = 0;
     double t_map_ = 0, t_read_ = 0, t_submit_ = 0, t_wait_ = 0, t_report_ = 0, t_unmap_ = 0;
     // pipeline state

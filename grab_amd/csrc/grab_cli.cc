@@ -38,6 +38,8 @@
 #include <thread>
 #include <vector>
 
+#include <fstream>
+
 #include "filegrep.h"
 #include "walk.h"
 
@@ -49,6 +51,20 @@ void mark(const char *what)
 {
     static const bool on = getenv("GRAB_TIMING") != nullptr;
     if (on) fprintf(stderr, "[grab timing] +%.3f s %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_t0).count(), what);
+}
+
+void mark_memory(const char *when)
+{
+    if (!getenv("GRAB_TIMING")) return;
+    std::ifstream st("/proc/self/status");
+    std::string line, all;
+    while (std::getline(st, line))
+        if (!line.compare(0, 5, "VmRSS") || !line.compare(0, 5, "VmHWM") || !line.compare(0, 7, "RssAnon") || !line.compare(0, 8, "RssShmem") || !line.compare(0, 7, "RssFile")) {
+            for (char &ch : line)
+                if (ch == '\t') ch = ' ';
+            all += line + "; ";
+        }
+    fprintf(stderr, "[grab timing] memory %s: %s\n", when, all.c_str());
 }
 
 struct Options {
@@ -211,15 +227,23 @@ int run_workers(const Options &o)
 
     const int ndev = std::max(1, gscan_device_count());
     mark("runtime up");
+    mark_memory("runtime up");
     std::mutex err_lock;
     std::string first_error;
     std::vector<std::thread> pool;
     for (int i = 0; i < o.workers; i++) {
         const int device = i % ndev;
         const cpu_set_t cpus = worker_cpus(i, device, allowed);
-        pool.emplace_back([&, device, cpus] {
+        pool.emplace_back([&, device, cpus, i] {
             (void)pthread_setaffinity_np(pthread_self(), sizeof cpus, &cpus);
-            FileGrep g; // one per thread, like the reference (main.cc:195-199); the context is opened by the thread that uses it
+            // one per thread, like the reference (main.cc:195-199); the context is opened by the thread that uses it.  It is
+            // NOT closed: once everything is retired and printed the process leaves through _exit (main), and freeing 8 x 3
+            // windows of HBM, their pinned blocks and streams one by one first costs ~50 ms of a 1-2 s run for nothing.
+            // (GRAB_CLOSE=1 closes them, for leak checkers.)
+            static const bool close_ctx = getenv("GRAB_CLOSE") != nullptr;
+            FileGrep *gp = new FileGrep;
+            FileGrep &g = *gp;
+            {
             auto cfg = o.cfg;
             cfg["device"] = size_t(device);
             g.config(cfg);
@@ -230,12 +254,23 @@ int run_workers(const Options &o)
                 queue.abandon();
                 return;
             }
+            if (i == 0) {
+                mark("worker 0: context open");
+                mark_memory("worker 0 open");
+            }
             for (Job j; queue.pop(j);) g.find(j.path.c_str(), &j.st, FTW_F); // per-file errors ignored (main.cc:97)
             g.flush(); // what is still in flight or waiting in a half-filled batch
+            g.report_timing();
+            if (i == 0) mark("worker 0: everything retired");
+            }
+            if (close_ctx) {
+                delete gp;
+                if (i == 0) mark("worker 0: context closed");
+            }
         });
     }
     for (auto &t : pool) t.join();
-    mark("workers joined, contexts closed");
+    mark("workers joined");
     walk.join();
     if (!first_error.empty()) {
         std::cerr << first_error << std::endl;
@@ -246,7 +281,17 @@ int run_workers(const Options &o)
 
 int run_serial(const Options &o)
 {
-    FileGrep grep;
+    // (not closed before _exit either, see run_workers; GRAB_CLOSE=1 does)
+    FileGrep *gp = new FileGrep;
+    struct Closer {
+        FileGrep *g;
+        ~Closer()
+        {
+            if (getenv("GRAB_CLOSE")) delete g;
+            else g->report_timing();
+        }
+    } closer{gp};
+    FileGrep &grep = *gp;
     auto cfg = o.cfg;
     if (const char *dev = getenv("GRAB_DEVICE")) cfg["device"] = size_t(atoi(dev));
     // a file of several windows is spread over the node's GPUs (contexts beyond the first open when such a file turns up)
@@ -281,8 +326,10 @@ int main(int argc, char **argv)
     mark("main");
     const Options o = parse(argc, argv);
     const int rc = o.workers > 1 ? run_workers(o) : run_serial(o);
-    mark("scan done, contexts closed");
+    mark("scan done");
     std::cout.flush();
+    mark_memory("at exit"); // what the kernel will have to take apart when the process leaves
+    mark("leaving");
     // GRAB_DIAG=1: say when the host matcher abandoned attempts at its resource limit (each ends its chunk silently, as a
     // pcre_exec error does in the reference: src/grab.cc:179); the differential tests skip such inputs
     if (getenv("GRAB_DIAG") && gscan_resource_errors())

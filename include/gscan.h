@@ -220,7 +220,8 @@ long gscan_parse_cpulist(const char *list, int *cpus, size_t cap);
 #define GSCAN_SLOTS 3
 int gscan_acquire(gscan_ctx *ctx, size_t len, void **pinned);
 size_t gscan_block_size(void);
-/* the ingest configuration in force (environment: GSCAN_BLOCK_MIB, GSCAN_READERS, GSCAN_COPY_STREAMS); any pointer may be NULL */
+/* the ingest configuration in force (environment: GSCAN_BLOCK_MIB, GSCAN_READERS; copy streams: GSCAN_SHARED_COPY per device,
+ * or GSCAN_COPY_STREAMS per context when GSCAN_SHARED_COPY=0); any pointer may be NULL */
 void gscan_ingest_info(size_t *block_bytes, int *readers, int *copy_streams);
 int gscan_submit(gscan_ctx *ctx, const gscan_db *db, const void *host_bytes, size_t len,
                  uint64_t tag);

@@ -91,7 +91,7 @@ def main():
             same = None
             if dt is not None and ref_out is not None:
                 same = sorted(out.splitlines()) == sorted(ref_out.splitlines())
-            tr = subprocess.run(argv, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, GRAB_TIMING="1", GSCAN_TIMING="1"))
+            tr = subprocess.run(argv, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, GRAB_TIMING="1", GSCAN_TIMING="1", GRAB_CLOSE="1"))
             lines = tr.stderr.decode("latin-1").splitlines()
             timing = [ln[14:] for ln in lines if ln.startswith("[grab timing]")][:2] + [ln[15:] for ln in lines if ln.startswith("[gscan timing]")][-1:]
             res["grab"][str(w)] = {"timing": timing, "s": dt and round(dt, 3), "GBps": dt and round(nbytes / dt / 1e9, 2), "lines": out.count(b"\n") if dt else out.decode("latin-1"),
