@@ -718,7 +718,11 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
     if (d.exact && d.alts.size() == 1 && !d.alts[0].gapped && !d.dev_pre && !d.dev_post) {
         const AltSeq &a0 = d.alts[0];
         size_t at = s;
-        if (!window_at(d, a0.window, content, clen, s)) {
+        if (d.solitary) { // every candidate is listed: the first one at or after s, without a look at the text (a fresh
+                          // mapping costs a page fault per match there -- half a second per 500 000 matches)
+            if (cur->li >= n) return 0;
+            at = starts[cur->li];
+        } else if (!window_at(d, a0.window, content, clen, s)) {
             size_t li = cur->li;
             while (li < n && starts[li] <= s) li++;
             if (li >= n) return 0;

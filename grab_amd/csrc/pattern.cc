@@ -2041,6 +2041,15 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         return 1;
     }
 
+    if (db.exact && db.alts.size() == 1 && !db.alts[0].gapped && !db.dev_pre && !db.dev_post && db.dev_windows[0] == db.alts[0].window) {
+        const std::vector<uint8_t> &w = db.dev_windows[0];
+        for (size_t i = 0; i + 1 < w.size() && !db.solitary; i++) {
+            bool common = false;
+            for (int k = 0; k < 8; k++) common = common || (db.classes[w[i]].w[k] & db.classes[w[i + 1]].w[k]) != 0;
+            db.solitary = !common;
+        }
+    }
+
     DevProgram &pg = db.prog;
     const std::vector<uint8_t> &w0 = db.dev_windows[0];
     const size_t m = w0.size();

@@ -205,6 +205,10 @@ struct Database {
     std::vector<std::vector<uint8_t>> dev_windows; // class ids, per alternative
     DevProgram prog;
     uint64_t id = 0; // unique per compile; contexts key their device copy on it
+    // One plain alternative whose window cannot match at two ADJACENT offsets (two neighbouring positions of it have no
+    // byte in common): every candidate is then the start of its own group, i.e. listed, and "the leftmost match from s" is
+    // the first listed start >= s -- the host's walk never has to look at the text (matcher.cc, gscan_next_match).
+    bool solitary = false;
     bool vm_ok = false; // prog.vm holds the tree as a VM program (vm.h): gscan_vm_verdict works; prog.vm_filter says whether the device uses it
 };
 

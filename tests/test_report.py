@@ -101,7 +101,7 @@ def test_next_match_any_restart_sequence(built):
     leftmost offset >= s at which the matcher reports a match with the subject starting at s."""
     rng = np.random.default_rng(77)
     alphabet = np.frombuffer(b"abcfoo01_ AZ.\n\n", np.uint8)
-    patterns = ["foo", "a|ab", r"\bfoo", r"o\b", "(?m)^f", "e$|o$", "a+b", r"[a-z]+\b", r"\w+@?\w+\.[a-c]+", "(?:fo|ab)+c", "a.*b.*c",
+    patterns = ["foo", "oo", "ofo", "abab", "[ab][ab]", "[ab]0[ab]", "a|ab", r"\bfoo", r"o\b", "(?m)^f", "e$|o$", "a+b", r"[a-z]+\b", r"\w+@?\w+\.[a-c]+", "(?:fo|ab)+c", "a.*b.*c",
                 "(?<=o)o|b(?=c)", r"(a|b)\1|c", r"fo\Ko|ab", r"(?>a+)b|o", "[a-c]{1,20}0", "(?:a|b|c|f|o|0|1|_){3}"]
     for pattern in patterns:
         db = engine.Database(pattern)
@@ -125,6 +125,33 @@ def test_next_match_any_restart_sequence(built):
                 else:
                     assert (got[0], got[2]) == (want[0], want[2]), (pattern, data.tobytes(), s, got, want)
                 s += int(rng.integers(1, 40))
+
+
+def test_listed_literals_are_walked_without_reading_the_text(built):
+    """A plain window that cannot match at two adjacent offsets (here: literals with two different neighbouring bytes) has
+    every candidate in the engine's list, so the walk takes "the first listed start >= s" and never reads the chunk -- with
+    offsets-only output a fresh mapping is then not faulted in at all (cfg5: a page fault per match was most of its time).
+    Stated as: the answers do not change when the text handed to the walk is blanked out.  A window that CAN match at
+    neighbouring offsets ("oo", a class pair) is listed by groups only and does read the text."""
+    rng = np.random.default_rng(5)
+    alphabet = np.frombuffer(b"fo ab\n", np.uint8)
+    data = alphabet[rng.integers(0, alphabet.size, 40000)]
+    blank = np.zeros_like(data)
+    for pattern, reads_text in (("foo", False), ("ab", False), ("abab", False), ("oo", True), ("[ab][ab]", True)):
+        db = engine.Database(pattern)
+        starts = engine_list(db, data)
+        answers = []
+        for text in (data, blank):
+            cur, s, got = engine.Cursor(), 0, []
+            while s < data.size:
+                rc, m0, m1 = db.next_match(text, starts, cur, s)
+                if rc != 1:
+                    break
+                got.append((m0, m1))
+                s = m1
+            answers.append(got)
+        assert len(answers[0]) >= 3, pattern
+        assert (answers[0] == answers[1]) == (not reads_text), pattern
 
 
 def test_long_lines_all_modes_match_libpcre(built, liboracle):
