@@ -150,6 +150,12 @@ struct TreeMatch {
     // Shared with the matchers of look-arounds / atomic groups; every setter restores the old value when what follows fails.
     std::vector<size_t> *caps = nullptr;
     size_t keep = SIZE_MAX; // \K: the reported start of the match (restored when what follows fails)
+    // subroutine calls: the groups of the pattern ([0]: the pattern itself), and the call this matcher runs inside
+    // (-1: none; what (?(R)..) and (?(Rn)..) ask about)
+    const std::vector<const Node *> *groups = nullptr;
+    int rec_group = -1;
+    uint32_t rec_depth = 0;
+    static constexpr uint32_t kMaxRecursion = 2000; // nested subroutine calls (each is a matcher of its own on the stack)
 
     // what is still to be matched after the current node
     struct Cont {
@@ -167,7 +173,9 @@ struct TreeMatch {
         case Node::SET: return 1;
         case Node::ASSERT:
         case Node::LOOK: return 0;
-        case Node::BACKREF: return -1;
+        case Node::BACKREF:
+        case Node::COND:
+        case Node::RECURSE: return -1;
         case Node::ATOMIC: return look_len(nd.kids[0]);
         case Node::CAT: {
             long t = 0;
@@ -284,6 +292,9 @@ struct TreeMatch {
         inner.max_stack = max_stack;
         inner.caps = caps;
         inner.keep = keep;
+        inner.groups = groups;
+        inner.rec_group = rec_group;
+        inner.rec_depth = rec_depth;
         const bool got = as_repeat ? inner.rep_group(what, 0, at, cap, &stop) : inner.m(what, at, cap, &stop);
         steps = inner.steps;
         gave_up = gave_up || inner.gave_up;
@@ -293,6 +304,30 @@ struct TreeMatch {
         cap_out = inner.captured;
         keep = inner.keep; // (the callers put the old value back when what follows the atomic part fails)
         return true;
+    }
+
+    // Does the body of the look-around n match at pos (before its negation is applied)?  The body is matched on its own, to
+    // its first success (assertions are atomic).  A look-behind body has a fixed length per top-level alternative and may
+    // not reach back over the subject start (the restart position: src/grab.cc:178 hands pcre_exec the subject FROM
+    // there).  What the body captured stays in *caps: the caller decides whether it may.
+    bool look_holds(const Node *n, size_t pos, bool cap, bool &inner_cap)
+    {
+        const Node *body = &n->kids[0];
+        bool ok = false;
+        size_t e = 0;
+        if (!n->behind) {
+            ok = atomic_run(body, false, pos, cap, e, inner_cap);
+        } else if (body->kind == Node::ALT) {
+            for (const Node &alt : body->kids) {
+                const long len = look_len(alt);
+                if (len >= 0 && pos >= s0 + (size_t)len) ok = atomic_run(&alt, false, pos - (size_t)len, cap, e, inner_cap) && e == pos;
+                if (ok || gave_up) break;
+            }
+        } else {
+            const long len = look_len(*body);
+            if (len >= 0 && pos >= s0 + (size_t)len) ok = atomic_run(body, false, pos - (size_t)len, cap, e, inner_cap) && e == pos;
+        }
+        return ok;
     }
 
     bool m(const Node *n, size_t pos, bool cap, const Cont *k)
@@ -312,26 +347,67 @@ struct TreeMatch {
                 return false;
             }
             return holds(n->acode, pos) && run(k, pos, cap);
-        case Node::LOOK: {
-            // The body is matched on its own, to its first success (assertions are atomic).  A look-behind body has a
-            // fixed length per top-level alternative and may not reach back over the subject start (the restart
-            // position: src/grab.cc:178 hands pcre_exec the subject FROM there).
-            const Node *body = &n->kids[0];
+        case Node::COND: {
+            const size_t base = n->cond == Node::C_ASSERT ? 1 : 0;
             const std::vector<size_t> saved = caps ? *caps : std::vector<size_t>();
-            bool ok = false, inner_cap = cap;
-            size_t e = 0;
-            if (!n->behind) {
-                ok = atomic_run(body, false, pos, cap, e, inner_cap);
-            } else if (body->kind == Node::ALT) {
-                for (const Node &alt : body->kids) {
-                    const long len = look_len(alt);
-                    if (len >= 0 && pos >= s0 + (size_t)len) ok = atomic_run(&alt, false, pos - (size_t)len, cap, e, inner_cap) && e == pos;
-                    if (ok || gave_up) break;
+            bool truth = false, inner_cap = cap;
+            switch (n->cond) {
+            case Node::C_GROUP: truth = caps && (*caps)[2 * (size_t)n->group + 1] != SIZE_MAX; break;
+            case Node::C_IN_RECURSION: truth = rec_group >= 0; break;
+            case Node::C_IN_RECURSION_OF: truth = rec_group == n->group; break;
+            case Node::C_ASSERT: {
+                const Node *look = &n->kids[0];
+                const bool ok = look_holds(look, pos, cap, inner_cap);
+                if (gave_up) return false;
+                truth = ok != look->neg;
+                // What the body captured stays captured whenever the body matched -- also under a NEGATIVE condition, where
+                // that means "condition false" (libpcre's JIT, the reference's build: a(?(?!(b))) on "ab" comes back as 0,
+                // the one-pair ovector overflowing; an ordinary (?!(b)) unsets the group again).
+                if (!ok) {
+                    if (caps) *caps = saved;
+                    inner_cap = cap;
                 }
-            } else {
-                const long len = look_len(*body);
-                if (len >= 0 && pos >= s0 + (size_t)len) ok = atomic_run(body, false, pos - (size_t)len, cap, e, inner_cap) && e == pos;
+                break;
             }
+            default: break; // DEFINE: never true
+            }
+            const Node *branch = truth ? &n->kids[base] : n->kids.size() > base + 1 ? &n->kids[base + 1] : nullptr;
+            if (branch ? m(branch, pos, inner_cap, k) : run(k, pos, inner_cap)) return true;
+            if (caps && n->cond == Node::C_ASSERT) *caps = saved;
+            return false;
+        }
+        case Node::RECURSE: {
+            // The called group's pattern on its own, to its first success, never re-entered (PCRE1: "a recursive subpattern
+            // call is always treated as an atomic group"); what was captured during the call is dropped when it returns.
+            const Node *target = groups && (size_t)n->group < groups->size() ? (*groups)[(size_t)n->group] : nullptr;
+            if (!target) return false;
+            if (rec_depth >= kMaxRecursion) gave_up = true;
+            if (gave_up) return false;
+            const Node *body = n->group == 0 ? target : &target->kids[0]; // (the group's content: a called group does not capture)
+            const std::vector<size_t> saved = caps ? *caps : std::vector<size_t>();
+            const Cont stop{Cont::ATOMIC_END, nullptr, 0, 0, nullptr};
+            TreeMatch inner{c, clen, s0};
+            inner.steps = steps;
+            inner.depth = depth;
+            inner.stack_base = stack_base;
+            inner.max_stack = max_stack;
+            inner.caps = caps;
+            inner.keep = keep;
+            inner.groups = groups;
+            inner.rec_group = n->group;
+            inner.rec_depth = rec_depth + 1;
+            const bool got = inner.m(body, pos, false, &stop);
+            steps = inner.steps;
+            gave_up = gave_up || inner.gave_up;
+            out_of_stack = out_of_stack || inner.out_of_stack;
+            if (caps) *caps = saved;
+            if (!got || gave_up) return false;
+            return run(k, inner.end, cap);
+        }
+        case Node::LOOK: {
+            const std::vector<size_t> saved = caps ? *caps : std::vector<size_t>();
+            bool inner_cap = cap;
+            const bool ok = look_holds(n, pos, cap, inner_cap);
             if (gave_up) return false;
             if (n->neg) { // (groups set inside a failed -- or a negative -- assertion are unset again)
                 if (caps) *caps = saved;
@@ -463,11 +539,13 @@ bool tree_match_at(const Database &d, const uint8_t *content, size_t clen, size_
     if (d.has_backref) caps.assign(2 * (size_t)d.n_groups + 2, SIZE_MAX);
     TreeMatch t{content, clen, subject_start};
     t.caps = d.has_backref ? &caps : nullptr;
+    t.groups = &d.group_nodes;
     bool hit = t.m(d.tree.get(), p, false, nullptr);
     if (t.out_of_stack) { // again, with room
         t = TreeMatch{content, clen, subject_start};
         if (d.has_backref) caps.assign(2 * (size_t)d.n_groups + 2, SIZE_MAX);
         t.caps = d.has_backref ? &caps : nullptr;
+        t.groups = &d.group_nodes;
         t.max_stack = kOwnStack - (256u << 10);
         hit = run_on_own_stack(t, d.tree.get(), p);
     }

@@ -1,5 +1,6 @@
 // pattern.cc -- see pattern.h.  Host only; no HIP.
 #include "pattern.h"
+#include "ucp_latin1.h"
 
 #include <algorithm>
 #include <atomic>
@@ -141,6 +142,9 @@ struct Parser {
     // inline options in force (PCRE: a change made inside a group lasts to the end of that
     // group, and carries into the alternatives that follow it there)
     bool caseless = false, dotall = false, multiline = false, extended = false;
+    bool ungreedy = false; // (?U): quantifiers are lazy unless followed by ?
+    bool dupnames = false; // (?J): two groups may share a name -- taken as long as none do
+    bool has_accept = false; // (*ACCEPT) somewhere: pcre_study gives no minimum length
 
     // (?x): white space and #-comments between the items of a pattern mean nothing (not inside [...] or \Q..\E)
     void skip_extended()
@@ -192,9 +196,11 @@ struct Parser {
 
     // After a backslash (i points at the escape letter).  Yields a set.  in_class
     // changes the meaning of \b and of \1..\7.
+    bool no_fold = false; // set by escape(): the set is a Unicode property, which (?i) leaves alone
     bool escape(ByteSet &out, bool in_class, bool &is_set_escape)
     {
         is_set_escape = false;
+        no_fold = false;
         if (eof()) return fail(-1, "\\ at end of pattern");
         int c = p[i++];
         ByteSet s;
@@ -221,6 +227,39 @@ struct Parser {
             saw_bare_hv = saw_bare_hv || !in_class;
             return true;
         case 'V': out = set_not(set_vspace()); is_set_escape = true; return true;
+        case 'R':
+        case 'X':
+        case 'B': // (outside a class these never get here: parse_cat deals with them)
+            if (!in_class) return fail(1, "escape sequence outside the engine's subset");
+            s.set((unsigned)c);
+            break;
+        case 'p':
+        case 'P': {
+            // \pL \p{Lu} \p{^Lu} \P{Latin}: without UTF every byte is the Latin-1 code point of the same value
+            // (ucp_latin1.h).  (?i) does not touch them.
+            if (eof()) return fail(-1, "malformed \\P or \\p sequence");
+            bool neg = c == 'P';
+            std::string name;
+            if (p[i] == '{') {
+                size_t j = i + 1;
+                if (j < n && p[j] == '^') neg = !neg, j++;
+                const size_t from = j;
+                while (j < n && p[j] != '}') j++;
+                if (j >= n) return fail(-1, "malformed \\P or \\p sequence");
+                name.assign((const char *)p + from, j - from);
+                i = j + 1;
+            } else {
+                name.assign(1, (char)p[i++]);
+            }
+            const UcpLatin1 *hit = nullptr;
+            for (const UcpLatin1 &e : kUcpLatin1)
+                if (name == e.name) hit = &e;
+            if (!hit) return fail(1, "Unicode property or script the engine has no Latin-1 table for");
+            for (int k = 0; k < 8; k++) out.w[k] = neg ? ~hit->w[k] : hit->w[k];
+            is_set_escape = true;
+            no_fold = true;
+            return true;
+        }
         case 'C': // one data unit: any byte, newline included (no UTF here)
             if (in_class) { // (libpcre: inside a class \C, like \R \X \B, is the letter)
                 s.set('C');
@@ -279,6 +318,23 @@ struct Parser {
             s.set(v);
             break;
         }
+        case 'o': {
+            if (eof() || p[i] != '{') return fail(-1, "missing opening brace after \\o");
+            size_t j = i + 1;
+            unsigned v = 0;
+            int digits = 0;
+            while (j < n && p[j] >= '0' && p[j] <= '7') {
+                v = v * 8 + (unsigned)(p[j] - '0');
+                if (v > 0xffffff) v = 0xffffff;
+                j++;
+                digits++;
+            }
+            if (j >= n || p[j] != '}' || digits == 0) return fail(-1, "non-octal character in \\o{} (closing brace missing?)");
+            if (v > 255) return fail(-1, "octal value is greater than \\377 in 8-bit non-UTF-8 mode");
+            i = j + 1;
+            s.set(v);
+            break;
+        }
         case '0': {
             unsigned v = 0;
             int k = 0;
@@ -321,17 +377,42 @@ struct Parser {
             neg = true;
             i++;
         }
-        bool first = true;
+        bool first = true, in_quote = false;
+        ByteSet props;
         for (;;) {
             if (eof()) return fail(-1, "missing terminating ] for character class");
             int c = p[i];
+            ByteSet lo;
+            bool lo_is_set = false;
+            if (in_quote) { // \Q..\E inside a class: every byte up to \E is a member, ']' and '-' included
+                if (c == '\\' && i + 1 < n && p[i + 1] == 'E') {
+                    in_quote = false;
+                    i += 2;
+                    continue;
+                }
+                lo.set((unsigned)c);
+                first = false;
+                i++;
+                while (i + 1 < n && p[i] == '\\' && p[i + 1] == 'E') { // the quote ends right behind this byte: it may begin a range
+                    in_quote = false;
+                    i += 2;
+                }
+                if (in_quote) {
+                    s.merge(lo);
+                    continue;
+                }
+                goto range_check;
+            }
+            if (c == '\\' && i + 1 < n && (p[i + 1] == 'Q' || p[i + 1] == 'E')) { // (a stray \E means nothing)
+                in_quote = p[i + 1] == 'Q';
+                i += 2;
+                continue;
+            }
             if (c == ']' && !first) {
                 i++;
                 break;
             }
             first = false;
-            ByteSet lo;
-            bool lo_is_set = false;
             if (c == '[' && i + 1 < n && (p[i + 1] == ':' || p[i + 1] == '.' || p[i + 1] == '=')) {
                 int kind = p[i + 1];
                 size_t j = i + 2;
@@ -357,19 +438,24 @@ struct Parser {
             }
             if (c == '\\') {
                 i++;
-                if (!eof() && (p[i] == 'Q' || p[i] == 'E')) return fail(1, "\\Q..\\E inside class");
                 if (!escape(lo, true, lo_is_set)) return false;
+                if (no_fold) { // a Unicode property: (?i) does not fold it
+                    props.merge(lo);
+                    continue;
+                }
             } else {
                 lo.set((unsigned)c);
                 i++;
             }
-            // range?
+        range_check:
             if (!lo_is_set && i + 1 < n && p[i] == '-' && p[i + 1] != ']') {
                 size_t save = i;
                 i++;
                 ByteSet hi;
                 bool hi_is_set = false;
-                if (p[i] == '\\') {
+                if (p[i] == '\\' && i + 1 < n && (p[i + 1] == 'Q' || p[i + 1] == 'E')) {
+                    return fail(1, "\\Q or \\E as the end of a class range");
+                } else if (p[i] == '\\') {
                     i++;
                     if (!escape(hi, true, hi_is_set)) return false;
                 } else if (p[i] == '[' && i + 1 < n && p[i + 1] == ':') {
@@ -397,6 +483,7 @@ struct Parser {
             s.merge(lo);
         }
         if (caseless) fold_case(s); // before negation: (?i)[^a] excludes 'A' too
+        s.merge(props);
         if (neg) s.negate();
         out = s;
         return true;
@@ -440,6 +527,8 @@ struct Parser {
     // the caller restores them at the closing parenthesis).
     int look_depth = 0; // nesting depth of look-arounds at the current position
     int special = 0; // set by group_head: 1 (?=  2 (?!  3 (?<=  4 (?<!  5 (?>  6 (?P=name) (a back reference, not a group)
+                     // 7 (?C) callout  8 (?( conditional  9 subroutine call (rec_num / rec_name)  10 (?| branch reset
+    int reset_depth = 0; // inside this many branch-reset groups
     // libpcre's auto-possessification table calls \S disjoint from \h and from \v; in the C locale it is not (0xa0 is \h
     // and 0x85 is \v, neither is isspace()): \S+\h and \v*\S keep bytes they would have to give back.  A pattern that
     // uses both kinds of escape outside classes is refused.
@@ -457,6 +546,9 @@ struct Parser {
     bool has_backref = false;
     std::vector<std::pair<std::string, int>> names; // named groups
     std::string group_name, ref_name;              // set by group_head
+    int rec_num = 0;                               // group_head, special == 9: the group a subroutine call names (0: the pattern) ...
+    std::string rec_name;                          // ... or its name
+    bool has_recursion = false;
 
     int named_group(const std::string &nm) const
     {
@@ -494,7 +586,36 @@ struct Parser {
             i = j;
         } else if (c == 'g') {
             size_t j = i + 1;
-            if (j < n && (p[j] == '<' || p[j] == '\'')) return bad(1, "subroutine call");
+            if (j < n && (p[j] == '<' || p[j] == '\'')) { // \g<n> \g<+n> \g<-n> \g<name>, or quotes: Oniguruma's subroutine call
+                const int close = p[j] == '<' ? '>' : '\'';
+                size_t q = j + 1;
+                int sign = 0;
+                if (q < n && (p[q] == '+' || p[q] == '-')) sign = p[q++] == '+' ? 1 : -1;
+                a = Node();
+                a.kind = Node::RECURSE;
+                if (q < n && isdigit(p[q])) {
+                    long v = 0;
+                    while (q < n && isdigit(p[q]) && v < 100000) v = v * 10 + (p[q++] - '0');
+                    if (q >= n || p[q] != close) return bad(-1, "\\g is not followed by a braced, angle-bracketed, or quoted name/number or by a plain number");
+                    if (sign && v == 0) return bad(-1, "a numbered reference must not be zero");
+                    if (sign > 0) v = ngroups + v;
+                    else if (sign < 0) v = ngroups - v + 1;
+                    if (v < 0 || (sign < 0 && v <= 0)) return bad(-1, "reference to non-existent subpattern");
+                    a.group = (int)v;
+                    i = q + 1;
+                } else if (!sign) {
+                    std::string nm;
+                    const size_t e = name_until(q, close, nm);
+                    if (!e) return bad(-1, "\\g is not followed by a braced, angle-bracketed, or quoted name/number or by a plain number");
+                    a.group = -1;
+                    a.refname = nm;
+                    i = e;
+                } else {
+                    return bad(-1, "\\g is not followed by a braced, angle-bracketed, or quoted name/number or by a plain number");
+                }
+                has_recursion = true;
+                return 1;
+            }
             const bool braced = j < n && p[j] == '{';
             if (braced) j++;
             bool neg = false;
@@ -539,6 +660,15 @@ struct Parser {
     // names -> numbers, and every reference must name a group of the pattern (forward references are fine)
     bool resolve_refs(Node &nd)
     {
+        if (nd.kind == Node::RECURSE || (nd.kind == Node::COND && (nd.cond == Node::C_GROUP || nd.cond == Node::C_IN_RECURSION_OF))) {
+            if (!nd.refname.empty()) {
+                nd.group = named_group(nd.refname);
+                nd.refname.clear();
+                if (!nd.group) return fail(-1, "reference to non-existent subpattern");
+            }
+            // ((?(Rn)..) is not checked by pcre_compile: without a group n the condition is never true)
+            if ((nd.group > ngroups || nd.group < 0) && !(nd.kind == Node::COND && nd.cond == Node::C_IN_RECURSION_OF)) return fail(-1, "reference to non-existent subpattern");
+        }
         if (nd.kind == Node::BACKREF) {
             if (!nd.refname.empty()) {
                 nd.group = named_group(nd.refname);
@@ -560,7 +690,9 @@ struct Parser {
         case Node::SET: return 1;
         case Node::ASSERT:
         case Node::LOOK: return 0;
-        case Node::BACKREF: return -1;
+        case Node::BACKREF:
+        case Node::COND:
+        case Node::RECURSE: return -1;
         case Node::ATOMIC: return fixed_len(nd.kids[0]);
         case Node::CAT: {
             long t = 0;
@@ -628,7 +760,11 @@ struct Parser {
             while (j < n && (isalnum(p[j]) || p[j] == '_')) j++;
             if (j == i + 1 || j >= n || p[j] != close) return fail(-1, "syntax error in group name");
             group_name.assign((const char *)p + i + 1, j - i - 1);
-            if (named_group(group_name)) return fail(-1, "two named subpatterns have the same name");
+            if (named_group(group_name)) {
+                if (dupnames) return fail(1, "two groups with the same name ((?J))");
+                if (reset_depth > 0) return fail(1, "two groups with the same name (allowed inside (?| when their numbers agree)");
+                return fail(-1, "two named subpatterns have the same name");
+            }
             i = j + 1;
             is_group = true;
             named = true;
@@ -640,7 +776,12 @@ struct Parser {
             is_group = true;
             return true;
         }
-        if (c == '|') return fail(1, "branch-reset group");
+        if (c == '|') { // (?|..|..): every alternative numbers its groups from the same start
+            i++;
+            special = 10;
+            is_group = true;
+            return true;
+        }
         if (c == 'P' && i + 1 < n && p[i + 1] == '=') { // (?P=name): a back reference in group clothing
             size_t j = i + 2;
             while (j < n && (isalnum(p[j]) || p[j] == '_')) j++;
@@ -650,9 +791,56 @@ struct Parser {
             special = 6;
             return true;
         }
-        if (c == 'P' || c == 'R' || c == '&' || c == '(' || c == 'C' || c == '+' || (c >= '0' && c <= '9'))
-            return fail(1, "recursion / conditional / callout / named reference");
-        bool on = true, ci = caseless, da = dotall, ml = multiline, ex = extended;
+        if (c == '(') { // (?(condition)yes|no): parse_cond takes over, i stays at the condition's parenthesis
+            special = 8;
+            is_group = true;
+            return true;
+        }
+        // subroutine calls: (?R) (?0) (?N) (?+N) (?-N) (?&name) (?P>name)
+        if (c == 'R' || (c >= '0' && c <= '9') || ((c == '+' || c == '-') && i + 1 < n && isdigit(p[i + 1]))) {
+            size_t j = i;
+            long v = 0;
+            if (c == 'R') {
+                j++;
+            } else {
+                const int sign = c == '+' ? 1 : c == '-' ? -1 : 0;
+                if (sign) j++;
+                while (j < n && isdigit(p[j]) && v < 100000) v = v * 10 + (p[j++] - '0');
+                if (sign && v == 0) return fail(-1, "a numbered reference must not be zero");
+                if (sign > 0) v = ngroups + v;
+                else if (sign < 0) v = ngroups - v + 1;
+                if (v < 0 || (sign < 0 && v <= 0)) return fail(-1, "reference to non-existent subpattern");
+            }
+            if (j >= n || p[j] != ')') return fail(-1, c == 'R' ? "(?R or (?[+-]digits must be followed by )" : "(?R or (?[+-]digits must be followed by )");
+            i = j + 1;
+            rec_num = (int)v;
+            rec_name.clear();
+            special = 9;
+            return true;
+        }
+        if (c == '&' || (c == 'P' && i + 1 < n && p[i + 1] == '>')) {
+            size_t j = i + (c == '&' ? 1 : 2);
+            const size_t from = j;
+            while (j < n && (isalnum(p[j]) || p[j] == '_')) j++;
+            if (j == from || j >= n || p[j] != ')') return fail(-1, "syntax error in subpattern name (missing terminator)");
+            rec_name.assign((const char *)p + from, j - from);
+            rec_num = -1;
+            i = j + 1;
+            special = 9;
+            return true;
+        }
+        if (c == 'P') return fail(-1, "unrecognized character after (?P");
+        if (c == 'C') { // (?C) (?Cn): a callout point; the reference sets no callout function, so nothing happens there
+            size_t j = i + 1;
+            long v = 0;
+            while (j < n && isdigit(p[j]) && v < 1000) v = v * 10 + (p[j++] - '0');
+            if (j >= n || p[j] != ')') return fail(-1, "closing ) for (?C expected");
+            if (v > 255) return fail(-1, "number after (?C is > 255");
+            i = j + 1;
+            special = 7;
+            return true;
+        }
+        bool on = true, ci = caseless, da = dotall, ml = multiline, ex = extended, ug = ungreedy;
         for (;; i++) {
             if (eof()) return fail(-1, "missing ) after option setting");
             c = p[i];
@@ -667,8 +855,12 @@ struct Parser {
                 ml = on;
             } else if (c == 'x') {
                 ex = on;
-            } else if (c == 'J' || c == 'U' || c == 'X') {
-                return fail(1, "inline option outside the engine's subset");
+            } else if (c == 'U') {
+                ug = on;
+            } else if (c == 'J') {
+                dupnames = dupnames || on; // (nothing to do: duplicate names are still refused where they occur)
+            } else if (c == 'X') {
+                // PCRE_EXTRA: unknown escapes are errors instead of literals -- libpcre has validated the pattern text already
             } else if (c == ')' || c == ':') {
                 break;
             } else {
@@ -679,19 +871,142 @@ struct Parser {
         dotall = da;
         multiline = ml;
         extended = ex;
+        ungreedy = ug;
         is_group = (p[i] == ':');
         i++;
         return true;
     }
 
+    static bool has_kind_p(const Node &nd, Node::Kind kind)
+    {
+        if (nd.kind == kind) return true;
+        for (const Node &k : nd.kids)
+            if (has_kind_p(k, kind)) return true;
+        return false;
+    }
+
+    // "(?" consumed, i at the parenthesis that opens the condition.  (?(1)..) (?(+1)..) (?(<name>)..) (?('name')..) (?(name)..)
+    // (?(R)..) (?(R1)..) (?(R&name)..) (?(DEFINE)..) (?(?=..)..) (?(?!..)..) (?(?<=..)..) (?(?<!..)..); then yes [| no] and ")".
+    bool parse_cond(Node &a)
+    {
+        a = Node();
+        a.kind = Node::COND;
+        i++; // the condition's "("
+        if (eof()) return fail(-1, "malformed number or name after (?(");
+        if (p[i] == '?') { // an assertion
+            int sp = 0;
+            if (i + 1 < n && p[i + 1] == '=') sp = 1, i += 2;
+            else if (i + 1 < n && p[i + 1] == '!') sp = 2, i += 2;
+            else if (i + 2 < n && p[i + 1] == '<' && p[i + 2] == '=') sp = 3, i += 3;
+            else if (i + 2 < n && p[i + 1] == '<' && p[i + 2] == '!') sp = 4, i += 3;
+            else return fail(-1, "assertion expected after (?(");
+            const bool ci = caseless, da = dotall, ml = multiline, ex = extended, ug = ungreedy;
+            Node body;
+            depth++;
+            look_depth++;
+            const bool ok = parse_alt(body);
+            look_depth--;
+            if (!ok) return false;
+            depth--;
+            if (eof() || p[i] != ')') return fail(-1, "missing )");
+            i++;
+            caseless = ci, dotall = da, multiline = ml, extended = ex, ungreedy = ug;
+            if (sp >= 3) {
+                if (has_kind_p(body, Node::COND) || has_kind_p(body, Node::RECURSE)) return fail(1, "conditional group or subroutine call inside a look-behind");
+                bool fixed = true;
+                if (body.kind == Node::ALT)
+                    for (const Node &k : body.kids) fixed = fixed && fixed_len(k) >= 0;
+                else
+                    fixed = fixed_len(body) >= 0;
+                if (!fixed) return fail(-1, "lookbehind assertion is not fixed length");
+            }
+            Node w;
+            w.kind = Node::LOOK;
+            w.behind = sp >= 3;
+            w.neg = sp == 2 || sp == 4;
+            w.kids.push_back(std::move(body));
+            a.cond = Node::C_ASSERT;
+            a.kids.push_back(std::move(w));
+        } else {
+            size_t j = i;
+            while (j < n && p[j] != ')') j++;
+            if (j >= n) return fail(-1, "missing )");
+            std::string t((const char *)p + i, j - i);
+            i = j + 1;
+            auto all_digits = [](const std::string &x, size_t from) {
+                if (from >= x.size()) return false;
+                for (size_t k = from; k < x.size(); k++)
+                    if (!isdigit((unsigned char)x[k])) return false;
+                return true;
+            };
+            auto is_name = [](const std::string &x) {
+                if (x.empty() || isdigit((unsigned char)x[0])) return false;
+                for (char ch : x)
+                    if (!isalnum((unsigned char)ch) && ch != '_') return false;
+                return true;
+            };
+            if (all_digits(t, 0) || ((t[0] == '+' || t[0] == '-') && all_digits(t, 1))) {
+                const int sign = t[0] == '+' ? 1 : t[0] == '-' ? -1 : 0;
+                long v = atol(t.c_str() + (sign ? 1 : 0));
+                if (v == 0) return fail(-1, sign ? "a numbered reference must not be zero" : "invalid condition (?(0)");
+                if (sign > 0) v = ngroups + v;
+                else if (sign < 0) v = ngroups - v + 1;
+                if (v <= 0 || v > 100000) return fail(-1, "reference to non-existent subpattern");
+                a.cond = Node::C_GROUP;
+                a.group = (int)v;
+            } else if (t == "R") {
+                a.cond = Node::C_IN_RECURSION;
+            } else if (t.size() > 1 && t[0] == 'R' && all_digits(t, 1)) {
+                a.cond = Node::C_IN_RECURSION_OF;
+                a.group = atoi(t.c_str() + 1);
+            } else if (t.size() > 2 && t[0] == 'R' && t[1] == '&' && is_name(t.substr(2))) {
+                a.cond = Node::C_IN_RECURSION_OF;
+                a.group = -1;
+                a.refname = t.substr(2);
+            } else if (t == "DEFINE") {
+                a.cond = Node::C_DEFINE;
+            } else {
+                std::string nm = t;
+                if (nm.size() >= 2 && ((nm.front() == '<' && nm.back() == '>') || (nm.front() == '\'' && nm.back() == '\''))) nm = nm.substr(1, nm.size() - 2);
+                if (!is_name(nm)) return fail(-1, "malformed number or name after (?(");
+                a.cond = Node::C_GROUP;
+                a.group = -1;
+                a.refname = nm;
+            }
+            if (a.cond == Node::C_GROUP) has_backref = true; // (the matcher has to keep track of what the groups captured)
+        }
+        // the branches
+        const bool ci = caseless, da = dotall, ml = multiline, ex = extended, ug = ungreedy;
+        Node body;
+        depth++;
+        if (!parse_alt(body)) return false;
+        depth--;
+        if (eof() || p[i] != ')') return fail(-1, "missing )");
+        i++;
+        caseless = ci, dotall = da, multiline = ml, extended = ex, ungreedy = ug;
+        if (body.kind == Node::ALT && !body.kids.empty()) {
+            if (body.kids.size() > 2) return fail(-1, "conditional group contains more than two branches");
+            if (a.cond == Node::C_DEFINE) return fail(-1, "DEFINE group contains more than one branch");
+            for (Node &k : body.kids) a.kids.push_back(std::move(k));
+        } else {
+            a.kids.push_back(std::move(body));
+        }
+        return true;
+    }
+
     // alternation := cat ('|' cat)*
-    bool parse_alt(Node &out)
+    bool parse_alt(Node &out, bool reset_numbers = false)
     {
         Node alt;
         alt.kind = Node::ALT;
+        const int base = ngroups;
+        int highest = ngroups;
         for (;;) {
             Node cat;
+            if (reset_numbers) ngroups = base;
             if (!parse_cat(cat)) return false;
+            highest = std::max(highest, ngroups);
+            if (reset_numbers) ngroups = highest;
             alt.kids.push_back(std::move(cat));
             if (!eof() && !quoting && p[i] == '|') {
                 i++;
@@ -781,13 +1096,40 @@ struct Parser {
                         if (br > 0) break;
                         i = save;
                     }
-                    // (\R is refused: libpcre's auto-possessification treats \R as disjoint from \s and from ".", which it is not
-                    // under the LF newline convention -- \R?\s misses "\n", \N+\R never ends in \r, VT, FF or NEL)
+                    if (i + 1 < n && (p[i + 1] == 'R' || p[i + 1] == 'X')) {
+                        // \R = (?>\r\n|\n|\x0b|\f|\r|\x85); \X, an extended grapheme cluster, is (?>\r\n|any byte) over Latin-1 (no
+                        // byte below 256 extends another; CR LF is the only pair that stays together).  libpcre's
+                        // auto-possessification treats \R as disjoint from \s and from "." -- \R?\s misses "\n", \N+\R never
+                        // ends in \r, VT, FF or NEL -- so a variable count of it, or a greedy class repeat in front of it, is
+                        // refused (compile_pattern: ends_in_greedy_repeat).
+                        const bool any = p[i + 1] == 'X';
+                        i += 2;
+                        Node crlf, cr, lf, one;
+                        crlf.kind = Node::CAT;
+                        cr.set.set('\r');
+                        lf.set.set('\n');
+                        crlf.kids.push_back(cr);
+                        crlf.kids.push_back(lf);
+                        if (any) {
+                            one.set = set_all();
+                        } else {
+                            one.set.set('\n'), one.set.set(0x0b), one.set.set('\f'), one.set.set('\r'), one.set.set(0x85);
+                        }
+                        Node alt;
+                        alt.kind = Node::ALT;
+                        alt.kids.push_back(std::move(crlf));
+                        alt.kids.push_back(std::move(one));
+                        a = Node();
+                        a.kind = Node::ATOMIC;
+                        a.newline_seq = true;
+                        a.kids.push_back(std::move(alt));
+                        break;
+                    }
                     i++;
                     {
                         bool is_set;
                         if (!escape(a.set, false, is_set)) return false;
-                        if (caseless) fold_case(a.set);
+                        if (caseless && !no_fold) fold_case(a.set);
                     }
                     break;
                 case '.':
@@ -802,8 +1144,31 @@ struct Parser {
                 case '(': {
                     i++;
                     if (eof()) return fail(-1, "missing )");
-                    if (p[i] == '*') return fail(1, "backtracking control verb");
-                    const bool ci = caseless, da = dotall, ml = multiline, ex = extended;
+                    if (p[i] == '*') {
+                        // (*FAIL) / (*F): an empty negative look-ahead.  (*ACCEPT): pcre_study finds no minimum length
+                        // ("ACCEPT makes things far too complicated"), PCRE_INFO_MINLENGTH is -1 and the reference skips every
+                        // file -- nothing is ever matched, so the verb needs no meaning here.  The verbs that
+                        // steer the search over start offsets (COMMIT, PRUNE, SKIP, THEN) and the (*UTF8) / newline settings
+                        // are outside the subset.
+                        size_t j = i + 1;
+                        while (j < n && p[j] != ')') j++;
+                        if (j >= n) return fail(-1, "missing )");
+                        const std::string verb((const char *)p + i + 1, j - i - 1);
+                        if (verb == "FAIL" || verb == "F" || verb == "ACCEPT") {
+                            if (verb == "ACCEPT") has_accept = true;
+                            a = Node();
+                            a.kind = Node::LOOK;
+                            a.neg = true;
+                            Node none;
+                            none.kind = Node::CAT;
+                            a.kids.push_back(std::move(none));
+                            i = j + 1;
+                            if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?')) return fail(-1, "nothing to repeat");
+                            break;
+                        }
+                        return fail(1, "backtracking control verb / start-of-pattern setting");
+                    }
+                    const bool ci = caseless, da = dotall, ml = multiline, ex = extended, ug = ungreedy;
                     bool capture = true, named = false;
                     if (p[i] == '?') {
                         i++;
@@ -819,6 +1184,27 @@ struct Parser {
                             note_reference(named_group(ref_name));
                             caseless = ci, dotall = da, multiline = ml;
                             break;
+                        }
+                        if (special == 9) { // a subroutine call
+                            special = 0;
+                            a = Node();
+                            a.kind = Node::RECURSE;
+                            a.group = rec_num;
+                            a.refname = rec_name;
+                            has_recursion = true;
+                            caseless = ci, dotall = da, multiline = ml;
+                            break;
+                        }
+                        if (special == 8) { // a conditional group
+                            special = 0;
+                            if (!parse_cond(a)) return false;
+                            caseless = ci, dotall = da, multiline = ml, extended = ex, ungreedy = ug;
+                            break;
+                        }
+                        if (special == 7) { // (?C): nothing
+                            special = 0;
+                            if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?')) return fail(-1, "nothing to repeat");
+                            continue;
                         }
                         if (!is_group) { // "(?i)": stays in force to the end of the enclosing group
                             if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?')) return fail(-1, "nothing to repeat");
@@ -836,7 +1222,9 @@ struct Parser {
                     }
                     depth++;
                     if (sp >= 1 && sp <= 4) look_depth++;
-                    const bool body_ok = parse_alt(a);
+                    if (sp == 10) reset_depth++;
+                    const bool body_ok = sp == 10 ? parse_alt(a, true) : parse_alt(a);
+                    if (sp == 10) reset_depth--;
                     if (sp >= 1 && sp <= 4) look_depth--;
                     if (!body_ok) return false;
                     depth--;
@@ -846,7 +1234,12 @@ struct Parser {
                     dotall = da;
                     multiline = ml;
                     extended = ex;
-                    if (sp) { // look-around / atomic group: a wrapper node around the body
+                    ungreedy = ug;
+                    if (sp == 10) { // a plain group as far as matching goes
+                        capture = false;
+                    } else if (sp) { // look-around / atomic group: a wrapper node around the body
+                        if ((sp == 3 || sp == 4) && (has_kind_p(a, Node::COND) || has_kind_p(a, Node::RECURSE)))
+                            return fail(1, "conditional group or subroutine call inside a look-behind");
                         if (sp == 3 || sp == 4) {
                             bool fixed = true;
                             if (a.kind == Node::ALT)
@@ -926,6 +1319,7 @@ struct Parser {
                     skip_extended(); // (?x): white space and comments may stand between a quantifier and its ? / + suffix
                     if (!eof() && p[i] == '?') { mode = 1; i++; }
                     else if (!eof() && p[i] == '+') { mode = 2; i++; }
+                    if (ungreedy && mode != 2) mode ^= 1; // (?U): lazy by default, ? makes it greedy
                     if (look_quant) { // PCRE: {0} drops the assertion, a minimum of 0 makes it optional, anything else means once
                         if (qmax == 0) {
                             a = Node();
@@ -946,6 +1340,7 @@ struct Parser {
                     // it fails, so a later group-free match of the same pcre_exec call comes back as 0 -- x|(a)*+b on "a x".
                     // Only this form does ((a)++, ((a))*+, (?:(a))*+ do not); what it depends on -- every start offset
                     // pcre_exec tries, candidate or not -- is not something the engine looks at.  Refused.
+                    if (a.kind == Node::ATOMIC && a.newline_seq && qmin != qmax) return fail(1, "a variable count of \\R or \\X (libpcre's auto-possessification misjudges what may follow it)");
                     if (mode == 2 && qmin == 0 && qmax == kInf && a.kind == Node::CAT && a.cap)
                         return fail(1, "possessive * directly on a capturing group (libpcre's JIT reports the group as set after failed attempts)");
                     Node rep;
@@ -989,6 +1384,22 @@ struct Unfold {
     std::string why;
     int rc = 0;
     int gap_ids = 0;
+    const Node *root = nullptr; // the whole tree: where subroutine calls find their groups
+    std::vector<int> calling;   // groups whose bodies are being unfolded on behalf of a call
+    static const Node *find_group_in(const Node &n, int g)
+    {
+        if (n.kind == Node::CAT && n.cap && n.group == g) return &n;
+        for (const Node &k : n.kids)
+            if (const Node *f = find_group_in(k, g)) return f;
+        return nullptr;
+    }
+    static bool contains_node(const Node &n, const Node *x)
+    {
+        if (&n == x) return true;
+        for (const Node &k : n.kids)
+            if (contains_node(k, x)) return true;
+        return false;
+    }
     bool fail(const char *msg)
     {
         if (rc == 0) {
@@ -1233,6 +1644,48 @@ struct Unfold {
             if (!run(nd.kids[0], out)) return false;
             for (Seq &s : out) s.inexact = true;
             return true;
+        case Node::RECURSE: {
+            // What the called group matches is the matcher's to find out: the path stops here -- after what one call must
+            // begin with, if the call is not into a group it stands in (no bytes are known then: the path stops at once).
+            const Node *grp = root && nd.group > 0 ? find_group_in(*root, nd.group) : nullptr;
+            bool inside = !grp;
+            for (int g : calling) inside = inside || g == nd.group;
+            if (!inside && grp && !contains_node(*grp, &nd) && calling.size() < 4) {
+                calling.push_back(nd.group);
+                std::vector<Seq> body;
+                const bool ok = run(grp->kids[0], body);
+                calling.pop_back();
+                if (!ok) return false;
+                for (const Seq &b : body) {
+                    Seq f = freeze(b);
+                    f.cap = false; // (a called group does not capture, and what it captured inside is dropped)
+                    f.needs_cap = false;
+                    if (!push_frozen(out, f)) return false;
+                }
+                return true;
+            }
+            Seq s;
+            s.frozen = true;
+            s.inexact = true;
+            out.push_back(std::move(s));
+            return true;
+        }
+        case Node::COND: { // either branch may be the one taken (which one is decided at match time): necessary conditions
+            const size_t base = nd.cond == Node::C_ASSERT ? 1 : 0;
+            const bool cond_caps = base && has_cap_group(nd.kids[0]); // (also a negative one: matcher.cc, COND)
+            for (size_t b = base; b < nd.kids.size(); b++) {
+                std::vector<Seq> kid;
+                if (!run(nd.kids[b], kid)) return false;
+                out.insert(out.end(), kid.begin(), kid.end());
+                if (!room(out.size())) return false;
+            }
+            if (nd.kids.size() == base + 1) out.push_back(Seq()); // no "no" branch: the group matches "" when the condition fails
+            for (Seq &s : out) {
+                s.inexact = true;
+                if (cond_caps) s.cap = true; // (a group the condition's assertion closed stays set, see LOOK)
+            }
+            return room(out.size());
+        }
         case Node::CAT: {
             out.push_back(Seq());
             for (const Node &k : nd.kids) {
@@ -1539,6 +1992,7 @@ int byte_rank(unsigned b)
 std::atomic<uint64_t> g_next_id{1};
 
 uint64_t node_minlen(const Node &n);
+const Node *find_group(const Node &n, int g);
 
 // libpcre quirk no. 2 (8.39 and 8.45, interpreter and JIT): a group whose first item is a positive look-ahead that begins
 // with a literal byte -- (?:(?=x))x\B -- gives pcre_exec both a "first byte" and a "required byte" that are the same
@@ -1574,6 +2028,84 @@ bool lookahead_first_in_group(const Node &n, bool top)
     return false;
 }
 
+// libpcre quirks around the two new constructs (8.39 JIT and 8.45 alike), refused rather than imitated:
+//  * a ^ inside a conditional group -- in the condition's assertion, in a branch, in a DEFINE -- is read by pcre_compile's
+//    is_anchored / is_startline as if it stood at the head of the pattern: (?(DEFINE)^)\w is only tried at line starts,
+//    (?:(?(?=^))[.]) only at the subject start;
+//  * an OPTIONAL subroutine call that a match can begin with -- (?1)* (\s)?, \g<1>?b(..){0} -- is left out of the start-up
+//    optimisation's first byte / start bits: offsets whose first byte only the call can take are skipped.
+bool cond_holds_circumflex(const Node &n, bool inside)
+{
+    if (inside && n.kind == Node::ASSERT && (n.acode == A_BOS || n.acode == A_MBOL)) return true;
+    for (const Node &k : n.kids)
+        if (cond_holds_circumflex(k, inside || n.kind == Node::COND)) return true;
+    return false;
+}
+// can the first byte of a match be taken inside an optional (min 0) item that holds a subroutine call?
+bool begins_with_optional_call(const Node &n, bool optional)
+{
+    switch (n.kind) {
+    case Node::RECURSE: return optional;
+    case Node::SET:
+    case Node::ASSERT:
+    case Node::BACKREF:
+    case Node::LOOK: return false;
+    case Node::ATOMIC: return begins_with_optional_call(n.kids[0], optional);
+    case Node::REP: return n.max != 0 && begins_with_optional_call(n.kids[0], optional || n.min == 0);
+    case Node::ALT:
+        for (const Node &k : n.kids)
+            if (begins_with_optional_call(k, optional)) return true;
+        return false;
+    case Node::COND:
+        for (size_t b = n.cond == Node::C_ASSERT ? 1 : 0; b < n.kids.size(); b++)
+            if (begins_with_optional_call(n.kids[b], optional)) return true;
+        return false;
+    case Node::CAT:
+        for (const Node &k : n.kids) {
+            if (begins_with_optional_call(k, optional)) return true;
+            if (node_minlen(k) > 0) return false; // (find_minlength's count: zero for anything that may match "")
+        }
+        return false;
+    }
+    return false;
+}
+
+//  * a group that is called as a subroutine and whose pattern begins with an unbounded greedy or possessive repeat of one
+//    class -- b(?1)c|(A*)x, b(?1)c|([^x]*)x -- : after an attempt that made the call has failed, the JIT build does not
+//    find matches that begin before the place the call had reached ("bAAx x": the interpreter reports 1, the JIT 5).
+//    It takes the group to stand at the head of an alternative of the pattern proper: behind another item (y(A*)x), or
+//    inside a (?(DEFINE)..) that only the calls reach, both builds agree.
+bool group_heads_a_branch(const Node &n, int g)
+{
+    if (n.kind == Node::COND && n.cond == Node::C_DEFINE) return false;
+    if (n.kind == Node::CAT && !n.cap && !n.kids.empty()) {
+        const Node *f = &n.kids[0];
+        while (f->kind == Node::ATOMIC) f = &f->kids[0];
+        if (f->kind == Node::CAT && f->cap && f->group == g) return true;
+    }
+    for (const Node &k : n.kids)
+        if (group_heads_a_branch(k, g)) return true;
+    return false;
+}
+bool called_group_begins_with_repeat(const Node &n, const Node &root)
+{
+    if (n.kind == Node::RECURSE && n.group > 0) {
+        if (const Node *g = find_group(root, n.group)) {
+            const Node &body = g->kids[0];
+            const Node *branches = body.kind == Node::ALT ? body.kids.data() : &body;
+            const size_t nb = body.kind == Node::ALT ? body.kids.size() : 1;
+            for (size_t b = 0; b < nb; b++) {
+                const Node *f = first_item(branches[b]);
+                while (f && (f->kind == Node::ATOMIC || (f->kind == Node::CAT && !f->kids.empty()))) f = first_item(f->kids[0]);
+                if (f && f->kind == Node::REP && f->kids[0].kind == Node::SET && f->max == kInf && f->mode != 1 && group_heads_a_branch(root, n.group)) return true;
+            }
+        }
+    }
+    for (const Node &k : n.kids)
+        if (called_group_begins_with_repeat(k, root)) return true;
+    return false;
+}
+
 bool has_optional_group(const Node &n)
 {
     if (n.kind == Node::REP && n.kids[0].kind != Node::SET && n.min == 0) return true;
@@ -1588,18 +2120,31 @@ bool has_optional_group(const Node &n)
 // the group's first bytes cannot continue the repeat, WITHOUT looking at what follows the group:  b[x.]{0,2}(?:0)?+[x.] x
 // never matches "b.x x".  Such patterns are refused rather than imitated.  Returns whether the node can END with a
 // greedy variable repeat of a class (`prev`: whether what precedes it can); sets `quirk` when the construct is met.
+// (g_lazy_counts: the second pass -- auto-possessification also turns LAZY repeats into possessive GREEDY ones when its tables
+// say the next item cannot continue them, and for \R / \X the tables are wrong: \S??\R takes NEL for \S.  That pass looks at
+// \R / \X only.)
+static thread_local bool g_lazy_counts = false;
 bool ends_in_greedy_repeat(const Node &n, bool prev, bool &quirk)
 {
     switch (n.kind) {
     case Node::SET: return false;
     case Node::ASSERT: return n.acode == A_KEEP ? false : prev; // (\K is an opcode of its own: the look-ahead stops there)
     case Node::BACKREF: return false; // (not an opcode auto-possessification looks through)
+    case Node::RECURSE: return false;
+    case Node::COND: { // (OP_COND is not an opcode it looks through either; the branches are patterns of their own)
+        for (const Node &k : n.kids) ends_in_greedy_repeat(k.kind == Node::LOOK ? k.kids[0] : k, false, quirk);
+        return false;
+    }
     case Node::LOOK: { // an assertion opcode stops auto-possessification's look-ahead; its body is a pattern of its own
         ends_in_greedy_repeat(n.kids[0], false, quirk);
         return false;
     }
     case Node::ATOMIC: { // (?>..) is what a possessive group repeat compiles to: the same quirk when a branch of it can match ""
-        if (prev && node_minlen(n.kids[0]) == 0) quirk = true;
+        if (n.newline_seq) { // \R, \X: one opcode; a greedy class repeat in front of it is made possessive by a wrong table
+            if (prev) quirk = true;
+            return false;
+        }
+        if (!g_lazy_counts && prev && node_minlen(n.kids[0]) == 0) quirk = true;
         return ends_in_greedy_repeat(n.kids[0], prev, quirk);
     }
     case Node::CAT: {
@@ -1616,10 +2161,10 @@ bool ends_in_greedy_repeat(const Node &n, bool prev, bool &quirk)
         const Node &k = n.kids[0];
         if (n.max == 0) return prev;
         if (k.kind == Node::SET) {
-            if (n.max > n.min && n.mode == 0) return true;
+            if (n.max > n.min && (n.mode == 0 || (g_lazy_counts && n.mode == 1))) return true;
             return n.min == 0 ? prev : false;
         }
-        if (n.mode == 2 && n.max > n.min && prev) quirk = true;
+        if (!g_lazy_counts && n.mode == 2 && n.max > n.min && prev) quirk = true;
         bool f = ends_in_greedy_repeat(k, prev, quirk);
         if (n.max > 1) f = ends_in_greedy_repeat(k, f || prev, quirk) || f; // the end of one iteration precedes the next
         return (n.min == 0 || node_minlen(k) == 0) ? (f || prev) : f;
@@ -1672,6 +2217,16 @@ bool recursive_ref(const Node &item, const MinCtx &cx)
         if (r->mode == 2) return false; // \1?+ is compiled as (?>\1?): a group of its own, whose recursion flag stays inside it
         r = &r->kids[0];
     }
+    if (item.kind == Node::RECURSE) { // (?R), or (?n) inside group n: find_minlength's had_recurse
+        if (cx.plain) return false;
+        if (item.group == 0) return true;
+        for (const auto &fx : cx.fixed)
+            if (fx.first == item.group) return false;
+        for (int a : cx.active)
+            if (a == item.group) return true;
+        const Node *grp = find_group(*cx.root, item.group);
+        return grp && contains(*grp, &item);
+    }
     if (r->kind != Node::BACKREF) return false;
     if (cx.plain) return false;
     for (const auto &fx : cx.fixed)
@@ -1702,6 +2257,41 @@ uint64_t node_minlen(const Node &n, MinCtx &cx)
         return d;
     }
     case Node::ATOMIC: return node_minlen(n.kids[0], cx);
+    case Node::RECURSE: {
+        // find_minlength, OP_RECURSE: a call from inside the called group, or into a group whose length is being worked
+        // out further up (mutual recursion), counts nothing; any other call counts what the called group counts
+        if (n.group == 0) return 0;
+        if (!cx.plain)
+            for (const auto &fx : cx.fixed) // (a later copy of a counted repeat: the call goes to the FIRST copy's bracket, see REP)
+                if (fx.first == n.group) return fx.second;
+        const Node *grp = find_group(*cx.root, n.group);
+        if (!grp || contains(*grp, &n)) return 0;
+        for (int a : cx.active) // (8.39's recurse_check chain: one list for the groups entered through calls and through references)
+            if (a == n.group) return 0;
+        cx.active.push_back(n.group);
+        const uint64_t d = node_minlen(*grp, cx);
+        cx.active.pop_back();
+        return d;
+    }
+    case Node::COND: {
+        // find_minlength, OP_COND: a condition with one branch has an implied empty second one and counts nothing (that
+        // covers DEFINE); with two it is a bracket like any other -- the shorter branch
+        const size_t base = n.cond == Node::C_ASSERT ? 1 : 0;
+        if (n.kids.size() < base + 2) return 0;
+        if (cx.plain) return std::min(node_minlen(n.kids[base], cx), node_minlen(n.kids[base + 1], cx));
+        bool first = true;
+        uint64_t t = cap;
+        for (size_t b = base; b < n.kids.size(); b++) {
+            const Node &k = n.kids[b];
+            const uint64_t bl = node_minlen(k, cx);
+            bool rec = recursive_ref(k, cx);
+            if (k.kind == Node::CAT && !k.cap)
+                for (const Node &item : k.kids) rec = rec || recursive_ref(item, cx);
+            if (first || (!rec && bl < t)) t = bl;
+            first = false;
+        }
+        return t;
+    }
     case Node::CAT: {
         uint64_t t = 0;
         for (const Node &k : n.kids) t = std::min(cap, t + node_minlen(k, cx));
@@ -1728,7 +2318,7 @@ uint64_t node_minlen(const Node &n, MinCtx &cx)
         // A counted repeat is compiled into copies; a group that refers to itself finds, from its second copy on, the
         // FIRST copy's bracket: there the reference counts what that copy counts (and is no recursion any more).
         // (every capturing group inside the repeated item, whether the reference stands inside that group or next to it)
-        if (n.min >= 2 && !cx.plain && has_kind(k, Node::BACKREF)) {
+        if (n.min >= 2 && !cx.plain && (has_kind(k, Node::BACKREF) || has_kind(k, Node::RECURSE))) {
             std::vector<const Node *> groups;
             collect_groups(k, groups);
             const size_t keep = cx.fixed.size();
@@ -1757,13 +2347,21 @@ uint64_t node_true_minlen(const Node &n)
 
 } // namespace
 
+// what a subroutine call (?g) runs: the capturing groups of the finished tree by number
+static void index_groups(Database &db, int n_groups)
+{
+    db.group_nodes.assign((size_t)n_groups + 1, nullptr);
+    db.group_nodes[0] = db.tree.get();
+    for (int g = 1; g <= n_groups; g++) db.group_nodes[(size_t)g] = find_group(*db.tree, g);
+}
+
 int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, std::string &why)
 {
     std::vector<Seq> seqs;
     Seq literal_seq;
     Node root;
     int n_groups = 0;
-    bool has_backref = false;
+    bool has_backref = false, has_accept = false;
     if (flags & GSCAN_LITERAL) {
         Seq &s = literal_seq;
         root.kind = Node::CAT;
@@ -1787,10 +2385,28 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         }
         n_groups = ps.ngroups;
         has_backref = ps.has_backref;
+        has_accept = ps.has_accept;
         bool quirk = false;
         ends_in_greedy_repeat(root, false, quirk);
+        if (!quirk && has_kind(root, Node::ATOMIC)) { // (a pattern with \R or \X: once more, lazy repeats counting as well)
+            g_lazy_counts = true;
+            ends_in_greedy_repeat(root, false, quirk);
+            g_lazy_counts = false;
+        }
         if (quirk) {
-            why = "possessive group repeat behind a greedy repeat (libpcre's auto-possessification treats it inconsistently)";
+            why = "possessive group repeat, \\R or \\X behind a greedy repeat (libpcre's auto-possessification treats it inconsistently)";
+            return 1;
+        }
+        if (cond_holds_circumflex(root, false)) {
+            why = "^ inside a conditional group (libpcre's anchoring analysis reads it as the head of the pattern)";
+            return 1;
+        }
+        if (ps.has_recursion && begins_with_optional_call(root, false)) {
+            why = "a match can begin inside an optional subroutine call (libpcre's start-up optimisation leaves the call out)";
+            return 1;
+        }
+        if (ps.has_recursion && called_group_begins_with_repeat(root, root)) {
+            why = "a subroutine call to a group that begins with an unbounded repeat of one class (libpcre's JIT loses matches behind a failed attempt that made the call)";
             return 1;
         }
         if (lookahead_first_in_group(root, true)) {
@@ -1810,9 +2426,11 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         why = "the pattern can match the empty string although PCRE_INFO_MINLENGTH is positive (a recursive back reference)";
         return 1;
     }
-    if (pcre_min == 0) { // can match the empty string: PCRE_INFO_MINLENGTH == -1 and every file is skipped
+    if (pcre_min == 0 || has_accept) { // can match the empty string (or holds (*ACCEPT): no minimum length either): PCRE_INFO_MINLENGTH == -1 and every file is skipped
         db = Database();
         db.tree = std::make_shared<Node>(std::move(root));
+        index_groups(db, n_groups);
+    index_groups(db, n_groups);
         db.id = g_next_id.fetch_add(1);
         memset(&db.prog, 0, sizeof db.prog);
         db.tier = GSCAN_TIER_NULL;
@@ -1830,6 +2448,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         } else {
             Unfold uf;
             uf.cap_len = cap;
+            uf.root = &root;
             if (!uf.run(root, seqs)) {
                 why = uf.why;
                 return uf.overflow ? 2 : uf.rc;
@@ -1931,6 +2550,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     db.n_groups = n_groups;
     db.has_backref = has_backref;
     db.tree = std::make_shared<Node>(std::move(root));
+    index_groups(db, n_groups);
     db.id = g_next_id.fetch_add(1);
     memset(&db.prog, 0, sizeof db.prog);
     db.vm_ok = vm_compile(*db.tree, db.n_groups, db.has_backref, db.prog.vm); // the tree as a program for the device's VM (vm.h)

@@ -82,8 +82,13 @@ enum { A_BOS = 1, // ^ without (?m), \A, \G: the subject start (the restart posi
 
 // Parse tree.  SET = one byte drawn from a class; REP repeats its single child (max == UINT32_MAX: unbounded).
 // LOOK = (?=..) (?!..) (?<=..) (?<!..) around its single child; ATOMIC = (?>..); BACKREF = \1 \g{2} \k<name> (?P=name).
+// COND = (?(condition)yes|no): kids = [the condition's assertion (cond == C_ASSERT only),] yes [, no].
+// RECURSE = (?R) (?1) (?&name) (?P>name) \g<1>: the group's pattern (group 0: the whole pattern) matched as an atomic
+// subroutine; what it captures is dropped when it returns (PCRE1's rule, unlike Perl's).
 struct Node {
-    enum Kind { SET, CAT, ALT, REP, ASSERT, LOOK, ATOMIC, BACKREF } kind = SET;
+    enum Kind { SET, CAT, ALT, REP, ASSERT, LOOK, ATOMIC, BACKREF, COND, RECURSE } kind = SET;
+    enum { C_NONE, C_GROUP, C_ASSERT, C_IN_RECURSION, C_IN_RECURSION_OF, C_DEFINE };
+    int cond = C_NONE;                // COND: what is tested (C_GROUP / C_IN_RECURSION_OF: `group`, by name until resolved)
     bool behind = false, neg = false; // LOOK
     int group = 0;                    // capturing CAT: its number (1..);  BACKREF: the group referred to
     bool icase = false;               // BACKREF under (?i)
@@ -94,6 +99,7 @@ struct Node {
     uint32_t min = 1, max = 1; // REP; max == kInf: unbounded
     int mode = 0;              // REP: 0 greedy, 1 lazy, 2 possessive
     bool cap = false;          // the node is the body of a capturing group
+    bool newline_seq = false;  // ATOMIC: this is \R or \X (pattern.cc: what may stand in front of it is restricted)
 };
 
 constexpr int kMaxWindow = 256; // window positions a database may hold
@@ -209,6 +215,7 @@ struct Database {
     // byte in common): every candidate is then the start of its own group, i.e. listed, and "the leftmost match from s" is
     // the first listed start >= s -- the host's walk never has to look at the text (matcher.cc, gscan_next_match).
     bool solitary = false;
+    std::vector<const Node *> group_nodes; // [g] = the capturing group g inside `tree` (what (?g) calls), [0] = the tree
     bool vm_ok = false; // prog.vm holds the tree as a VM program (vm.h): gscan_vm_verdict works; prog.vm_filter says whether the device uses it
 };
 

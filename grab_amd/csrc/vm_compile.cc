@@ -76,7 +76,9 @@ struct Builder {
         case Node::SET: return 1;
         case Node::ASSERT:
         case Node::LOOK: return 0;
-        case Node::BACKREF: return -1;
+        case Node::BACKREF:
+        case Node::COND:
+        case Node::RECURSE: return -1;
         case Node::ATOMIC: return look_len(nd.kids[0]);
         case Node::CAT: {
             long t = 0;
@@ -161,6 +163,8 @@ struct Builder {
         case Node::ATOMIC: f = first_of(n.kids[0]); break;
         case Node::ASSERT:
         case Node::LOOK:
+        case Node::COND:
+        case Node::RECURSE:
         case Node::BACKREF: // (what a reference repeats is not known here, and it may be "")
             f.nullable = true;
             break;
@@ -266,6 +270,8 @@ struct Builder {
             if (ok) pg.ins[b].op |= here() << 16;
             break;
         }
+        case Node::COND:
+        case Node::RECURSE: ok = false; break; // not a program for this VM: the pattern stays with the host matcher
         case Node::BACKREF:
             if (!use_caps || n.group <= 0 || n.group > n_groups) {
                 emit(V_FAIL); // (a reference with no captures kept can only fail: TreeMatch, `if (!caps) return false`)

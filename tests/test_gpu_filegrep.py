@@ -69,7 +69,7 @@ def test_filegrep_interface(built, tmp_path):
     os.close(fd)
     assert outp.read_bytes() == b"Match at offset 6\nMatch at offset 30\nMatch at offset 47\nMatch at offset 62\n"
     g2 = filegrep.FileGrep()
-    assert g2.prepare(r"a(?R)?b") == -1 and "outside the GPU engine's subset" in g2.why()
+    assert g2.prepare(r"a(*COMMIT)b") == -1 and "outside the GPU engine's subset" in g2.why()
     g3 = filegrep.FileGrep()
     assert g3.prepare("a(") == -1 and g3.why() == "FileGrep::prepare::pcre_compile error"
 

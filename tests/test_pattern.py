@@ -1,11 +1,13 @@
 """Pattern compiler (grab_amd/csrc/pattern.cc through the C ABI): tiering, PCRE-equal minlen,
 class tables and greedy match ends, checked against libpcre (liboracle) and Python's re."""
 import ctypes as C
+import os
 import re
 
 import numpy as np
 import pytest
 
+from conftest import ROOT
 from grab_amd import engine
 
 SUPPORTED = [
@@ -85,11 +87,81 @@ SUPPORTED = [
     ("a{1,2}", engine.TIER_LITERAL, 1),
 ]
 
+# Round 2: conditional groups, subroutine calls / recursion, (*FAIL), callouts, \\o{}, \\Q..\\E in classes, (?U) (?J) (?X).
+# Each one against the reference's loop over libpcre on texts made for it (plus random ones): test_calls_and_conditions.
+CALLS_AND_CONDITIONS = [
+    (r"(a)?(?(1)b|c)", b"ab cb c ac b"), (r"x(a)?(?(1)b|c)", b"xab xc xb xac"), (r"(?<n>a)?(?(<n>)b|c)", b"ab c b"), (r"(?<n>a)?(?('n')b|c)", b"ab c"),
+    (r"(?<n>a)?(?(n)b|c)", b"ab c"), (r"(a)?(?(1)b)c", b"abc c bc ac"), (r"(?(?=a)ab|cd)", b"ab cd ad cb"), (r"(?(?!a)b|ab)c", b"bc abc ac"),
+    (r"x(?(?<=xa)b|c)", b"xc xab"), (r"(?(R)a|b)", b"a b"), (r"(?(R1)a|b)", b"a b"), (r"(?(DEFINE)(?<d>[0-9]+))x(?&d)", b"x12 x y9 x7"),
+    (r"\((?:[^()]|(?R))*\)", b"(a(b)c) ((x)) (() a(b"), (r"\((?:[^()]++|(?R))*\)", b"(a(b)c) ((x)) (() a(b"), (r"(a(?1)?b)", b"ab aabb aab abb"),
+    (r"x(?P>n)(?P<n>x1?)", b"xxx xx1x1 xx1x"), (r"(\()?[^()]+(?(1)\))", b"(abc) abc) (abc x"), (r"a(?1)(b|c)", b"abb acc abc ab"),
+    (r"(?:a|(b))(?(1)c|d)", b"ad bc ac bd"), (r"\b(?:(\w)(?:(?R)|\w?)\1)\b", b"abba racecar xyzzyx noon ab aa"), (r"(?<A>a|b(?&A)c)x", b"ax bacx bbaccx bax"),
+    (r"<(?:[^<>]+|(?R))*>", b"<a<b>c> <<>> <a"), (r"(a)(?(1)b|c)\1", b"aba aca"), (r"(?(1)a|b)(c)", b"bc ac"), (r"((?(R)a|b))(?1)", b"ba bb ab"),
+    (r"(x(?(R)a|b))(?1)?c", b"xbc xbxac xac"), (r"(a)\g<1>", b"aa a"), (r"(?<n>a.)\g<n>", b"a1a2 a1b2"), (r"(a|b\g'1'c)d", b"ad bacd bbaccd bd"),
+    (r"(ab)(?-1)", b"abab ab"), (r"(?+1)(ab)", b"abab ab"), (r"(?&w) (?<w>[a-c]+)", b"abc cab  ab"), (r"(?2)(a)(b\1?)", b"bab baba ab"),
+    (r"()(](?2)){2}", b"]] ]]] ]"), (r"(a(?1)?b){2}", b"abab aabbab"), (r"(?|x)?ab", None), (r"a(*FAIL)|b", b"a b ab"), (r"a(*F)b|ab", b"ab"),
+    (r"ab(?C)c", b"abc ab"), (r"ab(?C12)c", b"abc"), (r"a\o{142}c", b"abc aBc"), (r"[\Qa-z\E]x", b"-x mx ax zx"), (r"[\Qa\E-z]x", b"-x mx ax zx"),
+    (r"[\Q]\E]b", b"]b ab"), (r"[^\Qa-\E]x", b"-x mx ax"), (r"(?U)a+b", b"aab ab b"), (r"(?U)a+?b", b"aab"), (r"(?U)[ab]{1,3}c", b"ababc"),
+    (r"(?U:a+)b+ ", b"aabb  ab "), (r"x(?U)a*(?-U)b*c", b"xaabbc xc"), (r"(?X)ab", b"ab"), (r"(?J)(?<n>a)b", b"ab"),
+]
+
+
+@pytest.mark.parametrize("pattern,text", [c for c in CALLS_AND_CONDITIONS if c[1] is not None])
+def test_calls_and_conditions(pattern, text, built, liboracle):
+    from test_fuzz import check, make_texts
+    assert check(liboracle, pattern, [text, text + b"\n" + text[::-1], b" " + text] + make_texts(3)) is not None
+
+
+def test_unicode_properties_latin1(built, liboracle):
+    """\\p{..} / \\P{..} without UTF: every property the engine has a table for (grab_amd/csrc/ucp_latin1.h, generated from
+    Python's unicodedata by scripts/gen_ucp_latin1.py), every byte value, against what libpcre matches."""
+    import re
+    src = open(os.path.join(ROOT, "grab_amd", "csrc", "ucp_latin1.h")).read()
+    names = re.findall(r'\{"([^"]+)", \{', src)
+    assert len(names) >= 46 and "Lu" in names and "Latin" in names
+    subject = bytes(range(256))
+    for name in names:
+        for esc in ("\\p{%s}", "\\P{%s}", "\\p{^%s}", "[\\p{%s}]", "(?i)\\p{%s}"):
+            pattern = esc % name
+            s = np.zeros(300, np.uint32)
+            e = np.zeros(300, np.uint32)
+            n = liboracle.oracle_all_starts(pattern.encode(), subject, len(subject), s.ctypes.data, e.ctypes.data, 300)
+            assert n >= 0, pattern
+            want = sorted(s[:n].tolist())
+            if not want or len(want) == 0:
+                continue  # (an empty set: nothing to compile a window from)
+            db = engine.Database(pattern)
+            got = [b for b in range(256) if db.class_table(0)[b]]
+            assert got == want, (pattern, [hex(b) for b in sorted(set(got) ^ set(want))])
+    for short in ("\\pL", "\\PL", "\\pN"):
+        assert [b for b in range(256) if engine.Database(short).class_table(0)[b]] == [b for b in range(256) if engine.Database(short[:2] + "{" + short[2] + "}").class_table(0)[b]]
+
+
+NEWLINE_SEQUENCES = [r"a\Rb", r"\Rb", r"a\R", r"a\R\Rb", r"a\R{2}b", r"a\Xb", r"a\X\Xb", r"a\X{2}b", r"x\R\R\Ry", r"\s\Rb", r"a\R\s", r"a\R\nb", r"(?:a|\R)b", r"a(?=\R)", r"a\R(?!b)",
+                    r"a\Rb|a\Xc", r"\X\R", r"\R\X", r"a\X\s", r"[\R]b", r"[\X\B]b"]
+
+
+@pytest.mark.parametrize("pattern", NEWLINE_SEQUENCES)
+def test_newline_sequences(pattern, built, liboracle):
+    """\\R = (?>\\r\\n|\\n|\\x0b|\\f|\\r|\\x85), \\X = (?>\\r\\n|any byte) over Latin-1; inside a class both are their letters."""
+    from test_fuzz import check, make_texts
+    texts = [b"a\r\nb a\nb a\rb a\x0bb a\x0cb a\x85b a\r\n\nb a\n\rb ab Rb Xb Bb", b"x\r\n\r\ny x\n\ny \r\n", b"a\xadb a\r\nb a\n\rb axb a\r\n c a\n\n"]
+    assert check(liboracle, pattern, texts + make_texts(4)) is not None
+
+
+def test_accept_has_no_minimum_length(built, liboracle):
+    """(*ACCEPT): pcre_study gives no minimum length, PCRE_INFO_MINLENGTH is -1 and the reference skips every file (Q2)."""
+    for pattern in ("a(*ACCEPT)b", "(?:ab(*ACCEPT)|c)d"):
+        ml = C.c_int()
+        assert liboracle.oracle_minlen(pattern.encode(), C.byref(ml)) == 0 and ml.value == -1
+        db = engine.Database(pattern)
+        assert db.info.tier == engine.TIER_NULL and db.minlen == -1
+
+
 NULL_TIER = ["a?", "x*", "", "a{0}", "[a-z]{0,3}", "x{0}", "a|", "(?:foo|b?)", "a??", "(?:ab)?", "x*?y{0}"]
 
-UNSUPPORTED = [r"(a|\1?)b*", r"\pL",
-               r"\Xfoo", r"\Rfoo",
-               "(?|a|b)", r"\g<1>(a)", "(*UTF8)a", r"x*(?>(?:0)?)x", r"1\n{0,2}(?>a|[b0 ]{0,2}){2}c", r"(?:(?=x))x\B", r"(?:a|(?=x)x)b", r"\S+\h", r"\v*\S{2}", "x|(a)*+b", r"x*(?:ab)?+x", r"b[x.]{0,2}(?:0)?+[x.]{1,3} ", "a(?R)?b"]
+UNSUPPORTED = [r"(a|\1?)b*", r"\p{Greek}", r"a\R?b", r"a+\Rb", r"x\X+", r"(?|(?<n>a)|(?<n>b))",
+               "(*UTF8)a", "a(*COMMIT)b", "(*ANYCRLF)a$", r"(?(DEFINE)^)\w", r"(?1)* (\s)?", r"b(?1)c|(A*)x", r"(?<=(?(1)a|b))c(x)", r"x*(?>(?:0)?)x", r"1\n{0,2}(?>a|[b0 ]{0,2}){2}c", r"(?:(?=x))x\B", r"(?:a|(?=x)x)b", r"\S+\h", r"\v*\S{2}", "x|(a)*+b", r"x*(?:ab)?+x", r"b[x.]{0,2}(?:0)?+[x.]{1,3} "]
 
 # "a(" is reported as unsupported (groups) by the engine alone; FileGrep::prepare asks libpcre first and
 # gives the reference's "pcre_compile error" for it (tests/test_gpu_filegrep.py, golden case bad_regex)
