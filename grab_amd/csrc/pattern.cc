@@ -1656,13 +1656,29 @@ struct Unfold {
                 const bool ok = run(grp->kids[0], body);
                 calling.pop_back();
                 if (!ok) return false;
+                bool empty_call = false;
                 for (const Seq &b : body) {
+                    if (b.win.empty() && !b.gapped && !b.frozen) { // the call may match "": what follows it decides
+                        empty_call = true;
+                        if (b.has_tail) { // (x* as the whole call: a call that does consume begins with a byte of the repeat)
+                            Seq one = b;
+                            one.win.push_back(b.tail);
+                            one.cap = one.needs_cap = false;
+                            if (!push_frozen(out, one)) return false;
+                        }
+                        continue;
+                    }
                     Seq f = freeze(b);
                     f.cap = false; // (a called group does not capture, and what it captured inside is dropped)
                     f.needs_cap = false;
                     if (!push_frozen(out, f)) return false;
                 }
-                return true;
+                if (empty_call) {
+                    Seq none;
+                    none.inexact = true;
+                    out.push_back(none);
+                }
+                return room(out.size());
             }
             Seq s;
             s.frozen = true;
@@ -2078,10 +2094,14 @@ bool begins_with_optional_call(const Node &n, bool optional)
 bool group_heads_a_branch(const Node &n, int g)
 {
     if (n.kind == Node::COND && n.cond == Node::C_DEFINE) return false;
-    if (n.kind == Node::CAT && !n.cap && !n.kids.empty()) {
-        const Node *f = &n.kids[0];
-        while (f->kind == Node::ATOMIC) f = &f->kids[0];
-        if (f->kind == Node::CAT && f->cap && f->group == g) return true;
+    if (n.kind == Node::CAT && !n.cap) { // the first item that is not an assertion (\b(1*a) is hit like (1*a))
+        for (const Node &item : n.kids) {
+            if (item.kind == Node::ASSERT || item.kind == Node::LOOK) continue;
+            const Node *f = &item;
+            while (f->kind == Node::ATOMIC) f = &f->kids[0];
+            if (f->kind == Node::CAT && f->cap && f->group == g) return true;
+            break;
+        }
     }
     for (const Node &k : n.kids)
         if (group_heads_a_branch(k, g)) return true;
