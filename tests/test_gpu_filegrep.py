@@ -174,6 +174,55 @@ def test_random_patterns_cli_vs_oracle(built, oracle_built, tmp_path):
     assert done == 45
 
 
+def test_calls_and_conditions_cli_vs_oracle(built, oracle_built, tmp_path):
+    """The constructs taken in the second half of round 2 -- conditional groups, subroutine calls and recursion, branch reset,
+    \\R \\X \\p{..}, (*FAIL), callouts, (?U) -- end to end on the GPU: the hand-made list of tests/test_pattern.py and random
+    draws of tests/test_fuzz.py's second grammar, `grab` against the oracle (libpcre under the reference's loop)."""
+    import random
+
+    from test_fuzz import gen_calls_and_conditions
+    from test_pattern import CALLS_AND_CONDITIONS, NEWLINE_SEQUENCES
+
+    nrng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"abcxA01 .\n\nab  ()<>]-", np.uint8)
+    data = alpha[nrng.integers(0, alpha.size, 200_000)]
+    at = 500
+    for _, text in CALLS_AND_CONDITIONS:  # every hand-made text, planted a few times
+        if text is None:
+            continue
+        for rep in range(3):
+            data[at:at + len(text)] = np.frombuffer(text, np.uint8)
+            at += len(text) + 37
+    for w in (b"a\r\nb a\nb a\rb a\x0bb a\x85b a\r\n\nb", b"ab\xe9\xc9 12\xb2 x_\xb5\xaa\xd7"):
+        data[at:at + len(w)] = np.frombuffer(w, np.uint8)
+        at += len(w) + 11
+    (tmp_path / "f").write_bytes(data.tobytes())
+    rng = random.Random(99)
+    pats = [pt for pt, text in CALLS_AND_CONDITIONS if text is not None] + NEWLINE_SEQUENCES + [r"\p{Lu}\p{Ll}+", r"[\p{Nd}x]{2}\P{L}"]
+    pats += [gen_calls_and_conditions(rng) for _ in range(250)]
+    done = 0
+    for k, pat in enumerate(pats):
+        try:
+            db = engine.Database(pat)
+        except ValueError:
+            continue
+        if db.minlen < 0:
+            continue
+        flags = [["-O", "-l"], ["-O"], []][k % 3]
+        orc, oout, oerr = _run(os.path.join(oracle_built, "grab_oracle"), flags + [pat, "f"], str(tmp_path))
+        if orc != 0:
+            continue
+        rc, out, err = _run(built.bin_path(), flags + [pat, "f"], str(tmp_path))
+        assert rc == 0, (pat, err)
+        if b"gave up" in oerr or b"abandoned" in err:
+            continue
+        assert out == oout, (pat, flags, len(out), len(oout))
+        done += 1
+        if done == 130:
+            break
+    assert done >= 100
+
+
 def test_line_pass_equals_host_walk(built, oracle_built, tmp_path):
     """Line-printing modes with the device's line pass (GRAB_LINE_PASS=1: k_lines picks the printed matches and their line
     extents) and without it (the host's walk) print the same bytes, and both equal the oracle: long lines (511-byte caps),
