@@ -793,6 +793,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
     const uint32_t koff = a.k3_off, m = a.m;
     const bool exact = DEPTH == 4 && a.k3_exact != 0; // (the three-position form always confirms)
     const bool confirm_exact = a.prog->k3_confirm_exact != 0; // wave-uniform (scalar load)
+    const bool vm_quick = VM && a.prog->vm_pair_ok == 2;      // (DevProgram::vm_pair may drop a hit on its own)
     const uint8_t *tbl8 = reinterpret_cast<const uint8_t *>(tbl);
     {
         // dword q of the table = copy (q & 63) of entry (q >> 6), middle bytes swapped (see above); consecutive threads
@@ -835,6 +836,40 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
         for (int i = 0; i < (ITER + 1) / 2; i++) hits[i] = 0;
         uint32_t cnt = 0;
 
+        // a filter hit at p against the first kK3Confirm (24) window positions of every alternative, then (VM) against
+        // the pattern itself
+        auto confirm_hit = [&](uint32_t p) -> bool {
+            // aligned dword loads (each one bounds-checked on its own: an unaligned 16-byte load that
+            // straddles the segment end comes back as zeros altogether), shifted into place
+            const int pa = (int)(p & ~3u);
+            uint32_t dw[kK3Confirm / 4 + 1];
+#pragma unroll
+            for (int q = 0; q <= kK3Confirm / 4; q++) dw[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(c.rsrc, pa + 4 * q, 0, 0);
+            uint32_t w[kK3Confirm / 4];
+#pragma unroll
+            for (int q = 0; q < kK3Confirm / 4; q++) w[q] = __builtin_amdgcn_alignbyte(dw[q + 1], dw[q], p & 3u);
+            uint32_t mk = 0xffu;
+#pragma unroll
+            for (int q = 0; q < kK3Confirm; q++) mk &= s_pos[q * 256 + ((w[q >> 2] >> (8 * (q & 3))) & 0xffu)];
+            bool ok = false;
+            if (mk) {
+                if (confirm_exact) { // the tables are the pattern: only the segment end is left to check
+                    while (mk) {
+                        const uint32_t b = (uint32_t)__ffs((int)mk) - 1u;
+                        mk &= mk - 1u;
+                        if (p + s_blen[b] <= (uint32_t)c.slen) ok = true;
+                    }
+                } else {
+                    // shared buckets (> 8 alternatives) or windows longer than the tables: the tables may let a
+                    // cross-product through.  Accept the hit here; k3_settle decides it, record by record.
+                    ok = p + m <= (uint32_t)c.slen;
+                }
+            }
+            // the device's own confirmation: can a match start here (or, for a gapped alternative, along the run
+            // of repeat bytes that ends here) at all?
+            if (VM && ok) ok = vm_keep_hit_dev(a.prog, reinterpret_cast<const VmProg *>(s_vm), c.seg, (uint32_t)c.slen, p);
+            return ok;
+        };
         if (have) {
             if (!PF) load_subtile<ITER, NT, 1>(buf, c, sub_off, lane);
             // filter positions q = p + koff of window starts p with 0 <= p and p + m <= slen
@@ -879,7 +914,26 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                     for (int j = 0; j < 16; j++) hm |= h[j] ? 1u << j : 0u;
                     hm &= vm;
                     uint32_t bits = hm;
-                    if (!direct) {
+                    if (VM) {
+                        // Inexact patterns: here only the two-byte table (DevProgram::vm_pair) -- two byte loads and a bit per
+                        // hit, and most hits end there.  What is left is confirmed and put to the VM after the sub-tile's last
+                        // step (below), when the lanes' few survivors can be worked off side by side instead of one lane
+                        // running the VM while 63 wait for it, hit after hit.
+                        if (vm_quick) {
+                            bits = 0;
+                            while (hm) {
+                                const uint32_t j = (uint32_t)__ffs((int)hm) - 1u;
+                                hm &= hm - 1u;
+                                const uint32_t p = (uint32_t)pos0 + j - koff;
+                                bool ok = true;
+                                if (p + 1 < (uint32_t)c.slen) {
+                                    const uint32_t idx = (uint32_t)c.seg[p] << 8 | c.seg[p + 1];
+                                    ok = (a.prog->vm_pair[idx >> 5] >> (idx & 31)) & 1u;
+                                }
+                                if (ok) bits |= 1u << j;
+                            }
+                        }
+                    } else if (!direct) {
                         // confirm every hit against the first kK3Confirm (24) window positions: the window's bytes are
                         // re-read (beyond the segment the descriptor returns zeros), then one LDS byte per position
                         // gives the buckets that accept the byte there
@@ -887,37 +941,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                         while (hm) {
                             const uint32_t j = (uint32_t)__ffs((int)hm) - 1u;
                             hm &= hm - 1u;
-                            const uint32_t p = (uint32_t)pos0 + j - koff;
-                            // aligned dword loads (each one bounds-checked on its own: an unaligned 16-byte load that
-                            // straddles the segment end comes back as zeros altogether), shifted into place
-                            const int pa = (int)(p & ~3u);
-                            uint32_t dw[kK3Confirm / 4 + 1];
-#pragma unroll
-                            for (int q = 0; q <= kK3Confirm / 4; q++) dw[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(c.rsrc, pa + 4 * q, 0, 0);
-                            uint32_t w[kK3Confirm / 4];
-#pragma unroll
-                            for (int q = 0; q < kK3Confirm / 4; q++) w[q] = __builtin_amdgcn_alignbyte(dw[q + 1], dw[q], p & 3u);
-                            uint32_t mk = 0xffu;
-#pragma unroll
-                            for (int q = 0; q < kK3Confirm; q++) mk &= s_pos[q * 256 + ((w[q >> 2] >> (8 * (q & 3))) & 0xffu)];
-                            bool ok = false;
-                            if (mk) {
-                                if (confirm_exact) { // the tables are the pattern: only the segment end is left to check
-                                    while (mk) {
-                                        const uint32_t b = (uint32_t)__ffs((int)mk) - 1u;
-                                        mk &= mk - 1u;
-                                        if (p + s_blen[b] <= (uint32_t)c.slen) ok = true;
-                                    }
-                                } else {
-                                    // shared buckets (> 8 alternatives) or windows longer than the tables: the tables may let a
-                                    // cross-product through.  Accept the hit here; k3_settle decides it, record by record.
-                                    ok = p + m <= (uint32_t)c.slen;
-                                }
-                            }
-                            // the device's own confirmation: can a match start here (or, for a gapped alternative, along the run
-                            // of repeat bytes that ends here) at all?
-                            if (VM && ok) ok = vm_keep_hit_dev(a.prog, reinterpret_cast<const VmProg *>(s_vm), c.seg, (uint32_t)c.slen, p);
-                            if (ok) bits |= 1u << j;
+                            if (confirm_hit((uint32_t)pos0 + j - koff)) bits |= 1u << j;
                         }
                     }
                     // keep group starts (within the lane; a superset of them is fine) -- unless hits may still be struck
@@ -932,6 +956,22 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
             halo_n = load_step<ITER, NT, 1>(cn, sub_off_n, lane, ITER, have_n);
 #pragma unroll
             for (int j = 1; j < ITER; j++) buf[j] = load_step<ITER, NT, 1>(cn, sub_off_n, lane, j, have_n);
+        }
+        if (VM && cur) { // the survivors of the sub-tile, word by word: confirm + VM, the lanes side by side
+            cnt = 0;
+#pragma unroll
+            for (int w = 0; w < (ITER + 1) / 2; w++) {
+                uint32_t word = hits[w], keep = word;
+                while (word) {
+                    const uint32_t b = (uint32_t)__ffs((int)word) - 1u;
+                    word &= word - 1u;
+                    const uint32_t k = 2u * (uint32_t)w + (b >> 4), j = b & 15u;
+                    const uint32_t p = (uint32_t)(sub_off + (int)k * 1024 + (int)lane * 16) + j - koff;
+                    if (!confirm_hit(p)) keep &= ~(1u << b);
+                }
+                hits[w] = keep;
+                cnt += (uint32_t)__popc(keep);
+            }
         }
         if (cur) emit_wave<ITER>(a, t * NW + wave, hits, cnt, sub_off, koff - a.report_shift, lane);
         if (!next) break;

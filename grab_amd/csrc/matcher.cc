@@ -152,6 +152,15 @@ struct TreeMatch {
     size_t keep = SIZE_MAX; // \K: the reported start of the match (restored when what follows fails)
     // subroutine calls: the groups of the pattern ([0]: the pattern itself), and the call this matcher runs inside
     // (-1: none; what (?(R)..) and (?(Rn)..) ask about)
+    // Prefix probe (tree_prefix_viable): the text is only the first bytes of some longer subject.  Whatever the matcher decides
+    // by looking AT OR BEYOND the end of what it was given could come out differently on the real subject: the first such look
+    // sets touched_end and abandons the attempt (via gave_up) -- "a match may start here" is then the only safe answer.
+    bool probe = false, touched_end = false;
+    bool beyond(size_t pos)
+    {
+        if (probe && pos >= clen) touched_end = gave_up = true;
+        return pos >= clen;
+    }
     const std::vector<const Node *> *groups = nullptr;
     int rec_group = -1;
     uint32_t rec_depth = 0;
@@ -198,8 +207,14 @@ struct TreeMatch {
     static uint8_t lower(uint8_t b) { return b >= 'A' && b <= 'Z' ? (uint8_t)(b + 32) : b; }
     static bool is_word(uint8_t b) { return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_'; }
 
-    bool holds(int code, size_t pos) const
+    bool holds(int code, size_t pos)
     {
+        if (probe) { // (every one of these but \A looks at the byte at pos or asks whether the text ends there or one byte on)
+            if (code != gscan::A_BOS && pos + 1 >= clen) {
+                touched_end = gave_up = true;
+                return false;
+            }
+        }
         switch (code) {
         case gscan::A_BOS: return pos == s0;
         case gscan::A_MBOL: return pos == s0 || (pos > s0 && c[pos - 1] == '\n' && pos < clen);
@@ -295,9 +310,11 @@ struct TreeMatch {
         inner.groups = groups;
         inner.rec_group = rec_group;
         inner.rec_depth = rec_depth;
+        inner.probe = probe;
         const bool got = as_repeat ? inner.rep_group(what, 0, at, cap, &stop) : inner.m(what, at, cap, &stop);
         steps = inner.steps;
         gave_up = gave_up || inner.gave_up;
+        touched_end = touched_end || inner.touched_end;
         out_of_stack = out_of_stack || inner.out_of_stack;
         if (!got || gave_up) return false;
         end_out = inner.end;
@@ -337,7 +354,7 @@ struct TreeMatch {
         if (gave_up) return false;
         switch (n->kind) {
         case Node::SET:
-            return pos < clen && n->set.test(c[pos]) && run(k, pos + 1, cap);
+            return !beyond(pos) && n->set.test(c[pos]) && run(k, pos + 1, cap);
         case Node::ASSERT:
             if (n->acode == gscan::A_KEEP) {
                 const size_t old = keep;
@@ -396,9 +413,11 @@ struct TreeMatch {
             inner.groups = groups;
             inner.rec_group = n->group;
             inner.rec_depth = rec_depth + 1;
+            inner.probe = probe;
             const bool got = inner.m(body, pos, false, &stop);
             steps = inner.steps;
             gave_up = gave_up || inner.gave_up;
+            touched_end = touched_end || inner.touched_end;
             out_of_stack = out_of_stack || inner.out_of_stack;
             if (caps) *caps = saved;
             if (!got || gave_up) return false;
@@ -436,7 +455,10 @@ struct TreeMatch {
             const size_t lo = (*caps)[2 * (size_t)n->group], hi = (*caps)[2 * (size_t)n->group + 1];
             if (lo == SIZE_MAX) return false; // a reference to a group that has not been set fails
             const size_t len = hi - lo;
-            if (pos + len > clen) return false;
+            if (pos + len > clen) {
+                beyond(clen);
+                return false;
+            }
             if (n->icase) {
                 for (size_t q = 0; q < len; q++)
                     if (lower(c[lo + q]) != lower(c[pos + q])) return false;
@@ -455,6 +477,8 @@ struct TreeMatch {
             if (kid->kind == Node::SET) { // a loop over counts
                 size_t kmax = 0;
                 while (kmax < (size_t)n->max && pos + kmax < clen && kid->set.test(c[pos + kmax])) kmax++;
+                if (kmax < (size_t)n->max && pos + kmax >= clen) beyond(clen); // (the repeat stopped because the text did)
+                if (gave_up) return false;
                 if (kmax < (size_t)n->min) return false;
                 if (n->mode == 2) return run(k, pos + kmax, cap); // possessive: all of it, no giving back
                 if (n->mode == 1) {
@@ -556,6 +580,26 @@ bool tree_match_at(const Database &d, const uint8_t *content, size_t clen, size_
     out = {(uint32_t)t.end, t.captured, false, t.keep == SIZE_MAX ? UINT32_MAX : (uint32_t)t.keep};
     return true;
 }
+
+} // namespace
+
+// Can a match start at offset 0 of ANY subject that begins with these n bytes (no byte in front of them)?  false only if the
+// matcher fails without ever looking at or beyond byte n.  (pattern.cc builds the device VM's two-byte table from it.)
+bool gscan::tree_prefix_viable(const Database &d, const uint8_t *bytes, size_t n)
+{
+    if (!d.tree) return true;
+    std::vector<size_t> caps;
+    if (d.has_backref) caps.assign(2 * (size_t)d.n_groups + 2, SIZE_MAX);
+    TreeMatch t{bytes, n, 0};
+    t.caps = d.has_backref ? &caps : nullptr;
+    t.groups = &d.group_nodes;
+    t.probe = true;
+    t.max_stack = 64 * 1024; // (a probe that needs more than that is called viable)
+    const bool hit = t.m(d.tree.get(), 0, false, nullptr);
+    return hit || t.gave_up || t.touched_end;
+}
+
+namespace {
 
 // "The match reported AT p": the tree matcher decides; GSCAN_CHECK_TREE=1 (tests) also runs the rule on the unfolded
 // alternatives and aborts on any difference between the two.

@@ -1340,6 +1340,7 @@ struct Parser {
                     // it fails, so a later group-free match of the same pcre_exec call comes back as 0 -- x|(a)*+b on "a x".
                     // Only this form does ((a)++, ((a))*+, (?:(a))*+ do not); what it depends on -- every start offset
                     // pcre_exec tries, candidate or not -- is not something the engine looks at.  Refused.
+                    if (a.kind == Node::COND && a.cond == Node::C_DEFINE) return fail(1, "a quantified (?(DEFINE)..) group (libpcre never finds a match behind one)");
                     if (a.kind == Node::ATOMIC && a.newline_seq && qmin != qmax) return fail(1, "a variable count of \\R or \\X (libpcre's auto-possessification misjudges what may follow it)");
                     if (mode == 2 && qmin == 0 && qmax == kInf && a.kind == Node::CAT && a.cap)
                         return fail(1, "possessive * directly on a capturing group (libpcre's JIT reports the group as set after failed attempts)");
@@ -2086,7 +2087,7 @@ bool begins_with_optional_call(const Node &n, bool optional)
     return false;
 }
 
-//  * a group that is called as a subroutine and whose pattern begins with an unbounded greedy or possessive repeat of one
+//  * a group that is called as a subroutine and whose pattern begins with an unbounded repeat of one
 //    class -- b(?1)c|(A*)x, b(?1)c|([^x]*)x -- : after an attempt that made the call has failed, the JIT build does not
 //    find matches that begin before the place the call had reached ("bAAx x": the interpreter reports 1, the JIT 5).
 //    It takes the group to stand at the head of an alternative of the pattern proper: behind another item (y(A*)x), or
@@ -2117,7 +2118,8 @@ bool called_group_begins_with_repeat(const Node &n, const Node &root)
             for (size_t b = 0; b < nb; b++) {
                 const Node *f = first_item(branches[b]);
                 while (f && (f->kind == Node::ATOMIC || (f->kind == Node::CAT && !f->kids.empty()))) f = first_item(f->kids[0]);
-                if (f && f->kind == Node::REP && f->kids[0].kind == Node::SET && f->max == kInf && f->mode != 1 && group_heads_a_branch(root, n.group)) return true;
+                // (a lazy repeat too: auto-possessification makes a*? in front of a byte it cannot match a possessive a*+)
+                if (f && f->kind == Node::REP && f->kids[0].kind == Node::SET && f->max == kInf && group_heads_a_branch(root, n.group)) return true;
             }
         }
     }
@@ -2366,6 +2368,30 @@ uint64_t node_true_minlen(const Node &n)
 }
 
 } // namespace
+
+// DevProgram::vm_pair: the host matcher's verdict on every two-byte prefix a match could begin with (first the 256 one-byte
+// prefixes: a first byte no match can begin with spares its 256 pairs).  ~20 000 short matcher runs, a few milliseconds.
+static void fill_vm_pairs(Database &db)
+{
+    DevProgram &pg = db.prog;
+    memset(pg.vm_pair, 0, sizeof pg.vm_pair);
+    pg.vm_pair_ok = 0;
+    if (getenv("GSCAN_NO_VM_PAIRS")) return;
+    uint8_t t[2];
+    for (unsigned b0 = 0; b0 < 256; b0++) {
+        t[0] = (uint8_t)b0;
+        if (!tree_prefix_viable(db, t, 1)) continue;
+        for (unsigned b1 = 0; b1 < 256; b1++) {
+            t[1] = (uint8_t)b1;
+            if (tree_prefix_viable(db, t, 2)) pg.vm_pair[(b0 << 8 | b1) >> 5] |= 1u << (b1 & 31);
+        }
+    }
+    pg.vm_pair_ok = 1;
+    bool gapped = false; // (2: no gapped alternative -- a hit stands for a match AT the hit and nothing else: the kernel may drop it
+                         // on the table's word alone, without calling vm_keep_hit)
+    for (uint32_t i = 0; i < pg.n_alts; i++) gapped = gapped || pg.alt_gap_cls[i] != 0xffu;
+    if (!gapped) pg.vm_pair_ok = 2;
+}
 
 // what a subroutine call (?g) runs: the capturing groups of the finished tree by number
 static void index_groups(Database &db, int n_groups)
@@ -2788,6 +2814,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     if (db.alts.size() > 1) { // several alternatives: the bucket filter is the one kernel that takes them
         db.tier = GSCAN_TIER_BUCKET;
         pg.vm_filter = vm_dev;
+        if (vm_dev) fill_vm_pairs(db);
         return 0;
     }
 
@@ -2865,6 +2892,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     if (vm_dev && db.tier != GSCAN_TIER_LITERAL) {
         pg.vm_filter = 1;
         db.tier = GSCAN_TIER_BUCKET;
+        fill_vm_pairs(db);
     }
     return 0;
 }

@@ -151,6 +151,11 @@ struct DevProgram {
     // which no match can start.  For a gapped alternative the hit is the LAST byte of its unbounded repeat (device window =
     // repeat byte + the rest): the possible starts are walked back along the run of repeat bytes.
     uint32_t vm_filter;                  // 1: on
+    // bit b0 << 8 | b1: a match may begin with the bytes b0 b1 (matcher.cc, tree_prefix_viable: the host matcher run on
+    // every two-byte prefix at compile time).  The hits the filter passes are put to this table first: most die here,
+    // two loads instead of a VM run.  vm_pair_ok: the table is filled in.
+    uint32_t vm_pair_ok;
+    uint32_t vm_pair[2048];
     uint8_t alt_gap_cls[kMaxAlts];       // class id of a gapped alternative's repeat byte; 0xff: a plain alternative
     uint16_t alt_plen[kMaxAlts];         // gapped: length of the fixed part in front of the repeat
     VmProg vm;
@@ -219,6 +224,8 @@ struct Database {
     bool vm_ok = false; // prog.vm holds the tree as a VM program (vm.h): gscan_vm_verdict works; prog.vm_filter says whether the device uses it
 };
 
+// matcher.cc
+bool tree_prefix_viable(const Database &d, const uint8_t *bytes, size_t n);
 // vm_compile.cc
 bool vm_compile(const Node &root, int n_groups, bool has_backref, VmProg &out);
 bool vm_independent_of_subject_start(const Node &root);
@@ -226,9 +233,16 @@ bool vm_independent_of_subject_start(const Node &root);
 // Keep the device hit at q (the start of some alternative's device window)?  false only if NO match can start there: at q
 // itself for the plain alternatives, anywhere along the run of repeat bytes that ends at q for a gapped one.  Shared by
 // the K3 kernel and the host (gscan_vm_filter, tests).
+// may a match start at x, going by its first two bytes? (true when there is no table, or no second byte)
+GSCAN_HD inline bool vm_start_viable(const DevProgram *pg, const uint8_t *seg, uint32_t slen, uint32_t x)
+{
+    if (!pg->vm_pair_ok || x + 1 >= slen) return true;
+    const uint32_t idx = (uint32_t)seg[x] << 8 | seg[x + 1];
+    return (pg->vm_pair[idx >> 5] >> (idx & 31)) & 1u;
+}
 GSCAN_HD inline bool vm_keep_hit(const DevProgram *pg, const VmProg *vm, const uint8_t *seg, uint32_t slen, uint32_t q)
 {
-    if (vm_run(vm, seg, slen, q, 0) != 0) return true;
+    if (vm_start_viable(pg, seg, slen, q) && vm_run(vm, seg, slen, q, 0) != 0) return true;
     const uint32_t n = pg->n_alts;
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t gc = pg->alt_gap_cls[i];
@@ -254,7 +268,7 @@ GSCAN_HD inline bool vm_keep_hit(const DevProgram *pg, const VmProg *vm, const u
         const uint32_t plen = pg->alt_plen[i];
         for (uint32_t g = r0; g <= q; g++) {
             if (g < plen || g - plen == q) continue;
-            if (vm_run(vm, seg, slen, g - plen, 0) != 0) return true;
+            if (vm_start_viable(pg, seg, slen, g - plen) && vm_run(vm, seg, slen, g - plen, 0) != 0) return true;
         }
     }
     return false;
