@@ -2128,6 +2128,48 @@ bool called_group_begins_with_repeat(const Node &n, const Node &root)
     return false;
 }
 
+// libpcre quirk no. 2b (8.39 and 8.45, interpreter and JIT): pcre_compile takes a forward assertion's "required byte" over as
+// the pattern's own ("useful for /(?=abcde).+/"); when the item behind the assertion is that same byte and becomes the
+// FIRST byte, the start-up check asks for two occurrences: (?=1[a-c]| 1)1 never matches "1a".  Refused: a positive
+// look-ahead at the head of a branch, directly followed by a literal byte that also stands in the assertion as a literal.
+bool holds_literal(const Node &n, const ByteSet &lit)
+{
+    if (n.kind == Node::SET && n.set.count() <= 2 && set_and(n.set, lit).count() > 0) return true;
+    for (const Node &k : n.kids)
+        if (holds_literal(k, lit)) return true;
+    return false;
+}
+bool lookahead_hands_on_required_byte(const Node &n)
+{
+    if (n.kind == Node::CAT && !n.cap) {
+        const Node *look = nullptr;
+        for (const Node &item : n.kids) {
+            if (item.kind == Node::ASSERT) continue;
+            if (item.kind == Node::LOOK && !item.neg && !item.behind) {
+                if (!look) look = &item;
+                continue;
+            }
+            if (item.kind == Node::LOOK) continue;
+            const Node *f = &item;
+            if (f->kind == Node::REP && f->min >= 1) f = &f->kids[0];
+            if (look && f->kind == Node::SET && f->set.count() <= 2 && holds_literal(look->kids[0], f->set)) {
+                // (a literal byte further on in the branch becomes the required byte instead: (?=(a))ab is fine)
+                bool later_literal = false;
+                for (const Node *q = &item + 1; q < n.kids.data() + n.kids.size(); q++) {
+                    const Node *g = q;
+                    if (g->kind == Node::REP && g->min >= 1) g = &g->kids[0];
+                    later_literal = later_literal || (g->kind == Node::SET && g->set.count() <= 2);
+                }
+                if (!later_literal) return true;
+            }
+            break;
+        }
+    }
+    for (const Node &k : n.kids)
+        if (lookahead_hands_on_required_byte(k)) return true;
+    return false;
+}
+
 bool has_optional_group(const Node &n)
 {
     if (n.kind == Node::REP && n.kids[0].kind != Node::SET && n.min == 0) return true;
@@ -2453,6 +2495,10 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         }
         if (ps.has_recursion && called_group_begins_with_repeat(root, root)) {
             why = "a subroutine call to a group that begins with an unbounded repeat of one class (libpcre's JIT loses matches behind a failed attempt that made the call)";
+            return 1;
+        }
+        if (lookahead_hands_on_required_byte(root)) {
+            why = "a look-ahead at the head of a branch followed by a literal byte it also holds (libpcre hands the assertion's required byte on to the pattern and then asks for it twice)";
             return 1;
         }
         if (lookahead_first_in_group(root, true)) {
