@@ -882,6 +882,19 @@ int gscan_vm_verdict(const gscan_db *db, const void *content, size_t clen, uint3
     return gscan::vm_run(&db->db.prog.vm, (const uint8_t *)content, (uint32_t)clen, p, subject_start);
 }
 
+int gscan_vm_pair(const gscan_db *db, unsigned b0, unsigned b1)
+{
+    if (!db || !db->db.prog.vm_filter || !db->db.prog.vm_pair_ok || b0 > 255 || b1 > 255) return -1;
+    const uint32_t idx = b0 << 8 | b1;
+    return (db->db.prog.vm_pair[idx >> 5] >> (idx & 31)) & 1u;
+}
+
+int gscan_prefix_viable(const gscan_db *db, const void *bytes, size_t n)
+{
+    if (!db || (!bytes && n)) return -1;
+    return gscan::tree_prefix_viable(db->db, (const uint8_t *)bytes, n) ? 1 : 0;
+}
+
 long gscan_vm_filter(const gscan_db *db, const void *content, size_t clen, const uint32_t *hits, size_t n, uint32_t *kept)
 {
     if (!db || !db->db.prog.vm_filter || (!hits && n) || clen > 0xfffffff0u) return -1;

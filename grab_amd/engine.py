@@ -25,7 +25,7 @@ SYMBOLS = [
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
     "gscan_set_option", "gscan_kernel_time", "gscan_resource_errors",
     "gscan_ingest_info", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
-    "gscan_vm_verdict", "gscan_vm_filter",
+    "gscan_vm_verdict", "gscan_vm_filter", "gscan_vm_pair", "gscan_prefix_viable",
 ]
 
 
@@ -121,6 +121,8 @@ def lib():
         L.gscan_vm_verdict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]
         L.gscan_vm_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.gscan_vm_filter.restype = C.c_long
+        L.gscan_vm_pair.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+        L.gscan_prefix_viable.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -198,6 +200,15 @@ class Database:
         """The device VM's answer AT p, run on the host: 0 no match starts at p, 1 one does, 2 gave up, -1 no VM program."""
         buf = np.frombuffer(content, np.uint8)
         return int(lib().gscan_vm_verdict(self._h, buf.ctypes.data, buf.size, subject_start, p))
+
+    def vm_pair(self, b0, b1):
+        """The device's two-byte table: 1 a match may begin with b0 b1, 0 none can, -1 no table."""
+        return int(lib().gscan_vm_pair(self._h, b0, b1))
+
+    def prefix_viable(self, prefix):
+        """May a match begin at offset 0 of some subject that starts with `prefix`? (the probe the two-byte table is built from)"""
+        buf = np.frombuffer(bytes(prefix), np.uint8)
+        return bool(lib().gscan_prefix_viable(self._h, buf.ctypes.data if buf.size else None, buf.size))
 
     def vm_filter(self, content, hits):
         """What K3 does with its filter hits when info.vm is set: the hits it keeps (uint32 array)."""

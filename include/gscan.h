@@ -167,8 +167,14 @@ size_t gscan_tail_positions(const gscan_db *db, size_t clen, uint32_t *out, size
  *                     2 the VM gave up (step / stack limit), -1 the pattern has no VM program.  Never 0 where
  *                     gscan_match_info finds a match.
  *   gscan_vm_filter   what the K3 kernel does with its filter hits when gscan_info.vm is set: of hits[0..n) (offsets of device
- *                     windows) the ones it keeps, in order, into kept (may be NULL); returns how many, -1 if vm is not set. */
+ *                     windows) the ones it keeps, in order, into kept (may be NULL); returns how many, -1 if vm is not set.
+ *   gscan_vm_pair     the device's two-byte table (DevProgram::vm_pair): 1 a match may begin with the bytes b0 b1, 0 none can,
+ *                     -1 the pattern has no table.  gscan_prefix_viable: the probe the table is built from -- may a match
+ *                     begin at offset 0 of some subject that starts with these n bytes?  (0 only if the host matcher fails
+ *                     without looking at or beyond byte n.) */
 int gscan_vm_verdict(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p);
+int gscan_vm_pair(const gscan_db *db, unsigned b0, unsigned b1);
+int gscan_prefix_viable(const gscan_db *db, const void *bytes, size_t n);
 long gscan_vm_filter(const gscan_db *db, const void *content, size_t clen, const uint32_t *hits, size_t n, uint32_t *kept);
 /* What the kernels scan for alternative `alt`: the membership table of DEVICE window position `pos` (the window plus
  * its context positions), the device window length, and the shift from a device hit to the reported match start. */

@@ -73,6 +73,46 @@ def test_vm_never_drops_a_match(seed, built):
     assert exact > 0.995 * total, (exact, total, unknown)  # a filter that keeps everything would be sound and useless
 
 
+@pytest.mark.parametrize("seed", [61, 62, 63])
+def test_prefix_probe_is_one_sided(seed, built):
+    """The two-byte table in front of the VM (DevProgram::vm_pair) is filled by running the host matcher on two-byte prefixes in a
+    probe mode (tree_prefix_viable) that may only answer "no" when the failure is decided by those bytes alone.  Checked the
+    other way round: wherever the matcher finds a match at offset p of a text, the probe on text[p:p+1] and text[p:p+2] must
+    say "viable", and so must the table of a database that has one; how often the probe does say no is measured too."""
+    rng = random.Random(seed)
+    texts = make_texts(seed)[:10] + [b"xx aaaax bbbbbx foobardoesnot foo(a, b); a@b.com"]
+    checked = said_no = tables = 0
+    pats = TARGETS if seed == 61 else [gen(rng, BIN_ATOMS if seed == 63 else ATOMS) for _ in range(400)]
+    for pat in pats:
+        try:
+            db = engine.Database(pat)
+        except ValueError:
+            continue
+        if db.minlen < 0:
+            continue
+        # (the probe reads nothing in front of the prefix: only patterns the device may judge by offset alone get a table)
+        has_table = db.vm_pair(0, 0) >= 0
+        tables += has_table
+        if not has_table:
+            continue
+        for t in texts:
+            data = np.frombuffer(t, np.uint8)
+            for p in range(len(t)):
+                e0 = engine.resource_errors()
+                k = db.match_info(data, p, p)[0]
+                if engine.resource_errors() != e0:
+                    continue
+                one, two = db.prefix_viable(t[p:p + 1]), db.prefix_viable(t[p:p + 2])
+                if k:
+                    assert one and two, (pat, t, p, "the probe rules out a prefix a match begins with")
+                    if p + 1 < len(t):
+                        assert db.vm_pair(t[p], t[p + 1]) == 1, (pat, t, p)
+                checked += 1
+                said_no += not two
+    assert tables > (10 if seed == 61 else 20) and checked > 1000
+    assert said_no > 0.2 * checked  # (a probe that never says no would be sound and useless)
+
+
 @pytest.mark.parametrize("seed", [51, 52])
 def test_vm_filtered_list_prints_what_pcre_prints(seed, built, liboracle):
     """For patterns whose candidates the device confirms (info.vm): the list the kernel produces -- every device hit its VM
