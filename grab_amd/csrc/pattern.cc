@@ -2595,6 +2595,9 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
                 bool dup = false;
                 for (const Seq &u : uniq)
                     if (u.win.size() == s.win.size() && u.has_tail == s.has_tail &&
+                        // (a path that is about to be dropped as dead -- it begins with a reference to a group nothing has set --
+                        // must not stand in for a live one with the same window: ( ?\\3?)\\2x lost its empty-group path that way)
+                        (u.needs_cap && !u.cap) == (s.needs_cap && !s.cap) &&
                         (!u.has_tail || (u.tail == s.tail && u.tail_extra == s.tail_extra)) && u.pre == s.pre && u.post == s.post &&
                         u.pre_start == s.pre_start && u.post_end == s.post_end && u.post_final_nl == s.post_final_nl &&
                         u.gapped == s.gapped && !s.gapped && // gapped paths are kept as they are: their order inside a repeat instance matters
