@@ -244,6 +244,12 @@ int FileGrep::validate(const std::string &regex, bool literal, std::string &why,
         why = std::string("FileGrep::prepare: pattern is outside the GPU engine's subset (") + reason + ")";
         return -2;
     }
+    if (rc != GSCAN_OK && cross_check) {
+        // libpcre has just compiled this text: whatever the engine's parser makes of it, it is not the reference's
+        // "pcre_compile error" (and in -n mode that answer would mean a silent exit 0)
+        why = std::string("FileGrep::prepare: pattern is outside the GPU engine's subset (the engine's parser: ") + reason + ")";
+        return -2;
+    }
     if (rc != GSCAN_OK) {
         why = "FileGrep::prepare::pcre_compile error";
         return -1;

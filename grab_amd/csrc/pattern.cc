@@ -1295,6 +1295,10 @@ struct Parser {
             // quantifier (a quoted \Q..\E char may be quantified once the quote ended; PCRE
             // applies a quantifier after \E to the last quoted char -- same thing here)
             skip_extended();
+            while (!quoting && i + 1 < n && p[i] == '\\' && p[i + 1] == 'E') { // (a stray \E means nothing: a quantifier behind it is this item's)
+                i += 2;
+                skip_extended();
+            }
             if (!quoting && !eof()) {
                 int q = p[i];
                 bool have = false;

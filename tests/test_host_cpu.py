@@ -105,6 +105,11 @@ def test_validate_without_device(built):
     rc, why = filegrep.validate(r"a(*COMMIT)b|(x)")  # (valid PCRE, outside the engine: the search-steering verbs)
     assert rc == -2 and "outside the GPU engine's subset" in why
     assert filegrep.validate("a(", literal=True) == (0, "")
+    # a text libpcre compiles is never reported as its compile error, whatever the engine's own parser says about it
+    # (-n mode answers "pcre_compile error" with a silent exit 0, main.cc:198)
+    for pattern in ("(?|(?<n>a)|(?<n>b))", r"\p{Greek}x", "a(*PRUNE)b"):
+        rc, why = filegrep.validate(pattern)
+        assert rc == -2 and "outside the GPU engine's subset" in why, (pattern, rc, why)
 
 
 def test_ingest_configuration(built):

@@ -102,7 +102,7 @@ CALLS_AND_CONDITIONS = [
     (r"()(](?2)){2}", b"]] ]]] ]"), (r"(a(?1)?b){2}", b"abab aabbab"), (r"(?|x)?ab", None), (r"a(*FAIL)|b", b"a b ab"), (r"a(*F)b|ab", b"ab"),
     (r"ab(?C)c", b"abc ab"), (r"ab(?C12)c", b"abc"), (r"a\o{142}c", b"abc aBc"), (r"[\Qa-z\E]x", b"-x mx ax zx"), (r"[\Qa\E-z]x", b"-x mx ax zx"),
     (r"[\Q]\E]b", b"]b ab"), (r"[^\Qa-\E]x", b"-x mx ax"), (r"(?U)a+b", b"aab ab b"), (r"(?U)a+?b", b"aab"), (r"(?U)[ab]{1,3}c", b"ababc"),
-    (r"(?U:a+)b+ ", b"aabb  ab "), (r"x(?U)a*(?-U)b*c", b"xaabbc xc"), (r"(?X)ab", b"ab"), (r"(?J)(?<n>a)b", b"ab"),
+    (r"(?U:a+)b+ ", b"aabb  ab "), (r"a\E{2}b", b"aab ab"), (r"ab\E+c", b"abbc ac"), (r"x(?U)a*(?-U)b*c", b"xaabbc xc"), (r"(?X)ab", b"ab"), (r"(?J)(?<n>a)b", b"ab"),
 ]
 
 
