@@ -680,6 +680,7 @@ struct Walk {
                 in_group = false;
             }
             while (li < n && (size_t)starts[li] < x) li++;
+            if (li + 16 < n) __builtin_prefetch(content + starts[li + 16]); // (see gscan_next_match's fast path)
             while (ti < nt && (size_t)tails[ti] < x) ti++;
             const size_t a = li < n ? (size_t)starts[li] : kEnd, b = ti < nt ? (size_t)tails[ti] : kEnd;
             const size_t c = std::min(a, b);
@@ -839,6 +840,12 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
     // a group and is therefore listed; the kernels list candidates only, so it is not tested again.)
     if (d.exact && d.alts.size() == 1 && !d.alts[0].gapped && !d.dev_pre && !d.dev_post) {
         const AltSeq &a0 = d.alts[0];
+        // (the walk touches the text once per match, a few hundred bytes apart: every touch a cache and TLB miss -- 100 of the
+        // loop's 105 ns per match.  The list says where the next ones will be.)
+        if (cur->li + 16 < n) {
+            __builtin_prefetch(content + starts[cur->li + 16]);
+            __builtin_prefetch(content + starts[cur->li + 16] + 64);
+        }
         size_t at = s;
         if (d.solitary) { // every candidate is listed: the first one at or after s, without a look at the text (a fresh
                           // mapping costs a page fault per match there -- half a second per 500 000 matches)
