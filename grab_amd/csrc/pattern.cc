@@ -2174,6 +2174,41 @@ bool lookahead_hands_on_required_byte(const Node &n)
     return false;
 }
 
+// libpcre quirk no. 2c (both builds): a pattern of ONE top-level branch that begins with a positive look-ahead whose
+// alternatives all begin with the literal byte X gets X as its first byte; when the pattern's own X comes behind something
+// optional -- (?=1)c*1 -- it becomes the required byte as well, and the start-up check looks for it BEHIND the first byte:
+// "1" alone never matches.  (Directly behind the assertion -- (?=1)1 -- it is the first byte itself and all is well.)
+bool leading_lookahead_sets_first_byte(const Node &root)
+{
+    if (root.kind != Node::CAT || root.cap) return false;
+    size_t i = 0;
+    while (i < root.kids.size() && root.kids[i].kind == Node::ASSERT) i++;
+    if (i >= root.kids.size()) return false;
+    const Node &look = root.kids[i];
+    if (look.kind != Node::LOOK || look.neg || look.behind) return false;
+    const Node &body = look.kids[0];
+    const Node *branches = body.kind == Node::ALT ? body.kids.data() : &body;
+    const size_t nb = body.kind == Node::ALT ? body.kids.size() : 1;
+    ByteSet x;
+    for (size_t b = 0; b < nb; b++) {
+        const Node *f = first_item(branches[b]);
+        while (f && f->kind == Node::CAT && !f->kids.empty()) f = first_item(f->kids[0]);
+        if (f && f->kind == Node::REP && f->min >= 1) f = &f->kids[0];
+        if (!f || f->kind != Node::SET || f->set.count() > 2) return false;
+        if (b > 0 && !(f->set == x)) return false;
+        x = f->set;
+    }
+    size_t j = i + 1;
+    while (j < root.kids.size() && (root.kids[j].kind == Node::ASSERT || root.kids[j].kind == Node::LOOK)) j++;
+    if (j >= root.kids.size()) return false;
+    const Node *f = &root.kids[j];
+    if (f->kind == Node::REP && f->min >= 1) f = &f->kids[0];
+    if (f->kind == Node::SET && f->set.count() <= 2 && set_and(f->set, x).count() > 0) return false; // the first byte itself
+    for (size_t k = j; k < root.kids.size(); k++)
+        if (holds_literal(root.kids[k], x)) return true;
+    return false;
+}
+
 bool has_optional_group(const Node &n)
 {
     if (n.kind == Node::REP && n.kids[0].kind != Node::SET && n.min == 0) return true;
@@ -2499,6 +2534,10 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         }
         if (ps.has_recursion && called_group_begins_with_repeat(root, root)) {
             why = "a subroutine call to a group that begins with an unbounded repeat of one class (libpcre's JIT loses matches behind a failed attempt that made the call)";
+            return 1;
+        }
+        if (leading_lookahead_sets_first_byte(root)) {
+            why = "a leading look-ahead for a literal byte that the pattern itself holds behind an optional item (libpcre then asks for that byte twice)";
             return 1;
         }
         if (lookahead_hands_on_required_byte(root)) {
