@@ -201,6 +201,38 @@ CASES = [
     dict(name="big_l_L5", inputs={"big.txt": {"kind": "big"}}, args=L5 + ["-l", "NEEDLE", "big.txt"], big=True),
 ]
 
+R2TXT = ("f(a(b)c) ((x)) (() a(b\nab cb c ac xab xc\n12-34 x12 x y9\nabba racecar noon ab\n<a<b>c> <<>>\n"
+         "a\r\nb a\rb a\x85b ab\nab\xe9\xc9 12\xb2 x_\xb5\n1-23-4x ad bc\nabc ab aBc aab aaab\n")
+R2 = {"r2.txt": lit(R2TXT)}
+CASES += [
+    # ---- round 2, second half: the rest of PCRE1's syntax (conditionals, calls / recursion, branch reset, \R \X \p, verbs) ----
+    dict(name="r2_cond_group", inputs=R2, args=["-O", "-l", r"(a)?(?(1)b|c)", "r2.txt"]),
+    dict(name="r2_cond_group_lines", inputs=R2, args=["-O", r"x(a)?(?(1)b|c)", "r2.txt"]),
+    dict(name="r2_cond_name", inputs=R2, args=["-O", "-l", r"(?<n>x)?(?(<n>)a|c)b?", "r2.txt"]),
+    dict(name="r2_cond_lookahead", inputs=R2, args=["-O", "-l", r"(?(?=a)ab|cb)", "r2.txt"]),
+    dict(name="r2_cond_neg_capture", inputs=R2, args=["-O", "-l", r"a(?(?!(b)))", "r2.txt"]),
+    dict(name="r2_define_call", inputs=R2, args=["-O", "-l", r"(?(DEFINE)(?<d>[0-9]+))x(?&d)", "r2.txt"]),
+    dict(name="r2_recursion_parens", inputs=R2, args=["-O", "-l", r"\((?:[^()]++|(?R))*\)", "r2.txt"]),
+    dict(name="r2_recursion_parens_lines", inputs=R2, args=[r"\((?:[^()]|(?R))*\)", "r2.txt"]),
+    dict(name="r2_recursion_angle", inputs=R2, args=["-O", "-l", r"<(?:[^<>]+|(?R))*>", "r2.txt"]),
+    dict(name="r2_palindrome", inputs=R2, args=["-O", "-l", r"\b(?:(\w)(?:(?R)|\w?)\1)\b", "r2.txt"]),
+    dict(name="r2_call_forward", inputs=R2, args=["-O", "-l", r"(?+1)(ab)", "r2.txt"]),
+    dict(name="r2_call_in_define_free", inputs=R2, args=["-O", "-l", r"x(?1)?(a|c)", "r2.txt"]),
+    dict(name="r2_branch_reset", inputs=R2, args=["-O", "-l", r"(?|(a)b|(c)b)\1?", "r2.txt"]),
+    dict(name="r2_branch_reset_nocap", inputs=R2, args=["-O", "-l", r"(?|a|c)b", "r2.txt"]),
+    dict(name="r2_anynl", inputs=R2, args=["-O", "-l", r"a\Rb", "r2.txt"]),
+    dict(name="r2_extuni", inputs=R2, args=["-O", "-l", r"a\Xb", "r2.txt"]),
+    dict(name="r2_prop_letters", inputs=R2, args=["-O", "-l", r"\p{L}{3,}", "r2.txt"]),
+    dict(name="r2_prop_upper_lower", inputs=R2, args=["-O", "-l", r"\p{Lu}\p{Ll}|\P{L}\p{Nd}", "r2.txt"]),
+    dict(name="r2_fail_verb", inputs=R2, args=["-O", "-l", r"a(*FAIL)|cb", "r2.txt"]),
+    dict(name="r2_accept_verb", inputs=R2, args=["-O", "-l", r"a(*ACCEPT)b", "r2.txt"], jit_only=True),  # (8.45 finds a minimum length for it and prints; 8.39, the timing build, does not: Q2)
+    dict(name="r2_callout", inputs=R2, args=["-O", "-l", r"ab(?C)c", "r2.txt"]),
+    dict(name="r2_ungreedy", inputs=R2, args=["-O", "-l", r"(?U)a+b", "r2.txt"]),
+    dict(name="r2_octal_quoted_class", inputs=R2, args=["-O", "-l", r"[\Qa-\E]\o{142}", "r2.txt"]),
+    # the JIT build loses the match the interpreter finds ((\d+)-(?1)x on "1-23-4x": DESIGN.md section 2); the product refuses the pattern
+    dict(name="r2_jit_lost_match", inputs=R2, args=["-O", "-l", r"(\d+)-(?1)x", "r2.txt"], jit_only=True),
+]
+
 
 def run(binary, args, cwd):
     r = subprocess.run([binary] + args, cwd=cwd, capture_output=True)
