@@ -842,9 +842,11 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
         const AltSeq &a0 = d.alts[0];
         // (the walk touches the text once per match, a few hundred bytes apart: every touch a cache and TLB miss -- 100 of the
         // loop's 105 ns per match.  The list says where the next ones will be.)
-        if (cur->li + 16 < n) {
-            __builtin_prefetch(content + starts[cur->li + 16]);
-            __builtin_prefetch(content + starts[cur->li + 16] + 64);
+        if (cur->li + 16 < n) { // (the line in front as well: with lines printed the walk copies from the last newline on)
+            const uint8_t *ahead = content + starts[cur->li + 16];
+            __builtin_prefetch(ahead - 64);
+            __builtin_prefetch(ahead);
+            __builtin_prefetch(ahead + 64);
         }
         size_t at = s;
         if (d.solitary) { // every candidate is listed: the first one at or after s, without a look at the text (a fresh
