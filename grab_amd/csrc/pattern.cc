@@ -2103,7 +2103,7 @@ bool group_heads_a_branch(const Node &n, int g)
         for (const Node &item : n.kids) {
             if (item.kind == Node::ASSERT || item.kind == Node::LOOK) continue;
             const Node *f = &item;
-            while (f->kind == Node::ATOMIC) f = &f->kids[0];
+            while (f->kind == Node::ATOMIC || f->kind == Node::REP) f = &f->kids[0]; // ((a++){2}|(?1) as well)
             if (f->kind == Node::CAT && f->cap && f->group == g) return true;
             break;
         }
