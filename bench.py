@@ -251,6 +251,10 @@ def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=
     got = run_timed(argv, env, reps)
     if got is None or got[0] is None:
         return {"error": (got[2] if got else b"")[-300:].decode("latin-1")}
+    # The command line runs the scan in a child that hands back its status and leaves the GPU teardown (0.1 - 0.2 s) behind
+    # the caller's back (grab_cli.cc, GRAB_DETACH); the same run as ONE process is timed next to it.
+    one = run_timed(argv, dict(env, GRAB_DETACH="0"), reps)
+    one_s = one[0] if one and one[0] else None
     dt, out, err = got
     nbytes = nfiles * file_bytes
     lines = out.count(b"\n")
@@ -265,6 +269,8 @@ def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=
     scan_s = t_done - t_up if t_up is not None and t_done is not None and t_done > t_up else None
     return {"value": round(rate, 2), "unit": "GB/s", "scaling": "strong", "n_gpus": n_gpus, "workers": workers,
             "bytes": nbytes, "wall_s": round(dt, 4), "startup_s": marks.get("runtime up"),
+            "one_process_wall_s": one_s and round(one_s, 4), "one_process_GBps": one_s and round(nbytes / one_s / 1e9, 2),
+            "one_process_frac": one_s and round(nbytes / one_s / 1e9 / (PCIE_PEAK_GBPS * n_gpus), 4),
             "scan_phase_s": scan_s and round(scan_s, 4), "scan_phase_GBps": scan_s and round(nbytes / scan_s / 1e9, 2),
             "scan_phase_frac": scan_s and round(nbytes / scan_s / 1e9 / (PCIE_PEAK_GBPS * n_gpus), 4),
             "pcie_peak": PCIE_PEAK_GBPS * n_gpus, "frac": round(rate / (PCIE_PEAK_GBPS * n_gpus), 4),

@@ -19,7 +19,9 @@
 #include <ftw.h>
 #include <pthread.h>
 #include <sched.h>
+#include <signal.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -325,6 +327,40 @@ int main(int argc, char **argv)
 {
     mark("main");
     const Options o = parse(argc, argv);
+    // Taking the process's GPU state apart costs the kernel 0.1 - 0.2 s at exit (profiles/r02_o_exit_cost_and_open_order.txt),
+    // after the last byte of output.  The scan therefore runs in a child: when it has printed everything it closes its
+    // output, hands its exit status over a pipe and leaves; the parent returns that status at once and the child's
+    // teardown goes on behind the caller's back.  (GRAB_DETACH=0: one process, as before.  The fork comes before the first
+    // HIP call: the runtime is not up yet and there is one thread.)
+    int status_fd = -1;
+    if (!getenv("GRAB_DETACH") || atoi(getenv("GRAB_DETACH")) != 0) {
+        int pfd[2];
+        if (pipe(pfd) == 0) {
+            const pid_t child = fork();
+            if (child > 0) {
+                close(pfd[1]);
+                int rc = 0;
+                ssize_t got;
+                do got = read(pfd[0], &rc, sizeof rc);
+                while (got < 0 && errno == EINTR);
+                if (got == (ssize_t)sizeof rc) _exit(rc & 255);
+                int st = 0; // the child died without a word: its wait status says how
+                while (waitpid(child, &st, 0) < 0 && errno == EINTR) {}
+                if (WIFSIGNALED(st)) {
+                    signal(WTERMSIG(st), SIG_DFL);
+                    raise(WTERMSIG(st));
+                }
+                _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 255);
+            }
+            if (child == 0) {
+                close(pfd[0]);
+                status_fd = pfd[1];
+            } else { // no fork: carry on in this process
+                close(pfd[0]);
+                close(pfd[1]);
+            }
+        }
+    }
     const int rc = o.workers > 1 ? run_workers(o) : run_serial(o);
     mark("scan done");
     std::cout.flush();
@@ -337,5 +373,11 @@ int main(int argc, char **argv)
     // Everything is printed, every context is closed, every thread joined: leave without the HIP runtime's exit handlers (tens
     // of milliseconds of a run that takes one or two seconds).  -1 -> exit status 255, like the reference's `return -1` from main
     fflush(stderr);
+    if (status_fd >= 0) { // (see the top of main)
+        close(1);
+        close(2);
+        const int code = rc & 255;
+        (void)!write(status_fd, &code, sizeof code);
+    }
     _exit(rc & 255);
 }
