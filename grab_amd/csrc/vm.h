@@ -55,6 +55,8 @@ enum : uint32_t {
     V_BAR_BEGIN,   // op bits 8-9: 0 atomic group, 1 positive look-around, 2 negative; bits 16-31: pc behind the matching BAR_END
     V_BAR_END,     // op bits 8-9: the same
     V_BACK,        // a: length                                  look-behind: step back (fails in front of the subject start)
+    V_ISSET,       // a: first capture slot of a group; op bit 8: negated   holds iff the group is (is not) set: the two guards a
+                   //    conditional group (?(1)yes|no) is compiled into (vm_compile.cc)
     V_MATCH,
     V_FAIL,
 };
@@ -277,6 +279,12 @@ GSCAN_HD inline int vm_run_t(const VmProg *pg, const uint8_t *c, uint32_t clen, 
             if (vm_holds(in.a, c, clen, s0, pos)) pc++;
             else fail = true;
             break;
+        case V_ISSET: {
+            const bool set = slots.get(in.a) != kVmUnset && slots.get(in.a + 1) != kVmUnset;
+            if (set != (((in.op >> 8) & 1u) != 0)) pc++;
+            else fail = true;
+            break;
+        }
         case V_BACKREF: {
             const uint32_t lo = slots.get(in.a), hi = slots.get(in.a + 1);
             if (lo == kVmUnset || hi == kVmUnset || hi < lo) { // a reference to a group that has not been set fails

@@ -163,9 +163,12 @@ struct Builder {
         case Node::ATOMIC: f = first_of(n.kids[0]); break;
         case Node::ASSERT:
         case Node::LOOK:
+            f.nullable = true;
+            break;
         case Node::COND:
         case Node::RECURSE:
-        case Node::BACKREF: // (what a reference repeats is not known here, and it may be "")
+        case Node::BACKREF: // what a reference repeats (a condition picks, a call matches) is not known here: any byte, or ""
+            for (int k = 0; k < 8; k++) f.set.w[k] = 0xffffffffu;
             f.nullable = true;
             break;
         }
@@ -270,8 +273,43 @@ struct Builder {
             if (ok) pg.ins[b].op |= here() << 16;
             break;
         }
-        case Node::COND:
         case Node::RECURSE: ok = false; break; // not a program for this VM: the pattern stays with the host matcher
+        case Node::COND: {
+            // (?(c)yes|no) as  (?: <c holds> yes | <c does not hold> no ): exactly one guard passes, so the second branch is never
+            // a way out of a failed first one.  A group condition: V_ISSET; an assertion: the look-around itself and its
+            // negation (what it captured stays captured whenever its body matched -- also for (?(?!..)..), see matcher.cc).
+            // Inside a program for this VM there are no subroutine calls: (?(R)..) and (?(Rn)..) never hold, DEFINE never does.
+            const size_t base = n.cond == Node::C_ASSERT ? 1 : 0;
+            const Node *yes = &n.kids[base];
+            const Node *no = n.kids.size() > base + 1 ? &n.kids[base + 1] : nullptr;
+            if (n.cond == Node::C_DEFINE) break;
+            if (n.cond == Node::C_IN_RECURSION || n.cond == Node::C_IN_RECURSION_OF) {
+                if (no) gen(*no);
+                break;
+            }
+            if (n.cond == Node::C_GROUP && (!use_caps || n.group <= 0 || n.group > n_groups)) {
+                ok = false;
+                break;
+            }
+            auto guard = [&](bool holds) {
+                if (n.cond == Node::C_GROUP) {
+                    emit(V_ISSET | ((holds ? 0u : 1u) << 8), cap_slot(n.group));
+                } else {
+                    Node look = n.kids[0];
+                    if (!holds) look.neg = !look.neg;
+                    gen(look);
+                }
+            };
+            const uint32_t split = emit(V_SPLIT, here() + 1, 0, 0xffffu | (0xffffu << 16));
+            guard(true);
+            gen(*yes);
+            const uint32_t jump = emit(V_JMP, 0);
+            if (ok) pg.ins[split].b = here();
+            guard(false);
+            if (no) gen(*no);
+            if (ok) pg.ins[jump].a = here();
+            break;
+        }
         case Node::BACKREF:
             if (!use_caps || n.group <= 0 || n.group > n_groups) {
                 emit(V_FAIL); // (a reference with no captures kept can only fail: TreeMatch, `if (!caps) return false`)

@@ -13,11 +13,14 @@ import pytest
 
 from grab_amd import engine, filegrep
 from inputs import db_candidates, engine_list
-from test_fuzz import ATOMS, BIN_ATOMS, gen, make_texts, ref_chunk
+from test_fuzz import ATOMS, BIN_ATOMS, gen, gen_calls_and_conditions, make_texts, ref_chunk
 
 TARGETS = [r"(\w)\1{3,}x|foobardoes(?=not)", r"[a-z]+\([a-z0-9, ]*\);", r"[a-z]+_[0-9]+\.[a-z]+", r"(?:foo|bar|ab)+baz", r"\w+@\w+\.com",
            r"a.*b.*c", r"(?:ab|cd)+?e", r"e++f", r"(?>a+)b|(?>a+)a", r"(a|b\1)+c|z", r"(?i)(ab)\1+", r"foo(?!bar)\w+", r"x(?=(a))ab|ab",
-           r"(?:a|b)*?c{2,3}d", r"[0-9]{1,40}x", r"(?s)a.{2,}?b", r"(a)(b)?\2c|abc", r"(?:(?:ab)+c)+d", r"a{2,}+b", r"(?:\s|x)+y$"]
+           r"(?:a|b)*?c{2,3}d", r"[0-9]{1,40}x", r"(?s)a.{2,}?b", r"(a)(b)?\2c|abc", r"(?:(?:ab)+c)+d", r"a{2,}+b", r"(?:\s|x)+y$",
+           r"(a)(?:\1b|c)d*e*",  # (a back reference at the head of an alternative: the split's first-byte prediction must not rule it out)
+           # conditional groups: compiled into two guarded branches (vm_compile.cc)
+           r"(a)?(?(1)b|c)d*e", r"x(a)?(?(1)b|c)", r"(?(?=a)ab|cd)e+f+", r"(?(?!a)b|ab)c+d+", r"(?:a|(b))(?(1)c|d)e?f", r"(?<n>a)?(?(<n>)b)c+d", r"a(?(?!(b))c)d*e|ab"]
 
 
 def verdicts(db, text):
@@ -38,7 +41,8 @@ def verdicts(db, text):
 def test_vm_on_named_patterns(pattern, built):
     db = engine.Database(pattern)
     texts = [b"xx aaaax bbbbbx foobardoesnot foo(a, b); foobarbaz a@b.com abaz", b"abcde ababe cde e eef aab aaa abab ABab abAB 11ax x9x",
-             b"foobar foobaz food(x); f_1.a a_12.bc  \tx y\n", b"abc abbc ab c accd bccd aaccd ccd", b"aXXb a\nb a12b ab", b"ababcabcd abd ababd", b" x y\n  y"] + make_texts(3)
+             b"foobar foobaz food(x); f_1.a a_12.bc  \tx y\n", b"abc abbc ab c accd bccd aaccd ccd", b"aXXb a\nb a12b ab", b"ababcabcd abd ababd", b" x y\n  y",
+             b"abde ce abeef cdef bcd abccdd bcef adf abc cd acde ade abd aab ac aabde"] + make_texts(3)
     hits = agree = 0
     for t in texts:
         for p, s0, v, k in verdicts(db, t):
@@ -55,7 +59,7 @@ def test_vm_never_drops_a_match(seed, built):
     texts = make_texts(seed)[:10]
     total = exact = unknown = programs = 0
     for _ in range(500):
-        pat = gen(rng, BIN_ATOMS if seed == 44 else ATOMS)
+        pat = gen_calls_and_conditions(rng) if seed == 43 else gen(rng, BIN_ATOMS if seed == 44 else ATOMS)
         try:
             db = engine.Database(pat)
         except ValueError:
@@ -69,7 +73,7 @@ def test_vm_never_drops_a_match(seed, built):
                 total += 1
                 exact += (v == 1) == (k != 0) and v != 2
                 unknown += v == 2
-    assert programs > 200
+    assert programs > (100 if seed == 43 else 200)
     assert exact > 0.995 * total, (exact, total, unknown)  # a filter that keeps everything would be sound and useless
 
 
