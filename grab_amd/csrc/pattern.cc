@@ -2283,9 +2283,20 @@ bool ends_in_greedy_repeat(const Node &n, bool prev, bool &quirk)
 struct MinCtx {
     const Node *root;
     std::vector<int> active;
-    std::vector<std::pair<int, uint64_t>> fixed; // group -> the length a reference to it counts (later copies of a counted repeat)
+    // A counted repeat is compiled into copies, and every reference or call finds the FIRST copy's bracket (find_bracket):
+    // from the second copy on, a group's reference to "itself" is a reference to another bracket -- no recursion, and what it
+    // counts is worked out afresh, under the chain in force at that point.  `later`: the groups of a repeated item whose
+    // later copy is being counted; `first_eval`: the first copy is being counted on behalf of such a reference (inside it
+    // the groups are themselves again).
+    std::vector<int> later, first_eval;
     bool plain = false; // the true lower bound instead of find_minlength's: a reference may repeat "", every branch counts
 };
+static bool is_in(const std::vector<int> &v, int g)
+{
+    for (int x : v)
+        if (x == g) return true;
+    return false;
+}
 const Node *find_group(const Node &n, int g)
 {
     if (n.kind == Node::CAT && n.cap && n.group == g) return &n;
@@ -2323,21 +2334,34 @@ bool recursive_ref(const Node &item, const MinCtx &cx)
     if (item.kind == Node::RECURSE) { // (?R), or (?n) inside group n: find_minlength's had_recurse
         if (cx.plain) return false;
         if (item.group == 0) return true;
-        for (const auto &fx : cx.fixed)
-            if (fx.first == item.group) return false;
-        for (int a : cx.active)
-            if (a == item.group) return true;
+        if (is_in(cx.active, item.group)) return true;
+        if (is_in(cx.later, item.group) && !is_in(cx.first_eval, item.group)) return false;
         const Node *grp = find_group(*cx.root, item.group);
         return grp && contains(*grp, &item);
     }
     if (r->kind != Node::BACKREF) return false;
     if (cx.plain) return false;
-    for (const auto &fx : cx.fixed)
-        if (fx.first == r->group) return false;
-    for (int a : cx.active)
-        if (a == r->group) return true;
+    if (is_in(cx.active, r->group)) return true;
+    if (is_in(cx.later, r->group) && !is_in(cx.first_eval, r->group)) return false;
     const Node *grp = find_group(*cx.root, r->group);
     return grp && contains(*grp, r);
+}
+// what a back reference to / a call of group g at node n counts (find_minlength: OP_REF, OP_RECURSE)
+uint64_t node_minlen(const Node &n, MinCtx &cx);
+uint64_t reference_minlen(const Node &n, int g, MinCtx &cx)
+{
+    const Node *grp = find_group(*cx.root, g);
+    if (!grp) return 0;
+    bool inside = contains(*grp, &n), via_copy = false;
+    if (inside && is_in(cx.later, g) && !is_in(cx.first_eval, g)) inside = false, via_copy = true; // (a later copy's reference: see MinCtx)
+    if (inside || is_in(cx.active, g)) return 0; // recursion, directly or round the chain (8.39's recurse_check: one list for references and calls)
+    cx.active.push_back(g);
+    const size_t keep = cx.first_eval.size();
+    if (via_copy) cx.first_eval.insert(cx.first_eval.end(), cx.later.begin(), cx.later.end());
+    const uint64_t d = node_minlen(*grp, cx);
+    cx.first_eval.resize(keep);
+    cx.active.pop_back();
+    return d;
 }
 uint64_t node_minlen(const Node &n, MinCtx &cx)
 {
@@ -2346,35 +2370,21 @@ uint64_t node_minlen(const Node &n, MinCtx &cx)
     case Node::SET: return 1;
     case Node::ASSERT:
     case Node::LOOK: return 0;
-    case Node::BACKREF: {
-        if (cx.plain) return 0;
-        for (const auto &fx : cx.fixed)
-            if (fx.first == n.group) return fx.second;
-        const Node *grp = find_group(*cx.root, n.group);
-        if (!grp || contains(*grp, &n)) return 0;
-        for (int a : cx.active)
-            if (a == n.group) return 0;
-        cx.active.push_back(n.group);
-        const uint64_t d = node_minlen(*grp, cx);
-        cx.active.pop_back();
-        return d;
-    }
+    case Node::BACKREF: return cx.plain ? 0 : reference_minlen(n, n.group, cx);
     case Node::ATOMIC: return node_minlen(n.kids[0], cx);
     case Node::RECURSE: {
         // find_minlength, OP_RECURSE: a call from inside the called group, or into a group whose length is being worked
         // out further up (mutual recursion), counts nothing; any other call counts what the called group counts
         if (n.group == 0) return 0;
-        if (!cx.plain)
-            for (const auto &fx : cx.fixed) // (a later copy of a counted repeat: the call goes to the FIRST copy's bracket, see REP)
-                if (fx.first == n.group) return fx.second;
-        const Node *grp = find_group(*cx.root, n.group);
-        if (!grp || contains(*grp, &n)) return 0;
-        for (int a : cx.active) // (8.39's recurse_check chain: one list for the groups entered through calls and through references)
-            if (a == n.group) return 0;
-        cx.active.push_back(n.group);
-        const uint64_t d = node_minlen(*grp, cx);
-        cx.active.pop_back();
-        return d;
+        if (cx.plain) { // (the true lower bound: what the called group needs, unless the call is recursive)
+            const Node *grp = find_group(*cx.root, n.group);
+            if (!grp || contains(*grp, &n) || is_in(cx.active, n.group)) return 0;
+            cx.active.push_back(n.group);
+            const uint64_t d = node_minlen(*grp, cx);
+            cx.active.pop_back();
+            return d;
+        }
+        return reference_minlen(n, n.group, cx);
     }
     case Node::COND: {
         // find_minlength, OP_COND: a condition with one branch has an implied empty second one and counts nothing (that
@@ -2424,12 +2434,10 @@ uint64_t node_minlen(const Node &n, MinCtx &cx)
         if (n.min >= 2 && !cx.plain && (has_kind(k, Node::BACKREF) || has_kind(k, Node::RECURSE))) {
             std::vector<const Node *> groups;
             collect_groups(k, groups);
-            const size_t keep = cx.fixed.size();
-            std::vector<std::pair<int, uint64_t>> add;
-            for (const Node *g : groups) add.emplace_back(g->group, node_minlen(*g, cx));
-            cx.fixed.insert(cx.fixed.end(), add.begin(), add.end());
+            const size_t keep = cx.later.size();
+            for (const Node *g : groups) cx.later.push_back(g->group);
             const uint64_t m2 = node_minlen(k, cx);
-            cx.fixed.resize(keep);
+            cx.later.resize(keep);
             return std::min(cap, m1 + (uint64_t)(n.min - 1) * m2);
         }
         return std::min(cap, (uint64_t)n.min * m1);
@@ -2439,12 +2447,12 @@ uint64_t node_minlen(const Node &n, MinCtx &cx)
 }
 uint64_t node_minlen(const Node &n)
 {
-    MinCtx cx{&n, {}, {}, false};
+    MinCtx cx{&n, {}, {}, {}, false};
     return node_minlen(n, cx);
 }
 uint64_t node_true_minlen(const Node &n)
 {
-    MinCtx cx{&n, {}, {}, true};
+    MinCtx cx{&n, {}, {}, {}, true};
     return node_minlen(n, cx);
 }
 
