@@ -495,6 +495,8 @@ def main():
                         line["cpu_baseline"] = cpu_baseline(d, nfiles, file_bytes, pattern, flags)
                         if line["cpu_baseline"] and "value" in e:
                             e["vs_cpu_baseline"] = round(e["value"] / line["cpu_baseline"]["value"], 3)
+                except Exception as ex:  # (the kernel line above is the contract: whatever goes wrong out here must not lose it)
+                    line.setdefault("e2e", {})["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
                 finally:
                     shutil.rmtree(d, ignore_errors=True)
             else:
