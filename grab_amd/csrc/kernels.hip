@@ -766,9 +766,10 @@ __device__ __forceinline__ uint32_t and_b0_b1(uint32_t x, uint32_t y) // byte 0 
 // = 6 waves per SIMD within 80 VGPRs: the same 96 KiB tile, fewer bytes in flight per wave, more waves to hide the LDS
 // and HBM latency behind).
 // VM: the pattern is inexact (its alternatives only say what a match must begin with) and never looks behind the match
-// start: every filter hit is put to the pattern's backtracking VM (vm.h, program in LDS) right here, and a hit at which no
-// match can start is dropped instead of being recorded for the host's matcher (DevProgram::vm_filter).  The text is read with
-// the default cache policy in this form: the VM comes back to it.
+// start: a filter hit goes through the two-byte viability table (DevProgram::vm_pair) at once and, if it survives, at the
+// end of the sub-tile through the window tables and the pattern's backtracking VM (vm.h, program in LDS); a hit at which no
+// match can start is dropped instead of being recorded for the host's matcher (DevProgram::vm_filter).  The text is read
+// with the default cache policy in this form: the VM comes back to it.
 __device__ __noinline__ bool vm_keep_hit_dev(const DevProgram *pg, const VmProg *vm, const uint8_t *seg, uint32_t slen, uint32_t q)
 {
     return vm_keep_hit(pg, vm, seg, slen, q);
