@@ -2352,8 +2352,10 @@ uint64_t reference_minlen(const Node &n, int g, MinCtx &cx)
 {
     const Node *grp = find_group(*cx.root, g);
     if (!grp) return 0;
-    bool inside = contains(*grp, &n), via_copy = false;
-    if (inside && is_in(cx.later, g) && !is_in(cx.first_eval, g)) inside = false, via_copy = true; // (a later copy's reference: see MinCtx)
+    // (from a later copy EVERY reference into the repeated item lands in the first copy, whether or not it stands inside the
+    // group it names: see MinCtx)
+    const bool via_copy = is_in(cx.later, g) && !is_in(cx.first_eval, g);
+    const bool inside = !via_copy && contains(*grp, &n);
     if (inside || is_in(cx.active, g)) return 0; // recursion, directly or round the chain (8.39's recurse_check: one list for references and calls)
     cx.active.push_back(g);
     const size_t keep = cx.first_eval.size();
