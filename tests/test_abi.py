@@ -67,3 +67,15 @@ def test_fails_loudly_without_device(built, tmp_path):
     f.write_text("foo\n")
     r = subprocess.run([built.bin_path(), "foo", str(f)], capture_output=True, text=True)
     assert r.returncode == 255 and r.stdout == "" and "HIP device" in r.stderr
+    # the same through both process models of the command line: the scan in a child that hands its status back (the
+    # default, GRAB_DETACH) and in the calling process; usage errors leave before either
+    for detach in ("1", "0"):
+        env = dict(os.environ, GRAB_DETACH=detach)
+        r = subprocess.run([built.bin_path(), "-n", "2", "-r", "foo", str(tmp_path)], capture_output=True, text=True, env=env)
+        assert r.returncode == 255 and r.stdout == "" and "HIP device" in r.stderr, (detach, r)
+        r = subprocess.run([built.bin_path(), "a(", str(f)], capture_output=True, text=True, env=env)
+        assert r.returncode == 255 and "pcre_compile error" in r.stderr, (detach, r)
+        r = subprocess.run([built.bin_path(), "-n", "2", "foo", str(f)], capture_output=True, text=True, env=env)
+        assert r.returncode == 255 and "Multicore support only for recursive grabs" in r.stderr, (detach, r)
+    r = subprocess.run([built.bin_path()], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage" in r.stderr + r.stdout
