@@ -2024,6 +2024,17 @@ const Node *first_item(const Node &n)
     if (n.kind == Node::CAT) return n.kids.empty() ? nullptr : first_item(n.kids[0]);
     return &n;
 }
+// the first item of the node that is not a zero-width assertion (\b in front of a literal does not hide it from libpcre's
+// first-byte analysis)
+const Node *first_consuming_item(const Node &n)
+{
+    if (n.kind != Node::CAT) return &n;
+    for (const Node &k : n.kids) {
+        if (k.kind == Node::ASSERT) continue;
+        return first_consuming_item(k);
+    }
+    return nullptr;
+}
 bool lookahead_first_in_group(const Node &n, bool top)
 {
     if (!top && (n.kind == Node::CAT || n.kind == Node::ALT)) {
@@ -2031,8 +2042,10 @@ bool lookahead_first_in_group(const Node &n, bool top)
         const size_t nb = n.kind == Node::ALT ? n.kids.size() : 1;
         for (size_t b = 0; b < nb; b++) {
             const Node *f = first_item(branches[b]);
+            if (f && f->kind == Node::REP && f->min >= 1) f = &f->kids[0]; // ((?=x){2} is (?=x))
             if (f && f->kind == Node::LOOK && !f->neg && !f->behind) {
-                const Node *g = first_item(f->kids[0]);
+                const Node *g = first_consuming_item(f->kids[0]);
+                if (g && g->kind == Node::REP && g->min >= 1) g = &g->kids[0];
                 if (g && g->kind == Node::SET && g->set.count() <= 2) return true;
             }
         }
@@ -2149,11 +2162,13 @@ bool lookahead_hands_on_required_byte(const Node &n)
         const Node *look = nullptr;
         for (const Node &item : n.kids) {
             if (item.kind == Node::ASSERT) continue;
-            if (item.kind == Node::LOOK && !item.neg && !item.behind) {
-                if (!look) look = &item;
+            const Node *li = &item;
+            if (li->kind == Node::REP && li->min >= 1 && li->kids[0].kind == Node::LOOK) li = &li->kids[0];
+            if (li->kind == Node::LOOK && !li->neg && !li->behind) {
+                if (!look) look = li;
                 continue;
             }
-            if (item.kind == Node::LOOK) continue;
+            if (li->kind == Node::LOOK) continue;
             const Node *f = &item;
             if (f->kind == Node::REP && f->min >= 1) f = &f->kids[0];
             if (look && f->kind == Node::SET && f->set.count() <= 2 && holds_literal(look->kids[0], f->set)) {
@@ -2184,15 +2199,16 @@ bool leading_lookahead_sets_first_byte(const Node &root)
     size_t i = 0;
     while (i < root.kids.size() && root.kids[i].kind == Node::ASSERT) i++;
     if (i >= root.kids.size()) return false;
-    const Node &look = root.kids[i];
+    const Node *lk = &root.kids[i];
+    if (lk->kind == Node::REP && lk->min >= 1) lk = &lk->kids[0];
+    const Node &look = *lk;
     if (look.kind != Node::LOOK || look.neg || look.behind) return false;
     const Node &body = look.kids[0];
     const Node *branches = body.kind == Node::ALT ? body.kids.data() : &body;
     const size_t nb = body.kind == Node::ALT ? body.kids.size() : 1;
     ByteSet x;
     for (size_t b = 0; b < nb; b++) {
-        const Node *f = first_item(branches[b]);
-        while (f && f->kind == Node::CAT && !f->kids.empty()) f = first_item(f->kids[0]);
+        const Node *f = first_consuming_item(branches[b]);
         if (f && f->kind == Node::REP && f->min >= 1) f = &f->kids[0];
         if (!f || f->kind != Node::SET || f->set.count() > 2) return false;
         if (b > 0 && !(f->set == x)) return false;
