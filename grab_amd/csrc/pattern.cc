@@ -2304,7 +2304,10 @@ struct MinCtx {
     // counts is worked out afresh, under the chain in force at that point.  `later`: the groups of a repeated item whose
     // later copy is being counted; `first_eval`: the first copy is being counted on behalf of such a reference (inside it
     // the groups are themselves again).
-    std::vector<int> later, first_eval;
+    // (Counted, because repeats nest: inside the first copy of an outer repeat an inner repeat has later copies of its own.
+    // A reference is "from a later copy" while later_d[g] > first_d[g].)
+    std::vector<int> later_d, first_d;
+    bool from_later_copy(int g) const { return (size_t)g < later_d.size() && later_d[(size_t)g] > ((size_t)g < first_d.size() ? first_d[(size_t)g] : 0); }
     bool plain = false; // the true lower bound instead of find_minlength's: a reference may repeat "", every branch counts
 };
 static bool is_in(const std::vector<int> &v, int g)
@@ -2351,14 +2354,14 @@ bool recursive_ref(const Node &item, const MinCtx &cx)
         if (cx.plain) return false;
         if (item.group == 0) return true;
         if (is_in(cx.active, item.group)) return true;
-        if (is_in(cx.later, item.group) && !is_in(cx.first_eval, item.group)) return false;
+        if (cx.from_later_copy(item.group)) return false;
         const Node *grp = find_group(*cx.root, item.group);
         return grp && contains(*grp, &item);
     }
     if (r->kind != Node::BACKREF) return false;
     if (cx.plain) return false;
     if (is_in(cx.active, r->group)) return true;
-    if (is_in(cx.later, r->group) && !is_in(cx.first_eval, r->group)) return false;
+    if (cx.from_later_copy(r->group)) return false;
     const Node *grp = find_group(*cx.root, r->group);
     return grp && contains(*grp, r);
 }
@@ -2370,14 +2373,17 @@ uint64_t reference_minlen(const Node &n, int g, MinCtx &cx)
     if (!grp) return 0;
     // (from a later copy EVERY reference into the repeated item lands in the first copy, whether or not it stands inside the
     // group it names: see MinCtx)
-    const bool via_copy = is_in(cx.later, g) && !is_in(cx.first_eval, g);
+    const bool via_copy = cx.from_later_copy(g);
     const bool inside = !via_copy && contains(*grp, &n);
     if (inside || is_in(cx.active, g)) return 0; // recursion, directly or round the chain (8.39's recurse_check: one list for references and calls)
     cx.active.push_back(g);
-    const size_t keep = cx.first_eval.size();
-    if (via_copy) cx.first_eval.insert(cx.first_eval.end(), cx.later.begin(), cx.later.end());
+    const std::vector<int> saved = cx.first_d;
+    if (via_copy) { // everything of the repeated items is "first copy" from here on
+        cx.first_d.resize(cx.later_d.size(), 0);
+        for (size_t h = 0; h < cx.later_d.size(); h++) cx.first_d[h] = std::max(cx.first_d[h], cx.later_d[h]);
+    }
     const uint64_t d = node_minlen(*grp, cx);
-    cx.first_eval.resize(keep);
+    cx.first_d = saved;
     cx.active.pop_back();
     return d;
 }
@@ -2452,10 +2458,12 @@ uint64_t node_minlen(const Node &n, MinCtx &cx)
         if (n.min >= 2 && !cx.plain && (has_kind(k, Node::BACKREF) || has_kind(k, Node::RECURSE))) {
             std::vector<const Node *> groups;
             collect_groups(k, groups);
-            const size_t keep = cx.later.size();
-            for (const Node *g : groups) cx.later.push_back(g->group);
+            for (const Node *g : groups) {
+                if ((size_t)g->group >= cx.later_d.size()) cx.later_d.resize((size_t)g->group + 1, 0);
+                cx.later_d[(size_t)g->group]++;
+            }
             const uint64_t m2 = node_minlen(k, cx);
-            cx.later.resize(keep);
+            for (const Node *g : groups) cx.later_d[(size_t)g->group]--;
             return std::min(cap, m1 + (uint64_t)(n.min - 1) * m2);
         }
         return std::min(cap, (uint64_t)n.min * m1);

@@ -99,7 +99,7 @@ CALLS_AND_CONDITIONS = [
     (r"<(?:[^<>]+|(?R))*>", b"<a<b>c> <<>> <a"), (r"(a)(?(1)b|c)\1", b"aba aca"), (r"(?(1)a|b)(c)", b"bc ac"), (r"((?(R)a|b))(?1)", b"ba bb ab"),
     (r"(x(?(R)a|b))(?1)?c", b"xbc xbxac xac"), (r"(a)\g<1>", b"aa a"), (r"(?<n>a.)\g<n>", b"a1a2 a1b2"), (r"(a|b\g'1'c)d", b"ad bacd bbaccd bd"),
     (r"(ab)(?-1)", b"abab ab"), (r"(?+1)(ab)", b"abab ab"), (r"(?&w) (?<w>[a-c]+)", b"abc cab  ab"), (r"(?2)(a)(b\1?)", b"bab baba ab"),
-    (r"()(](?2)){2}", b"]] ]]] ]"), (r"(a(?1)?b){2}", b"abab aabbab"), (r"(?|(?<n>W\2))((?&n)){2}", b"WWW WW WWWW"), (r"(((?&n))((?<n>.\2)))", b"abab aaa"), (r"x(\2(\1>)){2}|>>>", b">>> x>>>"), (r"(?|x)?ab", None), (r"a(*FAIL)|b", b"a b ab"), (r"a(*F)b|ab", b"ab"),
+    (r"()(](?2)){2}", b"]] ]]] ]"), (r"(a(?1)?b){2}", b"abab aabbab"), (r"(?|(?<n>W\2))((?&n)){2}", b"WWW WW WWWW"), (r"(((?&n))((?<n>.\2)))", b"abab aaa"), (r"x(\2(\1>)){2}|>>>", b">>> x>>>"), (r"()(?<p>(.(?&p)(?-1)){2}){2}|q", b"q abcdefghijklmnop q"), (r"(?|x)?ab", None), (r"a(*FAIL)|b", b"a b ab"), (r"a(*F)b|ab", b"ab"),
     (r"ab(?C)c", b"abc ab"), (r"ab(?C12)c", b"abc"), (r"a\o{142}c", b"abc aBc"), (r"[\Qa-z\E]x", b"-x mx ax zx"), (r"[\Qa\E-z]x", b"-x mx ax zx"),
     (r"[\Q]\E]b", b"]b ab"), (r"[^\Qa-\E]x", b"-x mx ax"), (r"(?U)a+b", b"aab ab b"), (r"(?U)a+?b", b"aab"), (r"(?U)[ab]{1,3}c", b"ababc"),
     (r"(?U:a+)b+ ", b"aabb  ab "), (r"a\E{2}b", b"aab ab"), (r"ab\E+c", b"abbc ac"), (r"x(?U)a*(?-U)b*c", b"xaabbc xc"), (r"(?X)ab", b"ab"), (r"(?J)(?<n>a)b", b"ab"),
