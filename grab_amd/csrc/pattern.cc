@@ -2225,6 +2225,38 @@ bool leading_lookahead_sets_first_byte(const Node &root)
     return false;
 }
 
+// libpcre quirk no. 2d (both builds): is_startline / is_anchored look INTO a positive look-ahead at the head of the pattern: when
+// it begins with .* (or .*? .{0,} \N*) the whole pattern is taken to begin with .* -- tried at line starts only (at the
+// subject start only under (?s)): (?=.*)[a-c] never matches " b".  Refused when any top-level alternative begins that way
+// (an assertion or an optional item in front of the look-ahead switches the analysis off, and so does a class: [^\n]*).
+static bool begins_with_dot_star(const Node &n)
+{
+    switch (n.kind) {
+    case Node::REP: return n.kids[0].kind == Node::SET && n.min == 0 && n.max == kInf && n.mode != 2 && n.kids[0].set.count() >= 255;
+    case Node::CAT: return !n.kids.empty() && begins_with_dot_star(n.kids[0]);
+    case Node::ATOMIC: return begins_with_dot_star(n.kids[0]);
+    case Node::ALT:
+        for (const Node &k : n.kids)
+            if (begins_with_dot_star(k)) return true;
+        return false;
+    default: return false;
+    }
+}
+static bool head_is_lookahead_for_dot_star(const Node &n)
+{
+    switch (n.kind) {
+    case Node::LOOK: return !n.neg && !n.behind && begins_with_dot_star(n.kids[0]);
+    case Node::REP: return n.min >= 1 && head_is_lookahead_for_dot_star(n.kids[0]);
+    case Node::CAT: return !n.kids.empty() && head_is_lookahead_for_dot_star(n.kids[0]);
+    case Node::ATOMIC: return head_is_lookahead_for_dot_star(n.kids[0]);
+    case Node::ALT:
+        for (const Node &k : n.kids)
+            if (head_is_lookahead_for_dot_star(k)) return true;
+        return false;
+    default: return false;
+    }
+}
+
 bool has_optional_group(const Node &n)
 {
     if (n.kind == Node::REP && n.kids[0].kind != Node::SET && n.min == 0) return true;
@@ -2568,6 +2600,10 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         }
         if (ps.has_recursion && called_group_begins_with_repeat(root, root)) {
             why = "a subroutine call to a group that begins with an unbounded repeat of one class (libpcre's JIT loses matches behind a failed attempt that made the call)";
+            return 1;
+        }
+        if (head_is_lookahead_for_dot_star(root)) {
+            why = "a look-ahead for .* at the head of the pattern (libpcre then tries the pattern at line starts only)";
             return 1;
         }
         if (leading_lookahead_sets_first_byte(root)) {

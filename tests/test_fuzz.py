@@ -240,7 +240,8 @@ REGRESSIONS = [
 
 # libpcre quirks around conditional groups and subroutine calls that are refused rather than imitated (pattern.cc); should
 # one of them be taken after all, the output must still be the reference's
-CALL_AND_CONDITION_QUIRKS = [(r"(?>(?=\xff){2}[0]?\xff(N)?)", b"1\xff \xff\xff"), (r"(?>(?=\b\xff){2,}[\p{Ll}0]?\xff(?<!\pN)+ ?)", b"1\xff0\n a\xff \xff"),
+CALL_AND_CONDITION_QUIRKS = [(r"(?=.*)[a-c]", b" b\nb x b"), (r"(?=.*? [x.]* +)[a-c]+", b"a x \n b ."), (r"^(?=.*1)(?=.*a)\w{3,}", b"a1b\nab1 zz\n1a"),
+                             (r"(?>(?=\xff){2}[0]?\xff(N)?)", b"1\xff \xff\xff"), (r"(?>(?=\b\xff){2,}[\p{Ll}0]?\xff(?<!\pN)+ ?)", b"1\xff0\n a\xff \xff"),
                              (r"(a++){2}|(?1)", b"xa aa"),
                              (r"(?= )c* ", b". "), (r"(?=1)c*1", b"1 11 c1"), (r"(?Ui)(?= + ?)\Bc* +", b"a ba\n0.cb1 a\n. A \n "),
                              (r"(?<n>( ?\1?)\2(()( )|[^a]()))|.", b"\na b"), (r"(( ?\3?)\2[^a])()|.", b"\na  b"),  # (a dead path shadowed a live one with the same window)
