@@ -36,11 +36,17 @@ int grab_filegrep_engine_option(grab_filegrep *g, const char *name, long value) 
 int grab_report_chunk_c(const gscan_db *db, unsigned flags, const char *path, const void *content, size_t clen,
                         long long off, const uint32_t *starts, size_t nstarts, char **out, size_t *outlen)
 {
+    return grab_report_chunk_ends_c(db, flags, path, content, clen, off, starts, nullptr, nstarts, out, outlen);
+}
+
+int grab_report_chunk_ends_c(const gscan_db *db, unsigned flags, const char *path, const void *content, size_t clen,
+                             long long off, const uint32_t *starts, const uint32_t *ends, size_t nstarts, char **out, size_t *outlen)
+{
     if (!db || !out || !outlen) return -1;
     gscan_info info;
     if (gscan_db_info(db, &info) != GSCAN_OK) return -1;
     std::string text;
-    grab_report_chunk(db, info.minlen, flags, path ? path : "", (const char *)content, clen, off, starts, nstarts, text);
+    grab_report_chunk(db, info.minlen, flags, path ? path : "", (const char *)content, clen, off, starts, nstarts, text, nullptr, ends);
     char *buf = (char *)malloc(text.size() + 1);
     if (!buf) return -1;
     memcpy(buf, text.data(), text.size());

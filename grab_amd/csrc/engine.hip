@@ -548,12 +548,13 @@ struct Slot {
     size_t h_desc_cap = 0;
     uint32_t *h_spec = nullptr; // pinned, kShards rows of kSpecPer
     std::vector<uint32_t> raw, sorted;
-    // line extents (k_lines): 3 words per record, parallel to the records
+    // per-record extras, parallel to the records: line extents (k_lines, 3 words each) or match ends (k_ends, 1 word)
     uint32_t *d_ext = nullptr;
     size_t ext_cap = 0;          // records
     uint32_t *h_ext_spec = nullptr; // pinned, kShards rows of kSpecPer * 3
     std::vector<uint32_t> raw_ext, sorted_ext;
     bool has_ext = false;
+    uint32_t ext_words = 0;     // 3: {m1, lb, le} per record ("line_extents"), 1: the match end ("match_ends"), 0: none
     const void *ext = nullptr;  // caller's buffer this chunk was copied from (gscan_wait hands it back as *content)
     void *ext_reg = nullptr;    // ... registered with the runtime for direct DMA until the scan is done
     PinBlock *blk = nullptr; // pool block serving as this slot's pinned buffer (acquires of <= block_bytes() bytes)
@@ -602,10 +603,11 @@ struct gscan_ctx {
     // options
     // defaults from the sweeps under profiles/: 12 KiB per wave (110 VGPRs -> 4 waves/SIMD) with
     // nontemporal loads, one workgroup per tile
-    int variant = 6;
+    int variant = 38; // 12 KiB per wave, nontemporal loads, K2's lane-table form for windows of <= 17 bytes
     int blocks_per_cu = 0;
     size_t register_min = 1u << 20; // caller buffers of at least this many bytes are registered and DMA'd in place
     bool line_extents = false;      // run k_lines after the scan when the pattern allows it ("line_extents" option)
+    bool match_ends = false;        // run k_ends after the scan when the pattern allows it ("match_ends" option): -O -l without the text
     const Slot *last_waited = nullptr;
     // device-resident path
     size_t dev_cap_req = 0;
@@ -666,7 +668,7 @@ int ensure_prog(gscan_ctx *c, const gscan_db *db, hipStream_t st)
 uint32_t grid_for(const gscan_ctx *c, const Database &db, uint32_t n_tiles)
 {
     // kernels that stage a big LDS table once per workgroup always run as a persistent grid
-    const uint32_t fixed = gscan::scan_persistent_blocks(db.tier, c->variant, db.prog.n_classes);
+    const uint32_t fixed = gscan::scan_persistent_blocks(db.tier, c->variant, db.prog);
     const uint32_t bpc = fixed ? fixed : (uint32_t)std::max(c->blocks_per_cu, 0);
     if (bpc == 0) return n_tiles;
     uint64_t g = (uint64_t)c->cus * (uint64_t)bpc;
@@ -802,18 +804,21 @@ int slot_launch(gscan_ctx *c, Slot &s)
     gscan::fill_program(a, db.prog);
     if (s.n_tiles) HIPCHK(c, gscan::launch_scan(db.tier, c->variant, a, grid_for(c, db, s.n_tiles), c->compute));
     if (s.n_tiles && gscan::scan_needs_settle(db.tier, db.prog)) HIPCHK(c, gscan::launch_settle(a, nw, c->compute));
-    s.has_ext = c->line_extents && db.prog.lines_ok && s.n_tiles;
+    s.ext_words = !s.n_tiles ? 0u : (c->line_extents && db.prog.lines_ok) ? 3u : (c->match_ends && db.prog.ends_ok) ? 1u : 0u;
+    s.has_ext = s.ext_words != 0;
     if (s.has_ext) {
-        if (s.ext_cap < s.rec_cap) {
+        const size_t eb = 4 * (size_t)s.ext_words; // bytes per record
+        if (s.ext_cap < s.rec_cap * s.ext_words) {
             if (s.d_ext) hipFree(s.d_ext);
             s.d_ext = nullptr;
             s.ext_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&s.d_ext, s.rec_cap * 12));
-            s.ext_cap = s.rec_cap;
+            HIPCHK(c, hipMalloc((void **)&s.d_ext, s.rec_cap * eb));
+            s.ext_cap = s.rec_cap * s.ext_words;
         }
         if (!s.h_ext_spec) HIPCHK(c, hipHostMalloc((void **)&s.h_ext_spec, kSpecRecs * 12, hipHostMallocDefault));
-        HIPCHK(c, gscan::launch_lines(a, nw, tile_bytes / nw, s.d_ext, c->compute));
-        HIPCHK(c, hipMemcpy2DAsync(s.h_ext_spec, kSpecPer * 12, s.d_ext, (size_t)a.cap_shard * 12, kSpecPer * 12, gscan::kShards,
+        if (s.ext_words == 3) HIPCHK(c, gscan::launch_lines(a, nw, tile_bytes / nw, s.d_ext, c->compute));
+        else HIPCHK(c, gscan::launch_ends(a, nw, tile_bytes / nw, s.d_ext, c->compute));
+        HIPCHK(c, hipMemcpy2DAsync(s.h_ext_spec, kSpecPer * eb, s.d_ext, (size_t)a.cap_shard * eb, kSpecPer * eb, gscan::kShards,
                                    hipMemcpyDeviceToHost, c->compute));
     }
     HIPCHK(c, hipMemcpyAsync(s.h_counter, s.d_counter, kCounterWords * 4, hipMemcpyDeviceToHost, c->compute));
@@ -927,6 +932,7 @@ int gscan_db_info(const gscan_db *db, gscan_info *info)
     info->n_alts = (int)d.alts.size();
     info->has_context = (d.dev_pre ? 1 : 0) | (d.dev_post ? 2 : 0);
     info->lines_ok = (int)d.prog.lines_ok;
+    info->ends_ok = (int)d.prog.ends_ok;
     info->exact = d.exact ? 1 : 0;
     info->vm = d.prog.vm_filter ? 1 : 0;
     return GSCAN_OK;
@@ -1367,12 +1373,13 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
         s->raw.resize(s->rec_cap);
         HIPCHK(c, hipMemcpy2D(s->raw.data(), cap_shard * 4, s->d_recs, cap_shard * 4, fullest * 4, K, hipMemcpyDeviceToHost));
     }
+    const size_t ew = s->ext_words;
     if (s->has_ext && !spec_ok) {
-        s->raw_ext.resize(s->rec_cap * 3);
-        HIPCHK(c, hipMemcpy2D(s->raw_ext.data(), cap_shard * 12, s->d_ext, cap_shard * 12, fullest * 12, K, hipMemcpyDeviceToHost));
+        s->raw_ext.resize(s->rec_cap * ew);
+        HIPCHK(c, hipMemcpy2D(s->raw_ext.data(), cap_shard * 4 * ew, s->d_ext, cap_shard * 4 * ew, fullest * 4 * ew, K, hipMemcpyDeviceToHost));
     }
     s->sorted_ext.clear();
-    if (s->has_ext) s->sorted_ext.reserve(total * 3);
+    if (s->has_ext) s->sorted_ext.reserve(total * ew);
     s->sorted.clear();
     s->sorted.reserve(total);
     const bool multi = !s->segs.empty();
@@ -1389,15 +1396,18 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
         size_t base = (size_t)(d >> 32);
         if (!cnt) continue;
         const uint32_t *src = spec_ok ? s->h_spec + (base / cap_shard) * kSpecPer + base % cap_shard : s->raw.data() + base;
-        if (s->has_ext) { // (patterns that take the line pass never need the second K3 pass: struck == 0)
-            const uint32_t *ex = spec_ok ? s->h_ext_spec + ((base / cap_shard) * kSpecPer + base % cap_shard) * 3 : s->raw_ext.data() + base * 3;
-            s->sorted_ext.insert(s->sorted_ext.end(), ex, ex + (size_t)cnt * 3);
-        }
+        const uint32_t *ex = !s->has_ext ? nullptr
+                             : spec_ok   ? s->h_ext_spec + ((base / cap_shard) * kSpecPer + base % cap_shard) * ew
+                                         : s->raw_ext.data() + base * ew;
         if (struck == 0) {
             s->sorted.insert(s->sorted.end(), src, src + cnt);
-        } else {
+            if (ex) s->sorted_ext.insert(s->sorted_ext.end(), ex, ex + (size_t)cnt * ew);
+        } else { // (the second K3 pass struck records out: their extras go with them)
             for (uint32_t i = 0; i < cnt; i++)
-                if (src[i] != gscan::kStruck) s->sorted.push_back(src[i]);
+                if (src[i] != gscan::kStruck) {
+                    s->sorted.push_back(src[i]);
+                    if (ex) s->sorted_ext.insert(s->sorted_ext.end(), ex + (size_t)i * ew, ex + (size_t)(i + 1) * ew);
+                }
         }
     }
     if (s->sorted.size() + struck != total) return fail(c, GSCAN_EHIP, "descriptor total %zu + struck %zu != counter %zu", s->sorted.size(), struck, total);
@@ -1415,7 +1425,13 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
 
 const uint32_t *gscan_last_ext(const gscan_ctx *c)
 {
-    if (!c || !c->last_waited || !c->last_waited->has_ext) return nullptr;
+    if (!c || !c->last_waited || c->last_waited->ext_words != 3) return nullptr;
+    return c->last_waited->sorted_ext.data();
+}
+
+const uint32_t *gscan_last_ends(const gscan_ctx *c)
+{
+    if (!c || !c->last_waited || c->last_waited->ext_words != 1) return nullptr;
     return c->last_waited->sorted_ext.data();
 }
 
@@ -1440,7 +1456,7 @@ int gscan_set_option(gscan_ctx *c, const char *name, long value)
 {
     if (!c || !name) return GSCAN_EINVAL;
     if (!strcmp(name, "variant")) {
-        if (value != 13 && value != 14 && (value < 0 || value > 7 || (value & 3) == 3)) return GSCAN_EINVAL; // KiB per wave {16,8,12} | nontemporal<<2; 13: 768-thread workgroups for the table kernels
+        if (value != 13 && value != 14 && value != 38 && (value < 0 || value > 7 || (value & 3) == 3)) return GSCAN_EINVAL; // KiB per wave {16,8,12} | nontemporal<<2; 13: 768-thread workgroups for the table kernels; 38 = 6 + K2's lane-table form
         c->variant = (int)value;
         return GSCAN_OK;
     }
@@ -1451,6 +1467,10 @@ int gscan_set_option(gscan_ctx *c, const char *name, long value)
     }
     if (!strcmp(name, "line_extents")) {
         c->line_extents = value != 0;
+        return GSCAN_OK;
+    }
+    if (!strcmp(name, "match_ends")) {
+        c->match_ends = value != 0;
         return GSCAN_OK;
     }
     if (!strcmp(name, "blocks_per_cu")) {

@@ -71,7 +71,8 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 //   :211      -s stops after one match
 // ------------------------------------------------------------------------------------
 void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const char *path, const char *content,
-                       size_t clen, long long off, const uint32_t *starts, size_t nstarts, std::string &out, const uint32_t *ext)
+                       size_t clen, long long off, const uint32_t *starts, size_t nstarts, std::string &out, const uint32_t *ext,
+                       const uint32_t *ends)
 {
     if (minlen < 0) return;
     gscan_cursor cur;
@@ -125,10 +126,14 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
         if (i == nstarts) return; // whatever follows the last listed start belongs to its group, i.e. to its line
         // fall through: the reference's loop from s
     }
+    // -O -l with the match ends from the device (k_ends): s is always 0 or a match end, the next match is the next listed
+    // start and its end is in the list -- `content` is not looked at (a window that was never read stays unmapped pages)
+    const bool listed = ends && (flags & GRAB_NOLINE) && (flags & GRAB_OFFSETS);
     while (s + (size_t)minlen < clen) {
         // rc = pcre_exec(d_pcreh, d_extra, start, end - start, 0, 0, ovector, 3)            (grab.cc:178)
         uint32_t b0 = 0, b1 = 0;
-        const int rc = gscan_next_match(db, content, clen, starts, nstarts, &cur, (uint32_t)s, &b0, &b1);
+        int rc = listed ? gscan_next_listed(db, clen, starts, ends, nstarts, &cur, (uint32_t)s, &b0, &b1) : -1;
+        if (rc < 0) rc = gscan_next_match(db, content, clen, starts, nstarts, &cur, (uint32_t)s, &b0, &b1);
         if (rc != 1) break; // no match -- or one that sets a capturing group: 0 with ovector[3], same exit (grab.cc:179)
         const size_t m0 = b0, m1 = b1;
 
@@ -282,6 +287,7 @@ int FileGrep::prepare(const std::string &regex)
         never_ = anchored_ && info.n_alts == 0; // assertions that can never hold (a\Ab): nothing matches anywhere
         context_ = info.has_context != 0;
         lines_ = info.lines_ok != 0;
+        ends_ = info.ends_ok != 0;
     }
 
     flush();
@@ -306,6 +312,11 @@ int FileGrep::want_contexts(size_t n)
         gscan_ctx *c = nullptr;
         const int orc = gscan_open(dev, chunk_size_, &c);
         if (orc != GSCAN_OK) {
+            if (!ctxs_.empty()) { // a further device that cannot be opened (busy, out of HBM, permissions): go on with the ones there are
+                fprintf(stderr, "grab: HIP device %d cannot be opened (rc %d): scanning on %zu device(s)\n", dev, orc, ctxs_.size());
+                devices_ = ctxs_.size();
+                break;
+            }
             err_ = "FileGrep::prepare::gscan_open: no usable HIP device " + std::to_string(dev) + " (rc " + std::to_string(orc) + ")";
             return -1;
         }
@@ -313,6 +324,9 @@ int FileGrep::want_contexts(size_t n)
         // (k_lines).  Exact, but measured to buy nothing end to end -- the host's share of a printed line is
         // copying it, not finding it -- so it is opt-in: GRAB_LINE_PASS=1.
         if (lines_ && !noline_ && getenv("GRAB_LINE_PASS")) gscan_set_option(c, "line_extents", 1);
+        // -O -l: the device measures every listed match (k_ends) and the walk prints offsets without touching the window
+        // (grab.cc:175-213 with a == 0).  GRAB_NO_ENDS=1 keeps the host walk over the text (A/B runs).
+        if (ends_ && noline_ && offsets_ && !getenv("GRAB_NO_ENDS")) gscan_set_option(c, "match_ends", 1);
         ctxs_.push_back(c);
         inflight_.push_back(0);
         ctx_dev_.push_back(dev);
@@ -427,7 +441,7 @@ int FileGrep::retire_oldest(bool print)
                 status = -1;
             } else {
                 grab_report_chunk(db_, minlen_, rflags, f.path.c_str(), (const char *)map, job.len, (long long)job.off, starts, first[nseg], text,
-                                  gscan_last_ext(ctx));
+                                  gscan_last_ext(ctx), gscan_last_ends(ctx));
                 munmap(map, job.len); // grab.cc:215
                 if (!text.empty()) {
                     emit(text);
@@ -438,9 +452,9 @@ int FileGrep::retire_oldest(bool print)
     } else { // a batch: every segment is a whole small file, i.e. its one and only chunk
         for (size_t i = 0; i < job.files.size(); i++) {
             if (first[i + 1] == first[i] && !context_) continue;
-            const uint32_t *ext = gscan_last_ext(ctx);
+            const uint32_t *ext = gscan_last_ext(ctx), *ends = gscan_last_ends(ctx);
             grab_report_chunk(db_, minlen_, rflags, job.files[i]->path.c_str(), (const char *)bytes + job.segs[i].offset, job.segs[i].len, 0,
-                              starts + first[i], first[i + 1] - first[i], text, ext ? ext + 3 * first[i] : nullptr);
+                              starts + first[i], first[i + 1] - first[i], text, ext ? ext + 3 * first[i] : nullptr, ends ? ends + first[i] : nullptr);
         }
         if (!text.empty()) emit(text); // one lock per batch; per-file output stays contiguous and in order
     }

@@ -91,6 +91,7 @@ private:
     bool never_ = false;    // ... and not even there: the pattern's assertions contradict each other
     bool context_ = false;  // the pattern looks at the byte before / after its match
     bool lines_ = false;    // the device's line-extent pass applies to the pattern
+    bool ends_ = false;     // the device's match-end pass applies to the pattern (-O -l is then walked without the text)
     uid_t uid_;
     int device_ = 0, out_fd_ = 1;
     // GRAB_TIMING=1 in the environment: per-instance wall-clock split, printed to stderr by the destructor
@@ -121,4 +122,4 @@ private:
 // ascending candidate list instead of repeated pcre_exec calls.  Pure host function.
 void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const char *path,
                        const char *content, size_t clen, long long off, const uint32_t *starts,
-                       size_t nstarts, std::string &out, const uint32_t *ext = nullptr);
+                       size_t nstarts, std::string &out, const uint32_t *ext = nullptr, const uint32_t *ends = nullptr);

@@ -1,0 +1,307 @@
+// k2lane.hip -- K2, lane-table form (round 3): class runs of <= 4 classes with windows of <= 17 bytes.
+//
+// What it replaces: pcre_exec's scan for patterns like [A-Za-z_][A-Za-z0-9_]{15,} (/root/reference/src/grab.cc:178;
+// BASELINE configs[2]).  Same contract as every scan kernel here (kernels.hip): per wave sub-tile one descriptor
+// {count, base} and a run of ascending candidate offsets, at least the start of every group of consecutive candidates.
+//
+// Why a new form.  The pair-table form (k2_classrun_scan<.., PAIR = true>) looks the text up two bytes at a time in one
+// 64 KiB table shared by the workgroup: 8 ds_read_u8 per lane and KiB step whose bank is bits 2-6 of a TEXT byte.  Text
+// crowds those into a handful of banks: SQ_LDS_BANK_CONFLICT 254 M of 431 M SQ_LDS_IDX_ACTIVE cycles per 4 GiB, i.e. the
+// LDS was busy 82 % of the kernel's time (profiles/r02_final_sq_counters.txt) -- that, not HBM, bounded cfg3 at 0.63.
+// A hash of the index cannot fix it (32 random lanes on 32 banks still collide 3-4 deep); only a layout in which the bank
+// is the LANE can.  This form:
+//   * table = one 16-bit entry per (byte value, position of the byte inside its dword t = 0..3, lane mod 32) at byte
+//     address  b << 8 | (t >> 1) << 7 | (lane & 31) << 2 | (t & 1) << 1  -- 64 KiB.  The address is ONE v_perm_b32 of the
+//     text dword and a per-lane constant; the bank is the lane: no conflict, ever (ds_read_u16: 2 LDS cycles);
+//   * the entry is pre-shifted by t (class c of byte t -> bit 8c + t for two classes, 4c + t for four), so the four
+//     entries of a dword are simply OR-ed (v_or3_b32) instead of shifted into place one by one: 16 look-ups are merged
+//     into the lane's class masks by 11 operations (two classes) or 16 (four) -- the per-lane table tried in round 2
+//     (LT) spent 16 v_lshl_or_b32 on that and lost what the conflicts had cost;
+//   * no control flow inside a sub-tile: the run program is a template parameter (number of runs, doubling steps per
+//     run), validity (the last window start of the segment) and group-start suppression are applied once per sub-tile in
+//     the epilogue, on the transposed masks, 32 positions per operation;
+//   * the per-step candidate mask goes straight into the wave's LDS strip (one ds_write_b16, no VALU): the epilogue
+//     reads it back transposed -- lane L owns 192 consecutive text positions -- masks, suppresses, counts, reserves its
+//     run with one atomic per wave and writes the records through a buffer descriptor (out-of-range stores are dropped by
+//     the hardware: an overflowing shard cannot write past its region).
+#include "kcommon.h"
+
+namespace gscan {
+
+namespace {
+
+constexpr int kLIter = 12; // KiB per wave sub-tile
+constexpr int kLNW = 8;    // waves per workgroup (64 KiB table + 12 KiB of strips: two workgroups per CU)
+
+// 16-bit table entry of a byte whose k2_table word is v (bit 8c = member of class c), at dword position t
+template <int NCLS>
+__device__ __forceinline__ uint32_t lane_entry(uint32_t v, uint32_t t)
+{
+    if (NCLS == 2) return ((v & 1u) << t) | (((v >> 8) & 1u) << (8u + t));
+    return ((v & 1u) << t) | (((v >> 8) & 1u) << (4u + t)) | (((v >> 16) & 1u) << (8u + t)) | (((v >> 24) & 1u) << (12u + t));
+}
+
+// two classes: e[4k + t] = entry of byte t of dword k: class 0 at bit t, class 1 at bit 8 + t.
+// -> class 0's 16 positions in the low half, class 1's in the high half
+__device__ __forceinline__ uint32_t lane_merge2(const uint32_t (&e)[16])
+{
+    const uint32_t a0 = e[0] | e[1] | e[2], a1 = e[4] | e[5] | e[6];
+    const uint32_t g = ((a1 << 4) | a0) | ((e[7] << 4) | e[3]); // byte 0: class 0 of positions 0-7, byte 1: class 1
+    const uint32_t a2 = e[8] | e[9] | e[10], a3 = e[12] | e[13] | e[14];
+    const uint32_t h = ((a3 << 4) | a2) | ((e[15] << 4) | e[11]); // the same for positions 8-15
+    return __builtin_amdgcn_perm(h, g, 0x05010400u);             // [g.b0, h.b0, g.b1, h.b1]
+}
+
+// four classes: entry = one nibble per class (class c of byte t at bit 4c + t).  u_k = the four nibbles of dword k;
+// a 4 x 4 nibble transposition gives each class its 16 positions: p01 = class 0 | class 1 << 16, p23 = class 2 | class 3 << 16
+__device__ __forceinline__ void lane_merge4(const uint32_t (&e)[16], uint32_t &p01, uint32_t &p23)
+{
+    const uint32_t u0 = (e[0] | e[1] | e[2]) | e[3], u1 = (e[4] | e[5] | e[6]) | e[7];
+    const uint32_t u2 = (e[8] | e[9] | e[10]) | e[11], u3 = (e[12] | e[13] | e[14]) | e[15];
+    const uint32_t w02 = u0 | (u2 << 16), w13 = u1 | (u3 << 16);
+    const uint32_t M = 0x0f0f0f0fu;
+    const uint32_t t = (w02 & M) | ((w13 << 4) & ~M);  // bytes: [cls0 pos 0-7, cls2 pos 0-7, cls0 pos 8-15, cls2 pos 8-15]
+    const uint32_t s = ((w02 >> 4) & M) | (w13 & ~M);  // bytes: [cls1 pos 0-7, cls3 pos 0-7, cls1 pos 8-15, cls3 pos 8-15]
+    p01 = __builtin_amdgcn_perm(s, t, 0x06040200u);    // [t.b0, t.b2, s.b0, s.b2]
+    p23 = __builtin_amdgcn_perm(s, t, 0x07050301u);    // [t.b1, t.b3, s.b1, s.b3]
+}
+
+// One run of the program (ScanArgs::run_lane, wave-uniform): cls @0 (2 bits), window offset @2 (5 bits), the shift
+// amounts of up to five doubling steps @7, 12, 17, 22, 27 (5 bits each).  S = steps actually taken (a template
+// parameter where the launcher could specialise; 5 with zero shifts for the rest otherwise).
+// "class holds at n consecutive positions from p" by doubling: x &= x >> len verifies 2 len, one overlapping step closes
+// the remainder.
+template <int S>
+__device__ __forceinline__ uint32_t lane_run(uint32_t x, uint32_t d)
+{
+    if (S >= 1) x &= x >> ((d >> 7) & 31u);
+    if (S >= 2) x &= x >> ((d >> 12) & 31u);
+    if (S >= 3) x &= x >> ((d >> 17) & 31u);
+    if (S >= 4) x &= x >> ((d >> 22) & 31u);
+    if (S >= 5) x &= x >> ((d >> 27) & 31u);
+    return x >> ((d >> 2) & 31u);
+}
+
+// Epilogue of one wave's sub-tile: xp = the wave's strip, xp[k * 64 + lane] = step k's 16-bit candidate mask of `lane`,
+// i.e. a bitmap of the sub-tile in text order.  Lane L takes bits [192 L, 192 L + 192) of it.
+template <int ITER>
+__device__ __forceinline__ void lane_emit(const ScanArgs &a, uint32_t d, int sub_off, int hi, uint32_t lane, const uint16_t *xp)
+{
+    constexpr int NWORD = ITER / 2;
+    static_assert(ITER % 4 == 0, "the strip is read back in 8-byte pieces");
+    // the wave's own LDS writes, then its reads: LDS operations of one wave execute in order; the fences only keep the
+    // compiler from moving them across each other
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint32_t x[NWORD];
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xp + lane * ITER);
+#pragma unroll
+    for (int q = 0; q < NWORD / 2; q++) {
+        const unsigned long long v = src[q];
+        x[2 * q] = (uint32_t)v;
+        x[2 * q + 1] = (uint32_t)(v >> 32);
+    }
+    const int p0 = sub_off + (int)lane * (ITER * 16);
+    if (sub_off + ITER * 1024 - 1 > hi) { // the segment's last window start lies inside this sub-tile (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < NWORD; i++) {
+            const int nv = hi - (p0 + 32 * i) + 1; // valid positions of this word
+            x[i] &= nv >= 32 ? 0xffffffffu : nv <= 0 ? 0u : ((1u << nv) - 1u);
+        }
+    }
+    // keep the START of every group of consecutive candidates: drop a candidate whose predecessor is one (the
+    // predecessor of the sub-tile's first position is unknown: kept -- reporting more of a group is allowed)
+    const uint32_t prev = up1(x[NWORD - 1], 0u);
+    uint32_t y[NWORD];
+    y[0] = x[0] & ~((x[0] << 1) | (prev >> 31));
+    uint32_t c = (uint32_t)__popc(y[0]);
+#pragma unroll
+    for (int i = 1; i < NWORD; i++) {
+        y[i] = x[i] & ~__builtin_amdgcn_alignbit(x[i], x[i - 1], 31); // (x[i] << 1) | (x[i - 1] >> 31)
+        c += (uint32_t)__popc(y[i]);
+    }
+    const uint32_t inc = wave_scan(c);
+    const uint32_t wtot = __builtin_amdgcn_readlane(inc, 63);
+    if (wtot == 0) {
+        if (lane == 0) a.desc[d] = 0ull;
+        return;
+    }
+    const uint32_t shard = d & (kShards - 1);
+    uint32_t b = 0;
+    if (lane == 0) b = atomicAdd(a.counter + shard * kCtrStride, wtot); // index inside the shard's region
+    const uint32_t base = __builtin_amdgcn_readfirstlane(b);
+    const bool over = (unsigned long long)base + wtot > (unsigned long long)a.cap_shard;
+    if (lane == 0) {
+        a.desc[d] = (unsigned long long)wtot | ((unsigned long long)(shard * a.cap_shard + base) << 32);
+        if (over) atomicOr(a.counter + kShards * kCtrStride, 1u);
+    }
+    if (over) return; // the host re-runs with a bigger buffer
+    // the wave's run of records: a scalar base + a 32-bit byte offset per lane
+    char *out = reinterpret_cast<char *>(a.recs + ((size_t)shard * a.cap_shard + base));
+    uint32_t boff = (inc - c) * 4u;
+    const uint32_t pos = (uint32_t)p0 + a.report_shift;
+#pragma unroll
+    for (int i = 0; i < NWORD; i++) {
+        uint32_t bits = y[i];
+        while (bits) {
+            const uint32_t j = (uint32_t)__ffs((int)bits) - 1u;
+            bits &= bits - 1u;
+            *reinterpret_cast<uint32_t *>(out + boff) = pos + 32u * (uint32_t)i + j;
+            boff += 4u;
+        }
+    }
+}
+
+// NCLS: 2 or 4 (table entry layout).  NR: runs of the program -- 1 or 2: exactly that many, S0 / S1 doubling steps
+// each, everything about them wave-uniform and decoded before the tile loop; 0: any number, five steps each (zero
+// shifts where a run needs fewer), one v_readlane per run and step.
+template <int NCLS, int NR, int S0, int S1>
+__global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
+{
+    constexpr int ITER = kLIter;
+    constexpr uint32_t kTile = kLNW * ITER * 1024;
+    static_assert(NCLS == 2 || NCLS == 4, "two entry layouts");
+    static_assert(NR == 0 || NCLS == 2, "the specialised run programs are the two-class form's");
+    __shared__ uint32_t tbl[65536 / 4];
+    __shared__ __attribute__((aligned(8))) uint16_t s_xp[kLNW * ITER * 64];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave); // (scalar: the descriptor index, the shard and the record base follow)
+    const uint8_t *tbl8 = reinterpret_cast<const uint8_t *>(tbl);
+    const int m = (int)a.m;
+
+    { // stage the table: dword q sits at byte address 4 q = b << 8 | (t >> 1) << 7 | l << 2 and holds t = 2 (t >> 1) (low half) and t + 1
+        const uint32_t *k2 = a.prog->k2_table;
+        for (uint32_t q = threadIdx.x; q < 65536u / 4u; q += kLNW * 64) {
+            const uint32_t v = k2[q >> 6], th = (q >> 5) & 1u;
+            tbl[q] = lane_entry<NCLS>(v, 2u * th) | (lane_entry<NCLS>(v, 2u * th + 1u) << 16);
+        }
+    }
+    // the low address byte of this lane's entries for t = 0..3, one per byte of lc
+    const uint32_t l4 = (lane & 31u) << 2;
+    const uint32_t lc = l4 | ((l4 | 2u) << 8) | ((l4 | 128u) << 16) | ((l4 | 130u) << 24);
+    // the run program: lane r of one VGPR holds descriptor r
+    const uint32_t vrl = a.run_lane[lane & (kK2MaxRuns - 1)];
+    const uint32_t rd0 = __builtin_amdgcn_readlane(vrl, 0), rd1 = __builtin_amdgcn_readlane(vrl, 1);
+    const uint32_t sel0 = (rd0 & 1u) ? 0x07060302u : 0x05040100u, sel1 = (rd1 & 1u) ? 0x07060302u : 0x05040100u;
+    const uint32_t nruns = a.nruns;
+    __syncthreads();
+
+    // entry of byte t_ of dword d_: address = [lc.byte t, d.byte t, 0, 0]
+#define GL_LUT(d_, t_) ((uint32_t)*reinterpret_cast<const uint16_t *>(tbl8 + __builtin_amdgcn_perm((d_), lc, 0x0c0c0000u | ((4u + (t_)) << 8) | (t_))))
+#define GL_LOOKUPS(v_)                                                                                                  \
+    do {                                                                                                                \
+        e[0] = GL_LUT((v_).x, 0u), e[1] = GL_LUT((v_).x, 1u), e[2] = GL_LUT((v_).x, 2u), e[3] = GL_LUT((v_).x, 3u);     \
+        e[4] = GL_LUT((v_).y, 0u), e[5] = GL_LUT((v_).y, 1u), e[6] = GL_LUT((v_).y, 2u), e[7] = GL_LUT((v_).y, 3u);     \
+        e[8] = GL_LUT((v_).z, 0u), e[9] = GL_LUT((v_).z, 1u), e[10] = GL_LUT((v_).z, 2u), e[11] = GL_LUT((v_).z, 3u);   \
+        e[12] = GL_LUT((v_).w, 0u), e[13] = GL_LUT((v_).w, 1u), e[14] = GL_LUT((v_).w, 2u), e[15] = GL_LUT((v_).w, 3u); \
+    } while (0)
+#define GL_MERGE(p01_, p23_)                                    \
+    do {                                                        \
+        if (NCLS == 2) p01_ = lane_merge2(e), p23_ = 0u;        \
+        else lane_merge4(e, p01_, p23_);                        \
+    } while (0)
+
+    for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        const TileCtx c = tile_ctx(a, tiles, t, kTile);
+        const int sub_off = c.tile_off + (int)(wave * ITER * 1024);
+        const uint32_t d = t * kLNW + wave;
+        if (!(c.live && sub_off < c.slen)) { // nothing of this tile is this wave's (wave-uniform)
+            if (lane == 0) a.desc[d] = 0ull;
+            continue;
+        }
+        u32x4 buf[ITER + 1];
+        load_subtile<ITER, true, 1>(buf, c, sub_off, lane);
+        uint16_t *xp = s_xp + wave * (ITER * 64);
+        uint32_t e[16];
+        uint32_t pa, qa, pb, qb; // class masks of step k (pa, qa) and of step k + 1 (pb, qb)
+        GL_LOOKUPS(buf[0]);
+        GL_MERGE(pa, qa);
+        GL_LOOKUPS(buf[1]);
+#pragma unroll
+        for (int k = 0; k < ITER; k++) {
+            GL_MERGE(pb, qb);                        // step k + 1 (k + 1 == ITER: the halo; only lane 0 of it is looked at)
+            if (k + 2 <= ITER) GL_LOOKUPS(buf[k + 2]); // in flight while step k is computed
+            // the next lane's masks (lane 63: lane 0 of the next step)
+            const uint32_t a01 = down1(pa, __builtin_amdgcn_readfirstlane(pb));
+            uint32_t cand;
+            if (NR == 1) {
+                cand = lane_run<S0>(__builtin_amdgcn_perm(a01, pa, sel0), rd0);
+            } else if (NR == 2) {
+                cand = lane_run<S0>(__builtin_amdgcn_perm(a01, pa, sel0), rd0) & lane_run<S1>(__builtin_amdgcn_perm(a01, pa, sel1), rd1);
+            } else {
+                const uint32_t a23 = NCLS == 4 ? down1(qa, __builtin_amdgcn_readfirstlane(qb)) : 0u;
+                cand = 0xffffu;
+                for (uint32_t r = 0; r < nruns; r++) {
+                    const uint32_t dd = __builtin_amdgcn_readlane(vrl, r);
+                    const bool up = NCLS == 4 && (dd & 2u);
+                    const uint32_t own = up ? qa : pa, nb = up ? a23 : a01;
+                    cand &= lane_run<5>(__builtin_amdgcn_perm(nb, own, (dd & 1u) ? 0x07060302u : 0x05040100u), dd);
+                }
+            }
+            xp[k * 64 + lane] = (uint16_t)cand; // bit j: a window of the pattern starts at position 16 lane + j of this step
+            pa = pb;
+            qa = qb;
+        }
+        lane_emit<ITER>(a, d, sub_off, c.slen - m, lane, xp);
+    }
+#undef GL_LUT
+#undef GL_LOOKUPS
+#undef GL_MERGE
+}
+
+template <int NCLS, int NR, int S0, int S1>
+void launch_one(const ScanArgs &a, dim3 g, hipStream_t st)
+{
+    hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1>), g, dim3(kLNW * 64), 0, st, a, a.tiles);
+}
+
+} // namespace
+
+uint32_t k2_lane_tile_bytes() { return (uint32_t)(kLNW * kLIter * 1024); }
+uint32_t k2_lane_waves() { return (uint32_t)kLNW; }
+
+// Doubling steps a run of n positions takes: 1 -> 2 -> 4 ... while it fits, one overlapping step for the rest.
+uint32_t k2_lane_steps(uint32_t n, uint32_t *shifts /* [5] */)
+{
+    uint32_t have = 1, s = 0;
+    for (int i = 0; i < 5; i++) shifts[i] = 0;
+    while (2 * have <= n && s < 5) shifts[s++] = have, have *= 2;
+    if (have < n && s < 5) shifts[s++] = n - have, have = n;
+    return have == n ? s : 99u; // (99: does not fit five steps -- windows of <= 17 bytes always do)
+}
+
+// The launcher: picks the instantiation for the program fill_program() put into a.run_lane / a.lane_steps.
+hipError_t launch_k2_lane(const ScanArgs &a, uint32_t grid, hipStream_t st)
+{
+    const dim3 g(grid);
+    const uint32_t s0 = a.lane_steps[0], s1 = a.lane_steps[1];
+    if (a.n_classes > 2) {
+        launch_one<4, 0, 5, 5>(a, g, st);
+    } else if (a.nruns == 1) {
+        switch (s0) {
+        case 0: launch_one<2, 1, 0, 0>(a, g, st); break;
+        case 1: launch_one<2, 1, 1, 0>(a, g, st); break;
+        case 2: launch_one<2, 1, 2, 0>(a, g, st); break;
+        case 3: launch_one<2, 1, 3, 0>(a, g, st); break;
+        case 4: launch_one<2, 1, 4, 0>(a, g, st); break;
+        default: launch_one<2, 1, 5, 0>(a, g, st); break;
+        }
+    } else if (a.nruns == 2) { // fill_program() sorts the two runs by their step counts: s0 <= s1
+#define GL_CASE(a_, b_) case (a_) * 8 + (b_): launch_one<2, 2, a_, b_>(a, g, st); break;
+        switch (s0 * 8 + s1) {
+            GL_CASE(0, 0) GL_CASE(0, 1) GL_CASE(0, 2) GL_CASE(0, 3) GL_CASE(0, 4) GL_CASE(0, 5)
+            GL_CASE(1, 1) GL_CASE(1, 2) GL_CASE(1, 3) GL_CASE(1, 4) GL_CASE(1, 5)
+            GL_CASE(2, 2) GL_CASE(2, 3) GL_CASE(2, 4) GL_CASE(2, 5)
+            GL_CASE(3, 3) GL_CASE(3, 4) GL_CASE(3, 5)
+            GL_CASE(4, 4) GL_CASE(4, 5)
+        default: launch_one<2, 2, 5, 5>(a, g, st); break;
+        }
+#undef GL_CASE
+    } else {
+        launch_one<2, 0, 5, 5>(a, g, st);
+    }
+    return hipGetLastError();
+}
+
+} // namespace gscan

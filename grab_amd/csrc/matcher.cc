@@ -885,6 +885,26 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
     }
 }
 
+int gscan_next_listed(const gscan_db *db, size_t clen, const uint32_t *starts, const uint32_t *ends, size_t n, gscan_cursor *cur, uint32_t s,
+                      uint32_t *m0, uint32_t *m1)
+{
+    const Database &d = db->db;
+    if (d.minlen <= 0 || !cur || (size_t)s >= clen) return 0;
+    if (!d.prog.ends_ok || !ends) return -1;
+    if (!cur->ready) { // first call for this chunk (as gscan_next_match; such a pattern has no tail positions)
+        cur->li = 0;
+        cur->ntails = (uint32_t)std::min(tail_positions(d, clen, cur->tails, GSCAN_MAX_TAILS), (size_t)GSCAN_MAX_TAILS);
+        memset(cur->next_known, 0, sizeof cur->next_known);
+        cur->ready = 1;
+    }
+    while (cur->li < n && starts[cur->li] < s) cur->li++; // first entry >= s
+    if (cur->li >= n) return 0;
+    if (ends[cur->li] == 0) return -1;
+    *m0 = starts[cur->li];
+    *m1 = ends[cur->li];
+    return 1;
+}
+
 int gscan_vm_verdict(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p)
 {
     if (!db || !db->db.vm_ok || p < subject_start || (size_t)p > clen || clen > 0xfffffff0u) return -1;

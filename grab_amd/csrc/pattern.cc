@@ -2967,6 +2967,13 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             memcpy(pg.tail_bits, a0.tail.w, 32);
             pg.tail_extra = a0.tail_extra;
         }
+        // the match-end pass: the byte that stops the (unbounded) tail cannot begin a window
+        if (a0.has_tail && a0.tail_extra == UINT32_MAX && !a0.captures && !a0.window.empty()) {
+            bool sub = true;
+            const ByteSet &w0 = db.classes[a0.window[0]];
+            for (unsigned b = 0; b < 256 && sub; b++) sub = !w0.test(b) || a0.tail.test(b);
+            pg.ends_ok = sub;
+        }
     }
 
     // Inexact patterns: the device confirms its own candidates with the VM (vm.h) where one verdict per offset serves every

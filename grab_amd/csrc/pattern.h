@@ -147,6 +147,11 @@ struct DevProgram {
     uint32_t tail_bits[8];
     uint32_t tail_extra;                 // 0: no tail
     uint32_t lines_ok;                   // one plain alternative, no context, and no class of it contains a newline
+    // match-end pass (k_ends): one plain alternative without context or capturing group that ends in an UNBOUNDED greedy repeat
+    // whose class contains the window's first class.  The match at a listed start p then ends at the first byte from p + m on
+    // that is outside the tail class -- and that byte cannot begin a match, so after a match the leftmost next one is the next
+    // LISTED start: with the ends from the device the -O -l walk (grab.cc:175-213, a == 0) never looks at the text.
+    uint32_t ends_ok;
     // Candidates confirmed on the device (vm.h): K3 runs the pattern's VM program at every filter hit and drops the hits at
     // which no match can start.  For a gapped alternative the hit is the LAST byte of its unbounded repeat (device window =
     // repeat byte + the rest): the possible starts are walked back along the run of repeat bytes.

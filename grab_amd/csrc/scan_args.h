@@ -50,22 +50,37 @@ struct ScanArgs {
     // doubling steps (0 = step not taken) 1 @1, 2 @2 (2 bits), 4 @4 (3 bits), 8 @7 (4 bits), the remainder @11 (5 bits),
     // the run's window offset @16 (6 bits)
     uint32_t run_flat[kK2MaxRuns];
+    // K2, lane-table form (k2lane.hip; windows of <= 17 bytes): cls @0 (2 bits), the run's window offset @2 (5 bits), the
+    // shift amounts of its doubling steps @7, 12, 17, 22, 27 (5 bits each; 0 = no step).  lane_steps = the steps the first two
+    // runs take (two runs are sorted by them): the launcher picks the kernel instantiation with exactly that many.
+    uint32_t run_lane[kK2MaxRuns];
+    uint32_t lane_steps[2];
 };
 
-// variant: bits 0-1 select KiB per wave {0:16, 1:8, 2:12}; bit 2 = nontemporal loads; 13 / 21: bigger workgroups for the table kernels (kernels.hip, variant_wg)
+// variant: bits 0-1 select KiB per wave {0:16, 1:8, 2:12}; bit 2 = nontemporal loads; 13: bigger workgroups for the table kernels (kernels.hip, variant_wg);
+// bit 5 (38 = the default): K2 patterns with windows of <= 17 bytes run the lane-table form (k2lane.hip)
 uint32_t scan_tile_bytes(int tier, int variant, uint32_t n_classes);
 uint32_t scan_tile_bytes_vm();
 void scan_geometry(int tier, int variant, const DevProgram &pg, uint32_t *tile_bytes, uint32_t *waves);
 constexpr uint32_t kMaxWavesPerTile = 16;  // the largest workgroup any variant launches
 constexpr uint32_t kMinSubTileBytes = 8192; // the smallest sub-tile (8 KiB per wave)
 uint32_t scan_min_tile_bytes();
-uint32_t scan_persistent_blocks(int tier, int variant, uint32_t n_classes);
+uint32_t scan_persistent_blocks(int tier, int variant, const DevProgram &pg);
 void fill_program(ScanArgs &a, const DevProgram &pg);
 hipError_t launch_scan(int tier, int variant, const ScanArgs &a, uint32_t grid, hipStream_t st);
+// k2lane.hip
+constexpr int kVariantLane = 32;
+bool k2_lane_form(int tier, int variant, uint32_t m, uint32_t nruns);
+uint32_t k2_lane_tile_bytes();
+uint32_t k2_lane_waves();
+uint32_t k2_lane_steps(uint32_t n, uint32_t *shifts);
+hipError_t launch_k2_lane(const ScanArgs &a, uint32_t grid, hipStream_t st);
 bool scan_needs_settle(int tier, const DevProgram &pg);
 hipError_t launch_settle(const ScanArgs &a, uint32_t waves, hipStream_t st);
 // line extents + orbit selection for the line-printing modes: ext[3 * record index] = {m1, lb, le} (kernels.hip, k_lines)
 hipError_t launch_lines(const ScanArgs &a, uint32_t waves, uint32_t sub_bytes, uint32_t *ext, hipStream_t st);
 constexpr uint32_t kLineAskHost = 0xffffffffu;
+// match ends for -O -l: ends[record index] = end of the match that starts at the record (0: ask the host) (kernels.hip, k_ends)
+hipError_t launch_ends(const ScanArgs &a, uint32_t waves, uint32_t sub_bytes, uint32_t *ends, hipStream_t st);
 
 } // namespace gscan

@@ -21,7 +21,7 @@ SLOTS = 2
 SYMBOLS = [
     "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_match_info", "gscan_next_match", "gscan_tail_positions", "gscan_db_dev_window",
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
-    "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs", "gscan_last_ext",
+    "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_ends", "gscan_next_listed",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
     "gscan_set_option", "gscan_kernel_time", "gscan_resource_errors",
     "gscan_ingest_info", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
@@ -32,7 +32,7 @@ SYMBOLS = [
 class Info(C.Structure):
     _fields_ = [("tier", C.c_int), ("minlen", C.c_int), ("n_classes", C.c_int), ("has_tail", C.c_int),
                 ("tail_extra", C.c_uint32), ("anchor_off", C.c_int), ("anchor_len", C.c_int),
-                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int), ("lines_ok", C.c_int), ("exact", C.c_int), ("vm", C.c_int)]
+                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int), ("lines_ok", C.c_int), ("exact", C.c_int), ("vm", C.c_int), ("ends_ok", C.c_int)]
 
 
 class Cursor(C.Structure):
@@ -98,6 +98,10 @@ def lib():
         L.gscan_block_size.restype = C.c_size_t
         L.gscan_last_ext.argtypes = [C.c_void_p]
         L.gscan_last_ext.restype = C.POINTER(C.c_uint32)
+        L.gscan_last_ends.argtypes = [C.c_void_p]
+        L.gscan_last_ends.restype = C.POINTER(C.c_uint32)
+        L.gscan_next_listed.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Cursor), C.c_uint32,
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.gscan_submit_segs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Seg), C.c_size_t, C.c_uint64]
         L.gscan_submit_fd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_size_t, C.c_uint64]
         L.gscan_wait_segs.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint32)),
@@ -295,6 +299,13 @@ class Context:
         if not p:
             return None
         return np.ctypeslib.as_array(p, shape=(n * 3,)).copy().reshape(n, 3) if n else np.zeros((0, 3), np.uint32)
+
+    def last_ends(self, n):
+        """The match ends of the n records the last wait() returned (option "match_ends"; 0 = left to the host), or None."""
+        p = lib().gscan_last_ends(self._h)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
 
     def submit_fd(self, db, fd, offset, length, tag=0):
         """A range of an open file, read by the engine's reader threads straight into pinned blocks (gscan_submit_fd)."""

@@ -12,7 +12,7 @@ from .build import lib_path
 SYMBOLS = [
     "grab_filegrep_new", "grab_filegrep_free", "grab_filegrep_why", "grab_filegrep_recurse",
     "grab_filegrep_show_path", "grab_filegrep_config", "grab_filegrep_prepare", "grab_filegrep_find",
-    "grab_filegrep_find_recursive", "grab_filegrep_engine_option", "grab_report_chunk_c", "grab_free",
+    "grab_filegrep_find_recursive", "grab_filegrep_engine_option", "grab_report_chunk_c", "grab_report_chunk_ends_c", "grab_free",
     "grab_filegrep_find3", "grab_filegrep_flush", "grab_walk_parallel", "grab_validate",
 ]
 
@@ -49,6 +49,8 @@ def lib():
         L.grab_filegrep_engine_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         L.grab_report_chunk_c.argtypes = [C.c_void_p, C.c_uint, C.c_char_p, C.c_void_p, C.c_size_t, C.c_longlong,
                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.grab_report_chunk_ends_c.argtypes = [C.c_void_p, C.c_uint, C.c_char_p, C.c_void_p, C.c_size_t, C.c_longlong,
+                                               C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.grab_free.argtypes = [C.c_void_p]
         L.grab_free.restype = None
         L.grab_filegrep_find3.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
@@ -149,17 +151,26 @@ def validate(regex, literal=False):
     return rc, why.value.decode("latin-1")
 
 
-def report_chunk(db, flags, path, content, off, starts):
-    """grab_report_chunk_c: what the reference prints for one chunk, from the candidate list. Pure host."""
+def report_chunk(db, flags, path, content, off, starts, ends=None, clen=None):
+    """grab_report_chunk_c: what the reference prints for one chunk, from the candidate list. Pure host.
+    ends: the match ends the device measured (grab_report_chunk_ends_c); content may then be None (clen = its length)."""
     import numpy as np
 
-    buf = np.ascontiguousarray(np.frombuffer(content, np.uint8))
+    buf = np.ascontiguousarray(np.frombuffer(content, np.uint8)) if content is not None else np.zeros(0, np.uint8)
     st = np.ascontiguousarray(np.asarray(starts, np.uint32))
     out = C.c_void_p()
     n = C.c_size_t()
-    rc = lib().grab_report_chunk_c(db._h, flags, os.fsencode(path) if path is not None else None,
-                                   buf.ctypes.data if buf.size else None, buf.size, off,
-                                   st.ctypes.data if st.size else None, st.size, C.byref(out), C.byref(n))
+    if ends is None:
+        rc = lib().grab_report_chunk_c(db._h, flags, os.fsencode(path) if path is not None else None,
+                                       buf.ctypes.data if buf.size else None, buf.size, off,
+                                       st.ctypes.data if st.size else None, st.size, C.byref(out), C.byref(n))
+    else:
+        en = np.ascontiguousarray(np.asarray(ends, np.uint32))
+        assert en.size == st.size
+        rc = lib().grab_report_chunk_ends_c(db._h, flags, os.fsencode(path) if path is not None else None,
+                                            buf.ctypes.data if buf.size else None, buf.size if content is not None else clen, off,
+                                            st.ctypes.data if st.size else None, en.ctypes.data if en.size else None, st.size,
+                                            C.byref(out), C.byref(n))
     if rc != 0:
         raise RuntimeError("grab_report_chunk_c failed")
     data = C.string_at(out, n.value)

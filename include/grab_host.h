@@ -45,6 +45,11 @@ int grab_filegrep_engine_option(grab_filegrep *g, const char *name, long value);
 int grab_report_chunk_c(const gscan_db *db, unsigned flags, const char *path, const void *content,
                         size_t clen, long long off, const uint32_t *starts, size_t nstarts,
                         char **out, size_t *outlen);
+/* The same with the match ends the device measured (gscan_last_ends; NULL: none): under -O -l (flags 1 | 2) the walk
+ * then never reads `content`, except for a match whose end the device left open (ends[i] == 0). */
+int grab_report_chunk_ends_c(const gscan_db *db, unsigned flags, const char *path, const void *content,
+                             size_t clen, long long off, const uint32_t *starts, const uint32_t *ends, size_t nstarts,
+                             char **out, size_t *outlen);
 void grab_free(void *p);
 
 /*

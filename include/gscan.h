@@ -88,6 +88,8 @@ typedef struct gscan_info {
                             small backtracking VM at every filter hit and drops the hits at which no match can start -- and the
                             list it returns holds EVERY hit it kept (no group-start compression): gscan_next_match then asks the
                             host matcher at the listed offsets only */
+    int ends_ok;         /* 1 if the match-end pass applies (gscan_set_option "match_ends"): one plain alternative without context that
+                            ends in an unbounded greedy repeat whose class contains the window's first class (gscan_next_listed) */
 } gscan_info;
 
 /* one scan unit inside a device-resident arena (gscan_scan_device) */
@@ -257,6 +259,22 @@ int gscan_wait(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, size_t *n
  * starts, same lifetime), or NULL if that chunk has none.
  */
 const uint32_t *gscan_last_ext(const gscan_ctx *ctx);
+/*
+ * Match ends on the device, for -O -l (src/grab.cc:175-213 with d_print_line off: print the offset, restart at the match
+ * end).  With gscan_set_option(ctx, "match_ends", 1) and a pattern whose gscan_info.ends_ok is set, every chunk also
+ * carries ends[i] = ovector[1] of the match that starts at starts[i] (window + greedy tail, cut at the chunk end), or 0
+ * where the device left it to the host (a tail that runs on for more than 4 KiB).  gscan_last_ends returns the array for
+ * the chunk the last gscan_wait / gscan_wait_segs handed out (parallel to its starts, same lifetime), or NULL.
+ */
+const uint32_t *gscan_last_ends(const gscan_ctx *ctx);
+/*
+ * gscan_next_match for such a chunk, WITHOUT the text: valid when s is 0 or the end of the previous match of this walk
+ * (the byte that stopped its tail cannot begin a match, so the leftmost match from s is the first listed start >= s).
+ * Returns 0 no match, 1 match with [*m0, *m1), -1: this match's end is the host's to find -- make this step with
+ * gscan_next_match (same cursor).  `cur` as for gscan_next_match.
+ */
+int gscan_next_listed(const gscan_db *db, size_t clen, const uint32_t *starts, const uint32_t *ends, size_t n,
+                      gscan_cursor *cur, uint32_t s, uint32_t *m0, uint32_t *m1);
 /* the same for a chunk of several segments: the records of segment i are
  * starts[seg_first[i] .. seg_first[i+1]), segment-relative; seg_first has *nseg + 1 entries
  * (a single-segment chunk reports *nseg = 1). */
@@ -279,7 +297,7 @@ long gscan_dev_fetch(gscan_ctx *ctx, const gscan_dev_result *res, size_t seg, ui
 /* record-buffer capacity (records, split into 8 equal shard regions) for device scans;
  * default = arena bytes / 16 */
 int gscan_set_capacity(gscan_ctx *ctx, size_t n_records);
-/* tuning knobs for A/B runs: name in {"variant","blocks_per_cu","register_min","line_extents"}; see DESIGN.md */
+/* tuning knobs for A/B runs: name in {"variant","blocks_per_cu","register_min","line_extents","match_ends"}; see DESIGN.md */
 int gscan_set_option(gscan_ctx *ctx, const char *name, long value);
 /* scan-kernel time of the gscan_scan_device launches since the last reset: HIP events recorded
  * around each launch on the launch's own stream.  Waits for the launches to finish. */

@@ -17,7 +17,8 @@ import scan_oracle as so  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [0, 1, 2, 4, 5, 6, 13, 14]  # KiB per wave {16, 8, 12} x nontemporal loads {off, on}; 13: 768-thread table kernels; 14: table kernels prefetch the next tile
+VARIANTS = [0, 1, 2, 4, 5, 6, 13, 14, 38]  # KiB per wave {16, 8, 12} x nontemporal loads {off, on}; 13: 768-thread table kernels; 14: table kernels prefetch the next tile; 38 (the default): 6 + K2's lane-table form
+DEFAULT_VARIANT = 38
 PATTERNS = ["foobardoesnotexist", "foo", "e", "xy", "[A-Za-z_][A-Za-z0-9_]{15,}", "[a-z]{2,5}", "abc[0-9]*", r"\d{3}-\d{4}",
             "[Ll]inus", "a.c", "[^x]{5,}", "[0-9a-f]{32}", "[0-9A-F]{6}[a-z]", "e+", r"\w\s\w\s\w", "[a-z][0-9][A-Z][.,][;:]q",
             "[ab][cd][ef][gh]{20}", "[0-9]{17}", "[0-9]{18}", "[a-z_]{49}",
@@ -98,9 +99,12 @@ def sample(n, seed):
 KERNEL_FORMS = [
     ("K1 literal", "foobardoesnotexist", engine.TIER_LITERAL),
     ("K1 class sequence with an anchor", "[Ll]inus", engine.TIER_LITERAL),
-    ("K2 pair form", "[A-Za-z_][A-Za-z0-9_]{15,}", engine.TIER_CLASSRUN),
+    ("K2 lane form, two runs", "[A-Za-z_][A-Za-z0-9_]{15,}", engine.TIER_CLASSRUN),
+    ("K2 lane form, one run", "[0-9]{17}", engine.TIER_CLASSRUN),
+    ("K2 lane form, three runs", "[a-z][0-9][a-z]{9}", engine.TIER_CLASSRUN),
+    ("K2 lane form, 3 classes", "[a-z][0-9][A-Z]{3}", engine.TIER_CLASSRUN),
+    ("K2 lane form, 4 classes", "[a-z][0-9][A-Z]{2}[.,;]", engine.TIER_CLASSRUN),
     ("K2 pair form, wide", "[0-9a-f]{32}", engine.TIER_CLASSRUN),
-    ("K2 general form, 3 classes", "[a-z][0-9][A-Z]{3}", engine.TIER_CLASSRUN),
     ("K2 general form, wide", "[ab][cd][ef][gh]{20}", engine.TIER_CLASSRUN),
     ("K3, tables exact", "foobardoesnotexist|Linus|555-1234", engine.TIER_BUCKET),
     ("K3, three filter positions", "foo|bar", engine.TIER_BUCKET),
@@ -125,8 +129,15 @@ def test_kernels_against_libpcre(ctx, liboracle, name, pattern, tier):
         assert np.array_equal(want, table_candidates(db, data)), "the compiler's tables and libpcre agree as well"
 
 
+_PCRE_WANT = {}
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_parity_patterns(ctx, variant):
+def test_parity_patterns(ctx, liboracle, variant):
+    """Every kernel variant, every pattern: against the candidate set from the database's tables AND, wherever the candidate
+    set is by definition "libpcre matches at p" (exact patterns without context), against libpcre itself
+    (oracle_all_starts) -- no product table between the kernel and the reference's engine for any variant.  Databases the
+    device confirms itself (info.vm): everything libpcre matches is kept, nothing outside the filter's hits is reported."""
     ctx.set_option("variant", variant)
     data = sample(300_007, 1)
     for pattern in PATTERNS:
@@ -134,7 +145,58 @@ def test_parity_patterns(ctx, variant):
         got = ctx.scan(db, data)
         assert got.dtype == np.uint32
         assert as_specified(db, got, data), (pattern, variant, len(got))
-    ctx.set_option("variant", 6)
+        if not db.info.has_context and (db.info.exact or db.info.vm) and "(" not in pattern.replace("(?:", "").replace("(?i)", ""):
+            if pattern not in _PCRE_WANT:
+                _PCRE_WANT[pattern] = pcre_starts(liboracle, pattern, data)
+            want = _PCRE_WANT[pattern]
+            if db.info.exact:
+                assert same(got, want), (pattern, variant, len(got), len(want))
+            else:
+                g = np.asarray(got, np.int64)
+                assert np.all(np.isin(want, g)), (pattern, variant, "a match libpcre finds is missing from the device's list")
+                assert np.all(np.isin(g, table_candidates(db, data))), (pattern, variant)
+    ctx.set_option("variant", DEFAULT_VARIANT)
+
+
+def runs_text(n, seed):
+    """Digits, lower-case letters and a few others in runs of every length from 1 to 40: what the run programs of the
+    lane-table kernels (1..5 doubling steps, one or two runs) have to tell apart."""
+    rng = np.random.default_rng(seed)
+    out = np.empty(n + 64, np.uint8)
+    kinds = [np.frombuffer(b"0123456789", np.uint8), np.frombuffer(b"abcxyz", np.uint8), np.frombuffer(b" _.\n", np.uint8)]
+    at = 0
+    while at < n:
+        k = kinds[int(rng.integers(0, 3))]
+        ln = int(rng.integers(1, 41))
+        out[at:at + ln] = k[rng.integers(0, k.size, ln)]
+        at += ln
+    return out[:n]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17])
+def test_lane_run_programs_against_libpcre(ctx, liboracle, n):
+    """One instantiation of the lane-table kernel per (number of runs, doubling steps per run): a run of n digits alone
+    (n >= 2), in front of a letter, behind one, and between two runs of letters -- every step count 0..5, both orders of
+    the two-run programs, the generic three-run form -- against libpcre."""
+    data = runs_text(400_003, 100 + n)
+    pats = ["[0-9]{%d}[a-z]" % n, "[a-z][0-9]{%d}" % n]
+    if n >= 2:
+        pats.append("[0-9]{%d}" % n)
+    if n <= 13:
+        pats += ["[a-z]{2}[0-9]{%d}[a-z]{2}" % n, "[a-z]{%d}[0-9]{%d}" % (min(n, 17 - n), n) if n <= 8 else "[a-z]{3}[0-9]{%d}" % n]
+    if n <= 14:
+        pats.append("[a-z][0-9]{%d}[_ .]" % n)  # three classes: the four-class table layout
+    for pattern in pats:
+        db = engine.Database(pattern)
+        if db.info.tier != engine.TIER_CLASSRUN:
+            continue
+        want = pcre_starts(liboracle, pattern, data)
+        assert want.size > 0, pattern
+        for variant in (DEFAULT_VARIANT, 6):
+            ctx.set_option("variant", variant)
+            got = ctx.scan(db, data)
+            assert same(got, want), (pattern, variant, len(got), len(want))
+    ctx.set_option("variant", DEFAULT_VARIANT)
 
 
 SIZES = [0, 1, 2, 3, 4, 5, 15, 16, 17, 18, 19, 31, 32, 33, 63, 64, 65, 1023, 1024, 1025, 1039, 1040, 4095, 4096, 4097,
@@ -160,7 +222,7 @@ def test_ragged_sizes(ctx, variant):
             got = ctx.scan(db, data)
             want = table_candidates(db, data)
             assert same(got, want), (p, n, variant)
-    ctx.set_option("variant", 6)
+    ctx.set_option("variant", DEFAULT_VARIANT)
 
 
 def test_dense_output_and_regrow(ctx):
@@ -258,7 +320,7 @@ def test_device_resident_segments(ctx):
                 assert same(got, want), (pattern, variant, i)
                 n += len(got)
             assert n == total
-    ctx.set_option("variant", 6)
+    ctx.set_option("variant", DEFAULT_VARIANT)
     ms, launches = ctx.kernel_time()
     assert launches > 0 and ms > 0
     # a deliberately small record buffer reports overflow instead of writing out of bounds
@@ -356,7 +418,7 @@ def test_submit_batch_segments(ctx):
             assert tag == 7 and has_content and len(per_seg) == len(parts)
             for i, (part, got) in enumerate(zip(parts, per_seg)):
                 assert same(got, table_candidates(db, part)), (pattern, variant, i, len(part))
-    ctx.set_option("variant", 6)
+    ctx.set_option("variant", DEFAULT_VARIANT)
     # thousands of tiny segments (more tiles than len / tile size), and an empty batch
     tiny = [base[i * 37:i * 37 + int(rng.integers(0, 37))].copy() for i in range(3000)]
     db = engine.Database("[a-z]{2,5}")
@@ -472,4 +534,54 @@ def test_line_extents_on_device(ctx):
             assert not engine.Database(pattern).info.lines_ok
     finally:
         ctx.set_option("line_extents", 0)
-        ctx.set_option("variant", 6)
+        ctx.set_option("variant", DEFAULT_VARIANT)
+
+
+def test_match_ends_on_device(ctx):
+    """k_ends (-O -l without the text): with "match_ends" on, every listed start of an ends_ok pattern comes with the end of
+    its match -- window + greedy tail, cut at the segment end -- exactly gscan_match_end's (the host rule pinned against
+    libpcre in tests/test_pattern.py); a tail that runs on for more than 4 KiB is left to the host (0).  Single chunks and
+    batches of segments, the default kernel and an older variant."""
+    data = sample(700_001, 43)
+    data[300_000:309_000] = ord("q")                      # a 9000-byte identifier: beyond what the device follows
+    data[650_000:] = ord("e")                             # a tail that runs into the end of the chunk
+    ctx.set_option("match_ends", 1)
+    try:
+        for pattern in ["[A-Za-z_][A-Za-z0-9_]{15,}", "e+", r"foo\w*", "[0-9A-F]{2}[0-9A-Fa-f]*", r"[a-z][0-9][A-Z]\w*"]:
+            db = engine.Database(pattern)
+            assert db.info.ends_ok, pattern
+            for variant in (DEFAULT_VARIANT, 5):
+                ctx.set_option("variant", variant)
+                starts = ctx.scan(db, data)
+                ends = ctx.last_ends(len(starts))
+                assert ends is not None and len(ends) == len(starts) and len(starts) > 0, pattern
+                asked = 0
+                for p, e in zip(starts.tolist(), ends.tolist()):
+                    want = db.match_end(data, p)
+                    if e == 0:
+                        assert want - p > 4096, (pattern, p, want)
+                        asked += 1
+                    else:
+                        assert e == want, (pattern, variant, p, e, want)
+                assert asked <= 4, (pattern, asked)
+            # a batch of segments: ends are segment-relative like the starts
+            segs = [(0, 100_000), (100_000, 1), (100_016, 250_000), (350_016, 0), (350_016, 349_985)]
+            parts = [data[o:o + ln] for o, ln in segs]
+            ctx.submit_batch(db, parts)
+            _, per, _ = ctx.wait_segs()
+            ends = ctx.last_ends(sum(len(x) for x in per))
+            assert ends is not None
+            at = 0
+            for i, part in enumerate(parts):
+                for p, e in zip(per[i].tolist(), ends[at:at + len(per[i])].tolist()):
+                    want = db.match_end(part, p)
+                    assert e == want or (e == 0 and want - p > 4096), (pattern, i, p, e, want)
+                at += len(per[i])
+        for pattern in ["foo", "[a-f]{3}", "abc[0-9]*", "(f)o+", r"\bfoo\w*", "foo|ba+"]:
+            db = engine.Database(pattern)
+            assert not db.info.ends_ok
+            starts = ctx.scan(db, data)
+            assert ctx.last_ends(len(starts)) is None, pattern
+    finally:
+        ctx.set_option("match_ends", 0)
+        ctx.set_option("variant", DEFAULT_VARIANT)

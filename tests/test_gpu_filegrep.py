@@ -249,3 +249,29 @@ def test_line_pass_equals_host_walk(built, oracle_built, tmp_path):
             assert rc == r.returncode == orc == 0, err
             assert out == r.stdout, (pattern, flags)
             assert out == oout, (pattern, flags)
+
+
+def test_offsets_without_the_text_equals_host_walk(built, oracle_built, tmp_path):
+    """-O -l with the match ends from the device (k_ends, the default: the walk never looks at the window) and with the host
+    walk over the mapped text (GRAB_NO_ENDS=1) print the same bytes, and both equal the oracle: identifiers longer than the
+    4 KiB the device follows, one across a 32 MiB chunk boundary (printed by both chunks, the second as its suffix), one
+    that runs into the end of the file, several chunks, batches of small files, -s."""
+    rng = np.random.default_rng(19)
+    buf = synth.text(70 << 20, 13)
+    buf[3_000_000:3_009_000] = ord("q")                   # a 9000-byte identifier
+    buf[(32 << 20) - 5000:(32 << 20) + 3000] = ord("k")   # one across the first 32 MiB chunk boundary (4 KiB overlap)
+    buf[-40:] = ord("w")                                  # one that ends with the file
+    (tmp_path / "d").mkdir()
+    buf.tofile(str(tmp_path / "d" / "big"))
+    for i in range(40):                                   # small files: the batched path
+        n = int(rng.integers(1, 200_000))
+        synth.text(n, 700 + i).tofile(str(tmp_path / "d" / ("s%02d" % i)))
+    for pattern in ["[A-Za-z_][A-Za-z0-9_]{15,}", r"foo\w*", "[0-9]{3}[0-9a-f]*"]:
+        for flags in (["-r", "-O", "-l"], ["-L", "-L", "-L", "-L", "-L", "-r", "-O", "-l"], ["-r", "-O", "-l", "-s"]):
+            argv = flags + [pattern, "d"]
+            rc, out, err = _run(built.bin_path(), argv, str(tmp_path))
+            r = subprocess.run([built.bin_path()] + argv, cwd=str(tmp_path), capture_output=True, env=dict(os.environ, GRAB_NO_ENDS="1"))
+            orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), argv, str(tmp_path))
+            assert rc == r.returncode == orc == 0, err
+            assert out == r.stdout, (pattern, flags)
+            assert out == oout, (pattern, flags)

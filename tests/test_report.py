@@ -180,3 +180,44 @@ def test_long_lines_all_modes_match_libpcre(built, liboracle):
                 liboracle.oracle_free(out)
                 assert filegrep.report_chunk(db, f, b"", data, 0, starts) == want, (pattern, trial, f)
 
+
+
+ENDS_OK = ["[A-Za-z_][A-Za-z0-9_]{3,}", "e+", r"foo\w*", "[a-f]{2}[a-f0-9]*", r"\d\d+", "ab[a-z_]*"]
+ENDS_NOT = ["foo", "[a-f]{3}", "abc[0-9]*", "[a-z]{2,5}", "(f)o+", r"\bfoo\w*", "0|1+", r"fo+\b"]
+
+
+def test_ends_ok_flag(built):
+    """gscan_info.ends_ok: one plain alternative, unbounded greedy tail whose class contains the window's first class --
+    the byte that stops the tail cannot begin a match."""
+    for p in ENDS_OK:
+        assert engine.Database(p).info.ends_ok, p
+    for p in ENDS_NOT:
+        assert not engine.Database(p).info.ends_ok, p
+
+
+def test_offsets_walk_without_the_text(built):
+    """-O -l with the match ends in the list (the device's k_ends pass; here gscan_match_end stands in for it): the walk's
+    output equals the reference loop's (scan_oracle.grab_file over libpcre-free `re`) WITHOUT being handed the chunk, for
+    the minimal list (group starts) and for the full candidate list, with and without a path prefix, single-match mode
+    included.  An end the device left open (0) sends that one step to gscan_next_match, which does need the text."""
+    rng = np.random.default_rng(23)
+    alphabet = np.frombuffer(b"abcdeffoo0123456789_AZ \n\n", np.uint8)
+    for pattern in ENDS_OK:
+        db = engine.Database(pattern)
+        for trial in range(8):
+            n = int(rng.integers(0, 4000))
+            data = alphabet[rng.integers(0, alphabet.size, n)]
+            cands = db_candidates(db, data)
+            for starts in (so.group_starts(cands).astype(np.uint32), cands.astype(np.uint32)):
+                ends = np.array([db.match_end(data, int(p)) for p in starts], np.uint32)
+                assert (ends > starts).all()
+                for f in (filegrep.OFFSETS | filegrep.NOLINE, filegrep.OFFSETS | filegrep.NOLINE | filegrep.PREFIX, filegrep.OFFSETS | filegrep.NOLINE | filegrep.SINGLE):
+                    want = so.grab_file(pattern, data.tobytes(), f, 1 << 30, path=b"d/f")
+                    got = filegrep.report_chunk(db, f, "d/f", None, 0, starts, ends=ends, clen=n)
+                    assert got == want, (pattern, n, f)
+                    if len(ends):  # some ends left to the host: same output, with the text at hand
+                        holes = ends.copy()
+                        holes[rng.integers(0, len(ends), max(1, len(ends) // 3))] = 0
+                        assert filegrep.report_chunk(db, f, "d/f", data, 0, starts, ends=holes) == want, (pattern, n, f)
+                # the line-printing modes ignore the ends
+                assert filegrep.report_chunk(db, filegrep.OFFSETS, "d/f", data, 0, starts, ends=ends) == so.grab_file(pattern, data.tobytes(), 1, 1 << 30)
