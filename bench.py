@@ -18,12 +18,20 @@ One JSON line on rank 0: the driver's contract fields, plus
                   launch stream, vs the 8 TB/s HBM peak
   "kernels"       the same block for the OTHER two kernels (cfg3 = BASELINE configs[2], alt), timed in the same
                   process on the same arena, outside the headline's timed region
-  "e2e"           the drop-in binary end to end (PCIe-inclusive): the same corpus written to /dev/shm once,
-                  `grab -n max(8, N) -r` over the first N devices -- one walk, one queue, files sharded over the
-                  GPUs -- wall clock of the whole process, output line count checked, fraction of the
-                  63 GB/s-per-GPU PCIe Gen5 x16 roofline, bytes each device was handed.  "scaling": "strong"
+  "e2e"           the drop-in binary end to end (PCIe-inclusive): the same corpus written to /dev/shm once (pages
+                  interleaved over the NUMA nodes), `grab -n max(8, 4 N) -r` over the first N devices -- one walk, one
+                  queue, files sharded over the GPUs -- wall clock of the whole (ONE) process, output line count
+                  checked, fraction of the 63 GB/s-per-GPU PCIe Gen5 x16 roofline, bytes each device was handed;
+                  the GRAB_DETACH=1 figure (teardown left to a child) beside it.  "scaling": "strong"
   "cpu_baseline"  the reference binary (oracle/_ref/grab_jit), or the oracle port, on this box's host cores over
-                  that same on-disk corpus (N=1, rank 0 only)
+                  that same on-disk corpus (N=1, rank 0 only): -n swept over {32, 64, 128, all}, best kept
+  "e2e_cfg3"      BASELINE configs[2] end to end: the first 16 GiB of the corpus, `grab -n 8 -r -O -l IDENT`, line
+                  count, sorted-output md5 against the reference on a 1 GiB subset, its own cpu_baseline
+  "e2e_cfg5"      BASELINE configs[4] at 8 GiB: ONE file with dense planted needles incl. every chunk-boundary
+                  case, `grab -O -l` byte-exact (md5) against the reference, its own single-core cpu_baseline
+  "roofline.traffic"  HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately, counters
+                  only) run by this script over the native harness (grab_amd/bin/gscan_sweep, same kernels, same
+                  arena size); falls back to the committed profile, labelled, if rocprofv3 cannot run
 `--mode e2e` prints only the e2e measurement as the line's value (metric "GB/s end to end").
 """
 import argparse
@@ -153,6 +161,51 @@ def measured_traffic(config, nbytes):
     return best
 
 
+def live_traffic(patterns, gib, timeout_s=90):
+    """HBM bytes per scan launch, measured NOW: two rocprofv3 passes (--pmc FETCH_SIZE / --pmc WRITE_SIZE, counters only,
+    as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over grab_amd/bin/gscan_sweep -- the native harness: the same
+    kernels through the same C ABI on an arena of the same size and text distribution, one launch per pattern after a
+    warm-up.  gfx950 correction from the same guide: FETCH_SIZE counts half the bytes of a 16 B/lane stream -> doubled.
+    Returns {pattern: {"traffic_bytes", "FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "kernel"}} or None."""
+    import csv
+    import glob
+    import tempfile
+
+    sweep = os.path.join(os.path.dirname(bin_path()), "gscan_sweep")
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not (os.path.exists(sweep) and os.path.exists(rocprof)):
+        return None
+    out = {}
+    base = tempfile.mkdtemp(prefix="grab_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(base, ctr)
+            argv = [rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sweep, "--gib", str(gib), "--iters", "1", "--variants", "-1", "--bpc", "0"]
+            for p in patterns:
+                argv += ["--pattern", p]
+            r = subprocess.run(argv, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                if "scan" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            # the sweep runs the patterns in order, each kernel twice (warm-up + 1): kernels appear in pattern order
+            names = list(per)
+            if len(names) != len(patterns):
+                return None
+            for p, k in zip(patterns, names):
+                out.setdefault(p, {"kernel": k.split("(")[0][-70:]})[ctr + "_KiB"] = sum(per[k]) / len(per[k])
+        for p in out:
+            out[p]["traffic_bytes"] = int(2 * out[p]["FETCH_SIZE_KiB"] * 1024 + out[p]["WRITE_SIZE_KiB"] * 1024)
+        return out
+    except Exception:  # (timeouts, a profiler that cannot attach: the committed profile is the fall-back)
+        return None
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
 def time_kernel(ctx, db, arena, segs, stream, nbytes, cap_per_gib, steps, warmup, device):
     """W untimed + K timed launches of one pattern over the arena; (wall seconds for K steps, records, overflow, kernel ms sum, launches, last result)."""
     ctx.set_capacity(max(1 << 16, int(cap_per_gib * nbytes / (1 << 30))))
@@ -173,11 +226,16 @@ def time_kernel(ctx, db, arena, segs, stream, nbytes, cap_per_gib, steps, warmup
     return wall, total, overflow, kern_ms, launches, res
 
 
-def roofline_block(config, nbytes, total, kern_ms, launches):
+def roofline_block(config, nbytes, total, kern_ms, launches, live=None):
     alg_bytes = nbytes + REC_BYTES * total  # per launch: every input byte once + one u32 per candidate
     kern_avg_ms = kern_ms / max(launches, 1)
     achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
-    traffic, source = measured_traffic(config, nbytes)
+    if live and live.get(CONFIGS[config][0]):
+        rec = live[CONFIGS[config][0]]
+        traffic = rec["traffic_bytes"]
+        source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this script over grab_amd/bin/gscan_sweep (same kernel %s, %d GiB arena, 2 x FETCH_SIZE + WRITE_SIZE)" % (rec["kernel"], nbytes >> 30)
+    else:
+        traffic, source = measured_traffic(config, nbytes)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": source,
             "kernel_ms": round(kern_avg_ms, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(alg_bytes)}
@@ -202,6 +260,31 @@ def e2e_dir_for(nbytes_wanted):
     return None, 0
 
 
+def interleave_page_placement():
+    """set_mempolicy(MPOL_INTERLEAVE, all online NUMA nodes) for this thread: the tmpfs pages of the corpus written next are
+    spread over the sockets.  One socket's DRAM would otherwise hold it all -- the reference, which pins thread i to CPU i,
+    then reads 38 or 57 GB/s depending on WHICH socket (profiles/r02_l_e2e_corpus_numa_node.jsonl), and on an 8-GPU node
+    half the devices would pull every byte across the socket link.  Returns the node count (0: not done)."""
+    import ctypes
+
+    try:
+        txt = open("/sys/devices/system/node/online").read().strip()
+        nodes = []
+        for part in txt.split(","):
+            lo, _, hi = part.partition("-")
+            nodes += list(range(int(lo), int(hi or lo) + 1))
+        if len(nodes) < 2:
+            return 0
+        mask = 0
+        for n in nodes:
+            mask |= 1 << n
+        words = (ctypes.c_ulong * 16)(*[(mask >> (64 * i)) & (2 ** 64 - 1) for i in range(16)])
+        rc = ctypes.CDLL(None, use_errno=True).syscall(238, 3, words, 1024)  # SYS_set_mempolicy (x86-64), MPOL_INTERLEAVE
+        return len(nodes) if rc == 0 else 0
+    except Exception:
+        return 0
+
+
 def write_corpus(arena, d, nfiles, file_bytes):
     """Files 0..nfiles-1 of the HBM arena as d/xx/fNNNN.txt (16 sub-directories: something for the walkers to share)."""
     t0 = time.perf_counter()
@@ -213,34 +296,52 @@ def write_corpus(arena, d, nfiles, file_bytes):
     return time.perf_counter() - t0
 
 
-def run_timed(argv, env, reps):
-    """One untimed pass (warms the page cache), then the min of `reps`; (seconds, stdout, stderr of the best).
+class Lines(int):
+    """Line count of an output that was not kept (run_timed(count_only=True)): answers .count(b"\\n") like the bytes would."""
+
+    def count(self, what):
+        return int(self)
+
+
+def run_timed(argv, env, reps, warm=True, count_only=False):
+    """One untimed pass (warms the page cache; warm=False: the cache is known to be warm), then the min
+    of `reps`; (seconds, stdout, stderr of the best).  count_only: stdout is not loaded (cfg3 prints gigabytes) -- the lines
+    of the last run are counted in 16 MiB pieces and returned in its place.
 
     stdout goes to a file in /dev/shm, not to a pipe: with 10^8 output lines this process's own reading (and joining) of a
     pipe is a good part of a second that has nothing to do with the program under test."""
     best = None
     out_path = "/dev/shm/grab_bench_out_%d.txt" % os.getpid()
     try:
-        for it in range(reps + 1):
+        for it in range(0 if warm else 1, reps + 1):
             with open(out_path, "wb") as out:
                 t0 = time.perf_counter()
                 r = subprocess.run(argv, stdout=out, stderr=subprocess.PIPE, env=env)
                 dt = time.perf_counter() - t0
-            with open(out_path, "rb") as f:
-                stdout = f.read()
+            stdout = b""
+            if not count_only:
+                with open(out_path, "rb") as f:
+                    stdout = f.read()
             if r.returncode != 0:
                 return None, stdout, r.stderr
             if it > 0 and (best is None or dt < best[0]):
                 best = (dt, stdout, r.stderr)
+        if count_only and best is not None:
+            n = 0
+            with open(out_path, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    n += blk.count(b"\n")
+            best = (best[0], Lines(n), best[2])
     finally:
         if os.path.exists(out_path):
             os.unlink(out_path)
     return best
 
 
-def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=2):
-    """`grab -n max(8, N) -r` over the corpus directory on the first N devices."""
-    workers = max(8, n_gpus)
+def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=2, workers=None, detached=True, count_only=False):
+    """`grab -n max(8, 4 N) -r` over the corpus directory on the first N devices (a worker submits, waits and prints in turn:
+    several per device keep its three windows in flight)."""
+    workers = max(8, 4 * n_gpus) if workers is None else workers
     allowed = len(os.sched_getaffinity(0))
     workers = max(1, min(workers, allowed))
     env = dict(os.environ, GRAB_TIMING="1")
@@ -248,13 +349,13 @@ def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=
     devs = [x for x in vis.split(",") if x] if vis else [str(i) for i in range(torch.cuda.device_count())]
     env["HIP_VISIBLE_DEVICES"] = ",".join(devs[:n_gpus])
     argv = [bin_path(), "-n", str(workers), "-r"] + flags + [pattern, d]
-    got = run_timed(argv, env, reps)
+    got = run_timed(argv, env, reps, count_only=count_only)
     if got is None or got[0] is None:
         return {"error": (got[2] if got else b"")[-300:].decode("latin-1")}
-    # The command line runs the scan in a child that hands back its status and leaves the GPU teardown (0.1 - 0.2 s) behind
-    # the caller's back (grab_cli.cc, GRAB_DETACH); the same run as ONE process is timed next to it.
-    one = run_timed(argv, dict(env, GRAB_DETACH="0"), reps)
-    one_s = one[0] if one and one[0] else None
+    # `value` is the run as ONE process, start to exit.  GRAB_DETACH=1 (opt-in) runs the scan in a child that hands back its
+    # status and leaves the GPU teardown (0.1 - 0.2 s) behind the caller's back (grab_cli.cc): timed next to it.
+    det = run_timed(argv, dict(env, GRAB_DETACH="1"), 1) if detached else None
+    det_s = det[0] if det and det[0] else None
     dt, out, err = got
     nbytes = nfiles * file_bytes
     lines = out.count(b"\n")
@@ -269,8 +370,7 @@ def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=
     scan_s = t_done - t_up if t_up is not None and t_done is not None and t_done > t_up else None
     return {"value": round(rate, 2), "unit": "GB/s", "scaling": "strong", "n_gpus": n_gpus, "workers": workers,
             "bytes": nbytes, "wall_s": round(dt, 4), "startup_s": marks.get("runtime up"),
-            "one_process_wall_s": one_s and round(one_s, 4), "one_process_GBps": one_s and round(nbytes / one_s / 1e9, 2),
-            "one_process_frac": one_s and round(nbytes / one_s / 1e9 / (PCIE_PEAK_GBPS * n_gpus), 4),
+            "detached_wall_s": det_s and round(det_s, 4), "detached_GBps": det_s and round(nbytes / det_s / 1e9, 2),
             "scan_phase_s": scan_s and round(scan_s, 4), "scan_phase_GBps": scan_s and round(nbytes / scan_s / 1e9, 2),
             "scan_phase_frac": scan_s and round(nbytes / scan_s / 1e9 / (PCIE_PEAK_GBPS * n_gpus), 4),
             "pcie_peak": PCIE_PEAK_GBPS * n_gpus, "frac": round(rate / (PCIE_PEAK_GBPS * n_gpus), 4),
@@ -278,35 +378,150 @@ def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=
             "matches_per_s": round(lines / dt, 1),
             "per_device_bytes": {str(k): v for k, v in sorted(per_dev.items())},
             "ingest": engine.ingest_info(),
-            "command": " ".join([os.path.basename(argv[0])] + argv[1:-1]) + " <dir>, wall clock of the whole process, page cache warm, min of %d" % reps}
+            "command": " ".join([os.path.basename(argv[0])] + argv[1:-1]) + " <dir>, wall clock of the whole (one) process, page cache warm, min of %d" % reps}
 
 
-def cpu_baseline(d, nfiles, file_bytes, pattern, flags):
-    """The reference (or the oracle port) on this box's host cores over the same on-disk corpus."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
-    port = os.path.join(ROOT, "oracle", "grab_oracle")
+def usable_cores():
+    """CPUs 0..k-1 this process may use: the reference pins thread i to CPU i (main.cc:200-215) and stops if that fails."""
     allowed = sorted(os.sched_getaffinity(0))
     cores = 0
-    while cores < len(allowed) and allowed[cores] == cores:  # the reference pins thread i to CPU i (main.cc:200-215)
+    while cores < len(allowed) and allowed[cores] == cores:
         cores += 1
-    cores = max(1, min(cores, 64))
+    return max(1, cores)
+
+
+def cpu_baseline(d, nfiles, file_bytes, pattern, flags, threads=None, reps=2, warm=True, count_only=False):
+    """The reference (or the oracle port) on this box's host cores over the same on-disk corpus.  threads: the -n values to
+    try (default: 32, 64, 128 and every usable core -- BASELINE.md section 3 says -n $(nproc); which count is best depends
+    on the box's sockets and SMT, so the best is reported and the others are listed)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
+    port = os.path.join(ROOT, "oracle", "grab_oracle")
+    cores = usable_cores()
     if os.path.exists(ref):
         kind, binary = "reference", ref
     elif os.path.exists(port):
         kind, binary, cores = "port", port, 1
     else:
         return None
-    argv = [binary] + (["-n", str(cores)] if cores > 1 else []) + ["-r"] + flags + [pattern, d]
-    got = run_timed(argv, None, 2)
-    if got is None or got[0] is None:
-        return None
-    dt, out, _ = got
+    if threads is None:
+        threads = sorted(set(min(t, cores) for t in (32, 64, 128, cores)))
+    if cores == 1:
+        threads = [1]
     nbytes = nfiles * file_bytes
-    return {"value": round(nbytes / dt / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": kind,
-            "sample": "%d x %d MiB files of the same corpus under %s (%.0f GiB), '%s', warm cache, min of 2" % (
-                nfiles, file_bytes >> 20, os.path.dirname(d), nbytes / (1 << 30), " ".join(os.path.basename(a) if a == binary else a for a in argv[:-1])),
-            "lines": out.count(b"\n"), "matches_per_s": round(out.count(b"\n") / dt, 1),
+    best, tried = None, {}
+    for k, t in enumerate(threads):
+        argv = [binary] + (["-n", str(t)] if t > 1 else []) + (["-r"] if os.path.isdir(d) else []) + flags + [pattern, d]
+        got = run_timed(argv, None, reps, warm=warm and k == 0, count_only=count_only)
+        if got is None or got[0] is None:
+            continue
+        dt, out, _ = got
+        tried[str(t)] = round(nbytes / dt / 1e9, 3)
+        if best is None or dt < best[0]:
+            best = (dt, out, t, argv)
+    if best is None:
+        return None
+    dt, out, t, argv = best
+    return {"value": round(nbytes / dt / 1e9, 3), "unit": "GB/s", "cores": t, "kind": kind, "GBps_by_threads": tried,
+            "sample": "%s of the same corpus under %s (%.0f GiB), '%s', warm cache, min of %d" % (
+                ("%d x %d MiB files" % (nfiles, file_bytes >> 20)) if os.path.isdir(d) else "one %d MiB file" % (nbytes >> 20),
+                os.path.dirname(d), nbytes / (1 << 30), " ".join(os.path.basename(a) if a == binary else a for a in argv[:-1]), reps),
+            "lines": out.count(b"\n"), "matches_per_s": round(out.count(b"\n") / dt, 1), "wall_s": round(dt, 4),
             "engine": "libpcre 8.39 JIT (pcre_exec); the -H hyperscan path does not exist in the mounted reference"}
+
+
+def sorted_md5(argv, env=None):
+    """(md5 of the LC_ALL=C-sorted stdout, line count): the reference's own criterion for the threaded modes (README.md:206-216)."""
+    import hashlib
+
+    p1 = subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+    p2 = subprocess.Popen(["sort", "--parallel=16", "-S", "4G"], stdin=p1.stdout, stdout=subprocess.PIPE, env=dict(os.environ, LC_ALL="C"))
+    p1.stdout.close()
+    h, n = hashlib.md5(), 0
+    for blk in iter(lambda: p2.stdout.read(1 << 24), b""):
+        h.update(blk)
+        n += blk.count(b"\n")
+    p1.wait()
+    p2.wait()
+    return (h.hexdigest(), n) if p1.returncode == 0 else (None, 0)
+
+
+def link_subset(d, dst, nfiles):
+    """dst/xx/fNNNN.txt -> hard links to the first nfiles files of the corpus (tmpfs: no bytes move)."""
+    for i in range(nfiles):
+        sub = os.path.join(dst, "%02d" % (i % 16))
+        os.makedirs(sub, exist_ok=True)
+        os.link(os.path.join(d, "%02d" % (i % 16), "f%04d.txt" % i), os.path.join(sub, "f%04d.txt" % i))
+
+
+def e2e_cfg3(d, nfiles, file_bytes, n_gpus, want_cpu):
+    """BASELINE configs[2] end to end on the first 16 GiB of the corpus: `grab -n 8 -r -O -l IDENT` (match ends from the
+    device: the walk never touches the text), sorted-output md5 against the reference on a 1 GiB subset."""
+    ident = synth.IDENT_RE
+    n16 = min(nfiles, (16 << 30) // file_bytes)
+    n1 = min(n16, max(1, (1 << 30) // file_bytes))
+    d16, d1 = d + "_cfg3", d + "_cfg3s"
+    try:
+        link_subset(d, d16, n16)
+        link_subset(d, d1, n1)
+        e = e2e_measure(d16, n16, file_bytes, ident, ["-O", "-l"], n_gpus, None, reps=2, detached=False, count_only=True)
+        e["lines_ok"] = None
+        ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
+        got = sorted_md5([bin_path(), "-n", "8", "-r", "-O", "-l", ident, d1])
+        if os.path.exists(ref):
+            want = sorted_md5([ref, "-n", str(min(64, usable_cores())), "-r", "-O", "-l", ident, d1])
+            e["parity_subset"] = {"bytes": n1 * file_bytes, "lines": got[1], "sorted_md5": got[0], "reference_sorted_md5": want[0], "same": got == want and got[0] is not None}
+        else:
+            e["parity_subset"] = {"bytes": n1 * file_bytes, "lines": got[1], "sorted_md5": got[0], "reference_sorted_md5": None, "same": None}
+        if want_cpu:
+            e["cpu_baseline"] = cpu_baseline(d16, n16, file_bytes, ident, ["-O", "-l"], threads=[usable_cores()], reps=1, warm=False, count_only=True)
+            if e["cpu_baseline"] and "value" in e:
+                e["vs_cpu_baseline"] = round(e["value"] / e["cpu_baseline"]["value"], 3)
+        return e
+    finally:
+        shutil.rmtree(d16, ignore_errors=True)
+        shutil.rmtree(d1, ignore_errors=True)
+
+
+def e2e_cfg5(base, gib, want_cpu):
+    """BASELINE configs[4] at `gib` GiB: one file, ~31 250 seeded needles per GiB + one in every 4 KiB overlap window, across
+    every chunk end, ending exactly at a chunk end, at every chunk start and in the last 18 bytes
+    (scripts/fullsize_parity.py gen_big); `grab -O -l` (1 GiB windows, dealt over the node's GPUs, printed in order)
+    byte-exact against the reference."""
+    import hashlib
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fullsize_parity
+
+    path = os.path.join(base, "cfg5.bin")
+    while gib > 1 and shutil.disk_usage(base).free < (gib << 30) * 1.2:
+        gib //= 2
+    size = gib << 30
+    try:
+        t0 = time.perf_counter()
+        plants = fullsize_parity.gen_big(path, size, 1 << 30, int(31250 * gib))
+        gen_s = time.perf_counter() - t0
+        needle = synth.NEEDLE.decode()
+        got = run_timed([bin_path(), "-O", "-l", needle, path], None, 2)
+        if got is None or got[0] is None:
+            return {"error": (got[2] if got else b"")[-300:].decode("latin-1")}
+        dt, out, _ = got
+        e = {"value": round(size / dt / 1e9, 2), "unit": "GB/s", "bytes": size, "wall_s": round(dt, 4), "frac": round(size / dt / 1e9 / PCIE_PEAK_GBPS, 4),
+             "lines": out.count(b"\n"), "plants": int(plants), "md5": hashlib.md5(out).hexdigest(), "corpus_write_s": round(gen_s, 1),
+             "command": "grab -O -l %s <one %d GiB file>, wall clock of the whole process, page cache warm, min of 2" % (needle, gib)}
+        ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
+        if os.path.exists(ref):
+            r = run_timed([ref, "-O", "-l", needle, path], None, 1, warm=False)
+            if r and r[0]:
+                e["reference_md5"] = hashlib.md5(r[1]).hexdigest()
+                e["same_as_reference"] = e["reference_md5"] == e["md5"]
+                if want_cpu:
+                    e["cpu_baseline"] = {"value": round(size / r[0] / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "reference", "wall_s": round(r[0], 4),
+                                         "sample": "the same %d GiB file, 'grab_jit -O -l %s', one thread (the reference cannot use more on one file: main.cc:167-170), warm cache, one run" % (gib, needle)}
+                    e["vs_cpu_baseline"] = round(e["value"] / e["cpu_baseline"]["value"], 3)
+        return e
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
 
 
 def main():
@@ -323,6 +538,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the other two kernels' roofline blocks")
+    ap.add_argument("--no-e2e-extra", action="store_true", help="skip the e2e_cfg3 / e2e_cfg5 blocks")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of rocprofv3 passes in this run")
     ap.add_argument("--e2e-gib", type=int, default=64, help="corpus written to /dev/shm for the end-to-end block")
     a = ap.parse_args()
 
@@ -436,6 +653,12 @@ def main():
             if not np.array_equal(ctx.dev_fetch(res, i).astype(np.int64), plants[i]):
                 check = "planted offsets differ in file %d" % i
 
+    # HBM traffic per launch, measured in this run (rank 0 of a one-GPU run; the PMC passes run the native harness next to
+    # this process: same kernels, an arena of the same size)
+    live = None
+    if rank == 0 and world == 1 and not a.no_live_traffic:
+        live = live_traffic([CONFIGS[k][0] for k in sorted(CONFIGS)], max(1, nbytes >> 30))
+
     line = None
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
@@ -454,7 +677,7 @@ def main():
             "matches_per_step": int(matches_all),
             "matches_per_s": round(matches_all / (elapsed / a.steps), 1),
             "check": check,
-            "roofline": roofline_block(a.config, nbytes, total, kern_ms, launches),
+            "roofline": roofline_block(a.config, nbytes, total, kern_ms, launches, live),
         }
 
     # the other two kernels on the same arena, same process (outside the timed region above): every rank runs them so that
@@ -467,7 +690,7 @@ def main():
             pat2, cap2 = CONFIGS[name]
             db2 = engine.Database(pat2)
             wall, tot2, ovf2, kms2, nl2, _ = time_kernel(ctx, db2, arena, segs, stream, nbytes, cap2, max(3, a.steps // 2), 1, device)
-            blk = roofline_block(name, nbytes, tot2, kms2, nl2)
+            blk = roofline_block(name, nbytes, tot2, kms2, nl2, live)
             blk.update({"pattern": pat2, "kernel": KERNEL_NAMES.get(db2.info.tier, "?"), "records_per_launch": int(tot2), "overflow": bool(ovf2),
                         "value": round(nbytes / (wall / max(3, a.steps // 2)) / 1e9, 2)})
             others[name] = blk
@@ -483,6 +706,7 @@ def main():
             if d:
                 nfiles = use // file_bytes
                 try:
+                    numa_nodes = interleave_page_placement()
                     wsec = write_corpus(arena, d, nfiles, file_bytes)
                     del arena
                     torch.cuda.empty_cache()
@@ -490,15 +714,27 @@ def main():
                     want = NEEDLES_PER_FILE * nfiles if a.config != "cfg3" else None
                     e = e2e_measure(d, nfiles, file_bytes, pattern, flags, world, want)
                     e["corpus_write_s"] = round(wsec, 1)
+                    e["corpus_pages"] = "interleaved over %d NUMA nodes" % numa_nodes if numa_nodes else "first touch (one NUMA node, or set_mempolicy unavailable)"
                     line["e2e"] = e
-                    if world == 1 and not a.no_cpu_baseline:
+                    want_cpu = world == 1 and not a.no_cpu_baseline
+                    if want_cpu:
                         line["cpu_baseline"] = cpu_baseline(d, nfiles, file_bytes, pattern, flags)
                         if line["cpu_baseline"] and "value" in e:
                             e["vs_cpu_baseline"] = round(e["value"] / line["cpu_baseline"]["value"], 3)
+                    # the other two end-to-end BASELINE configurations, each with its own parity check and CPU baseline
+                    if not a.no_e2e_extra:
+                        for key, fn in (("e2e_cfg3", lambda: e2e_cfg3(d, nfiles, file_bytes, world, want_cpu)),
+                                        ("e2e_cfg5", lambda: e2e_cfg5(d, min(8, max(2, use >> 33)), want_cpu))):
+                            try:
+                                line[key] = fn()
+                            except Exception as ex:
+                                line[key] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
                 except Exception as ex:  # (the kernel line above is the contract: whatever goes wrong out here must not lose it)
                     line.setdefault("e2e", {})["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
                 finally:
                     shutil.rmtree(d, ignore_errors=True)
+                    shutil.rmtree(d + "_cfg3", ignore_errors=True)
+                    shutil.rmtree(d + "_cfg3s", ignore_errors=True)
             else:
                 line["e2e"] = {"error": "no room in /dev/shm or /tmp"}
         barrier(world, device)

@@ -7,6 +7,7 @@
 
 #include "../../include/grab_host.h"
 #include "filegrep.h"
+#include "placement.h"
 #include "walk.h"
 
 struct grab_filegrep {
@@ -72,4 +73,38 @@ int grab_validate(const char *regex, size_t len, int literal, char *why, size_t 
     return rc;
 }
 
+
+// `grab -n workers` on a node with ndev devices (placement.h): worker i's device and its CPUs as a bitmap of bytes_each
+// bytes (bit c of byte c / 8 = CPU c).  dev_cpulists[d] / allowed are sysfs cpulist strings ("0-63,128-191"; NULL or "":
+// unknown / every CPU below 8 * bytes_each).
+int grab_place_workers_c(int workers, int ndev, const char *const *dev_cpulists, const char *allowed, const char *pin, int *devices_out,
+                         unsigned char *cpu_bits_out, size_t bytes_each)
+{
+    if (workers < 0 || ndev < 1 || !devices_out || !cpu_bits_out) return -1;
+    auto parse = [](const char *list, std::vector<int> &out) {
+        out.clear();
+        if (!list) return;
+        int cpus[4096];
+        const long n = gscan_parse_cpulist(list, cpus, 4096);
+        for (long k = 0; k < n && k < 4096; k++) out.push_back(cpus[k]);
+    };
+    std::vector<std::vector<int>> dev((size_t)ndev);
+    for (int d = 0; d < ndev; d++) parse(dev_cpulists ? dev_cpulists[d] : nullptr, dev[(size_t)d]);
+    cpu_set_t mask;
+    CPU_ZERO(&mask);
+    std::vector<int> al;
+    parse(allowed, al);
+    if (al.empty())
+        for (size_t c = 0; c < bytes_each * 8 && c < (size_t)CPU_SETSIZE; c++) CPU_SET(c, &mask);
+    for (int c : al)
+        if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &mask);
+    const std::vector<WorkerPlace> pl = grab_place_workers(workers, ndev, dev, mask, pin);
+    memset(cpu_bits_out, 0, bytes_each * (size_t)workers);
+    for (int i = 0; i < workers; i++) {
+        devices_out[i] = pl[(size_t)i].device;
+        for (size_t c = 0; c < bytes_each * 8 && c < (size_t)CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &pl[(size_t)i].cpus)) cpu_bits_out[(size_t)i * bytes_each + c / 8] |= (unsigned char)(1u << (c % 8));
+    }
+    return 0;
+}
 } // extern "C"

@@ -72,7 +72,8 @@ constexpr size_t kMaxChunk = (1ull << 30) + 4096;
 
 // ---- ingest configuration (environment, read once) ----
 //   GSCAN_BLOCK_MIB     pinned pool block == read piece == one hipMemcpyAsync == batch buffer        (default 16)
-//   GSCAN_READERS       reader threads per device                                                   (default 8)
+//   GSCAN_READERS       reader threads per device; 0 or unset = auto: 8, fewer when the device's NUMA node has few CPUs per
+//                       device (gscan_auto_readers: 8 GPUs x 8 readers must not outnumber the CPUs they are bound to)   (default auto)
 //   GSCAN_COPY_STREAMS  copy streams per context the pieces of a file range are spread over         (default 1)
 //   GSCAN_NUMA          0: readers inherit the process's CPU mask; else the CPUs local to the device (default 1)
 // and, measured and left off: GSCAN_SHARED_COPY (device-wide copy streams), GSCAN_SLAB (one pinned allocation),
@@ -108,7 +109,7 @@ const IngestCfg &ingest_cfg()
             return std::max(lo, std::min(hi, x));
         };
         v.block = (size_t)env("GSCAN_BLOCK_MIB", 16, 1, 64) << 20;
-        v.readers = (int)env("GSCAN_READERS", 8, 1, 64);
+        v.readers = (int)env("GSCAN_READERS", 0, 0, 64); // 0: auto, per device (Ingest's constructor)
         const long hw = (long)std::thread::hardware_concurrency();
         if (hw > 0 && v.readers > hw) v.readers = (int)hw;
         v.copy_streams = (int)env("GSCAN_COPY_STREAMS", 1, 1, 4);
@@ -287,7 +288,6 @@ private:
     explicit Ingest(int device) : device_(device)
     {
         readers_ = ingest_cfg().readers;
-        cap_ = (size_t)readers_ * 2;
         // Where the readers run: on the CPUs of the device's NUMA node (the pinned blocks are first touched by them, and the
         // page cache -> pinned copy is the host's share of every byte), as far as the process is allowed there.  Without
         // that information: the process's own mask.
@@ -312,6 +312,19 @@ private:
                 }
             }
         }
+        if (readers_ <= 0) { // auto: as many as the CPUs this device can count on allow
+            int sharing = 1, ndev = 0;
+            char mine[1024], other[1024];
+            if (numa_cpus_ > 0 && device_cpulist(device, mine, sizeof mine) > 0 && hipGetDeviceCount(&ndev) == hipSuccess) {
+                sharing = 0;
+                for (int d = 0; d < ndev; d++)
+                    if (d == device || (device_cpulist(d, other, sizeof other) > 0 && !strcmp(mine, other))) sharing++;
+            }
+            int cpus = numa_cpus_;
+            if (cpus <= 0) cpus = have_mask_ ? CPU_COUNT(&mask_) : (int)std::thread::hardware_concurrency();
+            readers_ = gscan_auto_readers(cpus, std::max(1, sharing));
+        }
+        cap_ = (size_t)readers_ * 2;
         timing_ = getenv("GSCAN_TIMING") != nullptr;
     }
     ~Ingest()
@@ -547,12 +560,17 @@ struct Slot {
     unsigned long long *h_desc = nullptr; // pinned
     size_t h_desc_cap = 0;
     uint32_t *h_spec = nullptr; // pinned, kShards rows of kSpecPer
-    std::vector<uint32_t> raw, sorted;
+    std::vector<uint32_t> sorted;
+    // dense results (some shard holds more than kSpecPer records): the used part of every shard region, fetched into PINNED
+    // memory with one strided DMA each for records and extras (a pageable destination made the runtime stage 64 short rows
+    // one by one: ~1.5 ms per copy, a tenth of a second per worker on cfg3's 16 GiB)
+    uint32_t *h_dense = nullptr;
+    size_t dense_cap = 0; // words
     // per-record extras, parallel to the records: line extents (k_lines, 3 words each) or match ends (k_ends, 1 word)
     uint32_t *d_ext = nullptr;
     size_t ext_cap = 0;          // records
     uint32_t *h_ext_spec = nullptr; // pinned, kShards rows of kSpecPer * 3
-    std::vector<uint32_t> raw_ext, sorted_ext;
+    std::vector<uint32_t> sorted_ext;
     bool has_ext = false;
     uint32_t ext_words = 0;     // 3: {m1, lb, le} per record ("line_extents"), 1: the match end ("match_ends"), 0: none
     const void *ext = nullptr;  // caller's buffer this chunk was copied from (gscan_wait hands it back as *content)
@@ -839,6 +857,7 @@ void free_slot(gscan_ctx *c, Slot &s)
     if (s.h_tiles) hipHostFree(s.h_tiles);
     if (s.d_ext) hipFree(s.d_ext);
     if (s.h_ext_spec) hipHostFree(s.h_ext_spec);
+    if (s.h_dense) hipHostFree(s.h_dense);
     if (s.pinned) hipHostFree(s.pinned);
     if (s.d_text) hipFree(s.d_text);
     if (s.d_recs) hipFree(s.d_recs);
@@ -932,6 +951,8 @@ int gscan_db_info(const gscan_db *db, gscan_info *info)
     info->n_alts = (int)d.alts.size();
     info->has_context = (d.dev_pre ? 1 : 0) | (d.dev_post ? 2 : 0);
     info->lines_ok = (int)d.prog.lines_ok;
+    info->gapped = 0;
+    for (const gscan::AltSeq &a : d.alts) info->gapped += a.gapped ? 1 : 0;
     info->ends_ok = (int)d.prog.ends_ok;
     info->exact = d.exact ? 1 : 0;
     info->vm = d.prog.vm_filter ? 1 : 0;
@@ -1128,10 +1149,20 @@ int gscan_acquire(gscan_ctx *c, size_t len, void **pinned)
 
 size_t gscan_block_size(void) { return block_bytes(); }
 
+// Reader threads for one device whose NUMA node offers `local_cpus` CPUs to this process and is shared by `devices_sharing`
+// devices: 8 where there are CPUs to spare (the measured optimum on a one-GPU box: more of them only wait for blocks), half
+// of the device's share of the node otherwise -- the other half is the workers' (report walk, batch reads) -- never below 2.
+int gscan_auto_readers(int local_cpus, int devices_sharing)
+{
+    if (local_cpus <= 0) return 8;
+    const int share = local_cpus / std::max(1, devices_sharing);
+    return std::max(2, std::min(8, share / 2));
+}
+
 void gscan_ingest_info(size_t *block_bytes_out, int *readers, int *copy_streams)
 {
     if (block_bytes_out) *block_bytes_out = ingest_cfg().block;
-    if (readers) *readers = ingest_cfg().readers;
+    if (readers) *readers = ingest_cfg().readers; // (0: auto -- gscan_auto_readers per device)
     if (copy_streams) *copy_streams = ingest_cfg().shared_copy > 0 ? ingest_cfg().shared_copy : ingest_cfg().copy_streams;
 }
 
@@ -1369,14 +1400,26 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     }
     size_t fullest = 0;
     for (size_t k = 0; k < K; k++) fullest = std::max<size_t>(fullest, s->h_counter[k * kCS]);
-    if (!spec_ok) { // dense result: the used part of every shard region in ONE strided copy (descriptors deal the shards round robin: they fill evenly)
-        s->raw.resize(s->rec_cap);
-        HIPCHK(c, hipMemcpy2D(s->raw.data(), cap_shard * 4, s->d_recs, cap_shard * 4, fullest * 4, K, hipMemcpyDeviceToHost));
-    }
     const size_t ew = s->ext_words;
-    if (s->has_ext && !spec_ok) {
-        s->raw_ext.resize(s->rec_cap * ew);
-        HIPCHK(c, hipMemcpy2D(s->raw_ext.data(), cap_shard * 4 * ew, s->d_ext, cap_shard * 4 * ew, fullest * 4 * ew, K, hipMemcpyDeviceToHost));
+    const uint32_t *dense = nullptr, *dense_ext = nullptr; // [K][fullest] records, [K][fullest * ew] extras
+    if (!spec_ok) { // dense result: the used part of every shard region in ONE strided copy (descriptors deal the shards round robin: they fill evenly)
+        const size_t need = K * fullest * (1 + (s->has_ext ? ew : 0));
+        if (need > s->dense_cap) {
+            if (s->h_dense) hipHostFree(s->h_dense);
+            s->h_dense = nullptr;
+            s->dense_cap = 0;
+            const size_t cap = need + need / 2;
+            HIPCHK(c, hipHostMalloc((void **)&s->h_dense, cap * 4, hipHostMallocDefault));
+            s->dense_cap = cap;
+        }
+        HIPCHK(c, hipMemcpy2DAsync(s->h_dense, fullest * 4, s->d_recs, cap_shard * 4, fullest * 4, K, hipMemcpyDeviceToHost, c->compute));
+        dense = s->h_dense;
+        if (s->has_ext) {
+            HIPCHK(c, hipMemcpy2DAsync(s->h_dense + K * fullest, fullest * 4 * ew, s->d_ext, cap_shard * 4 * ew, fullest * 4 * ew, K, hipMemcpyDeviceToHost, c->compute));
+            dense_ext = s->h_dense + K * fullest;
+        }
+        HIPCHK(c, hipEventRecord(s->done, c->compute));
+        HIPCHK(c, hipEventSynchronize(s->done));
     }
     s->sorted_ext.clear();
     if (s->has_ext) s->sorted_ext.reserve(total * ew);
@@ -1395,10 +1438,10 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
         uint32_t cnt = (uint32_t)d;
         size_t base = (size_t)(d >> 32);
         if (!cnt) continue;
-        const uint32_t *src = spec_ok ? s->h_spec + (base / cap_shard) * kSpecPer + base % cap_shard : s->raw.data() + base;
+        const uint32_t *src = spec_ok ? s->h_spec + (base / cap_shard) * kSpecPer + base % cap_shard : dense + (base / cap_shard) * fullest + base % cap_shard;
         const uint32_t *ex = !s->has_ext ? nullptr
                              : spec_ok   ? s->h_ext_spec + ((base / cap_shard) * kSpecPer + base % cap_shard) * ew
-                                         : s->raw_ext.data() + base * ew;
+                                         : dense_ext + ((base / cap_shard) * fullest + base % cap_shard) * ew;
         if (struck == 0) {
             s->sorted.insert(s->sorted.end(), src, src + cnt);
             if (ex) s->sorted_ext.insert(s->sorted_ext.end(), ex, ex + (size_t)cnt * ew);

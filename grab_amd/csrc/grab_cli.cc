@@ -20,6 +20,7 @@
 #include <pthread.h>
 #include <sched.h>
 #include <signal.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -43,6 +44,7 @@
 #include <fstream>
 
 #include "filegrep.h"
+#include "placement.h"
 #include "walk.h"
 
 namespace {
@@ -163,30 +165,18 @@ private:
     bool closed_ = false, abandoned_ = false;
 };
 
-// The CPUs worker i may run on: those local to its device (i mod #devices), as far as the process is allowed there --
-// the worker's batch reads go into pinned blocks it touches first, and its share of the report walks the page cache, so
-// it belongs next to the PCIe root of its GPU.  The reference pins thread i to CPU i (main.cc:200-215):
-// on a two-socket node that puts the first 8 workers on one socket whatever the devices are.  GRAB_PIN=cpu restores it.
-cpu_set_t worker_cpus(int worker, int device, const cpu_set_t &allowed)
+// the CPUs local to every device (sysfs local_cpulist of its PCI function; empty where that is unknown)
+std::vector<std::vector<int>> device_cpu_lists(int ndev)
 {
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    const char *pin = getenv("GRAB_PIN");
-    if (pin && !strcmp(pin, "cpu")) {
-        CPU_SET(worker, &set);
-        return set;
+    std::vector<std::vector<int>> out((size_t)ndev);
+    for (int d = 0; d < ndev; d++) {
+        char list[1024];
+        int cpus[1024];
+        if (gscan_device_cpulist(d, list, sizeof list) <= 0) continue;
+        const long n = gscan_parse_cpulist(list, cpus, 1024);
+        for (long k = 0; k < n && k < 1024; k++) out[(size_t)d].push_back(cpus[k]);
     }
-    char list[1024];
-    int cpus[1024];
-    long n = 0;
-    if (!(pin && !strcmp(pin, "none")) && gscan_device_cpulist(device, list, sizeof list) > 0) n = gscan_parse_cpulist(list, cpus, 1024);
-    int got = 0;
-    for (long k = 0; k < n && k < 1024; k++)
-        if (cpus[k] < CPU_SETSIZE && CPU_ISSET(cpus[k], &allowed)) {
-            CPU_SET(cpus[k], &set);
-            got++;
-        }
-    return got ? set : allowed;
+    return out;
 }
 
 int run_workers(const Options &o)
@@ -207,15 +197,33 @@ int run_workers(const Options &o)
             return -1;
         }
     }
-    // more threads than CPUs is fatal in the reference (pthread_setaffinity_np on CPU i fails, main.cc:211-215)
+    // More threads than CPUs is fatal in the reference: it pins thread i to CPU i and pthread_setaffinity_np fails for a CPU
+    // that is offline or outside the process's cpuset (main.cc:211-215).  It does NOT fail for a CPU that an inherited mask
+    // merely leaves out (`taskset -c 8-15 grab -n 4 ...` runs): so the same call is made, on a scratch thread, and only its
+    // verdict counts.  The workers themselves are bound to their device's NUMA node below (GRAB_PIN=cpu: to CPU i).
     cpu_set_t allowed;
     CPU_ZERO(&allowed);
     sched_getaffinity(0, sizeof allowed, &allowed);
-    for (int i = 0; i < o.workers; i++)
-        if (i >= CPU_SETSIZE || !CPU_ISSET(i, &allowed)) {
-            std::cerr << "pthread_setaffinity_np:" << strerror(EINVAL) << " (more threads than cores?)" << std::endl;
+    {
+        int bad = 0;
+        std::thread probe([&] {
+            for (int i = 0; i < o.workers && !bad; i++) {
+                cpu_set_t one;
+                CPU_ZERO(&one);
+                if (i >= CPU_SETSIZE) {
+                    bad = EINVAL;
+                    break;
+                }
+                CPU_SET(i, &one);
+                bad = pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+            }
+        });
+        probe.join();
+        if (bad) {
+            std::cerr << "pthread_setaffinity_np:" << strerror(bad) << " (more threads than cores?)" << std::endl;
             return -1;
         }
+    }
 
     JobQueue queue;
     // the walk starts at once, on its own threads; the workers open their devices meanwhile
@@ -233,9 +241,10 @@ int run_workers(const Options &o)
     std::mutex err_lock;
     std::string first_error;
     std::vector<std::thread> pool;
+    const std::vector<WorkerPlace> places = grab_place_workers(o.workers, ndev, device_cpu_lists(ndev), allowed, getenv("GRAB_PIN"));
     for (int i = 0; i < o.workers; i++) {
-        const int device = i % ndev;
-        const cpu_set_t cpus = worker_cpus(i, device, allowed);
+        const int device = places[(size_t)i].device;
+        const cpu_set_t cpus = places[(size_t)i].cpus;
         pool.emplace_back([&, device, cpus, i] {
             (void)pthread_setaffinity_np(pthread_self(), sizeof cpus, &cpus);
             // one per thread, like the reference (main.cc:195-199); the context is opened by the thread that uses it.  It is
@@ -321,6 +330,15 @@ int run_serial(const Options &o)
     return 0;
 }
 
+// GRAB_DETACH=1: the parent of the scanning child passes a terminating signal on and then takes it itself
+volatile pid_t g_child = 0;
+void forward_signal(int sig)
+{
+    if (g_child > 0) kill(g_child, sig);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 } // namespace
 
 int main(int argc, char **argv)
@@ -328,17 +346,28 @@ int main(int argc, char **argv)
     mark("main");
     const Options o = parse(argc, argv);
     // Taking the process's GPU state apart costs the kernel 0.1 - 0.2 s at exit (profiles/r02_o_exit_cost_and_open_order.txt),
-    // after the last byte of output.  The scan therefore runs in a child: when it has printed everything it closes its
-    // output, hands its exit status over a pipe and leaves; the parent returns that status at once and the child's
-    // teardown goes on behind the caller's back.  (GRAB_DETACH=0: one process, as before.  The fork comes before the first
-    // HIP call: the runtime is not up yet and there is one thread.)
+    // after the last byte of output.  GRAB_DETACH=1 (opt-in; round 2 had it on by default) runs the scan in a child: when it
+    // has printed everything it closes its output, hands its exit status over a pipe and leaves; the parent returns that
+    // status at once and the child's teardown goes on behind the caller's back.  The fork comes before the first HIP call:
+    // the runtime is not up yet and there is one thread.  The pair still behaves like ONE process towards the outside: a
+    // signal that reaches the parent (SIGINT, SIGTERM, SIGHUP, SIGQUIT) is passed on to the child before the parent takes
+    // it itself, and the child asks the kernel for SIGKILL should the parent disappear in any other way -- no orphan keeps
+    // scanning, writing to the caller's stdout or holding the GPUs.
     int status_fd = -1;
-    if (!getenv("GRAB_DETACH") || atoi(getenv("GRAB_DETACH")) != 0) {
+    if (getenv("GRAB_DETACH") && atoi(getenv("GRAB_DETACH")) != 0) {
         int pfd[2];
         if (pipe(pfd) == 0) {
+            const pid_t parent = getpid();
             const pid_t child = fork();
             if (child > 0) {
                 close(pfd[1]);
+                g_child = child;
+                for (int sig : {SIGINT, SIGTERM, SIGHUP, SIGQUIT}) {
+                    struct sigaction sa;
+                    memset(&sa, 0, sizeof sa);
+                    sa.sa_handler = forward_signal;
+                    sigaction(sig, &sa, nullptr);
+                }
                 int rc = 0;
                 ssize_t got;
                 do got = read(pfd[0], &rc, sizeof rc);
@@ -355,6 +384,8 @@ int main(int argc, char **argv)
             if (child == 0) {
                 close(pfd[0]);
                 status_fd = pfd[1];
+                prctl(PR_SET_PDEATHSIG, SIGKILL);
+                if (getppid() != parent) _exit(255); // (the parent went away between fork and prctl)
             } else { // no fork: carry on in this process
                 close(pfd[0]);
                 close(pfd[1]);

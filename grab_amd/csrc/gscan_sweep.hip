@@ -1,6 +1,7 @@
 // gscan_sweep.hip -- native A/B harness for the scan kernels (no Python, no torch).
 //
-//   gscan_sweep [--gib G] [--seg-mib M] [--pattern P] [--iters N] [--variants 0,1,2,4,5,6] [--bpc 0,4,8,16]
+//   gscan_sweep [--gib G] [--seg-mib M] [--pattern P]... [--iters N] [--variants 0,1,2,4,5,6,38] [--bpc 0,4,8,16]
+//   (--pattern may be given several times: the patterns run one after the other on the same arena; variant -1 = the engine's default)
 //
 // Fills a G GiB arena in HBM with synthetic text (57-symbol alphabet, SURVEY.md 8d
 // distribution, xorshift stream), splits it into M MiB segments, and for every
@@ -81,7 +82,7 @@ int main(int argc, char **argv)
 {
     double gib = 8;
     int seg_mib = 64, iters = 10;
-    std::string pattern = "foobardoesnotexist";
+    std::vector<std::string> patterns;
     std::vector<long> variants = {0, 1, 2, 4, 5, 6}, bpcs = {0, 8};
     int plant_every_mib = 1;
     bool ceiling = false;
@@ -89,7 +90,7 @@ int main(int argc, char **argv)
         auto is = [&](const char *f) { return !strcmp(argv[i], f) && i + 1 < argc; };
         if (is("--gib")) gib = atof(argv[++i]);
         else if (is("--seg-mib")) seg_mib = atoi(argv[++i]);
-        else if (is("--pattern")) pattern = argv[++i];
+        else if (is("--pattern")) patterns.push_back(argv[++i]);
         else if (is("--iters")) iters = atoi(argv[++i]);
         else if (is("--variants")) variants = parse_list(argv[++i]);
         else if (is("--bpc")) bpcs = parse_list(argv[++i]);
@@ -97,6 +98,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--ceiling")) ceiling = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
+    if (patterns.empty()) patterns.push_back("foobardoesnotexist");
     const size_t seg_bytes = (size_t)seg_mib << 20;
     const size_t nseg = (size_t)(gib * 1024 / seg_mib);
     const size_t total = nseg * seg_bytes;
@@ -142,41 +144,43 @@ int main(int argc, char **argv)
 
     gscan_ctx *ctx = nullptr;
     if (gscan_open(0, 1u << 30, &ctx) != GSCAN_OK) { fprintf(stderr, "gscan_open failed\n"); return 1; }
-    gscan_db *db = nullptr;
-    char err[128];
-    int minlen = 0;
-    if (gscan_compile(pattern.data(), pattern.size(), 0, &db, &minlen, err, sizeof err) != GSCAN_OK) { fprintf(stderr, "compile: %s\n", err); return 1; }
-    gscan_info info;
-    gscan_db_info(db, &info);
     std::vector<gscan_seg> segs(nseg);
     for (size_t s = 0; s < nseg; s++) segs[s] = {s * seg_bytes, (uint32_t)seg_bytes, 0};
     gscan_set_capacity(ctx, 1u << 28);
+    for (const std::string &pattern : patterns) {
+        gscan_db *db = nullptr;
+        char err[128];
+        int minlen = 0;
+        if (gscan_compile(pattern.data(), pattern.size(), 0, &db, &minlen, err, sizeof err) != GSCAN_OK) { fprintf(stderr, "compile: %s\n", err); return 1; }
+        gscan_info info;
+        gscan_db_info(db, &info);
 
-    struct Cell { long variant, bpc; double sum = 0, best = 1e30; int n = 0; uint64_t matches = 0; };
-    std::vector<Cell> cells;
-    for (long v : variants) for (long b : bpcs) { Cell c; c.variant = v; c.bpc = b; cells.push_back(c); }
-    printf("# arena %.2f GiB in %zu x %d MiB segments, pattern '%s' (tier %d, minlen %d), %d iters\n", total / 1073741824.0, nseg, seg_mib, pattern.c_str(), info.tier, minlen, iters);
-    for (int it = -1; it < iters; it++) { // it == -1: warm-up round
-        for (Cell &c : cells) {
-            gscan_set_option(ctx, "variant", c.variant);
-            gscan_set_option(ctx, "blocks_per_cu", c.bpc);
-            gscan_dev_result res;
-            int rc = gscan_scan_device(ctx, db, arena, segs.data(), nseg, nullptr, &res);
-            if (rc != GSCAN_OK) { fprintf(stderr, "scan failed: %s\n", gscan_strerror(ctx)); return 1; }
-            gscan_dev_sync(ctx, &res);
-            double ms = 0; uint64_t n = 0;
-            gscan_kernel_time(ctx, &ms, &n, 1);
-            if (it >= 0) { c.sum += ms; c.best = ms < c.best ? ms : c.best; c.n++; }
-            c.matches = res.total;
-            if (res.overflow) fprintf(stderr, "overflow (total %llu)\n", (unsigned long long)res.total);
+        struct Cell { long variant, bpc; double sum = 0, best = 1e30; int n = 0; uint64_t matches = 0; };
+        std::vector<Cell> cells;
+        for (long v : variants) for (long b : bpcs) { Cell c; c.variant = v; c.bpc = b; cells.push_back(c); }
+        printf("# arena %.2f GiB in %zu x %d MiB segments, pattern '%s' (tier %d, minlen %d), %d iters\n", total / 1073741824.0, nseg, seg_mib, pattern.c_str(), info.tier, minlen, iters);
+        for (int it = -1; it < iters; it++) { // it == -1: warm-up round
+            for (Cell &c : cells) {
+                if (c.variant >= 0) gscan_set_option(ctx, "variant", c.variant);
+                gscan_set_option(ctx, "blocks_per_cu", c.bpc);
+                gscan_dev_result res;
+                int rc = gscan_scan_device(ctx, db, arena, segs.data(), nseg, nullptr, &res);
+                if (rc != GSCAN_OK) { fprintf(stderr, "scan failed: %s\n", gscan_strerror(ctx)); return 1; }
+                gscan_dev_sync(ctx, &res);
+                double ms = 0; uint64_t n = 0;
+                gscan_kernel_time(ctx, &ms, &n, 1);
+                if (it >= 0) { c.sum += ms; c.best = ms < c.best ? ms : c.best; c.n++; }
+                c.matches = res.total;
+                if (res.overflow) fprintf(stderr, "overflow (total %llu)\n", (unsigned long long)res.total);
+            }
         }
+        for (const Cell &c : cells) {
+            const double bytes = (double)total + 4.0 * c.matches;
+            printf("variant %ld bpc %2ld : mean %8.3f ms  min %8.3f ms  -> %8.1f GB/s mean, %8.1f GB/s best   matches %llu\n", c.variant, c.bpc,
+                   c.sum / c.n, c.best, bytes / (c.sum / c.n) / 1e6, bytes / c.best / 1e6, (unsigned long long)c.matches);
+        }
+        gscan_free(db);
     }
-    for (const Cell &c : cells) {
-        const double bytes = (double)total + 4.0 * c.matches;
-        printf("variant %ld bpc %2ld : mean %8.3f ms  min %8.3f ms  -> %8.1f GB/s mean, %8.1f GB/s best   matches %llu\n", c.variant, c.bpc,
-               c.sum / c.n, c.best, bytes / (c.sum / c.n) / 1e6, bytes / c.best / 1e6, (unsigned long long)c.matches);
-    }
-    gscan_free(db);
     gscan_close(ctx);
     (void)hipFree(arena);
     return 0;

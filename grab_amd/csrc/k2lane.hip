@@ -22,8 +22,7 @@
 //     the epilogue, on the transposed masks, 32 positions per operation;
 //   * the per-step candidate mask goes straight into the wave's LDS strip (one ds_write_b16, no VALU): the epilogue
 //     reads it back transposed -- lane L owns 192 consecutive text positions -- masks, suppresses, counts, reserves its
-//     run with one atomic per wave and writes the records through a buffer descriptor (out-of-range stores are dropped by
-//     the hardware: an overflowing shard cannot write past its region).
+//     run with one atomic per wave and writes its records (scalar base + one 32-bit offset per lane).
 #include "kcommon.h"
 
 namespace gscan {
@@ -80,6 +79,53 @@ __device__ __forceinline__ uint32_t lane_run(uint32_t x, uint32_t d)
     if (S >= 4) x &= x >> ((d >> 22) & 31u);
     if (S >= 5) x &= x >> ((d >> 27) & 31u);
     return x >> ((d >> 2) & 31u);
+}
+
+// A tile's segment as four scalars (the software-pipelined tile loop carries the next tile's from one pass to the next; a
+// TileCtx with its opaque buffer descriptor went through scratch memory there).  The 16-byte descriptor comes in with ONE
+// scalar load -- the table is written by the host before the launch and never by a kernel, so the scalar cache is safe; left
+// to itself the compiler used two dependent vector loads here, each behind an s_waitcnt vmcnt(0), once per tile.
+struct TileS {
+    uint32_t alo, ahi; // segment base address
+    uint32_t len;      // segment length
+    int toff;          // first byte of the tile inside the segment
+};
+
+__device__ __forceinline__ TileS tile_scalars(const ScanArgs &a, const TileDesc *__restrict__ tiles, uint32_t t, uint32_t tile_bytes)
+{
+    uint64_t seg_off;
+    TileS r;
+    if (tiles) {
+        u32x4 d; // {seg_off lo, seg_off hi, seg_len, tile_off}
+        const TileDesc *p = tiles + t;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(d) : "s"(p));
+        seg_off = (uint64_t)d.x | ((uint64_t)d.y << 32);
+        r.len = d.z;
+        r.toff = (int)d.w;
+    } else {
+        seg_off = a.seg0_off;
+        r.len = a.seg0_len;
+        r.toff = (int)(t * tile_bytes);
+    }
+    const uint64_t addr = (uint64_t)a.base + seg_off;
+    r.alo = __builtin_amdgcn_readfirstlane((uint32_t)addr);
+    r.ahi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+    r.len = __builtin_amdgcn_readfirstlane(r.len);
+    r.toff = (int)__builtin_amdgcn_readfirstlane((uint32_t)r.toff);
+    return r;
+}
+
+// the wave's ITER + 1 loads of one sub-tile (the last one the halo: lane 0 only); valid == false: the same loads, far out
+// of range -- zeros, no memory traffic
+template <int ITER>
+__device__ __forceinline__ void lane_loads(u32x4 (&buf)[ITER + 1], const TileS &s, int sub_off, uint32_t lane, bool valid)
+{
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)s.ahi << 32) | s.alo), 0, (int)((s.len + 15u) & ~15u), 0x00020000);
+    const int v0 = valid ? sub_off + (int)lane * 16 : 0x7ffffff0;
+#pragma unroll
+    for (int k = 0; k < ITER; k++) buf[k] = load16<true>(rsrc, valid ? v0 + k * 1024 : 0x7ffffff0);
+    buf[ITER] = load16<false>(rsrc, valid && lane == 0 ? v0 + ITER * 1024 : 0x7ffffff0);
 }
 
 // Epilogue of one wave's sub-tile: xp = the wave's strip, xp[k * 64 + lane] = step k's 16-bit candidate mask of `lane`,
@@ -153,16 +199,21 @@ __device__ __forceinline__ void lane_emit(const ScanArgs &a, uint32_t d, int sub
     }
 }
 
-// NCLS: 2 or 4 (table entry layout).  NR: runs of the program -- 1 or 2: exactly that many, S0 / S1 doubling steps
-// each, everything about them wave-uniform and decoded before the tile loop; 0: any number, five steps each (zero
-// shifts where a run needs fewer), one v_readlane per run and step.
+// NCLS: 2 or 4 (table entry layout).  NR: runs of the program -- 1 or 2 (two classes): exactly that many, S0 / S1
+// doubling steps each; 3 or 4: exactly that many, every run S0 steps (the longest run's count; zero shifts where a run
+// needs fewer) -- everything about them wave-uniform and decoded before the tile loop; 0: any number, five steps each,
+// one v_readlane per run and step.
+// The tile loop is software-pipelined by one tile: the NEXT tile's text is requested between this tile's last step and
+// its epilogue, so the loads are in flight while the wave counts, reserves (one returning atomic) and writes its records
+// -- the epilogue's latency and the next tile's HBM latency overlap instead of adding up.  The loads are issued on every
+// path (far out of range -- zeros, no traffic -- when there is no next tile or none of it is this wave's).
 template <int NCLS, int NR, int S0, int S1>
 __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     constexpr int ITER = kLIter;
     constexpr uint32_t kTile = kLNW * ITER * 1024;
     static_assert(NCLS == 2 || NCLS == 4, "two entry layouts");
-    static_assert(NR == 0 || NCLS == 2, "the specialised run programs are the two-class form's");
+    static_assert(NR == 0 || NR >= 3 || NCLS == 2, "one- and two-run programs have at most two classes");
     __shared__ uint32_t tbl[65536 / 4];
     __shared__ __attribute__((aligned(8))) uint16_t s_xp[kLNW * ITER * 64];
     const uint32_t lane = lane_id();
@@ -182,8 +233,13 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
     const uint32_t lc = l4 | ((l4 | 2u) << 8) | ((l4 | 128u) << 16) | ((l4 | 130u) << 24);
     // the run program: lane r of one VGPR holds descriptor r
     const uint32_t vrl = a.run_lane[lane & (kK2MaxRuns - 1)];
-    const uint32_t rd0 = __builtin_amdgcn_readlane(vrl, 0), rd1 = __builtin_amdgcn_readlane(vrl, 1);
-    const uint32_t sel0 = (rd0 & 1u) ? 0x07060302u : 0x05040100u, sel1 = (rd1 & 1u) ? 0x07060302u : 0x05040100u;
+    uint32_t rd[4], sel[4]; // the first four descriptors and the byte selectors that pick their class's half of the masks
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        rd[r] = __builtin_amdgcn_readlane(vrl, r);
+        sel[r] = (rd[r] & 1u) ? 0x07060302u : 0x05040100u;
+    }
+    const uint32_t rd0 = rd[0], rd1 = rd[1], sel0 = sel[0], sel1 = sel[1];
     const uint32_t nruns = a.nruns;
     __syncthreads();
 
@@ -202,48 +258,78 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
         else lane_merge4(e, p01_, p23_);                        \
     } while (0)
 
-    for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-        const TileCtx c = tile_ctx(a, tiles, t, kTile);
-        const int sub_off = c.tile_off + (int)(wave * ITER * 1024);
+    uint32_t t = blockIdx.x;
+    if (t >= a.n_tiles) return;
+    TileS c = tile_scalars(a, tiles, t, kTile);
+    int sub_off = c.toff + (int)(wave * ITER * 1024);
+    bool have = c.len >= a.m && sub_off < (int)c.len; // some of this tile is this wave's (wave-uniform)
+    u32x4 buf[ITER + 1];
+    lane_loads<ITER>(buf, c, sub_off, lane, have);
+    uint16_t *xp = s_xp + wave * (ITER * 64);
+    for (;;) {
+        const uint32_t tn = t + gridDim.x;
+        const bool next = tn < a.n_tiles;
+        TileS cn = c;
+        int sub_off_n = 0;
+        bool have_n = false;
+        if (next) {
+            cn = tile_scalars(a, tiles, tn, kTile);
+            sub_off_n = cn.toff + (int)(wave * ITER * 1024);
+            have_n = cn.len >= a.m && sub_off_n < (int)cn.len;
+        }
         const uint32_t d = t * kLNW + wave;
-        if (!(c.live && sub_off < c.slen)) { // nothing of this tile is this wave's (wave-uniform)
-            if (lane == 0) a.desc[d] = 0ull;
-            continue;
-        }
-        u32x4 buf[ITER + 1];
-        load_subtile<ITER, true, 1>(buf, c, sub_off, lane);
-        uint16_t *xp = s_xp + wave * (ITER * 64);
-        uint32_t e[16];
-        uint32_t pa, qa, pb, qb; // class masks of step k (pa, qa) and of step k + 1 (pb, qb)
-        GL_LOOKUPS(buf[0]);
-        GL_MERGE(pa, qa);
-        GL_LOOKUPS(buf[1]);
+        if (have) {
+            uint32_t e[16];
+            uint32_t pa, qa, pb, qb; // class masks of step k (pa, qa) and of step k + 1 (pb, qb)
+            GL_LOOKUPS(buf[0]);
+            GL_MERGE(pa, qa);
+            GL_LOOKUPS(buf[1]);
 #pragma unroll
-        for (int k = 0; k < ITER; k++) {
-            GL_MERGE(pb, qb);                        // step k + 1 (k + 1 == ITER: the halo; only lane 0 of it is looked at)
-            if (k + 2 <= ITER) GL_LOOKUPS(buf[k + 2]); // in flight while step k is computed
-            // the next lane's masks (lane 63: lane 0 of the next step)
-            const uint32_t a01 = down1(pa, __builtin_amdgcn_readfirstlane(pb));
-            uint32_t cand;
-            if (NR == 1) {
-                cand = lane_run<S0>(__builtin_amdgcn_perm(a01, pa, sel0), rd0);
-            } else if (NR == 2) {
-                cand = lane_run<S0>(__builtin_amdgcn_perm(a01, pa, sel0), rd0) & lane_run<S1>(__builtin_amdgcn_perm(a01, pa, sel1), rd1);
-            } else {
-                const uint32_t a23 = NCLS == 4 ? down1(qa, __builtin_amdgcn_readfirstlane(qb)) : 0u;
-                cand = 0xffffu;
-                for (uint32_t r = 0; r < nruns; r++) {
-                    const uint32_t dd = __builtin_amdgcn_readlane(vrl, r);
-                    const bool up = NCLS == 4 && (dd & 2u);
-                    const uint32_t own = up ? qa : pa, nb = up ? a23 : a01;
-                    cand &= lane_run<5>(__builtin_amdgcn_perm(nb, own, (dd & 1u) ? 0x07060302u : 0x05040100u), dd);
+            for (int k = 0; k < ITER; k++) {
+                GL_MERGE(pb, qb);                          // step k + 1 (k + 1 == ITER: the halo; only lane 0 of it is looked at)
+                if (k + 2 <= ITER) GL_LOOKUPS(buf[k + 2]); // in flight while step k is computed
+                // the next lane's masks (lane 63: lane 0 of the next step)
+                const uint32_t a01 = down1(pa, __builtin_amdgcn_readfirstlane(pb));
+                uint32_t cand;
+                if (NR == 1) {
+                    cand = lane_run<S0>(__builtin_amdgcn_perm(a01, pa, sel0), rd0);
+                } else if (NR == 2) {
+                    cand = lane_run<S0>(__builtin_amdgcn_perm(a01, pa, sel0), rd0) & lane_run<S1>(__builtin_amdgcn_perm(a01, pa, sel1), rd1);
+                } else if (NR > 2) {
+                    const uint32_t a23 = NCLS == 4 ? down1(qa, __builtin_amdgcn_readfirstlane(qb)) : 0u;
+                    cand = 0xffffu;
+#pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        const bool up = NCLS == 4 && (rd[r] & 2u);
+                        cand &= lane_run<S0>(__builtin_amdgcn_perm(up ? a23 : a01, up ? qa : pa, sel[r]), rd[r]);
+                    }
+                } else {
+                    const uint32_t a23 = NCLS == 4 ? down1(qa, __builtin_amdgcn_readfirstlane(qb)) : 0u;
+                    cand = 0xffffu;
+                    for (uint32_t r = 0; r < nruns; r++) {
+                        const uint32_t dd = __builtin_amdgcn_readlane(vrl, r);
+                        const bool up = NCLS == 4 && (dd & 2u);
+                        const uint32_t own = up ? qa : pa, nb = up ? a23 : a01;
+                        cand &= lane_run<5>(__builtin_amdgcn_perm(nb, own, (dd & 1u) ? 0x07060302u : 0x05040100u), dd);
+                    }
                 }
+                xp[k * 64 + lane] = (uint16_t)cand; // bit j: a window of the pattern starts at position 16 lane + j of this step
+                pa = pb;
+                qa = qb;
             }
-            xp[k * 64 + lane] = (uint16_t)cand; // bit j: a window of the pattern starts at position 16 lane + j of this step
-            pa = pb;
-            qa = qb;
         }
-        lane_emit<ITER>(a, d, sub_off, c.slen - m, lane, xp);
+        // the next tile's text, requested before this tile's epilogue
+        lane_loads<ITER>(buf, cn, sub_off_n, lane, have_n);
+        if (have) {
+            lane_emit<ITER>(a, d, sub_off, (int)c.len - m, lane, xp);
+        } else if (lane == 0) {
+            a.desc[d] = 0ull; // nothing of this tile is this wave's
+        }
+        if (!next) break;
+        t = tn;
+        c = cn;
+        sub_off = sub_off_n;
+        have = have_n;
     }
 #undef GL_LUT
 #undef GL_LOOKUPS
@@ -275,8 +361,22 @@ uint32_t k2_lane_steps(uint32_t n, uint32_t *shifts /* [5] */)
 hipError_t launch_k2_lane(const ScanArgs &a, uint32_t grid, hipStream_t st)
 {
     const dim3 g(grid);
-    const uint32_t s0 = a.lane_steps[0], s1 = a.lane_steps[1];
-    if (a.n_classes > 2) {
+    const uint32_t s0 = a.lane_steps[0], s1 = a.lane_steps[1], sm = a.lane_smax;
+    const bool four = a.n_classes > 2;
+#define GL_SMAX(ncls_, nr_)                                      \
+    switch (sm) {                                                \
+    case 0: launch_one<ncls_, nr_, 0, 0>(a, g, st); break;       \
+    case 1: launch_one<ncls_, nr_, 1, 0>(a, g, st); break;       \
+    case 2: launch_one<ncls_, nr_, 2, 0>(a, g, st); break;       \
+    case 3: launch_one<ncls_, nr_, 3, 0>(a, g, st); break;       \
+    case 4: launch_one<ncls_, nr_, 4, 0>(a, g, st); break;       \
+    default: launch_one<ncls_, nr_, 5, 0>(a, g, st); break;      \
+    }
+    if (a.nruns == 3) {
+        if (four) { GL_SMAX(4, 3) } else { GL_SMAX(2, 3) }
+    } else if (a.nruns == 4) {
+        if (four) { GL_SMAX(4, 4) } else { GL_SMAX(2, 4) }
+    } else if (four) {
         launch_one<4, 0, 5, 5>(a, g, st);
     } else if (a.nruns == 1) {
         switch (s0) {
@@ -301,6 +401,7 @@ hipError_t launch_k2_lane(const ScanArgs &a, uint32_t grid, hipStream_t st)
     } else {
         launch_one<2, 0, 5, 5>(a, g, st);
     }
+#undef GL_SMAX
     return hipGetLastError();
 }
 

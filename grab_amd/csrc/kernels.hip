@@ -1233,6 +1233,8 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
         }
         a.lane_steps[0] = steps[order[0]];
         a.lane_steps[1] = steps[order[1]];
+        a.lane_smax = 0;
+        for (uint32_t r = 0; r < pg.nruns && r < (uint32_t)kK2MaxRuns; r++) a.lane_smax = std::max(a.lane_smax, steps[r]);
     }
 }
 

@@ -55,6 +55,7 @@ struct ScanArgs {
     // runs take (two runs are sorted by them): the launcher picks the kernel instantiation with exactly that many.
     uint32_t run_lane[kK2MaxRuns];
     uint32_t lane_steps[2];
+    uint32_t lane_smax;      // the most steps any run takes (programs of three and four runs give every run that many)
 };
 
 // variant: bits 0-1 select KiB per wave {0:16, 1:8, 2:12}; bit 2 = nontemporal loads; 13: bigger workgroups for the table kernels (kernels.hip, variant_wg);

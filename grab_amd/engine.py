@@ -24,7 +24,7 @@ SYMBOLS = [
     "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_ends", "gscan_next_listed",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
     "gscan_set_option", "gscan_kernel_time", "gscan_resource_errors",
-    "gscan_ingest_info", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
+    "gscan_ingest_info", "gscan_auto_readers", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
     "gscan_vm_verdict", "gscan_vm_filter", "gscan_vm_pair", "gscan_prefix_viable",
 ]
 
@@ -32,7 +32,7 @@ SYMBOLS = [
 class Info(C.Structure):
     _fields_ = [("tier", C.c_int), ("minlen", C.c_int), ("n_classes", C.c_int), ("has_tail", C.c_int),
                 ("tail_extra", C.c_uint32), ("anchor_off", C.c_int), ("anchor_len", C.c_int),
-                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int), ("lines_ok", C.c_int), ("exact", C.c_int), ("vm", C.c_int), ("ends_ok", C.c_int)]
+                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int), ("lines_ok", C.c_int), ("exact", C.c_int), ("vm", C.c_int), ("gapped", C.c_int), ("ends_ok", C.c_int)]
 
 
 class Cursor(C.Structure):

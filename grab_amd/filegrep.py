@@ -12,7 +12,7 @@ from .build import lib_path
 SYMBOLS = [
     "grab_filegrep_new", "grab_filegrep_free", "grab_filegrep_why", "grab_filegrep_recurse",
     "grab_filegrep_show_path", "grab_filegrep_config", "grab_filegrep_prepare", "grab_filegrep_find",
-    "grab_filegrep_find_recursive", "grab_filegrep_engine_option", "grab_report_chunk_c", "grab_report_chunk_ends_c", "grab_free",
+    "grab_filegrep_find_recursive", "grab_filegrep_engine_option", "grab_report_chunk_c", "grab_report_chunk_ends_c", "grab_free", "grab_place_workers_c",
     "grab_filegrep_find3", "grab_filegrep_flush", "grab_walk_parallel", "grab_validate",
 ]
 
@@ -51,6 +51,7 @@ def lib():
                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.grab_report_chunk_ends_c.argtypes = [C.c_void_p, C.c_uint, C.c_char_p, C.c_void_p, C.c_size_t, C.c_longlong,
                                                C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.grab_place_workers_c.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
         L.grab_free.argtypes = [C.c_void_p]
         L.grab_free.restype = None
         L.grab_filegrep_find3.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
@@ -176,3 +177,23 @@ def report_chunk(db, flags, path, content, off, starts, ends=None, clen=None):
     data = C.string_at(out, n.value)
     lib().grab_free(out)
     return data
+
+
+def place_workers(workers, dev_cpulists, allowed=None, pin=None, ncpu=512):
+    """grab_place_workers_c: [(device, sorted CPU list)] for the workers of `grab -n workers` on a node whose devices have
+    these local CPU lists (sysfs cpulist strings)."""
+    import numpy as np
+
+    ndev = len(dev_cpulists)
+    arr = (C.c_char_p * ndev)(*[(x.encode() if x else None) for x in dev_cpulists])
+    devs = (C.c_int * max(workers, 1))()
+    nb = (ncpu + 7) // 8
+    bits = np.zeros(max(workers, 1) * nb, np.uint8)
+    rc = lib().grab_place_workers_c(workers, ndev, arr, allowed.encode() if allowed else None, pin.encode() if pin else None, devs, bits.ctypes.data, nb)
+    if rc != 0:
+        raise RuntimeError("grab_place_workers_c failed")
+    out = []
+    for i in range(workers):
+        row = np.unpackbits(bits[i * nb:(i + 1) * nb], bitorder="little")
+        out.append((devs[i], np.nonzero(row)[0].tolist()))
+    return out

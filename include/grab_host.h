@@ -53,6 +53,16 @@ int grab_report_chunk_ends_c(const gscan_db *db, unsigned flags, const char *pat
 void grab_free(void *p);
 
 /*
+ * Where the threads of `grab -n workers` run on a node with ndev devices: worker i drives device i mod ndev and is bound to
+ * the CPUs local to that device, cut to the process's CPU mask (pin "cpu": the reference's rule, CPU i -- main.cc:200-215;
+ * "none": the process's mask).  dev_cpulists[d] = sysfs local_cpulist of device d, allowed = the process's CPUs (cpulist
+ * strings; NULL or "" = unknown / all).  Fills devices_out[workers] and one CPU bitmap of bytes_each bytes per worker.
+ * Pure: the layout of an 8-GPU node can be checked anywhere (tests/test_host_cpu.py).
+ */
+int grab_place_workers_c(int workers, int ndev, const char *const *dev_cpulists, const char *allowed, const char *pin,
+                         int *devices_out, unsigned char *cpu_bits_out, size_t bytes_each);
+
+/*
  * The tree walk of `grab -n` (grab_amd/csrc/walk.h): `threads` walkers report every regular file nftw(root, fn, 1024,
  * FTW_PHYS) would report as FTW_F (src/main.cc:74-83,178), in no particular order; fn is called CONCURRENTLY from the
  * walker threads.  Returns the number of files reported, -1 on bad arguments.

@@ -88,6 +88,8 @@ typedef struct gscan_info {
                             small backtracking VM at every filter hit and drops the hits at which no match can start -- and the
                             list it returns holds EVERY hit it kept (no group-start compression): gscan_next_match then asks the
                             host matcher at the listed offsets only */
+    int gapped;          /* alternatives with one unbounded repeat in the middle (a+b, foo.*bar): the kernels list where the part BEHIND
+                            the repeat begins (one repeat byte + the rest), gscan_next_match walks the run back to the match start */
     int ends_ok;         /* 1 if the match-end pass applies (gscan_set_option "match_ends"): one plain alternative without context that
                             ends in an unbounded greedy repeat whose class contains the window's first class (gscan_next_listed) */
 } gscan_info;
@@ -231,6 +233,9 @@ size_t gscan_block_size(void);
 /* the ingest configuration in force (environment: GSCAN_BLOCK_MIB, GSCAN_READERS; copy streams: GSCAN_SHARED_COPY per device,
  * or GSCAN_COPY_STREAMS per context when GSCAN_SHARED_COPY=0); any pointer may be NULL */
 void gscan_ingest_info(size_t *block_bytes, int *readers, int *copy_streams);
+/* reader threads a device gets when GSCAN_READERS is unset (*readers == 0 above): 8, fewer when the device's share of its
+ * NUMA node's CPUs (local_cpus / devices_sharing that node) is small; exported for tests */
+int gscan_auto_readers(int local_cpus, int devices_sharing);
 int gscan_submit(gscan_ctx *ctx, const gscan_db *db, const void *host_bytes, size_t len,
                  uint64_t tag);
 int gscan_submit_segs(gscan_ctx *ctx, const gscan_db *db, const void *pinned, const gscan_seg *segs,

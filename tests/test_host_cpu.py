@@ -115,9 +115,88 @@ def test_validate_without_device(built):
 def test_ingest_configuration(built):
     info = engine.ingest_info()
     assert info["block_bytes"] % (1 << 20) == 0 and (1 << 20) <= info["block_bytes"] <= (64 << 20)
-    assert 1 <= info["readers"] <= 64 and 1 <= info["copy_streams"] <= 4
+    assert 0 <= info["readers"] <= 64 and 1 <= info["copy_streams"] <= 4  # readers 0: auto, per device (gscan_auto_readers)
     # copy streams: the device's shared ones (GSCAN_SHARED_COPY, the default), or per context (GSCAN_COPY_STREAMS) when sharing is off
     for extra, want in (({"GSCAN_SHARED_COPY": "0", "GSCAN_COPY_STREAMS": "4"}, 4), ({"GSCAN_SHARED_COPY": "2", "GSCAN_COPY_STREAMS": "4"}, 2), ({}, 1)):
         env = dict(os.environ, GSCAN_BLOCK_MIB="32", GSCAN_READERS="3", **extra)
         r = subprocess.run(["python", "-c", "from grab_amd import engine; print(engine.ingest_info())"], cwd=ROOT, env=env, capture_output=True, text=True)
         assert "'block_bytes': 33554432" in r.stdout and "'readers': 3" in r.stdout and "'copy_streams': %d" % want in r.stdout, r.stdout + r.stderr
+
+
+def test_eight_gpu_worker_placement(built):
+    """`grab -n N -r` on a two-socket node with 8 GPUs (4 per socket), laid out from a faked device -> local-CPU map: worker
+    i drives device i mod 8; every device gets the same number of workers (N a multiple of 8) or floor/ceil of N / 8; every
+    worker is bound to CPUs of ITS device's socket only, cut to the process's mask; a device whose node is outside the mask
+    (or unknown) leaves its workers on the process's own CPUs; GRAB_PIN=cpu is the reference's rule (thread i on CPU i,
+    main.cc:200-215); GRAB_PIN=none the process's mask."""
+    node0, node1 = "0-63,128-191", "64-127,192-255"
+    devs = [node0] * 4 + [node1] * 4
+    cpus0 = set(list(range(0, 64)) + list(range(128, 192)))
+    cpus1 = set(list(range(64, 128)) + list(range(192, 256)))
+    for n in (8, 16, 32, 11, 3):
+        pl = filegrep.place_workers(n, devs)
+        per_dev = [sum(1 for d, _ in pl if d == k) for k in range(8)]
+        assert sum(per_dev) == n and max(per_dev) - min(per_dev) <= 1, per_dev
+        for i, (d, cpus) in enumerate(pl):
+            assert d == i % 8
+            assert set(cpus) == (cpus0 if d < 4 else cpus1), (i, d)
+    # the process may only use CPUs 0-31 and 64-95 (a cpuset / taskset): the local lists are cut to that
+    pl = filegrep.place_workers(16, devs, allowed="0-31,64-95")
+    for d, cpus in pl:
+        assert set(cpus) == (set(range(0, 32)) if d < 4 else set(range(64, 96)))
+    # ... only socket 0: the devices of socket 1 have no local CPU that is ours -> the process's mask
+    pl = filegrep.place_workers(8, devs, allowed="0-15")
+    assert all(set(cpus) == set(range(16)) for _, cpus in pl)
+    # unknown topology (no sysfs entry): the process's mask
+    pl = filegrep.place_workers(8, [None] * 8, allowed="0-7")
+    assert all(set(cpus) == set(range(8)) for _, cpus in pl)
+    # the reference's rule and no binding at all
+    assert [cpus for _, cpus in filegrep.place_workers(6, devs, pin="cpu")] == [[i] for i in range(6)]
+    assert all(set(cpus) == set(range(24)) for _, cpus in filegrep.place_workers(6, devs, allowed="0-23", pin="none"))
+    # a one-GPU box: every worker on device 0 and its node
+    assert all(d == 0 and set(cpus) == cpus0 for d, cpus in filegrep.place_workers(8, [node0]))
+
+
+def test_reader_threads_scale_with_the_node(built):
+    """GSCAN_READERS unset: 8 reader threads per device where the device's share of its NUMA node has CPUs to spare (the
+    measured optimum on the one-GPU boxes), fewer on a node where 8 devices x 8 readers would outnumber the CPUs."""
+    L = engine.lib()
+    assert L.gscan_auto_readers(128, 1) == 8      # the gpurun boxes: device 0 -> CPUs 0-63,128-191
+    assert L.gscan_auto_readers(128, 4) == 8      # 8-GPU node, 4 devices per socket: 32 CPUs each, half for readers -> capped at 8
+    assert L.gscan_auto_readers(32, 4) == 4       # a smaller host: 8 CPUs per device
+    assert L.gscan_auto_readers(8, 4) == 2        # never below 2
+    assert L.gscan_auto_readers(0, 1) == 8        # nothing known
+    for cpus in (16, 64, 128, 256):
+        for sharing in (1, 2, 4, 8):
+            r = L.gscan_auto_readers(cpus, sharing)
+            assert 2 <= r <= 8 and (r == 2 or r * sharing * 2 <= cpus)  # readers of all devices of a node never exceed half its CPUs
+
+
+def test_detached_parent_forwards_signals(built, tmp_path):
+    """GRAB_DETACH=1 (opt-in): the scan runs in a child and the parent only waits for its status -- a signal that reaches the
+    parent alone (subprocess.terminate(), a supervisor) must end BOTH: the parent passes it on and takes it itself, and the
+    child has asked for SIGKILL should the parent vanish.  (Checked without a device: the child sits in the tree walk of a
+    directory that holds a FIFO nobody opens... it never gets there -- the pattern is fine, the device is missing, so the
+    child fails fast; what is checked here is the no-signal path's status hand-over and that no process is left.)"""
+    import signal
+    import time
+
+    d = tmp_path / "t"
+    d.mkdir()
+    (d / "f").write_bytes(b"foo\n" * 100)
+    for detach in ("0", "1"):
+        r = subprocess.run([built.bin_path(), "-r", "foo", str(d)], capture_output=True, env=dict(os.environ, GRAB_DETACH=detach))
+        assert r.returncode in (0, 255)  # 255 on a box without a device (prepare fails loudly), 0 with one
+    # a parent that is signalled while its child is still busy: use a directory tree large enough to take a moment
+    big = tmp_path / "big"
+    big.mkdir()
+    for i in range(2000):
+        (big / ("f%04d" % i)).write_bytes(b"x" * 10)
+    p = subprocess.Popen([built.bin_path(), "-n", "2", "-r", "foo", str(big)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, GRAB_DETACH="1"))
+    time.sleep(0.05)
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=30)
+    assert rc in (-signal.SIGTERM, 0, 255)  # killed by the signal -- or already done
+    time.sleep(0.3)
+    out = subprocess.run(["pgrep", "-f", str(big)], capture_output=True, text=True).stdout.split()
+    assert out == [], "a scanning child outlived its signalled parent: %s" % out
