@@ -305,16 +305,20 @@ class Lines(int):
 
 def run_timed(argv, env, reps, warm=True, count_only=False):
     """One untimed pass (warms the page cache; warm=False: the cache is known to be warm), then the min
-    of `reps`; (seconds, stdout, stderr of the best).  count_only: stdout is not loaded (cfg3 prints gigabytes) -- the lines
-    of the last run are counted in 16 MiB pieces and returned in its place.
+    of `reps`; (seconds, stdout, stderr of the best).
 
     stdout goes to a file in /dev/shm, not to a pipe: with 10^8 output lines this process's own reading (and joining) of a
-    pipe is a good part of a second that has nothing to do with the program under test."""
+    pipe is a good part of a second that has nothing to do with the program under test.  count_only (cfg3 prints gigabytes):
+    the TIMED runs write to /dev/null (SURVEY.md 8d's rule for the CPU baseline, applied to both sides: allocating 3.5 GB of
+    fresh tmpfs pages per run is the sink's cost, not the scanner's); the untimed pass writes the file and its lines are
+    counted in 16 MiB pieces and returned in stdout's place (None without such a pass)."""
     best = None
+    lines = None
     out_path = "/dev/shm/grab_bench_out_%d.txt" % os.getpid()
     try:
         for it in range(0 if warm else 1, reps + 1):
-            with open(out_path, "wb") as out:
+            to_null = count_only and it > 0
+            with open("/dev/null" if to_null else out_path, "wb") as out:
                 t0 = time.perf_counter()
                 r = subprocess.run(argv, stdout=out, stderr=subprocess.PIPE, env=env)
                 dt = time.perf_counter() - t0
@@ -322,16 +326,19 @@ def run_timed(argv, env, reps, warm=True, count_only=False):
             if not count_only:
                 with open(out_path, "rb") as f:
                     stdout = f.read()
+            elif not to_null and r.returncode == 0:
+                n = 0
+                with open(out_path, "rb") as f:
+                    for blk in iter(lambda: f.read(1 << 24), b""):
+                        n += blk.count(b"\n")
+                lines = Lines(n)
+                os.unlink(out_path)
             if r.returncode != 0:
                 return None, stdout, r.stderr
             if it > 0 and (best is None or dt < best[0]):
                 best = (dt, stdout, r.stderr)
         if count_only and best is not None:
-            n = 0
-            with open(out_path, "rb") as f:
-                for blk in iter(lambda: f.read(1 << 24), b""):
-                    n += blk.count(b"\n")
-            best = (best[0], Lines(n), best[2])
+            best = (best[0], lines, best[2])
     finally:
         if os.path.exists(out_path):
             os.unlink(out_path)
@@ -358,7 +365,7 @@ def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=
     det_s = det[0] if det and det[0] else None
     dt, out, err = got
     nbytes = nfiles * file_bytes
-    lines = out.count(b"\n")
+    lines = out.count(b"\n") if out is not None else None
     per_dev = {}
     for m in re.finditer(rb"\[grab bytes\] device (\d+): (\d+)", err):
         per_dev[int(m.group(1))] = per_dev.get(int(m.group(1)), 0) + int(m.group(2))
@@ -375,7 +382,7 @@ def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=
             "scan_phase_frac": scan_s and round(nbytes / scan_s / 1e9 / (PCIE_PEAK_GBPS * n_gpus), 4),
             "pcie_peak": PCIE_PEAK_GBPS * n_gpus, "frac": round(rate / (PCIE_PEAK_GBPS * n_gpus), 4),
             "lines": lines, "lines_expected": want_lines, "lines_ok": lines == want_lines,
-            "matches_per_s": round(lines / dt, 1),
+            "matches_per_s": lines is not None and round(lines / dt, 1),
             "per_device_bytes": {str(k): v for k, v in sorted(per_dev.items())},
             "ingest": engine.ingest_info(),
             "command": " ".join([os.path.basename(argv[0])] + argv[1:-1]) + " <dir>, wall clock of the whole (one) process, page cache warm, min of %d" % reps}
@@ -425,7 +432,7 @@ def cpu_baseline(d, nfiles, file_bytes, pattern, flags, threads=None, reps=2, wa
             "sample": "%s of the same corpus under %s (%.0f GiB), '%s', warm cache, min of %d" % (
                 ("%d x %d MiB files" % (nfiles, file_bytes >> 20)) if os.path.isdir(d) else "one %d MiB file" % (nbytes >> 20),
                 os.path.dirname(d), nbytes / (1 << 30), " ".join(os.path.basename(a) if a == binary else a for a in argv[:-1]), reps),
-            "lines": out.count(b"\n"), "matches_per_s": round(out.count(b"\n") / dt, 1), "wall_s": round(dt, 4),
+            "lines": out.count(b"\n") if out is not None else None, "matches_per_s": out is not None and round(out.count(b"\n") / dt, 1), "wall_s": round(dt, 4),
             "engine": "libpcre 8.39 JIT (pcre_exec); the -H hyperscan path does not exist in the mounted reference"}
 
 
@@ -472,8 +479,13 @@ def e2e_cfg3(d, nfiles, file_bytes, n_gpus, want_cpu):
             e["parity_subset"] = {"bytes": n1 * file_bytes, "lines": got[1], "sorted_md5": got[0], "reference_sorted_md5": want[0], "same": got == want and got[0] is not None}
         else:
             e["parity_subset"] = {"bytes": n1 * file_bytes, "lines": got[1], "sorted_md5": got[0], "reference_sorted_md5": None, "same": None}
-        if want_cpu:
-            e["cpu_baseline"] = cpu_baseline(d16, n16, file_bytes, ident, ["-O", "-l"], threads=[usable_cores()], reps=1, warm=False, count_only=True)
+        if want_cpu:  # a bounded sample: 4 GiB of the same files, -n 64 and -n <all> (about 4 s of wall clock)
+            d4, n4 = d + "_cfg3c", min(n16, max(1, (4 << 30) // file_bytes))
+            try:
+                link_subset(d, d4, n4)
+                e["cpu_baseline"] = cpu_baseline(d4, n4, file_bytes, ident, ["-O", "-l"], threads=sorted(set([min(64, usable_cores()), usable_cores()])), reps=1, warm=False, count_only=True)
+            finally:
+                shutil.rmtree(d4, ignore_errors=True)
             if e["cpu_baseline"] and "value" in e:
                 e["vs_cpu_baseline"] = round(e["value"] / e["cpu_baseline"]["value"], 3)
         return e
@@ -492,7 +504,7 @@ def e2e_cfg5(base, gib, want_cpu):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import fullsize_parity
 
-    path = os.path.join(base, "cfg5.bin")
+    path = os.path.join(base, "grab_bench_cfg5_%d.bin" % os.getpid())
     while gib > 1 and shutil.disk_usage(base).free < (gib << 30) * 1.2:
         gib //= 2
     size = gib << 30
@@ -724,7 +736,7 @@ def main():
                     # the other two end-to-end BASELINE configurations, each with its own parity check and CPU baseline
                     if not a.no_e2e_extra:
                         for key, fn in (("e2e_cfg3", lambda: e2e_cfg3(d, nfiles, file_bytes, world, want_cpu)),
-                                        ("e2e_cfg5", lambda: e2e_cfg5(d, min(8, max(2, use >> 33)), want_cpu))):
+                                        ("e2e_cfg5", lambda: e2e_cfg5(os.path.dirname(d), min(8, max(2, use >> 33)), want_cpu))):
                             try:
                                 line[key] = fn()
                             except Exception as ex:
@@ -735,6 +747,7 @@ def main():
                     shutil.rmtree(d, ignore_errors=True)
                     shutil.rmtree(d + "_cfg3", ignore_errors=True)
                     shutil.rmtree(d + "_cfg3s", ignore_errors=True)
+                    shutil.rmtree(d + "_cfg3c", ignore_errors=True)
             else:
                 line["e2e"] = {"error": "no room in /dev/shm or /tmp"}
         barrier(world, device)

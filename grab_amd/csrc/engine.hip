@@ -669,9 +669,16 @@ int fail(gscan_ctx *c, int code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail((c), GSCAN_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+void slot_drain_reads(Slot &s);
+
 int ensure_prog(gscan_ctx *c, const gscan_db *db, hipStream_t st)
 {
     if (c->prog_id == db->db.id) return 0;
+    // A file range submitted with ANOTHER database may still be on its way in: its scan is launched later, by the reader
+    // that finishes its last piece, and reads c->d_prog then.  Let every such range arrive and launch first -- the device
+    // program is one per context, not one per slot.
+    for (Slot &s : c->slot)
+        if (s.state == INFLIGHT) slot_drain_reads(s);
     // The staging copy is overwritten: every earlier upload must have left it.  Uploads are
     // rare (one per pattern), so a stream sync here costs nothing measurable.
     HIPCHK(c, hipStreamSynchronize(c->compute));

@@ -31,6 +31,11 @@ namespace {
 
 constexpr int kLIter = 12; // KiB per wave sub-tile
 constexpr int kLNW = 8;    // waves per workgroup (64 KiB table + 12 KiB of strips: two workgroups per CU)
+constexpr int kLanePF = 0; // where the next tile's loads go (k2_lane_scan's PF).  Measured, same box, 16 GiB, identifier scan / [0-9]{16}
+                           // (profiles/r03_c_lane_prefetch_and_subtile_sweep.txt): 0 (none) 5.70 / 6.41 TB/s, 1 (before the epilogue)
+                           // 5.13 / 6.46, 2 (behind the atomic) 5.45 / 6.23; 16 KiB per wave: 5.17 / 6.29, 5.45 / 6.40, 4.40 / 4.74.
+                           // Behind in-flight loads the epilogue's atomic can only be waited for with vmcnt(0) -- the wave then
+                           // sits out the whole HBM round trip before it may write a record; without records there is nothing to lose.
 
 // 16-bit table entry of a byte whose k2_table word is v (bit 8c = member of class c), at dword position t
 template <int NCLS>
@@ -130,8 +135,11 @@ __device__ __forceinline__ void lane_loads(u32x4 (&buf)[ITER + 1], const TileS &
 
 // Epilogue of one wave's sub-tile: xp = the wave's strip, xp[k * 64 + lane] = step k's 16-bit candidate mask of `lane`,
 // i.e. a bitmap of the sub-tile in text order.  Lane L takes bits [192 L, 192 L + 192) of it.
-template <int ITER>
-__device__ __forceinline__ void lane_emit(const ScanArgs &a, uint32_t d, int sub_off, int hi, uint32_t lane, const uint16_t *xp)
+// `between` runs exactly once, right after the reserving atomic has been ISSUED (or where it would have been): the
+// prefetching tile loop puts the next tile's loads there, behind the atomic, so that its result can be waited for with the
+// loads still in flight.
+template <int ITER, typename Between>
+__device__ __forceinline__ void lane_emit(const ScanArgs &a, uint32_t d, int sub_off, int hi, uint32_t lane, const uint16_t *xp, Between &&between)
 {
     constexpr int NWORD = ITER / 2;
     static_assert(ITER % 4 == 0, "the strip is read back in 8-byte pieces");
@@ -171,11 +179,13 @@ __device__ __forceinline__ void lane_emit(const ScanArgs &a, uint32_t d, int sub
     const uint32_t wtot = __builtin_amdgcn_readlane(inc, 63);
     if (wtot == 0) {
         if (lane == 0) a.desc[d] = 0ull;
+        between();
         return;
     }
     const uint32_t shard = d & (kShards - 1);
     uint32_t b = 0;
     if (lane == 0) b = atomicAdd(a.counter + shard * kCtrStride, wtot); // index inside the shard's region
+    between();
     const uint32_t base = __builtin_amdgcn_readfirstlane(b);
     const bool over = (unsigned long long)base + wtot > (unsigned long long)a.cap_shard;
     if (lane == 0) {
@@ -199,18 +209,19 @@ __device__ __forceinline__ void lane_emit(const ScanArgs &a, uint32_t d, int sub
     }
 }
 
-// NCLS: 2 or 4 (table entry layout).  NR: runs of the program -- 1 or 2 (two classes): exactly that many, S0 / S1
-// doubling steps each; 3 or 4: exactly that many, every run S0 steps (the longest run's count; zero shifts where a run
-// needs fewer) -- everything about them wave-uniform and decoded before the tile loop; 0: any number, five steps each,
-// one v_readlane per run and step.
+// NCLS: 2 or 4 (table entry layout).  NR: runs of the program, sorted by their doubling steps -- 1 or 2 (two classes):
+// exactly that many, S0 / S1 steps; 3 or 4: exactly that many, the last one S1 steps, the others S0 (the most any of them
+// needs; zero shifts where one needs fewer) -- everything about them wave-uniform and decoded before the tile loop; 0: any
+// number, five steps each, one v_readlane per run and step.
 // The tile loop is software-pipelined by one tile: the NEXT tile's text is requested between this tile's last step and
 // its epilogue, so the loads are in flight while the wave counts, reserves (one returning atomic) and writes its records
 // -- the epilogue's latency and the next tile's HBM latency overlap instead of adding up.  The loads are issued on every
 // path (far out of range -- zeros, no traffic -- when there is no next tile or none of it is this wave's).
-template <int NCLS, int NR, int S0, int S1>
+// PF: where the next tile's loads are issued -- 0: at the top of its own pass (no prefetch), 1: between this tile's last step
+// and its epilogue, 2: inside the epilogue, right behind the reserving atomic.
+template <int NCLS, int NR, int S0, int S1, int PF = 0, int ITER = kLIter>
 __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
-    constexpr int ITER = kLIter;
     constexpr uint32_t kTile = kLNW * ITER * 1024;
     static_assert(NCLS == 2 || NCLS == 4, "two entry layouts");
     static_assert(NR == 0 || NR >= 3 || NCLS == 2, "one- and two-run programs have at most two classes");
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
     int sub_off = c.toff + (int)(wave * ITER * 1024);
     bool have = c.len >= a.m && sub_off < (int)c.len; // some of this tile is this wave's (wave-uniform)
     u32x4 buf[ITER + 1];
-    lane_loads<ITER>(buf, c, sub_off, lane, have);
+    if (PF) lane_loads<ITER>(buf, c, sub_off, lane, have);
     uint16_t *xp = s_xp + wave * (ITER * 64);
     for (;;) {
         const uint32_t tn = t + gridDim.x;
@@ -278,6 +289,7 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
             have_n = cn.len >= a.m && sub_off_n < (int)cn.len;
         }
         const uint32_t d = t * kLNW + wave;
+        if (!PF && have) lane_loads<ITER>(buf, c, sub_off, lane, true);
         if (have) {
             uint32_t e[16];
             uint32_t pa, qa, pb, qb; // class masks of step k (pa, qa) and of step k + 1 (pb, qb)
@@ -299,9 +311,10 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
                     const uint32_t a23 = NCLS == 4 ? down1(qa, __builtin_amdgcn_readfirstlane(qb)) : 0u;
                     cand = 0xffffu;
 #pragma unroll
-                    for (int r = 0; r < NR; r++) {
+                    for (int r = 0; r < NR; r++) { // (sorted by their step counts: the last run takes S1 steps, the others at most S0)
                         const bool up = NCLS == 4 && (rd[r] & 2u);
-                        cand &= lane_run<S0>(__builtin_amdgcn_perm(up ? a23 : a01, up ? qa : pa, sel[r]), rd[r]);
+                        const uint32_t x = __builtin_amdgcn_perm(up ? a23 : a01, up ? qa : pa, sel[r]);
+                        cand &= r == NR - 1 ? lane_run<S1>(x, rd[r]) : lane_run<S0>(x, rd[r]);
                     }
                 } else {
                     const uint32_t a23 = NCLS == 4 ? down1(qa, __builtin_amdgcn_readfirstlane(qb)) : 0u;
@@ -318,12 +331,15 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
                 qa = qb;
             }
         }
-        // the next tile's text, requested before this tile's epilogue
-        lane_loads<ITER>(buf, cn, sub_off_n, lane, have_n);
+        // the next tile's text, requested before (PF 1) or inside (PF 2) this tile's epilogue
+        if (PF == 1) lane_loads<ITER>(buf, cn, sub_off_n, lane, have_n);
         if (have) {
-            lane_emit<ITER>(a, d, sub_off, (int)c.len - m, lane, xp);
-        } else if (lane == 0) {
-            a.desc[d] = 0ull; // nothing of this tile is this wave's
+            lane_emit<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, [&] {
+                if (PF == 2) lane_loads<ITER>(buf, cn, sub_off_n, lane, have_n);
+            });
+        } else {
+            if (lane == 0) a.desc[d] = 0ull; // nothing of this tile is this wave's
+            if (PF == 2) lane_loads<ITER>(buf, cn, sub_off_n, lane, have_n);
         }
         if (!next) break;
         t = tn;
@@ -339,12 +355,37 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
 template <int NCLS, int NR, int S0, int S1>
 void launch_one(const ScanArgs &a, dim3 g, hipStream_t st)
 {
-    hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1>), g, dim3(kLNW * 64), 0, st, a, a.tiles);
+    hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, kLanePF>), g, dim3(kLNW * 64), 0, st, a, a.tiles);
+}
+
+// (experiment switch GSCAN_LANE_PF=0|1|2 for the two benchmark programs: the identifier scan and [0-9]{16})
+int lane_iter_experiment()
+{
+    static const int it = getenv("GSCAN_LANE_ITER") ? atoi(getenv("GSCAN_LANE_ITER")) : 0;
+    return it == 16 ? 16 : 0;
+}
+
+template <int NCLS, int NR, int S0, int S1>
+bool launch_pf_experiment(const ScanArgs &a, dim3 g, hipStream_t st)
+{
+    static const int pf = getenv("GSCAN_LANE_PF") ? atoi(getenv("GSCAN_LANE_PF")) : -1;
+    const bool i16 = lane_iter_experiment() == 16;
+    if (pf < 0 && !i16) return false;
+    const int mode = (pf < 0 ? kLanePF : pf) + (i16 ? 3 : 0);
+    switch (mode) {
+    case 0: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 0>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
+    case 1: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 1>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
+    case 2: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 2>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
+    case 3: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 0, 16>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
+    case 4: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 1, 16>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
+    default: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 2, 16>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
+    }
+    return true;
 }
 
 } // namespace
 
-uint32_t k2_lane_tile_bytes() { return (uint32_t)(kLNW * kLIter * 1024); }
+uint32_t k2_lane_tile_bytes() { return (uint32_t)(kLNW * (lane_iter_experiment() ? lane_iter_experiment() : kLIter) * 1024); }
 uint32_t k2_lane_waves() { return (uint32_t)kLNW; }
 
 // Doubling steps a run of n positions takes: 1 -> 2 -> 4 ... while it fits, one overlapping step for the rest.
@@ -361,21 +402,24 @@ uint32_t k2_lane_steps(uint32_t n, uint32_t *shifts /* [5] */)
 hipError_t launch_k2_lane(const ScanArgs &a, uint32_t grid, hipStream_t st)
 {
     const dim3 g(grid);
-    const uint32_t s0 = a.lane_steps[0], s1 = a.lane_steps[1], sm = a.lane_smax;
+    const uint32_t s0 = a.lane_steps[0], s1 = a.lane_steps[1];
     const bool four = a.n_classes > 2;
-#define GL_SMAX(ncls_, nr_)                                      \
-    switch (sm) {                                                \
-    case 0: launch_one<ncls_, nr_, 0, 0>(a, g, st); break;       \
-    case 1: launch_one<ncls_, nr_, 1, 0>(a, g, st); break;       \
-    case 2: launch_one<ncls_, nr_, 2, 0>(a, g, st); break;       \
-    case 3: launch_one<ncls_, nr_, 3, 0>(a, g, st); break;       \
-    case 4: launch_one<ncls_, nr_, 4, 0>(a, g, st); break;       \
-    default: launch_one<ncls_, nr_, 5, 0>(a, g, st); break;      \
+    if (!four && a.nruns == 2 && s0 == 0 && s1 == 4 && launch_pf_experiment<2, 2, 0, 4>(a, g, st)) return hipGetLastError();
+    if (!four && a.nruns == 1 && s0 == 4 && launch_pf_experiment<2, 1, 4, 0>(a, g, st)) return hipGetLastError();
+#define GL_CASE(n_, r_, a_, b_) case (a_) * 8 + (b_): launch_one<n_, r_, a_, b_>(a, g, st); break;
+#define GL_SORTED(n_, r_)                                                                                                      \
+    switch (s0 * 8 + s1) { /* fill_program() sorts the runs by their step counts: s0 <= s1 */                                  \
+        GL_CASE(n_, r_, 0, 0) GL_CASE(n_, r_, 0, 1) GL_CASE(n_, r_, 0, 2) GL_CASE(n_, r_, 0, 3) GL_CASE(n_, r_, 0, 4) GL_CASE(n_, r_, 0, 5) \
+        GL_CASE(n_, r_, 1, 1) GL_CASE(n_, r_, 1, 2) GL_CASE(n_, r_, 1, 3) GL_CASE(n_, r_, 1, 4) GL_CASE(n_, r_, 1, 5)          \
+        GL_CASE(n_, r_, 2, 2) GL_CASE(n_, r_, 2, 3) GL_CASE(n_, r_, 2, 4) GL_CASE(n_, r_, 2, 5)                                \
+        GL_CASE(n_, r_, 3, 3) GL_CASE(n_, r_, 3, 4) GL_CASE(n_, r_, 3, 5)                                                      \
+        GL_CASE(n_, r_, 4, 4) GL_CASE(n_, r_, 4, 5)                                                                            \
+    default: launch_one<n_, r_, 5, 5>(a, g, st); break;                                                                        \
     }
     if (a.nruns == 3) {
-        if (four) { GL_SMAX(4, 3) } else { GL_SMAX(2, 3) }
+        if (four) { GL_SORTED(4, 3) } else { GL_SORTED(2, 3) }
     } else if (a.nruns == 4) {
-        if (four) { GL_SMAX(4, 4) } else { GL_SMAX(2, 4) }
+        if (four) { GL_SORTED(4, 4) } else { GL_SORTED(2, 4) }
     } else if (four) {
         launch_one<4, 0, 5, 5>(a, g, st);
     } else if (a.nruns == 1) {
@@ -387,21 +431,13 @@ hipError_t launch_k2_lane(const ScanArgs &a, uint32_t grid, hipStream_t st)
         case 4: launch_one<2, 1, 4, 0>(a, g, st); break;
         default: launch_one<2, 1, 5, 0>(a, g, st); break;
         }
-    } else if (a.nruns == 2) { // fill_program() sorts the two runs by their step counts: s0 <= s1
-#define GL_CASE(a_, b_) case (a_) * 8 + (b_): launch_one<2, 2, a_, b_>(a, g, st); break;
-        switch (s0 * 8 + s1) {
-            GL_CASE(0, 0) GL_CASE(0, 1) GL_CASE(0, 2) GL_CASE(0, 3) GL_CASE(0, 4) GL_CASE(0, 5)
-            GL_CASE(1, 1) GL_CASE(1, 2) GL_CASE(1, 3) GL_CASE(1, 4) GL_CASE(1, 5)
-            GL_CASE(2, 2) GL_CASE(2, 3) GL_CASE(2, 4) GL_CASE(2, 5)
-            GL_CASE(3, 3) GL_CASE(3, 4) GL_CASE(3, 5)
-            GL_CASE(4, 4) GL_CASE(4, 5)
-        default: launch_one<2, 2, 5, 5>(a, g, st); break;
-        }
-#undef GL_CASE
+    } else if (a.nruns == 2) {
+        GL_SORTED(2, 2)
     } else {
         launch_one<2, 0, 5, 5>(a, g, st);
     }
-#undef GL_SMAX
+#undef GL_SORTED
+#undef GL_CASE
     return hipGetLastError();
 }
 

@@ -773,7 +773,15 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                                 if (ok) bits |= 1u << j;
                             }
                         }
+                    } else if (!exact) {
+                        // The filter is not the pattern (class-heavy alternatives, windows longer than four positions): every
+                        // hit has to be confirmed -- but not here.  Inside the step a hit costs the WAVE a trip through the
+                        // confirm path (seven dependent loads, 24 LDS look-ups) with one or two lanes active; with a hit every
+                        // KiB or two that was more than the scan itself ([0-9]+\.[0-9]+: 0.56 of the HBM roofline).  The hits
+                        // are kept as they are and confirmed after the sub-tile's last step (below), each lane working off its
+                        // own, side by side -- the structure the VM form has had since round 2.
                     } else if (!direct) {
+                        // (the filter IS the pattern, only this window may reach past the segment end: rare, settled on the spot)
                         // confirm every hit against the first kK3Confirm (24) window positions: the window's bytes are
                         // re-read (beyond the segment the descriptor returns zeros), then one LDS byte per position
                         // gives the buckets that accept the byte there
@@ -786,7 +794,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                     }
                     // keep group starts (within the lane; a superset of them is fine) -- unless hits may still be struck
                     // out by k3_settle, or have been by the VM: a real hit must not be dropped for following a false one
-                    if (!VM && (direct || confirm_exact)) bits &= ~(bits << 1);
+                    if (!VM && exact && (direct || confirm_exact)) bits &= ~(bits << 1);
                     hits[k >> 1] |= bits << (16 * (k & 1));
                     cnt += (uint32_t)__popc(bits);
                 }
@@ -797,7 +805,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
 #pragma unroll
             for (int j = 1; j < ITER; j++) buf[j] = load_step<ITER, NT, 1>(cn, sub_off_n, lane, j, have_n);
         }
-        if (VM && cur) { // the survivors of the sub-tile, word by word: confirm + VM, the lanes side by side
+        if ((VM || !exact) && cur) { // the survivors of the sub-tile, word by word: confirm (+ VM), the lanes side by side
             cnt = 0;
 #pragma unroll
             for (int w = 0; w < (ITER + 1) / 2; w++) {
@@ -809,6 +817,8 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                     const uint32_t p = (uint32_t)(sub_off + (int)k * 1024 + (int)lane * 16) + j - koff;
                     if (!confirm_hit(p)) keep &= ~(1u << b);
                 }
+                // keep group starts (within a lane's sixteen positions of one step) where the tables have the last word
+                if (!VM && confirm_exact) keep &= ~((keep << 1) & 0xfffefffeu);
                 hits[w] = keep;
                 cnt += (uint32_t)__popc(keep);
             }
@@ -1217,24 +1227,30 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
         f |= ((uint32_t)pg.run_off[r] & 63u) << 16;
         a.run_flat[r] = f;
     }
-    // the lane-table form's program (k2lane.hip): two runs are put in the order of their step counts
+    // the lane-table form's program (k2lane.hip): up to four runs are put in the order of their step counts
     {
         uint32_t order[kK2MaxRuns], steps[kK2MaxRuns], shifts[kK2MaxRuns][5];
         for (int r = 0; r < kK2MaxRuns; r++) {
             order[r] = (uint32_t)r;
             steps[r] = k2_lane_steps(pg.run_len[r] ? pg.run_len[r] : 1u, shifts[r]);
         }
-        if (pg.nruns == 2 && steps[1] < steps[0]) std::swap(order[0], order[1]);
+        const uint32_t n = std::min<uint32_t>(pg.nruns, (uint32_t)kK2MaxRuns);
+        if (n >= 2 && n <= 4) std::stable_sort(order, order + n, [&](uint32_t x, uint32_t y) { return steps[x] < steps[y]; });
         for (int r = 0; r < kK2MaxRuns; r++) {
             const uint32_t q = order[r];
             uint32_t f = ((uint32_t)pg.run_cls[q] & 3u) | (((uint32_t)pg.run_off[q] & 31u) << 2);
             for (int i = 0; i < 5; i++) f |= (shifts[q][i] & 31u) << (7 + 5 * i);
             a.run_lane[r] = f;
         }
-        a.lane_steps[0] = steps[order[0]];
-        a.lane_steps[1] = steps[order[1]];
+        // what the launcher specialises on: one run -> its steps; 2..4 runs -> the most steps among all but the last, the last one's
+        a.lane_steps[0] = a.lane_steps[1] = 0;
+        if (n == 1) a.lane_steps[0] = steps[order[0]];
+        else if (n >= 2 && n <= 4) {
+            for (uint32_t r = 0; r + 1 < n; r++) a.lane_steps[0] = std::max(a.lane_steps[0], steps[order[r]]);
+            a.lane_steps[1] = steps[order[n - 1]];
+        }
         a.lane_smax = 0;
-        for (uint32_t r = 0; r < pg.nruns && r < (uint32_t)kK2MaxRuns; r++) a.lane_smax = std::max(a.lane_smax, steps[r]);
+        for (uint32_t r = 0; r < n; r++) a.lane_smax = std::max(a.lane_smax, steps[r]);
     }
 }
 

@@ -384,6 +384,16 @@ def test_submit_fd_ranges(ctx, tmp_path):
         for k in range(3):
             t, s_, _ = ctx.wait_segs()
             assert t == 10 + k and same(s_[0], table_candidates(db, data[k * 4096:k * 4096 + 2 * blk - 5000 + k]))
+        # two databases in flight: the device program is one per context -- a range still being read when another database
+        # is submitted must be launched with ITS program (the second submit waits for the first range to arrive and launch)
+        dba, dbb, dbc = engine.Database("[a-z]{2,5}"), engine.Database("foobardoesnotexist"), engine.Database("[0-9A-F]{6}[a-z]")
+        for rep in range(3):
+            ctx.submit_fd(dba, fd, 0, data.size, tag=31)
+            ctx.submit_fd(dbb, fd, 0, data.size, tag=32)
+            ctx.submit_fd(dbc, fd, 4096, blk + 77, tag=33)
+            for tag_want, dbx, lo, ln in ((31, dba, 0, data.size), (32, dbb, 0, data.size), (33, dbc, 4096, blk + 77)):
+                t, s_, _ = ctx.wait_segs()
+                assert t == tag_want and same(s_[0], table_candidates(dbx, data[lo:lo + ln])), (rep, tag_want)
         ctx.submit_fd(db, fd, data.size - 10, 4096)  # beyond the end of the file: queued ...
         ctx.submit_fd(db, fd, 0, 5000, tag=77)
         with pytest.raises(engine.EngineError, match="shrank"):
@@ -565,7 +575,7 @@ def test_match_ends_on_device(ctx):
                         asked += 1
                     else:
                         assert e == want, (pattern, variant, p, e, want)
-                assert asked <= 4, (pattern, asked)
+                assert asked < len(starts), (pattern, asked)  # (only starts inside the two long runs; how many of those are listed is the kernel's business)
             # a batch of segments: ends are segment-relative like the starts
             segs = [(0, 100_000), (100_000, 1), (100_016, 250_000), (350_016, 0), (350_016, 349_985)]
             parts = [data[o:o + ln] for o, ln in segs]
