@@ -598,6 +598,32 @@ __device__ __forceinline__ uint32_t and_b0_b1(uint32_t x, uint32_t y) // byte 0 
     asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
+// byte BYTE of dst = byte 0 of x & byte 1 of y; the other bytes of dst are kept (BYTE 0: zeroed) -- the SDWA destination
+// select packs four one-byte results into one register at no cost, so "any hit in this step" is the OR of four registers
+// instead of sixteen, and the hit mask is made of four dot products (below)
+template <int BYTE>
+__device__ __forceinline__ void and_b0_b1_into(uint32_t &dst, uint32_t x, uint32_t y)
+{
+    if constexpr (BYTE == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(dst) : "v"(x), "v"(y));
+    else if constexpr (BYTE == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1" : "+v"(dst) : "v"(x), "v"(y));
+    else if constexpr (BYTE == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1" : "+v"(dst) : "v"(x), "v"(y));
+    else asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1" : "+v"(dst) : "v"(x), "v"(y));
+}
+// 16-bit mask of the NONZERO bytes of H[0..3] (byte k of H[q] = position 4 q + k).  one: every byte is 0 or 1 already (a
+// single bucket).  Bytes -> 0 / 1 by the exact SWAR test, then one v_dot4_u32_u8 per register with the weights 1 2 4 8 /
+// 16 32 64 128 adds the four bits of a register into place.
+__device__ __forceinline__ uint32_t nonzero_bytes16(const uint32_t (&H)[4], bool one)
+{
+    uint32_t x[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        x[q] = H[q];
+        if (!one) x[q] = ((((H[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | H[q]) >> 7) & 0x01010101u;
+    }
+    const uint32_t lo = __builtin_amdgcn_udot4(x[1], 0x80402010u, __builtin_amdgcn_udot4(x[0], 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(x[3], 0x80402010u, __builtin_amdgcn_udot4(x[2], 0x08040201u, 0u, false), false);
+    return lo | (hi << 8);
+}
 // DEPTH: window positions the filter looks at.  4 by default; 3 when the compiler expects three positions to be selective
 // enough (ScanArgs::k3_depth: literal-like alternatives) -- two SDWA operations per byte instead of three and one look-up
 // less per step, paid for with more trips into the confirm path.
@@ -631,9 +657,10 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t lane4 = lane << 2;
     const uint32_t koff = a.k3_off, m = a.m;
-    const bool exact = DEPTH == 4 && a.k3_exact != 0; // (the three-position form always confirms)
+    const bool exact = (DEPTH == 4 ? a.k3_exact : a.k3_exact3) != 0; // the filtered positions ARE the pattern (three positions: windows of <= 3 bytes)
     const bool confirm_exact = a.prog->k3_confirm_exact != 0; // wave-uniform (scalar load)
     const bool vm_quick = VM && a.prog->vm_pair_ok == 2;      // (DevProgram::vm_pair may drop a hit on its own)
+    const bool one_bucket = a.k3_one_bucket != 0;             // every table byte is 0 or 1
     const uint8_t *tbl8 = reinterpret_cast<const uint8_t *>(tbl);
     {
         // dword q of the table = copy (q & 63) of entry (q >> 6), middle bytes swapped (see above); consecutive threads
@@ -714,6 +741,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
             if (!PF) load_subtile<ITER, NT, 1>(buf, c, sub_off, lane);
             // filter positions q = p + koff of window starts p with 0 <= p and p + m <= slen
             const int lo = (int)koff, hi = c.slen - (int)m + (int)koff;
+            const bool interior = sub_off >= lo && sub_off + ITER * 1024 - 1 <= hi; // every filter position of the sub-tile belongs to a window inside the segment
 #pragma unroll
             for (int k = 0; k < ITER; k++) {
                 const u32x4 d = buf[k];
@@ -736,23 +764,23 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                 // Y_j = [P_0(t_j) & P_1(t_{j+1}), P_2(t_j) & P_3(t_{j+1})]; h_j = Y_j.b0 & Y_{j+2}.b1 (four positions) or
                 // Y_j.b0 & e_{j+2}.b1 = ... & P_2(t_{j+2}) (three): two VALU operations per byte either way
                 // (plain shift + and in place of the selects: twice that -- profiles/r01_o_sweep_k3_sdwa.txt)
-                uint32_t h[16], any = 0;
+                uint32_t H[4]; // byte k of H[q] = h_{4q+k}: the buckets that accept the four filter positions from position 4 q + k on
                 uint32_t Y[18];
 #pragma unroll
                 for (int j = 0; j < (DEPTH == 3 ? 16 : 18); j++) Y[j] = and_w0_w1(e[j], e[j + 1]);
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    h[j] = and_b0_b1(Y[j], DEPTH == 3 ? e[j + 2] : Y[j + 2]);
-                    any |= h[j];
+                for (int q = 0; q < 4; q++) {
+                    and_b0_b1_into<0>(H[q], Y[4 * q], DEPTH == 3 ? e[4 * q + 2] : Y[4 * q + 2]);
+                    and_b0_b1_into<1>(H[q], Y[4 * q + 1], DEPTH == 3 ? e[4 * q + 3] : Y[4 * q + 3]);
+                    and_b0_b1_into<2>(H[q], Y[4 * q + 2], DEPTH == 3 ? e[4 * q + 4] : Y[4 * q + 4]);
+                    and_b0_b1_into<3>(H[q], Y[4 * q + 3], DEPTH == 3 ? e[4 * q + 5] : Y[4 * q + 5]);
                 }
+                const uint32_t any = (H[0] | H[1] | H[2]) | H[3];
                 if (any) { // cold: which positions, bounds, full windows
                     const int pos0 = sub_off + k * 1024 + (int)lane * 16;
-                    const uint32_t vm = valid16(pos0, lo, hi);
                     const bool direct = !VM && exact && pos0 + 16 + kK3Depth <= c.slen; // filter == pattern, windows in bounds
-                    uint32_t hm = 0;
-#pragma unroll
-                    for (int j = 0; j < 16; j++) hm |= h[j] ? 1u << j : 0u;
-                    hm &= vm;
+                    uint32_t hm = nonzero_bytes16(H, one_bucket);
+                    if (!interior) hm &= valid16(pos0, lo, hi);
                     uint32_t bits = hm;
                     if (VM) {
                         // Inexact patterns: here only the two-byte table (DevProgram::vm_pair) -- two byte loads and a bit per
@@ -1193,9 +1221,15 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
     a.k2_lane_table = lane_table;
     a.report_shift = pg.report_shift;
     // the filter IS the pattern when every alternative has its own bucket and lies inside the filtered positions
+    a.k3_one_bucket = 1;
+    for (int b = 0; b < 256; b++)
+        if (pg.k3_table[b] & 0xfefefefeu) a.k3_one_bucket = 0;
     a.k3_exact = pg.n_alts <= (uint32_t)kK3Buckets && pg.k3_off == 0;
-    for (uint32_t i = 0; i < pg.n_alts; i++)
+    a.k3_exact3 = a.k3_exact;
+    for (uint32_t i = 0; i < pg.n_alts; i++) {
         if (pg.alt_len[i] > (uint32_t)kK3Depth) a.k3_exact = 0;
+        if (pg.alt_len[i] > 3u) a.k3_exact3 = 0;
+    }
     // Three filter positions are enough when a hit of theirs is rare: expected hits per KiB step of a wave, pricing a
     // class by its size over the ~64 byte values text is made of, below 2 %.  (GSCAN_K3_DEPTH overrides: measurements.)
     {
@@ -1212,7 +1246,7 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
             }
             p3 += prod;
         }
-        a.k3_depth = p3 * 1024.0 < 0.02 ? 3u : 4u;
+        a.k3_depth = p3 * 1024.0 < 0.02 || a.k3_exact3 ? 3u : 4u; // (windows of <= 3 bytes: three positions are the whole pattern)
         if (const char *e = getenv("GSCAN_K3_DEPTH")) a.k3_depth = (uint32_t)atoi(e);
     }
     for (int r = 0; r < kK2MaxRuns; r++) {

@@ -42,6 +42,8 @@ struct ScanArgs {
     uint32_t anchor, anchor_mask, anchor_off, anchor_len; // K1
     uint32_t n_classes, nruns;                            // K2
     uint32_t k3_off, k3_exact, k3_depth;                  // K3 (k3_depth: 3 or 4 filter positions)
+    uint32_t k3_exact3;                                   // K3: ... and within THREE positions (the three-position filter is exact too)
+    uint32_t k3_one_bucket;                               // K3: the filter table uses bucket 0 only (its bytes are 0 / 1)
     uint32_t vm_filter;                                   // K3: every filter hit is put to the VM (DevProgram::vm_filter)
     uint32_t k2_lane_table;                               // K2, two classes: the per-lane single-byte table instead of the pair table (experiment switch)
     uint32_t report_shift;   // reported offset = device window start + this (1 when the windows carry a leading context position)
