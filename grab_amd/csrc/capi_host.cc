@@ -43,11 +43,18 @@ int grab_report_chunk_c(const gscan_db *db, unsigned flags, const char *path, co
 int grab_report_chunk_ends_c(const gscan_db *db, unsigned flags, const char *path, const void *content, size_t clen,
                              long long off, const uint32_t *starts, const uint32_t *ends, size_t nstarts, char **out, size_t *outlen)
 {
+    return grab_report_chunk_ext_c(db, flags, path, content, clen, off, starts, ends, nullptr, nullptr, nstarts, out, outlen);
+}
+
+int grab_report_chunk_ext_c(const gscan_db *db, unsigned flags, const char *path, const void *content, size_t clen, long long off,
+                            const uint32_t *starts, const uint32_t *ends, const uint32_t *ext, const unsigned char *gather, size_t nstarts,
+                            char **out, size_t *outlen)
+{
     if (!db || !out || !outlen) return -1;
     gscan_info info;
     if (gscan_db_info(db, &info) != GSCAN_OK) return -1;
     std::string text;
-    grab_report_chunk(db, info.minlen, flags, path ? path : "", (const char *)content, clen, off, starts, nstarts, text, nullptr, ends);
+    grab_report_chunk(db, info.minlen, flags, path ? path : "", (const char *)content, clen, off, starts, nstarts, text, ext, ends, gather);
     char *buf = (char *)malloc(text.size() + 1);
     if (!buf) return -1;
     memcpy(buf, text.data(), text.size());

@@ -66,7 +66,8 @@ constexpr size_t kPad = 4096;          // slack behind every text buffer
 constexpr size_t kSpecPer = 256;        // records of EACH shard region fetched speculatively with the header
 constexpr size_t kSpecRecs = kSpecPer * gscan::kShards;
 constexpr size_t kCS = gscan::kCtrStride;                  // the shard counters sit one per 128-byte line (scan_args.h)
-constexpr size_t kCounterWords = gscan::kShards * kCS + 2; // per-shard counts + overflow flag + records struck out by the second pass
+constexpr size_t kCounterWords = gscan::kShards * kCS + 3; // per-shard counts + overflow flag + records struck out by the second pass + bytes of line text gathered (k_lines)
+constexpr size_t kGatherPinnedMax = 512u << 20;             // a window's gathered lines are fetched only up to this size (beyond: the host copies from the file)
 constexpr size_t kCopyPiece = 32u << 20; // memcpy/H2D pipelining granule for foreign host buffers
 constexpr size_t kMaxChunk = (1ull << 30) + 4096;
 
@@ -572,7 +573,13 @@ struct Slot {
     uint32_t *h_ext_spec = nullptr; // pinned, kShards rows of kSpecPer * 3
     std::vector<uint32_t> sorted_ext;
     bool has_ext = false;
-    uint32_t ext_words = 0;     // 3: {m1, lb, le} per record ("line_extents"), 1: the match end ("match_ends"), 0: none
+    uint32_t ext_words = 0;     // 4: {m1, lb, le, goff} per record ("line_extents"), 1: the match end ("match_ends"), 0: none
+    // the text of the printed lines, gathered by k_lines ("line_extents"): device buffer, pinned copy of the used part
+    uint8_t *d_gather = nullptr;
+    size_t gather_cap = 0;
+    uint8_t *h_gather = nullptr;
+    size_t h_gather_cap = 0, gather_bytes = 0;
+    bool gather_ok = false;
     const void *ext = nullptr;  // caller's buffer this chunk was copied from (gscan_wait hands it back as *content)
     void *ext_reg = nullptr;    // ... registered with the runtime for direct DMA until the scan is done
     PinBlock *blk = nullptr; // pool block serving as this slot's pinned buffer (acquires of <= block_bytes() bytes)
@@ -829,7 +836,7 @@ int slot_launch(gscan_ctx *c, Slot &s)
     gscan::fill_program(a, db.prog);
     if (s.n_tiles) HIPCHK(c, gscan::launch_scan(db.tier, c->variant, a, grid_for(c, db, s.n_tiles), c->compute));
     if (s.n_tiles && gscan::scan_needs_settle(db.tier, db.prog)) HIPCHK(c, gscan::launch_settle(a, nw, c->compute));
-    s.ext_words = !s.n_tiles ? 0u : (c->line_extents && db.prog.lines_ok) ? 3u : (c->match_ends && db.prog.ends_ok) ? 1u : 0u;
+    s.ext_words = !s.n_tiles ? 0u : (c->line_extents && db.prog.lines_ok) ? 4u : (c->match_ends && db.prog.ends_ok) ? 1u : 0u;
     s.has_ext = s.ext_words != 0;
     if (s.has_ext) {
         const size_t eb = 4 * (size_t)s.ext_words; // bytes per record
@@ -840,9 +847,21 @@ int slot_launch(gscan_ctx *c, Slot &s)
             HIPCHK(c, hipMalloc((void **)&s.d_ext, s.rec_cap * eb));
             s.ext_cap = s.rec_cap * s.ext_words;
         }
-        if (!s.h_ext_spec) HIPCHK(c, hipHostMalloc((void **)&s.h_ext_spec, kSpecRecs * 12, hipHostMallocDefault));
-        if (s.ext_words == 3) HIPCHK(c, gscan::launch_lines(a, nw, tile_bytes / nw, s.d_ext, c->compute));
-        else HIPCHK(c, gscan::launch_ends(a, nw, tile_bytes / nw, s.d_ext, c->compute));
+        if (!s.h_ext_spec) HIPCHK(c, hipHostMalloc((void **)&s.h_ext_spec, kSpecRecs * 16, hipHostMallocDefault));
+        if (s.ext_words == 4) {
+            // the printed lines never overlap (the loop restarts at the end of the line it printed): their text fits the window
+            const size_t want = std::min<size_t>(std::max<size_t>(s.len, 1u << 20), 0xfffffff0u);
+            if (s.gather_cap < want) {
+                if (s.d_gather) hipFree(s.d_gather);
+                s.d_gather = nullptr;
+                s.gather_cap = 0;
+                HIPCHK(c, hipMalloc((void **)&s.d_gather, want));
+                s.gather_cap = want;
+            }
+            HIPCHK(c, gscan::launch_lines(a, nw, tile_bytes / nw, s.d_ext, s.d_gather, (uint32_t)s.gather_cap, c->compute));
+        } else {
+            HIPCHK(c, gscan::launch_ends(a, nw, tile_bytes / nw, s.d_ext, c->compute));
+        }
         HIPCHK(c, hipMemcpy2DAsync(s.h_ext_spec, kSpecPer * eb, s.d_ext, (size_t)a.cap_shard * eb, kSpecPer * eb, gscan::kShards,
                                    hipMemcpyDeviceToHost, c->compute));
     }
@@ -865,6 +884,8 @@ void free_slot(gscan_ctx *c, Slot &s)
     if (s.d_ext) hipFree(s.d_ext);
     if (s.h_ext_spec) hipHostFree(s.h_ext_spec);
     if (s.h_dense) hipHostFree(s.h_dense);
+    if (s.d_gather) hipFree(s.d_gather);
+    if (s.h_gather) hipHostFree(s.h_gather);
     if (s.pinned) hipHostFree(s.pinned);
     if (s.d_text) hipFree(s.d_text);
     if (s.d_recs) hipFree(s.d_recs);
@@ -1428,6 +1449,28 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
         HIPCHK(c, hipEventRecord(s->done, c->compute));
         HIPCHK(c, hipEventSynchronize(s->done));
     }
+    s->gather_ok = false;
+    s->gather_bytes = 0;
+    if (s->ext_words == 4) { // the printed lines' text: the used part of the gather buffer, into pinned memory
+        const size_t used = std::min<size_t>(s->h_counter[K * kCS + 2], s->gather_cap);
+        if (used <= kGatherPinnedMax) {
+            if (used > s->h_gather_cap) {
+                if (s->h_gather) hipHostFree(s->h_gather);
+                s->h_gather = nullptr;
+                s->h_gather_cap = 0;
+                const size_t cap = used + used / 2 + 4096;
+                HIPCHK(c, hipHostMalloc((void **)&s->h_gather, cap, hipHostMallocDefault));
+                s->h_gather_cap = cap;
+            }
+            if (used) {
+                HIPCHK(c, hipMemcpyAsync(s->h_gather, s->d_gather, used, hipMemcpyDeviceToHost, c->compute));
+                HIPCHK(c, hipEventRecord(s->done, c->compute));
+                HIPCHK(c, hipEventSynchronize(s->done));
+            }
+            s->gather_ok = true;
+            s->gather_bytes = used;
+        }
+    }
     s->sorted_ext.clear();
     if (s->has_ext) s->sorted_ext.reserve(total * ew);
     s->sorted.clear();
@@ -1475,8 +1518,16 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
 
 const uint32_t *gscan_last_ext(const gscan_ctx *c)
 {
-    if (!c || !c->last_waited || c->last_waited->ext_words != 3) return nullptr;
+    if (!c || !c->last_waited || c->last_waited->ext_words != 4) return nullptr;
     return c->last_waited->sorted_ext.data();
+}
+
+const uint8_t *gscan_last_gather(const gscan_ctx *c, size_t *bytes)
+{
+    if (bytes) *bytes = 0;
+    if (!c || !c->last_waited || c->last_waited->ext_words != 4 || !c->last_waited->gather_ok) return nullptr;
+    if (bytes) *bytes = c->last_waited->gather_bytes;
+    return c->last_waited->h_gather ? c->last_waited->h_gather : (const uint8_t *)"";
 }
 
 const uint32_t *gscan_last_ends(const gscan_ctx *c)

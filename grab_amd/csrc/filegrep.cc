@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <chrono>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -37,6 +38,8 @@
 namespace {
 
 std::mutex g_out_lock; // one writer at a time, whole chunks only (grab.cc:56,217-226)
+// GRAB_TIMING: how the printed lines came about (device line pass with gathered text / with text from the window / the host's loop)
+std::atomic<unsigned long long> g_lines_gathered{0}, g_lines_window{0}, g_lines_loop{0};
 
 constexpr size_t kContext = 511; // bytes of line context kept on each side (grab.cc:173: char[512])
 constexpr off_t kOverlap = 0x1000; // consecutive chunks share 4 KiB (grab.cc:151)
@@ -72,7 +75,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // ------------------------------------------------------------------------------------
 void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const char *path, const char *content,
                        size_t clen, long long off, const uint32_t *starts, size_t nstarts, std::string &out, const uint32_t *ext,
-                       const uint32_t *ends)
+                       const uint32_t *ends, const uint8_t *gather)
 {
     if (minlen < 0) return;
     gscan_cursor cur;
@@ -103,33 +106,58 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
     // (dense outputs: one allocation instead of the doublings -- 21 bytes of text per offset line, a line of context otherwise)
     if (nstarts > 1024) out.reserve(out.size() + nstarts * (plen + ((flags & GRAB_NOLINE) ? 28 : 96)));
     size_t s = 0;
-    if (ext && !(flags & GRAB_NOLINE)) {
-        // The device already decided which candidates the loop prints and where their lines begin and end (k_lines):
-        // nothing to search here, only to copy.  It stops at the first record that needs the loop itself.
-        size_t i = 0;
-        for (; i < nstarts; i++) {
-            const uint32_t m1 = ext[3 * i], lb = ext[3 * i + 1], le = ext[3 * i + 2];
-            if (m1 == 0) continue;
-            if (lb == 0xffffffffu) break;
-            if (!(s + (size_t)minlen < clen)) return; // grab.cc:175
-            const size_t m0 = starts[i];
-            put_head(m0);
-            out.append(content + lb, m0 - lb);
-            if (flags & GRAB_COLOR) out += kInvOn;
-            out.append(content + m0, m1 - m0);
-            if (flags & GRAB_COLOR) out += kInvOff;
-            out.append(content + m1, le - m1);
-            out += '\n';
-            s = le; // grab.cc:209
-            if (flags & GRAB_SINGLE) return;
+    unsigned long long n_gathered = 0, n_window = 0, n_loop = 0;
+    struct Tally {
+        unsigned long long &a, &b, &c;
+        ~Tally()
+        {
+            if (a) g_lines_gathered += a;
+            if (b) g_lines_window += b;
+            if (c) g_lines_loop += c;
         }
-        if (i == nstarts) return; // whatever follows the last listed start belongs to its group, i.e. to its line
-        // fall through: the reference's loop from s
-    }
+    } tally{n_gathered, n_window, n_loop};
+    // Line-printing modes with the device's line pass (k_lines): it has already decided which candidates the loop prints and
+    // where their lines begin and end, and copied the text of those lines into one buffer -- for those records there is
+    // nothing to search and nothing to read from the window, only to format.  Its verdicts hold while the restart position
+    // is 0 or the newline that ended the last printed line.  A record it marks "ask the host" (a line that runs on past the
+    // 511 bytes of printed context, a line start or a tail further than 4 KiB away) is handed to the reference's loop
+    // below, which keeps going until a printed line has ended at its newline again: from there the device's verdicts apply
+    // once more.  (A corpus with one line in ten thousand longer than 511 bytes has a hundred such records per 64 MiB
+    // window: falling back for the REST of the window at the first of them, as round 2 did, left the pass 5 % of the lines.)
+    size_t di = 0;                                         // next record of the device's pass
+    bool device = ext && !(flags & GRAB_NOLINE);           // its verdicts apply at s
     // -O -l with the match ends from the device (k_ends): s is always 0 or a match end, the next match is the next listed
     // start and its end is in the list -- `content` is not looked at (a window that was never read stays unmapped pages)
     const bool listed = ends && (flags & GRAB_NOLINE) && (flags & GRAB_OFFSETS);
     while (s + (size_t)minlen < clen) {
+        if (device) {
+            while (di < nstarts && (starts[di] < s || ext[4 * di] == 0)) di++; // behind s, or not printed (an earlier candidate in its line)
+            if (di >= nstarts) return; // whatever follows the last listed start belongs to its group, i.e. to its line
+            const uint32_t m1 = ext[4 * di], lb = ext[4 * di + 1], le = ext[4 * di + 2], goff = ext[4 * di + 3];
+            if (lb != 0xffffffffu) {
+                const size_t m0 = starts[di];
+                put_head(m0);
+                // the line [lb, le): from the gathered text when the device put it there, else from the window itself
+                const bool got = gather && goff != 0xffffffffu;
+                const char *line_text = got ? (const char *)gather + goff : content + lb;
+                (got ? n_gathered : n_window)++;
+                if (flags & GRAB_COLOR) {
+                    out.append(line_text, m0 - lb);
+                    out += kInvOn;
+                    out.append(line_text + (m0 - lb), m1 - m0);
+                    out += kInvOff;
+                    out.append(line_text + (m1 - lb), le - m1);
+                } else {
+                    out.append(line_text, le - lb);
+                }
+                out += '\n';
+                s = le; // grab.cc:209
+                di++;
+                if (flags & GRAB_SINGLE) return;
+                continue;
+            }
+            device = false; // this one is the loop's; back to the device's verdicts when a printed line has ended at its newline
+        }
         // rc = pcre_exec(d_pcreh, d_extra, start, end - start, 0, 0, ovector, 3)            (grab.cc:178)
         uint32_t b0 = 0, b1 = 0;
         int rc = listed ? gscan_next_listed(db, clen, starts, ends, nstarts, &cur, (uint32_t)s, &b0, &b1) : -1;
@@ -138,6 +166,7 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
         const size_t m0 = b0, m1 = b1;
 
         put_head(m0);
+        n_loop++;
 
         size_t tail = 0;
         if (!(flags & GRAB_NOLINE)) {
@@ -154,6 +183,7 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
             out.append(content + m1, line_end - m1);
             out += '\n';
             tail = line_end - m1;
+            if (ext && nr) device = true; // the printed line ended at its newline: every later record lies in a later line
         } else if (!(flags & GRAB_OFFSETS)) {
             out += "matches\n";
             break;
@@ -184,8 +214,10 @@ void FileGrep::report_timing()
 {
     if (timing_ && !timing_reported_) {
         timing_reported_ = true;
-        fprintf(stderr, "[grab timing] device %d: files %zu launches %zu bytes %zu | open %.3f s  read(batch) %.3f s  submit %.3f s  wait %.3f s  map+report %.3f s  close %.3f s\n",
-                device_, t_files_, t_chunks_, t_bytes_, t_map_, t_read_, t_submit_, t_wait_, t_report_, t_unmap_);
+        fprintf(stderr, "[grab timing] device %d: files %zu launches %zu bytes %zu | open %.3f s  read(batch) %.3f s  submit %.3f s  wait %.3f s  map+report %.3f s (of which writing it out, lock included: %.3f s)  close %.3f s\n",
+                device_, t_files_, t_chunks_, t_bytes_, t_map_, t_read_, t_submit_, t_wait_, t_report_, t_emit_, t_unmap_);
+        fprintf(stderr, "[grab timing] printed so far (all workers): %llu via the device's line pass + gathered text, %llu via the pass with text from the window, %llu by the host's loop\n",
+                g_lines_gathered.load(), g_lines_window.load(), g_lines_loop.load());
         for (size_t k = 0; k < ctxs_.size(); k++) // what each device was handed: the work queue's balance (bench.py --mode e2e sums these)
             fprintf(stderr, "[grab bytes] device %d: %zu\n", ctx_dev_[k], ctx_bytes_[k]);
     }
@@ -356,6 +388,15 @@ int FileGrep::read_chunk(int fd, void *dst, size_t len, off_t at)
 
 void FileGrep::emit(std::string &text)
 {
+    const double t_emit0 = timing_ ? now_s() : 0;
+    struct Stop {
+        FileGrep *g;
+        double t0;
+        ~Stop()
+        {
+            if (g->timing_) g->t_emit_ += now_s() - t0;
+        }
+    } stop{this, t_emit0};
     std::lock_guard<std::mutex> hold(g_out_lock);
     if (out_fd_ == 1) {
         std::cout << text; // same stream the reference prints to
@@ -441,7 +482,7 @@ int FileGrep::retire_oldest(bool print)
                 status = -1;
             } else {
                 grab_report_chunk(db_, minlen_, rflags, f.path.c_str(), (const char *)map, job.len, (long long)job.off, starts, first[nseg], text,
-                                  gscan_last_ext(ctx), gscan_last_ends(ctx));
+                                  gscan_last_ext(ctx), gscan_last_ends(ctx), gscan_last_gather(ctx, nullptr));
                 munmap(map, job.len); // grab.cc:215
                 if (!text.empty()) {
                     emit(text);
@@ -454,7 +495,8 @@ int FileGrep::retire_oldest(bool print)
             if (first[i + 1] == first[i] && !context_) continue;
             const uint32_t *ext = gscan_last_ext(ctx), *ends = gscan_last_ends(ctx);
             grab_report_chunk(db_, minlen_, rflags, job.files[i]->path.c_str(), (const char *)bytes + job.segs[i].offset, job.segs[i].len, 0,
-                              starts + first[i], first[i + 1] - first[i], text, ext ? ext + 3 * first[i] : nullptr, ends ? ends + first[i] : nullptr);
+                              starts + first[i], first[i + 1] - first[i], text, ext ? ext + 4 * first[i] : nullptr, ends ? ends + first[i] : nullptr,
+                              gscan_last_gather(ctx, nullptr));
         }
         if (!text.empty()) emit(text); // one lock per batch; per-file output stays contiguous and in order
     }

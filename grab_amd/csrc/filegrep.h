@@ -97,7 +97,7 @@ private:
     // GRAB_TIMING=1 in the environment: per-instance wall-clock split, printed to stderr by the destructor
     bool timing_ = false, timing_reported_ = false;
     size_t t_files_ = 0, t_chunks_ = 0, t_bytes_ = 0;
-    double t_map_ = 0, t_read_ = 0, t_submit_ = 0, t_wait_ = 0, t_report_ = 0, t_unmap_ = 0;
+    double t_map_ = 0, t_read_ = 0, t_submit_ = 0, t_wait_ = 0, t_report_ = 0, t_unmap_ = 0, t_emit_ = 0;
     // pipeline state
     std::deque<Job> flight_;
     std::vector<gscan_ctx *> ctxs_;   // [0] == ctx_; further devices for the windows of one big file ("devices")
@@ -122,4 +122,5 @@ private:
 // ascending candidate list instead of repeated pcre_exec calls.  Pure host function.
 void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const char *path,
                        const char *content, size_t clen, long long off, const uint32_t *starts,
-                       size_t nstarts, std::string &out, const uint32_t *ext = nullptr, const uint32_t *ends = nullptr);
+                       size_t nstarts, std::string &out, const uint32_t *ext = nullptr, const uint32_t *ends = nullptr,
+                       const uint8_t *gather = nullptr);

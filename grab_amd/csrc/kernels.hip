@@ -936,8 +936,10 @@ __device__ __forceinline__ unsigned long long load8(const uint8_t *q) // any ali
 // carried from record to record.  Newlines are searched 8 bytes at a time.
 // (descriptors are per wave sub-tile: st = tile * nw + wave covers sub_bytes bytes; the descriptors of a segment are
 // consecutive, those of a segment's last tile beyond its end are empty)
-__global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t sub_bytes, uint32_t *__restrict__ ext)
+__global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t sub_bytes, uint32_t *__restrict__ ext,
+                                              uint8_t *__restrict__ gather, uint32_t gather_cap)
 {
+    __shared__ uint32_t s_lb[64], s_len[64];
     const uint32_t st = blockIdx.x;
     const uint32_t t = st / nw;
     const uint32_t tile_bytes = sub_bytes; // (the walk back over earlier descriptors below steps by sub-tiles)
@@ -960,86 +962,117 @@ __global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__rest
     const DevProgram *pg = a.prog;
     const uint32_t m = a.m, tail_extra = pg->tail_extra;
     const unsigned long long kNl = 0x0a0a0a0a0a0a0a0aull;
-    for (uint32_t i = threadIdx.x; i < cnt; i += 64) {
-        const uint32_t p = a.recs[base + i];
-        uint32_t *e = ext + 3ull * (base + i);
-        // start of p's line: the byte after the last newline before p
-        uint32_t ls = p;
-        bool found = false;
-        while (!found && ls >= 8 && p - ls < kLineBack) {
-            const unsigned long long z = zero_bytes(load8(seg + ls - 8) ^ kNl);
-            if (z) {
-                ls = ls - 8 + (uint32_t)((63 - __clzll((long long)z)) >> 3) + 1; // highest zero byte = the nearest newline
-                found = true;
-            } else {
-                ls -= 8;
-            }
-        }
-        while (!found && ls > 0 && p - ls < kLineBack + 8) {
-            if (seg[ls - 1] == '\n') found = true;
-            else ls--;
-        }
-        if (!found && ls > 0) { // no line start within reach
-            e[0] = 1;
-            e[1] = kLineAsk;
-            continue;
-        }
-        // an earlier candidate in [ls, p)?  In this tile: the previous record.  Before it: the last record of the nearest
-        // earlier tile of this segment that has one (tiles of a segment are consecutive: tile t - k starts k tiles earlier).
-        bool first = true;
-        if (i > 0) {
-            first = a.recs[base + i - 1] < ls;
-        } else if (ls < tile_off) {
-            uint32_t u = st, uoff = tile_off;
-            while (uoff > ls) { // descriptor u - 1 covers [uoff - tile_bytes, uoff)
-                u--;
-                uoff -= tile_bytes;
-                const unsigned long long du = a.desc[u];
-                if ((uint32_t)du) {
-                    first = a.recs[(uint32_t)(du >> 32) + (uint32_t)du - 1u] < ls;
-                    break;
+    const uint32_t lane = threadIdx.x;
+    // 64 records at a time: every lane settles one record (printed? its match end, line begin, line end), then the wave
+    // copies the printed lines' text into the gather buffer together -- one reservation per 64 records
+    for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        uint32_t mylen = 0, mylb = 0; // the printed line [lb, le) of this lane's record (0: nothing to gather)
+        uint32_t *e = ext + 4ull * (base + i);
+        if (i < cnt) {
+            const uint32_t p = a.recs[base + i];
+            // start of p's line: the byte after the last newline before p
+            uint32_t ls = p;
+            bool found = false;
+            while (!found && ls >= 8 && p - ls < kLineBack) {
+                const unsigned long long z = zero_bytes(load8(seg + ls - 8) ^ kNl);
+                if (z) {
+                    ls = ls - 8 + (uint32_t)((63 - __clzll((long long)z)) >> 3) + 1; // highest zero byte = the nearest newline
+                    found = true;
+                } else {
+                    ls -= 8;
                 }
             }
-        }
-        if (!first) {
-            e[0] = 0;
-            continue;
-        }
-        // the match: window + greedy tail
-        uint32_t m1 = p + m, extra = 0;
-        bool ask = false;
-        while (m1 < slen && extra < tail_extra) {
-            const uint32_t b = seg[m1];
-            if (!((pg->tail_bits[b >> 5] >> (b & 31)) & 1u)) break;
-            m1++;
-            extra++;
-            if (extra >= kLineBack && extra < tail_extra) {
-                ask = true;
-                break;
+            while (!found && ls > 0 && p - ls < kLineBack + 8) {
+                if (seg[ls - 1] == '\n') found = true;
+                else ls--;
             }
-        }
-        // the rest of the line, at most 511 bytes of it (grab.cc:173,194-196)
-        uint32_t le = m1;
-        found = false;
-        while (!found && le + 8 <= slen && le - m1 < 504u) {
-            const unsigned long long z = zero_bytes(load8(seg + le) ^ kNl);
-            if (z) {
-                le += (uint32_t)(__ffsll((long long)z) - 1) >> 3; // lowest zero byte = the next newline
-                found = true;
+            int verdict = 1; // 0 not printed, 1 printed, 2 ask the host
+            if (!found && ls > 0) verdict = 2; // no line start within reach
+            // an earlier candidate in [ls, p)?  In this tile: the previous record.  Before it: the last record of the nearest
+            // earlier tile of this segment that has one (tiles of a segment are consecutive: tile t - k starts k tiles earlier).
+            if (verdict == 1) {
+                bool first = true;
+                if (i > 0) {
+                    first = a.recs[base + i - 1] < ls;
+                } else if (ls < tile_off) {
+                    uint32_t u = st, uoff = tile_off;
+                    while (uoff > ls) { // descriptor u - 1 covers [uoff - tile_bytes, uoff)
+                        u--;
+                        uoff -= tile_bytes;
+                        const unsigned long long du = a.desc[u];
+                        if ((uint32_t)du) {
+                            first = a.recs[(uint32_t)(du >> 32) + (uint32_t)du - 1u] < ls;
+                            break;
+                        }
+                    }
+                }
+                if (!first) verdict = 0;
+            }
+            uint32_t m1 = p + m, le = 0;
+            if (verdict == 1) {
+                // the match: window + greedy tail
+                uint32_t extra = 0;
+                while (m1 < slen && extra < tail_extra) {
+                    const uint32_t b = seg[m1];
+                    if (!((pg->tail_bits[b >> 5] >> (b & 31)) & 1u)) break;
+                    m1++;
+                    extra++;
+                    if (extra >= kLineBack && extra < tail_extra) {
+                        verdict = 2;
+                        break;
+                    }
+                }
+                // the rest of the line, at most 511 bytes of it (grab.cc:173,194-196)
+                le = m1;
+                found = false;
+                while (!found && le + 8 <= slen && le - m1 < 504u) {
+                    const unsigned long long z = zero_bytes(load8(seg + le) ^ kNl);
+                    if (z) {
+                        le += (uint32_t)(__ffsll((long long)z) - 1) >> 3; // lowest zero byte = the next newline
+                        found = true;
+                    } else {
+                        le += 8;
+                    }
+                }
+                while (!found && le < slen && seg[le] != '\n' && le - m1 < 511u) le++;
+                if (le < slen && seg[le] != '\n') verdict = 2; // the line runs on: what follows may print again
+            }
+            if (verdict == 0) {
+                e[0] = 0;
+            } else if (verdict == 2) {
+                e[0] = 1;
+                e[1] = kLineAsk;
             } else {
-                le += 8;
+                e[0] = m1;
+                e[1] = mylb = p - ls > 511u ? p - 511u : ls; // at most 511 bytes in front of the match (grab.cc:173,190-193)
+                e[2] = le;
+                mylen = le - mylb;
             }
         }
-        while (!found && le < slen && seg[le] != '\n' && le - m1 < 511u) le++;
-        if (le < slen && seg[le] != '\n') ask = true; // the line runs on: what follows may print again
-        if (ask) {
-            e[0] = 1;
-            e[1] = kLineAsk;
-            continue;
+        // gather: the wave's printed lines, back to back; every record learns where its text went (kLineAsk: nowhere --
+        // the buffer is full or there is none, the host copies from the file)
+        const uint32_t incl = wave_scan(mylen);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        uint32_t gb = 0;
+        if (gather && total && lane == 0) gb = atomicAdd(a.counter + kShards * kCtrStride + 2, total);
+        gb = __builtin_amdgcn_readfirstlane(gb);
+        const bool room = gather && total && (unsigned long long)gb + total <= (unsigned long long)gather_cap;
+        if (i < cnt && mylen) e[3] = room ? gb + incl - mylen : kLineAsk;
+        if (room) {
+            s_lb[lane] = mylb;
+            s_len[lane] = mylen;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint32_t at = gb;
+            for (uint32_t r = 0; r < 64u && i0 + r < cnt; r++) {
+                const uint32_t ln = s_len[r], lb = s_lb[r];
+                for (uint32_t b = lane; b < ln; b += 64u) gather[at + b] = seg[lb + b];
+                at += ln;
+            }
+            __builtin_amdgcn_wave_barrier(); // (the next chunk overwrites s_lb / s_len)
         }
-        e[0] = m1;
-        e[1] = p - ls > 511u ? p - 511u : ls; // at most 511 bytes in front of the match (grab.cc:173,190-193)
-        e[2] = le;
     }
 }
 
@@ -1309,10 +1342,10 @@ hipError_t launch_ends(const ScanArgs &a, uint32_t nw, uint32_t sub_bytes, uint3
     return hipGetLastError();
 }
 
-hipError_t launch_lines(const ScanArgs &a, uint32_t nw, uint32_t sub_bytes, uint32_t *ext, hipStream_t st)
+hipError_t launch_lines(const ScanArgs &a, uint32_t nw, uint32_t sub_bytes, uint32_t *ext, uint8_t *gather, uint32_t gather_cap, hipStream_t st)
 {
     if (a.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_lines, dim3(a.n_tiles * nw), dim3(64), 0, st, a, a.tiles, nw, sub_bytes, ext);
+    hipLaunchKernelGGL(k_lines, dim3(a.n_tiles * nw), dim3(64), 0, st, a, a.tiles, nw, sub_bytes, ext, gather, gather_cap);
     return hipGetLastError();
 }
 

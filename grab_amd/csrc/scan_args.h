@@ -35,7 +35,7 @@ struct ScanArgs {
     uint32_t cap_shard;      // record capacity of ONE shard region (regions are back to back)
     uint32_t *recs;          // candidate starts, segment-relative
     unsigned long long *desc; // [n_tiles * waves per workgroup] one per wave sub-tile: count | base<<32 (base = absolute record index)
-    uint32_t *counter;       // [k * kCtrStride] records reserved in shard k, [kShards * kCtrStride] overflow flag, [.. + 1] records struck out by k3_settle
+    uint32_t *counter;       // [k * kCtrStride] records reserved in shard k, [kShards * kCtrStride] overflow flag, [.. + 1] records struck out by k3_settle, [.. + 2] bytes of line text gathered by k_lines
     const DevProgram *prog;  // cold paths only (K1 verify, K2 table staging)
     // pattern program, hot-loop copy
     uint32_t m;              // window length
@@ -80,8 +80,9 @@ uint32_t k2_lane_steps(uint32_t n, uint32_t *shifts);
 hipError_t launch_k2_lane(const ScanArgs &a, uint32_t grid, hipStream_t st);
 bool scan_needs_settle(int tier, const DevProgram &pg);
 hipError_t launch_settle(const ScanArgs &a, uint32_t waves, hipStream_t st);
-// line extents + orbit selection for the line-printing modes: ext[3 * record index] = {m1, lb, le} (kernels.hip, k_lines)
-hipError_t launch_lines(const ScanArgs &a, uint32_t waves, uint32_t sub_bytes, uint32_t *ext, hipStream_t st);
+// line extents + orbit selection + line gather for the line-printing modes: ext[4 * record index] = {m1, lb, le, goff}, the
+// printed lines' text [lb, le) copied to gather[goff ..] (kernels.hip, k_lines); counter[kShards * kCtrStride + 2] = bytes gathered
+hipError_t launch_lines(const ScanArgs &a, uint32_t waves, uint32_t sub_bytes, uint32_t *ext, uint8_t *gather, uint32_t gather_cap, hipStream_t st);
 constexpr uint32_t kLineAskHost = 0xffffffffu;
 // match ends for -O -l: ends[record index] = end of the match that starts at the record (0: ask the host) (kernels.hip, k_ends)
 hipError_t launch_ends(const ScanArgs &a, uint32_t waves, uint32_t sub_bytes, uint32_t *ends, hipStream_t st);

@@ -21,7 +21,7 @@ SLOTS = 2
 SYMBOLS = [
     "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_match_info", "gscan_next_match", "gscan_tail_positions", "gscan_db_dev_window",
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
-    "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_ends", "gscan_next_listed",
+    "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_gather", "gscan_last_ends", "gscan_next_listed",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
     "gscan_set_option", "gscan_kernel_time", "gscan_resource_errors",
     "gscan_ingest_info", "gscan_auto_readers", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
@@ -98,6 +98,8 @@ def lib():
         L.gscan_block_size.restype = C.c_size_t
         L.gscan_last_ext.argtypes = [C.c_void_p]
         L.gscan_last_ext.restype = C.POINTER(C.c_uint32)
+        L.gscan_last_gather.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        L.gscan_last_gather.restype = C.c_void_p
         L.gscan_last_ends.argtypes = [C.c_void_p]
         L.gscan_last_ends.restype = C.POINTER(C.c_uint32)
         L.gscan_next_listed.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Cursor), C.c_uint32,
@@ -294,11 +296,19 @@ class Context:
         return self.wait()[1]
 
     def last_ext(self, n):
-        """The line extents {m1, lb, le} of the n records the last wait() returned (option "line_extents"), or None."""
+        """The line extents {m1, lb, le, goff} of the n records the last wait() returned (option "line_extents"), or None."""
         p = lib().gscan_last_ext(self._h)
         if not p:
             return None
-        return np.ctypeslib.as_array(p, shape=(n * 3,)).copy().reshape(n, 3) if n else np.zeros((0, 3), np.uint32)
+        return np.ctypeslib.as_array(p, shape=(n * 4,)).copy().reshape(n, 4) if n else np.zeros((0, 4), np.uint32)
+
+    def last_gather(self):
+        """The text of the printed lines the device gathered for the last wait()'s chunk (uint8 array), or None."""
+        n = C.c_size_t()
+        p = lib().gscan_last_gather(self._h, C.byref(n))
+        if not p:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint8)
 
     def last_ends(self, n):
         """The match ends of the n records the last wait() returned (option "match_ends"; 0 = left to the host), or None."""

@@ -12,7 +12,7 @@ from .build import lib_path
 SYMBOLS = [
     "grab_filegrep_new", "grab_filegrep_free", "grab_filegrep_why", "grab_filegrep_recurse",
     "grab_filegrep_show_path", "grab_filegrep_config", "grab_filegrep_prepare", "grab_filegrep_find",
-    "grab_filegrep_find_recursive", "grab_filegrep_engine_option", "grab_report_chunk_c", "grab_report_chunk_ends_c", "grab_free", "grab_place_workers_c",
+    "grab_filegrep_find_recursive", "grab_filegrep_engine_option", "grab_report_chunk_c", "grab_report_chunk_ends_c", "grab_report_chunk_ext_c", "grab_free", "grab_place_workers_c",
     "grab_filegrep_find3", "grab_filegrep_flush", "grab_walk_parallel", "grab_validate",
 ]
 
@@ -51,6 +51,8 @@ def lib():
                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.grab_report_chunk_ends_c.argtypes = [C.c_void_p, C.c_uint, C.c_char_p, C.c_void_p, C.c_size_t, C.c_longlong,
                                                C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.grab_report_chunk_ext_c.argtypes = [C.c_void_p, C.c_uint, C.c_char_p, C.c_void_p, C.c_size_t, C.c_longlong,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.grab_place_workers_c.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
         L.grab_free.argtypes = [C.c_void_p]
         L.grab_free.restype = None
@@ -150,6 +152,28 @@ def validate(regex, literal=False):
     why = C.create_string_buffer(512)
     rc = lib().grab_validate(regex, len(regex), 1 if literal else 0, why, 512)
     return rc, why.value.decode("latin-1")
+
+
+def report_chunk_ext(db, flags, path, content, off, starts, ext, gather=None):
+    """grab_report_chunk_ext_c: the chunk's output with the device's line pass (ext: n x 4 uint32 {m1, lb, le, goff}; gather: the
+    printed lines' text or None)."""
+    import numpy as np
+
+    buf = np.ascontiguousarray(np.frombuffer(content, np.uint8))
+    st = np.ascontiguousarray(np.asarray(starts, np.uint32))
+    ex = np.ascontiguousarray(np.asarray(ext, np.uint32).reshape(-1))
+    assert ex.size == 4 * st.size
+    ga = np.ascontiguousarray(np.frombuffer(gather, np.uint8)) if gather is not None else None
+    out = C.c_void_p()
+    n = C.c_size_t()
+    rc = lib().grab_report_chunk_ext_c(db._h, flags, os.fsencode(path) if path is not None else None, buf.ctypes.data if buf.size else None, buf.size, off,
+                                       st.ctypes.data if st.size else None, None, ex.ctypes.data if ex.size else None,
+                                       ga.ctypes.data if ga is not None and ga.size else (C.c_char_p(b"") if ga is not None else None), st.size, C.byref(out), C.byref(n))
+    if rc != 0:
+        raise RuntimeError("grab_report_chunk_ext_c failed")
+    data = C.string_at(out, n.value)
+    lib().grab_free(out)
+    return data
 
 
 def report_chunk(db, flags, path, content, off, starts, ends=None, clen=None):

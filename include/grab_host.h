@@ -50,6 +50,11 @@ int grab_report_chunk_c(const gscan_db *db, unsigned flags, const char *path, co
 int grab_report_chunk_ends_c(const gscan_db *db, unsigned flags, const char *path, const void *content,
                              size_t clen, long long off, const uint32_t *starts, const uint32_t *ends, size_t nstarts,
                              char **out, size_t *outlen);
+/* ... and with the device's line pass for the line-printing modes (gscan_last_ext: 4 words per start; gscan_last_gather: the
+ * printed lines' text; either may be NULL). */
+int grab_report_chunk_ext_c(const gscan_db *db, unsigned flags, const char *path, const void *content, size_t clen,
+                            long long off, const uint32_t *starts, const uint32_t *ends, const uint32_t *ext,
+                            const unsigned char *gather, size_t nstarts, char **out, size_t *outlen);
 void grab_free(void *p);
 
 /*

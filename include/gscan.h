@@ -253,17 +253,22 @@ int gscan_submit_fd(gscan_ctx *ctx, const gscan_db *db, int fd, long long file_o
 int gscan_wait(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, size_t *n,
                const void **content);
 /*
- * Line extents and orbit selection on the device, for the reference's line-printing modes (src/grab.cc:188-209: print
- * the line around the match, restart at the end of that line).  With gscan_set_option(ctx, "line_extents", 1) and a
- * pattern whose gscan_info.lines_ok is set, every chunk also carries ext[3*i .. 3*i+2] = {m1, lb, le} for starts[i]:
+ * Line extents, orbit selection and line gather on the device, for the reference's line-printing modes (src/grab.cc:188-209:
+ * print the line around the match, restart at the end of that line).  With gscan_set_option(ctx, "line_extents", 1) and a
+ * pattern whose gscan_info.lines_ok is set, every chunk also carries ext[4*i .. 4*i+3] = {m1, lb, le, goff} for starts[i]:
  *   m1 == 0            starts[i] is not printed (an earlier candidate sits in the same line);
  *   lb == 0xffffffff   ask the host: from here on the reference's loop itself is needed (gscan_next_match) -- a line
  *                      that runs on past the 511 bytes of printed context, a line start or tail too far away;
  *   else               print [lb, starts[i]) + the match [starts[i], m1) + [m1, le) + '\n'; the loop restarts at le.
+ *                      goff != 0xffffffff: the bytes [lb, le) of the chunk are at gscan_last_gather()[goff ..] -- the device
+ *                      copied the text of every printed line into one buffer, so the caller never reads the chunk itself
+ *                      (for a file range that was never mapped: no page is faulted in); 0xffffffff: take them from the chunk.
  * gscan_last_ext returns the array for the chunk the last gscan_wait / gscan_wait_segs call handed out (parallel to its
- * starts, same lifetime), or NULL if that chunk has none.
+ * starts, same lifetime), or NULL if that chunk has none; gscan_last_gather the gathered text (NULL: none was fetched --
+ * treat every goff as 0xffffffff).
  */
 const uint32_t *gscan_last_ext(const gscan_ctx *ctx);
+const uint8_t *gscan_last_gather(const gscan_ctx *ctx, size_t *bytes);
 /*
  * Match ends on the device, for -O -l (src/grab.cc:175-213 with d_print_line off: print the offset, restart at the match
  * end).  With gscan_set_option(ctx, "match_ends", 1) and a pattern whose gscan_info.ends_ok is set, every chunk also

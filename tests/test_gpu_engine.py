@@ -526,17 +526,20 @@ def test_line_extents_on_device(ctx):
                 ctx.set_option("variant", variant)
                 starts = ctx.scan(db, data)
                 ext = ctx.last_ext(len(starts))
-                assert ext is not None and ext.shape == (len(starts), 3)
+                assert ext is not None and ext.shape == (len(starts), 4)
+                text = ctx.last_gather()
+                assert text is not None
                 want = _orbit_lines(pattern, data)
                 got = []
                 asked = False
-                for p, (m1, lb, le) in zip(starts.tolist(), ext.tolist()):
+                for p, (m1, lb, le, goff) in zip(starts.tolist(), ext.tolist()):
                     if m1 == 0:
                         continue
                     if lb == 0xFFFFFFFF:
                         asked = True
                         break
                     got.append((p, m1, lb, le))
+                    assert goff != 0xFFFFFFFF and np.array_equal(text[goff:goff + le - lb], data[lb:le]), (pattern, variant, p)  # the line's text, gathered by the device
                 assert got == want[:len(got)], (pattern, variant)
                 if not asked:
                     assert len(got) == len(want), (pattern, variant)

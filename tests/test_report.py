@@ -221,3 +221,62 @@ def test_offsets_walk_without_the_text(built):
                         assert filegrep.report_chunk(db, f, "d/f", data, 0, starts, ends=holes) == want, (pattern, n, f)
                 # the line-printing modes ignore the ends
                 assert filegrep.report_chunk(db, filegrep.OFFSETS, "d/f", data, 0, starts, ends=ends) == so.grab_file(pattern, data.tobytes(), 1, 1 << 30)
+
+
+def _lines_pass(db, data, starts, rng, ask_rate):
+    """What the device's line pass (k_lines) hands over for one chunk, restated in Python: per listed start {m1, lb, le,
+    goff} + the gathered text.  m1 == 0: not printed (an earlier listed start in the same line); lb == 0xffffffff: ask the
+    host (the line runs on past the printed context, a line start or tail out of reach -- here also at random, ask_rate:
+    the kernel may ask whenever it likes); else the printed line [lb, le), whose text sits at gather[goff:]."""
+    ASK = 0xFFFFFFFF
+    content = data.tobytes()
+    n = len(content)
+    ext = np.zeros((len(starts), 4), np.uint32)
+    gathered = bytearray()
+    for i, p in enumerate(starts.tolist()):
+        nl = content.rfind(b"\n", 0, p)
+        ls = nl + 1
+        if i > 0 and starts[i - 1] >= ls:
+            continue  # not printed
+        m1 = db.match_end(data, p)
+        end = content.find(b"\n", m1, min(n, m1 + 511))
+        le = end if end >= 0 else min(n, m1 + 511)
+        runs_on = le < n and content[le] != 0x0A
+        if p - ls > 4096 or m1 - p > 4096 or runs_on or rng.random() < ask_rate:
+            ext[i] = (1, ASK, 0, 0)
+            continue
+        lb = max(ls, p - 511)
+        goff = len(gathered) if rng.random() > 0.1 else ASK  # (a few lines the device could not gather: taken from the window)
+        if goff != ASK:
+            gathered += content[lb:le]
+        ext[i] = (m1, lb, le, goff)
+    return ext, bytes(gathered)
+
+
+def test_line_pass_with_resync(built):
+    """The line-printing modes driven by the device's line pass: printed lines come from the gathered text, "ask the host"
+    records go through the reference's loop, and the pass takes over again once a printed line has ended at its newline --
+    byte-identical to the reference's loop (scan_oracle.grab_file) on texts with lines far longer than the 511 bytes of
+    printed context and the 4 KiB the device searches, with random extra asks, with and without gathered text, -s included."""
+    rng = np.random.default_rng(31)
+    words = [b"foo", b"foobar_identifier_0123456789", b"x1", b"abc0123456789", b"e", b" ", b"_", b"9", b"zz zz", b"\n", b"\n"]
+    for pattern in ["[A-Za-z_][A-Za-z0-9_]{15,}", "foo", "e+", "[0-9]{3}[0-9a-f]*", "[a-f]{2}[a-f0-9]*"]:
+        db = engine.Database(pattern)
+        assert db.info.lines_ok, pattern
+        for trial in range(10):
+            parts = []
+            for _ in range(int(rng.integers(1, 400))):
+                w = words[int(rng.integers(0, len(words)))]
+                parts.append(w)
+                if rng.random() < 0.03:  # a long run without a newline: 600 .. 6000 bytes
+                    parts.append(bytes(rng.choice(np.frombuffer(b"abcdefoo_0189 ", np.uint8), int(rng.integers(600, 6000))).tolist()))
+            data = np.frombuffer(b"".join(parts), np.uint8)
+            starts = so.group_starts(db_candidates(db, data)).astype(np.uint32)
+            for ask_rate in (0.0, 0.3):
+                ext, gathered = _lines_pass(db, data, starts, rng, ask_rate)
+                for f in (filegrep.OFFSETS, 0, filegrep.OFFSETS | filegrep.PREFIX, filegrep.SINGLE, filegrep.OFFSETS | filegrep.COLOR):
+                    want = so.grab_file(pattern, data.tobytes(), f, 1 << 30, path=b"d/f")
+                    assert filegrep.report_chunk_ext(db, f, "d/f", data, 0, starts, ext, gathered) == want, (pattern, trial, ask_rate, f)
+                    noga = ext.copy()
+                    noga[:, 3] = 0xFFFFFFFF
+                    assert filegrep.report_chunk_ext(db, f, "d/f", data, 0, starts, noga, None) == want, (pattern, trial, ask_rate, f)
