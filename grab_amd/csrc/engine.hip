@@ -66,7 +66,7 @@ constexpr size_t kPad = 4096;          // slack behind every text buffer
 constexpr size_t kSpecPer = 256;        // records of EACH shard region fetched speculatively with the header
 constexpr size_t kSpecRecs = kSpecPer * gscan::kShards;
 constexpr size_t kCS = gscan::kCtrStride;                  // the shard counters sit one per 128-byte line (scan_args.h)
-constexpr size_t kCounterWords = gscan::kShards * kCS + 3; // per-shard counts + overflow flag + records struck out by the second pass + bytes of line text gathered (k_lines)
+constexpr size_t kCounterWords = gscan::kShards * kCS + 4; // per-shard counts + overflow flag + records struck out by the second pass + bytes of line text gathered (k_lines) + records in the ordered copy (k_order_prefix)
 constexpr size_t kGatherPinnedMax = 512u << 20;             // a window's gathered lines are fetched only up to this size (beyond: the host copies from the file)
 constexpr size_t kCopyPiece = 32u << 20; // memcpy/H2D pipelining granule for foreign host buffers
 constexpr size_t kMaxChunk = (1ull << 30) + 4096;
@@ -562,11 +562,14 @@ struct Slot {
     size_t h_desc_cap = 0;
     uint32_t *h_spec = nullptr; // pinned, kShards rows of kSpecPer
     std::vector<uint32_t> sorted;
-    // dense results (some shard holds more than kSpecPer records): the used part of every shard region, fetched into PINNED
-    // memory with one strided DMA each for records and extras (a pageable destination made the runtime stage 64 short rows
-    // one by one: ~1.5 ms per copy, a tenth of a second per worker on cfg3's 16 GiB)
-    uint32_t *h_dense = nullptr;
-    size_t dense_cap = 0; // words
+    // the result in text order, made on the device (k_order_*): [0, rec_cap) records, from rec_cap on their extras.  The host
+    // fetches one linear range of each and hands it out as it is (out_starts / out_ext point into pinned memory then)
+    uint32_t *d_sorted = nullptr;
+    size_t sorted_cap = 0; // words
+    uint32_t *d_dpos = nullptr;
+    size_t dpos_cap = 0;
+    bool ordered = false;
+    const uint32_t *out_starts = nullptr, *out_ext = nullptr;
     // per-record extras, parallel to the records: line extents (k_lines, 3 words each) or match ends (k_ends, 1 word)
     uint32_t *d_ext = nullptr;
     size_t ext_cap = 0;          // records
@@ -577,8 +580,8 @@ struct Slot {
     // the text of the printed lines, gathered by k_lines ("line_extents"): device buffer, pinned copy of the used part
     uint8_t *d_gather = nullptr;
     size_t gather_cap = 0;
-    uint8_t *h_gather = nullptr;
-    size_t h_gather_cap = 0, gather_bytes = 0;
+    bool gather_in_text = false; // d_gather is the second half of the d_text allocation (contexts that had "line_extents" on when the slot was sized)
+    size_t gather_bytes = 0;
     bool gather_ok = false;
     const void *ext = nullptr;  // caller's buffer this chunk was copied from (gscan_wait hands it back as *content)
     void *ext_reg = nullptr;    // ... registered with the runtime for direct DMA until the scan is done
@@ -634,6 +637,18 @@ struct gscan_ctx {
     bool line_extents = false;      // run k_lines after the scan when the pattern allows it ("line_extents" option)
     bool match_ends = false;        // run k_ends after the scan when the pattern allows it ("match_ends" option): -O -l without the text
     const Slot *last_waited = nullptr;
+    // Pinned staging of what gscan_wait fetches AFTER the scan has finished and its sizes are known -- dense record lists (some
+    // shard holds more than kSpecPer records: the used part of every shard region, one strided DMA each for records and
+    // extras; a pageable destination made the runtime stage 64 short rows one by one, ~1.5 ms per copy) and the gathered
+    // line text.  One of each per CONTEXT, not per slot, and grown in big steps: a pinned allocation costs milliseconds and
+    // the runtime serialises them -- 24 slots growing their own buffers were a third of a 16 GiB run's wait time.
+    uint32_t *h_dense = nullptr;
+    size_t dense_cap = 0; // words
+    uint8_t *h_gather = nullptr; // valid until the next gscan_wait* on this context
+    size_t h_gather_cap = 0;
+    // GSCAN_TIMING: where gscan_wait's time goes (seconds, this context)
+    double tw_reads = 0, tw_scan = 0, tw_dense = 0, tw_gather = 0, tw_merge = 0, tw_alloc = 0;
+    size_t tw_n = 0, tw_dense_bytes = 0, tw_gather_bytes = 0;
     // device-resident path
     size_t dev_cap_req = 0;
     uint32_t *dv_recs = nullptr;
@@ -722,13 +737,23 @@ int slot_reserve_pinned(gscan_ctx *c, Slot &s, size_t len)
 
 int slot_reserve_device(gscan_ctx *c, Slot &s, size_t len)
 {
-    if (len > s.d_text_cap) {
+    if (len > s.d_text_cap || (c->line_extents && !s.gather_in_text)) {
         if (s.d_text) hipFree(s.d_text);
+        if (s.d_gather && !s.gather_in_text) hipFree(s.d_gather);
         s.d_text = nullptr;
-        s.d_text_cap = 0;
-        size_t cap = std::max<size_t>((len + kPad + 0xfffff) & ~(size_t)0xfffff, 1u << 20);
-        HIPCHK(c, hipMalloc((void **)&s.d_text, cap));
+        s.d_gather = nullptr;
+        s.d_text_cap = s.gather_cap = 0;
+        s.gather_in_text = false;
+        size_t cap = std::max<size_t>((std::max(len, s.d_text_cap) + kPad + 0xfffff) & ~(size_t)0xfffff, 1u << 20);
+        // with the line pass on, the window's gather buffer (the printed lines never overlap: their text fits the window) comes
+        // out of the same allocation: hipMalloc is not cheap and every slot of every context would make a second one
+        HIPCHK(c, hipMalloc((void **)&s.d_text, c->line_extents ? 2 * cap : cap));
         s.d_text_cap = cap - kPad;
+        if (c->line_extents) {
+            s.d_gather = s.d_text + cap;
+            s.gather_cap = std::min<size_t>(cap, 0xfffffff0u);
+            s.gather_in_text = true;
+        }
     }
     // descriptors: one per wave sub-tile, at the smallest sub-tile any variant uses (+ the padding of a last, partial tile)
     size_t tiles = len / gscan::kMinSubTileBytes + 2 * gscan::kMaxWavesPerTile;
@@ -851,8 +876,9 @@ int slot_launch(gscan_ctx *c, Slot &s)
         if (s.ext_words == 4) {
             // the printed lines never overlap (the loop restarts at the end of the line it printed): their text fits the window
             const size_t want = std::min<size_t>(std::max<size_t>(s.len, 1u << 20), 0xfffffff0u);
-            if (s.gather_cap < want) {
-                if (s.d_gather) hipFree(s.d_gather);
+            if (s.gather_cap < want) { // (a slot sized before the option was switched on)
+                if (s.d_gather && !s.gather_in_text) hipFree(s.d_gather);
+                s.gather_in_text = false;
                 s.d_gather = nullptr;
                 s.gather_cap = 0;
                 HIPCHK(c, hipMalloc((void **)&s.d_gather, want));
@@ -862,15 +888,43 @@ int slot_launch(gscan_ctx *c, Slot &s)
         } else {
             HIPCHK(c, gscan::launch_ends(a, nw, tile_bytes / nw, s.d_ext, c->compute));
         }
-        HIPCHK(c, hipMemcpy2DAsync(s.h_ext_spec, kSpecPer * eb, s.d_ext, (size_t)a.cap_shard * eb, kSpecPer * eb, gscan::kShards,
-                                   hipMemcpyDeviceToHost, c->compute));
+    }
+    // The result once more in text order (not where a second pass may still strike records out: k3_settle's patterns keep the
+    // host's merge over the shard regions).
+    s.ordered = s.n_tiles && !gscan::scan_needs_settle(db.tier, db.prog);
+    if (s.ordered) {
+        const size_t n_desc = (size_t)s.n_tiles * nw, need = s.rec_cap * (1 + (size_t)s.ext_words);
+        if (s.dpos_cap < n_desc) {
+            if (s.d_dpos) hipFree(s.d_dpos);
+            s.d_dpos = nullptr;
+            s.dpos_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&s.d_dpos, (n_desc + n_desc / 4 + 64) * 4));
+            s.dpos_cap = n_desc + n_desc / 4 + 64;
+        }
+        if (s.sorted_cap < need) {
+            if (s.d_sorted) hipFree(s.d_sorted);
+            s.d_sorted = nullptr;
+            s.sorted_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&s.d_sorted, need * 4));
+            s.sorted_cap = need;
+        }
+        HIPCHK(c, gscan::launch_order(a, nw, s.d_ext, s.ext_words, s.d_dpos, s.d_sorted, s.d_sorted + s.rec_cap, c->compute));
     }
     HIPCHK(c, hipMemcpyAsync(s.h_counter, s.d_counter, kCounterWords * 4, hipMemcpyDeviceToHost, c->compute));
     if (s.n_tiles)
         HIPCHK(c, hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)s.n_tiles * nw * 8, hipMemcpyDeviceToHost, c->compute));
-    // the head of every shard region in one strided copy: enough for any sparse result
-    HIPCHK(c, hipMemcpy2DAsync(s.h_spec, kSpecPer * 4, s.d_recs, (size_t)a.cap_shard * 4, kSpecPer * 4, gscan::kShards,
-                               hipMemcpyDeviceToHost, c->compute));
+    if (s.ordered) { // the first kSpecRecs records (and their extras) of the ordered result: enough for any sparse one
+        HIPCHK(c, hipMemcpyAsync(s.h_spec, s.d_sorted, std::min<size_t>(kSpecRecs, s.rec_cap) * 4, hipMemcpyDeviceToHost, c->compute));
+        if (s.has_ext)
+            HIPCHK(c, hipMemcpyAsync(s.h_ext_spec, s.d_sorted + s.rec_cap, std::min<size_t>(kSpecRecs, s.rec_cap) * 4 * s.ext_words, hipMemcpyDeviceToHost, c->compute));
+    } else {
+        // the head of every shard region in one strided copy: enough for any sparse result
+        HIPCHK(c, hipMemcpy2DAsync(s.h_spec, kSpecPer * 4, s.d_recs, (size_t)a.cap_shard * 4, kSpecPer * 4, gscan::kShards,
+                                   hipMemcpyDeviceToHost, c->compute));
+        if (s.has_ext)
+            HIPCHK(c, hipMemcpy2DAsync(s.h_ext_spec, kSpecPer * 4 * s.ext_words, s.d_ext, (size_t)a.cap_shard * 4 * s.ext_words, kSpecPer * 4 * s.ext_words,
+                                       gscan::kShards, hipMemcpyDeviceToHost, c->compute));
+    }
     HIPCHK(c, hipEventRecord(s.done, c->compute));
     return 0;
 }
@@ -883,9 +937,9 @@ void free_slot(gscan_ctx *c, Slot &s)
     if (s.h_tiles) hipHostFree(s.h_tiles);
     if (s.d_ext) hipFree(s.d_ext);
     if (s.h_ext_spec) hipHostFree(s.h_ext_spec);
-    if (s.h_dense) hipHostFree(s.h_dense);
-    if (s.d_gather) hipFree(s.d_gather);
-    if (s.h_gather) hipHostFree(s.h_gather);
+    if (s.d_sorted) hipFree(s.d_sorted);
+    if (s.d_dpos) hipFree(s.d_dpos);
+    if (s.d_gather && !s.gather_in_text) hipFree(s.d_gather);
     if (s.pinned) hipHostFree(s.pinned);
     if (s.d_text) hipFree(s.d_text);
     if (s.d_recs) hipFree(s.d_recs);
@@ -1115,11 +1169,16 @@ void gscan_close(gscan_ctx *c)
     if (!c) return;
     for (Slot &s : c->slot) slot_drain_reads(s); // a file range still being read: its last piece launches into this context
     if (c->ingest) c->ingest->report_if_timing();
+    if (getenv("GSCAN_TIMING") && c->tw_n)
+        fprintf(stderr, "[gscan timing] context on device %d: %zu waits | reads still arriving %.3f s  scan + fixed readback %.3f s  dense records %.3f s (%.1f MB, of which pinned (re)allocation %.3f s)  gathered lines %.3f s (%.1f MB)  merge %.3f s\n",
+                c->device, c->tw_n, c->tw_reads, c->tw_scan, c->tw_dense, c->tw_dense_bytes / 1e6, c->tw_alloc, c->tw_gather, c->tw_gather_bytes / 1e6, c->tw_merge);
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (Slot &s : c->slot) free_slot(c, s);
     if (c->d_arena) hipFree(c->d_arena);
     if (c->h_arena) hipHostFree(c->h_arena);
+    if (c->h_dense) hipHostFree(c->h_dense);
+    if (c->h_gather) hipHostFree(c->h_gather);
     if (c->dv_recs) hipFree(c->dv_recs);
     if (c->dv_desc) hipFree(c->dv_desc);
     if (c->dv_tiles) hipFree(c->dv_tiles);
@@ -1390,7 +1449,11 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
             }
         }
     } release{s};
+    static const bool tw_on = getenv("GSCAN_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tw0 = tw_on ? tnow() : 0;
     slot_drain_reads(*s);
+    if (tw_on) c->tw_reads += tnow() - tw0, tw0 = tnow(), c->tw_n++;
     if (s->grp && s->grp->rc) {
         c->err = s->grp->msg;
         const int rc = s->grp->rc;
@@ -1399,6 +1462,7 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventSynchronize(s->done));
+    if (tw_on) c->tw_scan += tnow() - tw0, tw0 = tnow();
     slot_unregister(*s); // the DMA out of the caller's buffer is over (the text stays in HBM for a possible rescan)
     const size_t K = gscan::kShards;
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -1429,97 +1493,139 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     size_t fullest = 0;
     for (size_t k = 0; k < K; k++) fullest = std::max<size_t>(fullest, s->h_counter[k * kCS]);
     const size_t ew = s->ext_words;
-    const uint32_t *dense = nullptr, *dense_ext = nullptr; // [K][fullest] records, [K][fullest * ew] extras
-    if (!spec_ok) { // dense result: the used part of every shard region in ONE strided copy (descriptors deal the shards round robin: they fill evenly)
-        const size_t need = K * fullest * (1 + (s->has_ext ? ew : 0));
-        if (need > s->dense_cap) {
-            if (s->h_dense) hipHostFree(s->h_dense);
-            s->h_dense = nullptr;
-            s->dense_cap = 0;
-            const size_t cap = need + need / 2;
-            HIPCHK(c, hipHostMalloc((void **)&s->h_dense, cap * 4, hipHostMallocDefault));
-            s->dense_cap = cap;
+    const uint32_t *dense = nullptr, *dense_ext = nullptr; // ordered: [total] records + [total * ew] extras; else [K][fullest] + [K][fullest * ew]
+    auto reserve_dense = [&](size_t need) -> int {
+        if (need > c->dense_cap) {
+            const double ta = tw_on ? tnow() : 0;
+            if (c->h_dense) hipHostFree(c->h_dense);
+            c->h_dense = nullptr;
+            c->dense_cap = 0;
+            const size_t cap = std::max<size_t>(2 * need, 2u << 20);
+            HIPCHK(c, hipHostMalloc((void **)&c->h_dense, cap * 4, hipHostMallocDefault));
+            c->dense_cap = cap;
+            if (tw_on) c->tw_alloc += tnow() - ta;
         }
-        HIPCHK(c, hipMemcpy2DAsync(s->h_dense, fullest * 4, s->d_recs, cap_shard * 4, fullest * 4, K, hipMemcpyDeviceToHost, c->compute));
-        dense = s->h_dense;
+        return 0;
+    };
+    const bool ordered = s->ordered && struck == 0;
+    if (ordered && s->h_counter[K * kCS + 3] != total) return fail(c, GSCAN_EHIP, "ordered copy holds %u records, the shard counters %zu", s->h_counter[K * kCS + 3], total);
+    if (ordered) {
+        if (total <= std::min<size_t>(kSpecRecs, s->rec_cap)) { // a sparse result: it came in with the counters
+            dense = s->h_spec;
+            dense_ext = s->h_ext_spec;
+        } else { // ONE linear range each for the records and their extras
+            const size_t need = total * (1 + (s->has_ext ? ew : 0));
+            if (int rc = reserve_dense(need)) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->h_dense, s->d_sorted, total * 4, hipMemcpyDeviceToHost, c->compute));
+            if (s->has_ext) HIPCHK(c, hipMemcpyAsync(c->h_dense + total, s->d_sorted + s->rec_cap, total * 4 * ew, hipMemcpyDeviceToHost, c->compute));
+            HIPCHK(c, hipEventRecord(s->done, c->compute));
+            HIPCHK(c, hipEventSynchronize(s->done));
+            dense = c->h_dense;
+            dense_ext = c->h_dense + total;
+            if (tw_on) c->tw_dense += tnow() - tw0, tw0 = tnow(), c->tw_dense_bytes += need * 4;
+        }
+    } else if (!spec_ok) { // dense result: the used part of every shard region in ONE strided copy (descriptors deal the shards round robin: they fill evenly)
+        const size_t need = K * fullest * (1 + (s->has_ext ? ew : 0));
+        if (int rc = reserve_dense(need)) return rc;
+        HIPCHK(c, hipMemcpy2DAsync(c->h_dense, fullest * 4, s->d_recs, cap_shard * 4, fullest * 4, K, hipMemcpyDeviceToHost, c->compute));
+        dense = c->h_dense;
         if (s->has_ext) {
-            HIPCHK(c, hipMemcpy2DAsync(s->h_dense + K * fullest, fullest * 4 * ew, s->d_ext, cap_shard * 4 * ew, fullest * 4 * ew, K, hipMemcpyDeviceToHost, c->compute));
-            dense_ext = s->h_dense + K * fullest;
+            HIPCHK(c, hipMemcpy2DAsync(c->h_dense + K * fullest, fullest * 4 * ew, s->d_ext, cap_shard * 4 * ew, fullest * 4 * ew, K, hipMemcpyDeviceToHost, c->compute));
+            dense_ext = c->h_dense + K * fullest;
         }
         HIPCHK(c, hipEventRecord(s->done, c->compute));
         HIPCHK(c, hipEventSynchronize(s->done));
+        if (tw_on) c->tw_dense += tnow() - tw0, tw0 = tnow(), c->tw_dense_bytes += need * 4;
     }
     s->gather_ok = false;
     s->gather_bytes = 0;
     if (s->ext_words == 4) { // the printed lines' text: the used part of the gather buffer, into pinned memory
         const size_t used = std::min<size_t>(s->h_counter[K * kCS + 2], s->gather_cap);
         if (used <= kGatherPinnedMax) {
-            if (used > s->h_gather_cap) {
-                if (s->h_gather) hipHostFree(s->h_gather);
-                s->h_gather = nullptr;
-                s->h_gather_cap = 0;
-                const size_t cap = used + used / 2 + 4096;
-                HIPCHK(c, hipHostMalloc((void **)&s->h_gather, cap, hipHostMallocDefault));
-                s->h_gather_cap = cap;
+            if (used > c->h_gather_cap) {
+                if (c->h_gather) hipHostFree(c->h_gather);
+                c->h_gather = nullptr;
+                c->h_gather_cap = 0;
+                const size_t cap = std::max<size_t>(2 * used, 8u << 20);
+                HIPCHK(c, hipHostMalloc((void **)&c->h_gather, cap, hipHostMallocDefault));
+                c->h_gather_cap = cap;
             }
             if (used) {
-                HIPCHK(c, hipMemcpyAsync(s->h_gather, s->d_gather, used, hipMemcpyDeviceToHost, c->compute));
+                HIPCHK(c, hipMemcpyAsync(c->h_gather, s->d_gather, used, hipMemcpyDeviceToHost, c->compute));
                 HIPCHK(c, hipEventRecord(s->done, c->compute));
                 HIPCHK(c, hipEventSynchronize(s->done));
             }
             s->gather_ok = true;
             s->gather_bytes = used;
+            if (tw_on) c->tw_gather += tnow() - tw0, tw0 = tnow(), c->tw_gather_bytes += used;
         }
     }
-    s->sorted_ext.clear();
-    if (s->has_ext) s->sorted_ext.reserve(total * ew);
-    s->sorted.clear();
-    s->sorted.reserve(total);
     const bool multi = !s->segs.empty();
     const size_t ns = multi ? s->segs.size() : 1;
     s->seg_first.assign(ns + 1, 0);
     size_t seg = 0;
     const size_t n_desc = (size_t)s->n_tiles * s->nw;
-    for (size_t di = 0; di < n_desc; di++) { // descriptors are in (segment, text) order: concatenating their runs sorts the list
-        const uint32_t t = (uint32_t)(di / s->nw);
+    if (ordered) {
+        // the list is there as it is; the descriptors' counts say where the segments begin in it
+        size_t at = 0;
         if (multi)
-            while (seg + 1 <= ns && t >= s->tile_first[seg + 1]) s->seg_first[++seg] = s->sorted.size();
-        unsigned long long d = s->h_desc[di];
-        uint32_t cnt = (uint32_t)d;
-        size_t base = (size_t)(d >> 32);
-        if (!cnt) continue;
-        const uint32_t *src = spec_ok ? s->h_spec + (base / cap_shard) * kSpecPer + base % cap_shard : dense + (base / cap_shard) * fullest + base % cap_shard;
-        const uint32_t *ex = !s->has_ext ? nullptr
-                             : spec_ok   ? s->h_ext_spec + ((base / cap_shard) * kSpecPer + base % cap_shard) * ew
-                                         : dense_ext + ((base / cap_shard) * fullest + base % cap_shard) * ew;
-        if (struck == 0) {
-            s->sorted.insert(s->sorted.end(), src, src + cnt);
-            if (ex) s->sorted_ext.insert(s->sorted_ext.end(), ex, ex + (size_t)cnt * ew);
-        } else { // (the second K3 pass struck records out: their extras go with them)
-            for (uint32_t i = 0; i < cnt; i++)
-                if (src[i] != gscan::kStruck) {
-                    s->sorted.push_back(src[i]);
-                    if (ex) s->sorted_ext.insert(s->sorted_ext.end(), ex + (size_t)i * ew, ex + (size_t)(i + 1) * ew);
-                }
+            for (size_t di = 0; di < n_desc; di++) {
+                const uint32_t t = (uint32_t)(di / s->nw);
+                while (seg + 1 <= ns && t >= s->tile_first[seg + 1]) s->seg_first[++seg] = at;
+                at += (uint32_t)s->h_desc[di];
+            }
+        while (seg < ns) s->seg_first[++seg] = total; // trailing segments without tiles / records (one segment: [0, total))
+        s->out_starts = dense;
+        s->out_ext = s->has_ext ? dense_ext : nullptr;
+    } else {
+        s->sorted_ext.clear();
+        if (s->has_ext) s->sorted_ext.reserve(total * ew);
+        s->sorted.clear();
+        s->sorted.reserve(total);
+        for (size_t di = 0; di < n_desc; di++) { // descriptors are in (segment, text) order: concatenating their runs sorts the list
+            const uint32_t t = (uint32_t)(di / s->nw);
+            if (multi)
+                while (seg + 1 <= ns && t >= s->tile_first[seg + 1]) s->seg_first[++seg] = s->sorted.size();
+            unsigned long long d = s->h_desc[di];
+            uint32_t cnt = (uint32_t)d;
+            size_t base = (size_t)(d >> 32);
+            if (!cnt) continue;
+            const uint32_t *src = spec_ok ? s->h_spec + (base / cap_shard) * kSpecPer + base % cap_shard : dense + (base / cap_shard) * fullest + base % cap_shard;
+            const uint32_t *ex = !s->has_ext ? nullptr
+                                 : spec_ok   ? s->h_ext_spec + ((base / cap_shard) * kSpecPer + base % cap_shard) * ew
+                                             : dense_ext + ((base / cap_shard) * fullest + base % cap_shard) * ew;
+            if (struck == 0) {
+                s->sorted.insert(s->sorted.end(), src, src + cnt);
+                if (ex) s->sorted_ext.insert(s->sorted_ext.end(), ex, ex + (size_t)cnt * ew);
+            } else { // (the second K3 pass struck records out: their extras go with them)
+                for (uint32_t i = 0; i < cnt; i++)
+                    if (src[i] != gscan::kStruck) {
+                        s->sorted.push_back(src[i]);
+                        if (ex) s->sorted_ext.insert(s->sorted_ext.end(), ex + (size_t)i * ew, ex + (size_t)(i + 1) * ew);
+                    }
+            }
         }
+        if (s->sorted.size() + struck != total) return fail(c, GSCAN_EHIP, "descriptor total %zu + struck %zu != counter %zu", s->sorted.size(), struck, total);
+        while (seg < ns) s->seg_first[++seg] = s->sorted.size(); // trailing segments without tiles / records
+        s->out_starts = s->sorted.data();
+        s->out_ext = s->has_ext ? s->sorted_ext.data() : nullptr;
     }
-    if (s->sorted.size() + struck != total) return fail(c, GSCAN_EHIP, "descriptor total %zu + struck %zu != counter %zu", s->sorted.size(), struck, total);
-    while (seg < ns) s->seg_first[++seg] = s->sorted.size(); // trailing segments without tiles / records
     if (tag) *tag = s->tag;
-    *starts = s->sorted.data();
+    *starts = s->out_starts;
     *seg_first = s->seg_first.data();
     *nseg = ns;
     if (content) *content = s->no_content ? nullptr : s->ext;
     c->last_waited = s;
     s->state = FREE;
     release.ok = true;
+    if (tw_on) c->tw_merge += tnow() - tw0;
     return GSCAN_OK;
 }
 
 const uint32_t *gscan_last_ext(const gscan_ctx *c)
 {
     if (!c || !c->last_waited || c->last_waited->ext_words != 4) return nullptr;
-    return c->last_waited->sorted_ext.data();
+    return c->last_waited->out_ext;
 }
 
 const uint8_t *gscan_last_gather(const gscan_ctx *c, size_t *bytes)
@@ -1527,13 +1633,13 @@ const uint8_t *gscan_last_gather(const gscan_ctx *c, size_t *bytes)
     if (bytes) *bytes = 0;
     if (!c || !c->last_waited || c->last_waited->ext_words != 4 || !c->last_waited->gather_ok) return nullptr;
     if (bytes) *bytes = c->last_waited->gather_bytes;
-    return c->last_waited->h_gather ? c->last_waited->h_gather : (const uint8_t *)"";
+    return c->h_gather ? c->h_gather : (const uint8_t *)"";
 }
 
 const uint32_t *gscan_last_ends(const gscan_ctx *c)
 {
     if (!c || !c->last_waited || c->last_waited->ext_words != 1) return nullptr;
-    return c->last_waited->sorted_ext.data();
+    return c->last_waited->out_ext;
 }
 
 int gscan_wait(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, size_t *n, const void **content)

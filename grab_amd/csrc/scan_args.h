@@ -35,7 +35,7 @@ struct ScanArgs {
     uint32_t cap_shard;      // record capacity of ONE shard region (regions are back to back)
     uint32_t *recs;          // candidate starts, segment-relative
     unsigned long long *desc; // [n_tiles * waves per workgroup] one per wave sub-tile: count | base<<32 (base = absolute record index)
-    uint32_t *counter;       // [k * kCtrStride] records reserved in shard k, [kShards * kCtrStride] overflow flag, [.. + 1] records struck out by k3_settle, [.. + 2] bytes of line text gathered by k_lines
+    uint32_t *counter;       // [k * kCtrStride] records reserved in shard k, [kShards * kCtrStride] overflow flag, [.. + 1] records struck out by k3_settle, [.. + 2] bytes of line text gathered by k_lines, [.. + 3] records in the ordered copy (k_order_prefix)
     const DevProgram *prog;  // cold paths only (K1 verify, K2 table staging)
     // pattern program, hot-loop copy
     uint32_t m;              // window length
@@ -84,6 +84,9 @@ hipError_t launch_settle(const ScanArgs &a, uint32_t waves, hipStream_t st);
 // printed lines' text [lb, le) copied to gather[goff ..] (kernels.hip, k_lines); counter[kShards * kCtrStride + 2] = bytes gathered
 hipError_t launch_lines(const ScanArgs &a, uint32_t waves, uint32_t sub_bytes, uint32_t *ext, uint8_t *gather, uint32_t gather_cap, hipStream_t st);
 constexpr uint32_t kLineAskHost = 0xffffffffu;
+// the chunk's records (and their ew extra words each) once more, in text order and back to back: out[0 .. total), out_ext[0 ..
+// total * ew); counter[kShards * kCtrStride + 3] = total (kernels.hip, k_order_prefix / k_order_copy); dpos: n_tiles * waves words
+hipError_t launch_order(const ScanArgs &a, uint32_t waves, const uint32_t *ext, uint32_t ew, uint32_t *dpos, uint32_t *out, uint32_t *out_ext, hipStream_t st);
 // match ends for -O -l: ends[record index] = end of the match that starts at the record (0: ask the host) (kernels.hip, k_ends)
 hipError_t launch_ends(const ScanArgs &a, uint32_t waves, uint32_t sub_bytes, uint32_t *ends, hipStream_t st);
 

@@ -248,8 +248,10 @@ int gscan_submit_fd(gscan_ctx *ctx, const gscan_db *db, int fd, long long file_o
  *     gscan_match_at(db, content, clen, s) ? s : first starts[i] > s
  * (if s is a candidate it is the answer; if not, the next candidate after s begins a group).
  * *content is the chunk's bytes on the host: the buffer the chunk was submitted from, NULL after
- * gscan_submit_fd.  starts (and a pinned *content) stay valid until the second gscan_acquire /
- * gscan_submit* after this call reuses the slot. */
+ * gscan_submit_fd.  starts (and gscan_last_ext / _ends / _gather) stay valid until the next gscan_wait* on this context (a
+ * dense list is handed out in the context's pinned staging buffer, exactly as the device put it together: in text order,
+ * one linear transfer, no merge on the host); a pinned *content until the second gscan_acquire / gscan_submit* after this
+ * call reuses the slot. */
 int gscan_wait(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, size_t *n,
                const void **content);
 /*
@@ -265,7 +267,7 @@ int gscan_wait(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, size_t *n
  *                      (for a file range that was never mapped: no page is faulted in); 0xffffffff: take them from the chunk.
  * gscan_last_ext returns the array for the chunk the last gscan_wait / gscan_wait_segs call handed out (parallel to its
  * starts, same lifetime), or NULL if that chunk has none; gscan_last_gather the gathered text (NULL: none was fetched --
- * treat every goff as 0xffffffff).
+ * treat every goff as 0xffffffff), valid until the next gscan_wait / gscan_wait_segs on this context.
  */
 const uint32_t *gscan_last_ext(const gscan_ctx *ctx);
 const uint8_t *gscan_last_gather(const gscan_ctx *ctx, size_t *bytes);

@@ -10,9 +10,9 @@ import e2e_sweep
 from grab_amd import bin_path
 d = "/dev/shm/r3i_cfg3"
 os.makedirs(d)
-e2e_sweep.gen_files(d, 64, 64 << 20, 1)
+e2e_sweep.gen_files(d, 256, 64 << 20, 1)
 ident = "[A-Za-z_][A-Za-z0-9_]{15,}"
-for n in (1, 8):
+for n in (8, 16):
     for env_extra, label in (({}, "host walk"), ({"GRAB_LINE_PASS": "1"}, "device line pass + gather")):
         argv = [bin_path()] + (["-n", str(n)] if n > 1 else []) + ["-r", "-O", ident, d]
         best = None
@@ -22,6 +22,6 @@ for n in (1, 8):
             dt = time.monotonic() - t0
             if best is None or dt < best[0]: best = (dt, r.stderr.decode())
         lines = [l for l in best[1].splitlines() if "device 0:" in l][:1] + [l for l in best[1].splitlines() if "printed so far" in l][-1:]
-        print("## 4 GiB -n %d -O (%s): wall %.3f s" % (n, label, best[0])); print("\n".join(lines))
+        print("## 16 GiB -n %d -O (%s): wall %.3f s" % (n, label, best[0])); print("\n".join(lines))
 shutil.rmtree(d)
 PY
