@@ -570,6 +570,15 @@ struct Slot {
     size_t dpos_cap = 0;
     bool ordered = false;
     const uint32_t *out_starts = nullptr, *out_ext = nullptr;
+    // Speculative readback of an ordered result, issued with the launch: the first spec_n records + their extras and the
+    // first gspec_n bytes of gathered line text, sized by what this context's last chunks produced (+25 %).  A chunk whose
+    // result fits needs no transfer after its scan at all -- fetching it then costs a blocking round trip of ~2-3 ms behind
+    // the 64 MiB window copies that are always in flight.
+    uint32_t *h_big = nullptr; // pinned: [big_recs] records, then [big_recs * 4] extras
+    size_t big_recs = 0, spec_n = 0;
+    uint8_t *h_gspec = nullptr; // pinned
+    size_t gspec_cap = 0, gspec_n = 0;
+    const uint8_t *out_gather = nullptr;
     // per-record extras, parallel to the records: line extents (k_lines, 3 words each) or match ends (k_ends, 1 word)
     uint32_t *d_ext = nullptr;
     size_t ext_cap = 0;          // records
@@ -646,6 +655,7 @@ struct gscan_ctx {
     size_t dense_cap = 0; // words
     uint8_t *h_gather = nullptr; // valid until the next gscan_wait* on this context
     size_t h_gather_cap = 0;
+    size_t hint_total = 0, hint_gather = 0; // what recent chunks produced (records, gathered bytes): sizes the speculative readback
     // GSCAN_TIMING: where gscan_wait's time goes (seconds, this context)
     double tw_reads = 0, tw_scan = 0, tw_dense = 0, tw_gather = 0, tw_merge = 0, tw_alloc = 0;
     size_t tw_n = 0, tw_dense_bytes = 0, tw_gather_bytes = 0;
@@ -913,10 +923,38 @@ int slot_launch(gscan_ctx *c, Slot &s)
     HIPCHK(c, hipMemcpyAsync(s.h_counter, s.d_counter, kCounterWords * 4, hipMemcpyDeviceToHost, c->compute));
     if (s.n_tiles)
         HIPCHK(c, hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)s.n_tiles * nw * 8, hipMemcpyDeviceToHost, c->compute));
-    if (s.ordered) { // the first kSpecRecs records (and their extras) of the ordered result: enough for any sparse one
-        HIPCHK(c, hipMemcpyAsync(s.h_spec, s.d_sorted, std::min<size_t>(kSpecRecs, s.rec_cap) * 4, hipMemcpyDeviceToHost, c->compute));
-        if (s.has_ext)
-            HIPCHK(c, hipMemcpyAsync(s.h_ext_spec, s.d_sorted + s.rec_cap, std::min<size_t>(kSpecRecs, s.rec_cap) * 4 * s.ext_words, hipMemcpyDeviceToHost, c->compute));
+    s.spec_n = s.gspec_n = 0;
+    if (s.ordered) { // the head of the ordered result: kSpecRecs records (enough for any sparse one), or what the last chunks suggest
+        const size_t want = std::min<size_t>(s.rec_cap, c->hint_total + c->hint_total / 4);
+        if (want > kSpecRecs) {
+            if (want > s.big_recs) {
+                if (s.h_big) hipHostFree(s.h_big);
+                s.h_big = nullptr;
+                s.big_recs = 0;
+                const size_t cap = want + want / 4;
+                HIPCHK(c, hipHostMalloc((void **)&s.h_big, cap * 4 * 5, hipHostMallocDefault));
+                s.big_recs = cap;
+            }
+            s.spec_n = want;
+            HIPCHK(c, hipMemcpyAsync(s.h_big, s.d_sorted, want * 4, hipMemcpyDeviceToHost, c->compute));
+            if (s.has_ext) HIPCHK(c, hipMemcpyAsync(s.h_big + s.big_recs, s.d_sorted + s.rec_cap, want * 4 * s.ext_words, hipMemcpyDeviceToHost, c->compute));
+        } else {
+            s.spec_n = std::min<size_t>(kSpecRecs, s.rec_cap);
+            HIPCHK(c, hipMemcpyAsync(s.h_spec, s.d_sorted, s.spec_n * 4, hipMemcpyDeviceToHost, c->compute));
+            if (s.has_ext) HIPCHK(c, hipMemcpyAsync(s.h_ext_spec, s.d_sorted + s.rec_cap, s.spec_n * 4 * s.ext_words, hipMemcpyDeviceToHost, c->compute));
+        }
+        if (s.ext_words == 4 && c->hint_gather) { // ... and of the gathered line text
+            const size_t gw = std::min<size_t>(std::min<size_t>(s.gather_cap, kGatherPinnedMax), c->hint_gather + c->hint_gather / 4);
+            if (gw > s.gspec_cap) {
+                if (s.h_gspec) hipHostFree(s.h_gspec);
+                s.h_gspec = nullptr;
+                s.gspec_cap = 0;
+                HIPCHK(c, hipHostMalloc((void **)&s.h_gspec, gw + gw / 4, hipHostMallocDefault));
+                s.gspec_cap = gw + gw / 4;
+            }
+            s.gspec_n = gw;
+            HIPCHK(c, hipMemcpyAsync(s.h_gspec, s.d_gather, gw, hipMemcpyDeviceToHost, c->compute));
+        }
     } else {
         // the head of every shard region in one strided copy: enough for any sparse result
         HIPCHK(c, hipMemcpy2DAsync(s.h_spec, kSpecPer * 4, s.d_recs, (size_t)a.cap_shard * 4, kSpecPer * 4, gscan::kShards,
@@ -939,6 +977,8 @@ void free_slot(gscan_ctx *c, Slot &s)
     if (s.h_ext_spec) hipHostFree(s.h_ext_spec);
     if (s.d_sorted) hipFree(s.d_sorted);
     if (s.d_dpos) hipFree(s.d_dpos);
+    if (s.h_big) hipHostFree(s.h_big);
+    if (s.h_gspec) hipHostFree(s.h_gspec);
     if (s.d_gather && !s.gather_in_text) hipFree(s.d_gather);
     if (s.pinned) hipHostFree(s.pinned);
     if (s.d_text) hipFree(s.d_text);
@@ -1510,9 +1550,11 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     const bool ordered = s->ordered && struck == 0;
     if (ordered && s->h_counter[K * kCS + 3] != total) return fail(c, GSCAN_EHIP, "ordered copy holds %u records, the shard counters %zu", s->h_counter[K * kCS + 3], total);
     if (ordered) {
-        if (total <= std::min<size_t>(kSpecRecs, s->rec_cap)) { // a sparse result: it came in with the counters
-            dense = s->h_spec;
-            dense_ext = s->h_ext_spec;
+        c->hint_total = std::max(total, c->hint_total - c->hint_total / 8); // (follows a growing result at once, a shrinking one slowly)
+        if (total <= s->spec_n) { // it came in with the counters: a sparse result, or one the last chunks foretold
+            const bool big = s->spec_n > kSpecRecs;
+            dense = big ? s->h_big : s->h_spec;
+            dense_ext = big ? s->h_big + s->big_recs : s->h_ext_spec;
         } else { // ONE linear range each for the records and their extras
             const size_t need = total * (1 + (s->has_ext ? ew : 0));
             if (int rc = reserve_dense(need)) return rc;
@@ -1539,9 +1581,15 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     }
     s->gather_ok = false;
     s->gather_bytes = 0;
+    s->out_gather = nullptr;
     if (s->ext_words == 4) { // the printed lines' text: the used part of the gather buffer, into pinned memory
         const size_t used = std::min<size_t>(s->h_counter[K * kCS + 2], s->gather_cap);
-        if (used <= kGatherPinnedMax) {
+        c->hint_gather = std::max(used, c->hint_gather - c->hint_gather / 8);
+        if (s->ordered && used <= s->gspec_n) { // it came in with the counters
+            s->gather_ok = true;
+            s->gather_bytes = used;
+            s->out_gather = s->h_gspec;
+        } else if (used <= kGatherPinnedMax) {
             if (used > c->h_gather_cap) {
                 if (c->h_gather) hipHostFree(c->h_gather);
                 c->h_gather = nullptr;
@@ -1557,6 +1605,7 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
             }
             s->gather_ok = true;
             s->gather_bytes = used;
+            s->out_gather = c->h_gather;
             if (tw_on) c->tw_gather += tnow() - tw0, tw0 = tnow(), c->tw_gather_bytes += used;
         }
     }
@@ -1633,7 +1682,7 @@ const uint8_t *gscan_last_gather(const gscan_ctx *c, size_t *bytes)
     if (bytes) *bytes = 0;
     if (!c || !c->last_waited || c->last_waited->ext_words != 4 || !c->last_waited->gather_ok) return nullptr;
     if (bytes) *bytes = c->last_waited->gather_bytes;
-    return c->h_gather ? c->h_gather : (const uint8_t *)"";
+    return c->last_waited->out_gather ? c->last_waited->out_gather : (const uint8_t *)"";
 }
 
 const uint32_t *gscan_last_ends(const gscan_ctx *c)

@@ -224,9 +224,10 @@ def test_calls_and_conditions_cli_vs_oracle(built, oracle_built, tmp_path):
 
 
 def test_line_pass_equals_host_walk(built, oracle_built, tmp_path):
-    """Line-printing modes with the device's line pass (GRAB_LINE_PASS=1: k_lines picks the printed matches and their line
-    extents) and without it (the host's walk) print the same bytes, and both equal the oracle: long lines (511-byte caps),
-    empty lines, dense matches, several chunks, batches."""
+    """Line-printing modes with the device's line pass (the default: k_lines picks the printed matches, finds their line
+    extents and gathers the lines' text; records it leaves to the host go through the reference's loop, after which the pass
+    takes over again) and without it (GRAB_LINE_PASS=0: the host's walk) print the same bytes, and both equal the oracle:
+    long lines (511-byte caps), empty lines, dense matches, several chunks, batches."""
     rng = np.random.default_rng(9)
     buf = synth.text(70 << 20, 11)
     buf[1_000_000:1_004_000] = ord("z")                   # one 4000-byte line with two needles in it
@@ -244,7 +245,7 @@ def test_line_pass_equals_host_walk(built, oracle_built, tmp_path):
         for flags in (["-r", "-O"], ["-r"], ["-L", "-L", "-L", "-L", "-L", "-r", "-O"], ["-r", "-s"]):
             argv = flags + [pattern, "d"]
             rc, out, err = _run(built.bin_path(), argv, str(tmp_path))
-            r = subprocess.run([built.bin_path()] + argv, cwd=str(tmp_path), capture_output=True, env=dict(os.environ, GRAB_LINE_PASS="1"))
+            r = subprocess.run([built.bin_path()] + argv, cwd=str(tmp_path), capture_output=True, env=dict(os.environ, GRAB_LINE_PASS="0"))
             orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), argv, str(tmp_path))
             assert rc == r.returncode == orc == 0, err
             assert out == r.stdout, (pattern, flags)
