@@ -135,11 +135,24 @@ __device__ __forceinline__ void lane_loads(u32x4 (&buf)[ITER + 1], const TileS &
 
 // Epilogue of one wave's sub-tile: xp = the wave's strip, xp[k * 64 + lane] = step k's 16-bit candidate mask of `lane`,
 // i.e. a bitmap of the sub-tile in text order.  Lane L takes bits [192 L, 192 L + 192) of it.
-// `between` runs exactly once, right after the reserving atomic has been ISSUED (or where it would have been): the
-// prefetching tile loop puts the next tile's loads there, behind the atomic, so that its result can be waited for with the
-// loads still in flight.
-template <int ITER, typename Between>
-__device__ __forceinline__ void lane_emit(const ScanArgs &a, uint32_t d, int sub_off, int hi, uint32_t lane, const uint16_t *xp, Between &&between)
+// The epilogue of a wave's sub-tile comes in two halves.  lane_count(): the strip read back transposed, masked, reduced to
+// group starts, counted, scanned.  lane_write(): descriptor and records, at a base handed in.  Between the two sits ONE
+// returning atomic for TWO sub-tiles (lane_flush): the wave keeps the first tile's 192 bits per lane in registers while it scans
+// its next tile and reserves for both at once -- the atomic's round trip (1-2 us, sat out behind s_waitcnt vmcnt(0): most of
+// the difference between the identifier scan and the same kernel without records) is paid once per 24 KiB instead of once
+// per 12.  (Tried and measured slower, profiles/r03_p_lane_reserve_ahead_sweep.txt: reserving by a guess AHEAD of a tile's
+// loads -- the answer then queues in front of the loads -- and, r03_c: the next tile's loads behind the atomic.)
+template <int NWORD>
+struct LaneCounted {
+    uint32_t y[NWORD]; // group starts of this lane's 32 * NWORD positions
+    uint32_t first;    // records of the lanes in front of this one
+    uint32_t wtot;     // records of the wave
+    uint32_t d;        // descriptor index
+    uint32_t pos;      // reported offset of this lane's first position
+};
+
+template <int ITER>
+__device__ __forceinline__ void lane_count(const ScanArgs &a, uint32_t d, int sub_off, int hi, uint32_t lane, const uint16_t *xp, LaneCounted<ITER / 2> &o)
 {
     constexpr int NWORD = ITER / 2;
     static_assert(ITER % 4 == 0, "the strip is read back in 8-byte pieces");
@@ -167,46 +180,70 @@ __device__ __forceinline__ void lane_emit(const ScanArgs &a, uint32_t d, int sub
     // keep the START of every group of consecutive candidates: drop a candidate whose predecessor is one (the
     // predecessor of the sub-tile's first position is unknown: kept -- reporting more of a group is allowed)
     const uint32_t prev = up1(x[NWORD - 1], 0u);
-    uint32_t y[NWORD];
-    y[0] = x[0] & ~((x[0] << 1) | (prev >> 31));
-    uint32_t c = (uint32_t)__popc(y[0]);
+    o.y[0] = x[0] & ~((x[0] << 1) | (prev >> 31));
+    uint32_t c = (uint32_t)__popc(o.y[0]);
 #pragma unroll
     for (int i = 1; i < NWORD; i++) {
-        y[i] = x[i] & ~__builtin_amdgcn_alignbit(x[i], x[i - 1], 31); // (x[i] << 1) | (x[i - 1] >> 31)
-        c += (uint32_t)__popc(y[i]);
+        o.y[i] = x[i] & ~__builtin_amdgcn_alignbit(x[i], x[i - 1], 31); // (x[i] << 1) | (x[i - 1] >> 31)
+        c += (uint32_t)__popc(o.y[i]);
     }
     const uint32_t inc = wave_scan(c);
-    const uint32_t wtot = __builtin_amdgcn_readlane(inc, 63);
-    if (wtot == 0) {
-        if (lane == 0) a.desc[d] = 0ull;
-        between();
+    o.wtot = __builtin_amdgcn_readlane(inc, 63);
+    o.first = inc - c;
+    o.d = d;
+    o.pos = (uint32_t)p0 + a.report_shift;
+}
+
+// descriptor + records of one counted sub-tile; `base` = absolute record index of its run (wave-uniform), over = it does not fit
+template <int ITER>
+__device__ __forceinline__ void lane_write(const ScanArgs &a, uint32_t lane, const LaneCounted<ITER / 2> &o, uint32_t base, bool over)
+{
+    constexpr int NWORD = ITER / 2;
+    if (o.wtot == 0) {
+        if (lane == 0) a.desc[o.d] = 0ull;
         return;
     }
-    const uint32_t shard = d & (kShards - 1);
-    uint32_t b = 0;
-    if (lane == 0) b = atomicAdd(a.counter + shard * kCtrStride, wtot); // index inside the shard's region
-    between();
-    const uint32_t base = __builtin_amdgcn_readfirstlane(b);
-    const bool over = (unsigned long long)base + wtot > (unsigned long long)a.cap_shard;
-    if (lane == 0) {
-        a.desc[d] = (unsigned long long)wtot | ((unsigned long long)(shard * a.cap_shard + base) << 32);
-        if (over) atomicOr(a.counter + kShards * kCtrStride, 1u);
-    }
+    if (lane == 0) a.desc[o.d] = (unsigned long long)o.wtot | ((unsigned long long)base << 32);
     if (over) return; // the host re-runs with a bigger buffer
     // the wave's run of records: a scalar base + a 32-bit byte offset per lane
-    char *out = reinterpret_cast<char *>(a.recs + ((size_t)shard * a.cap_shard + base));
-    uint32_t boff = (inc - c) * 4u;
-    const uint32_t pos = (uint32_t)p0 + a.report_shift;
+    char *out = reinterpret_cast<char *>(a.recs + base);
+    uint32_t boff = o.first * 4u;
 #pragma unroll
     for (int i = 0; i < NWORD; i++) {
-        uint32_t bits = y[i];
+        uint32_t bits = o.y[i];
         while (bits) {
             const uint32_t j = (uint32_t)__ffs((int)bits) - 1u;
             bits &= bits - 1u;
-            *reinterpret_cast<uint32_t *>(out + boff) = pos + 32u * (uint32_t)i + j;
+            *reinterpret_cast<uint32_t *>(out + boff) = o.pos + 32u * (uint32_t)i + j;
             boff += 4u;
         }
     }
+}
+
+#ifndef GSCAN_LANE_BATCH
+#define GSCAN_LANE_BATCH 2
+#endif
+constexpr int kLaneBatchMax = GSCAN_LANE_BATCH; // sub-tiles a wave holds counted but unwritten before it reserves for all of them (10 VGPRs each; 1..3)
+
+// one reservation for the sub-tiles in p[0 .. n): their runs lie back to back in the shard of the first one's descriptor
+template <int ITER>
+__device__ __forceinline__ void lane_flush(const ScanArgs &a, uint32_t lane, const LaneCounted<ITER / 2> (&p)[kLaneBatchMax], int n)
+{
+    const uint32_t total = p[0].wtot + (kLaneBatchMax > 1 && n > 1 ? p[kLaneBatchMax > 1 ? 1 : 0].wtot : 0u) + (kLaneBatchMax > 2 && n > 2 ? p[kLaneBatchMax > 2 ? 2 : 0].wtot : 0u);
+    uint32_t base = 0;
+    bool over = false;
+    if (total) {
+        const uint32_t shard = p[0].d & (kShards - 1);
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(a.counter + shard * kCtrStride, total); // index inside the shard's region
+        const uint32_t at = __builtin_amdgcn_readfirstlane(b);
+        over = (unsigned long long)at + total > (unsigned long long)a.cap_shard;
+        if (over && lane == 0) atomicOr(a.counter + kShards * kCtrStride, 1u);
+        base = shard * a.cap_shard + at;
+    }
+    lane_write<ITER>(a, lane, p[0], base, over);
+    if (kLaneBatchMax > 1 && n > 1) lane_write<ITER>(a, lane, p[kLaneBatchMax > 1 ? 1 : 0], base + p[0].wtot, over);
+    if (kLaneBatchMax > 2 && n > 2) lane_write<ITER>(a, lane, p[kLaneBatchMax > 2 ? 2 : 0], base + p[0].wtot + p[kLaneBatchMax > 1 ? 1 : 0].wtot, over);
 }
 
 // NCLS: 2 or 4 (table entry layout).  NR: runs of the program, sorted by their doubling steps -- 1 or 2 (two classes):
@@ -277,6 +314,8 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
     u32x4 buf[ITER + 1];
     if (PF) lane_loads<ITER>(buf, c, sub_off, lane, have);
     uint16_t *xp = s_xp + wave * (ITER * 64);
+    LaneCounted<ITER / 2> held[kLaneBatchMax]; // counted sub-tiles whose records are not written yet
+    int n_held = 0;
     for (;;) {
         const uint32_t tn = t + gridDim.x;
         const bool next = tn < a.n_tiles;
@@ -334,12 +373,17 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
         // the next tile's text, requested before (PF 1) or inside (PF 2) this tile's epilogue
         if (PF == 1) lane_loads<ITER>(buf, cn, sub_off_n, lane, have_n);
         if (have) {
-            lane_emit<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, [&] {
-                if (PF == 2) lane_loads<ITER>(buf, cn, sub_off_n, lane, have_n);
-            });
-        } else {
-            if (lane == 0) a.desc[d] = 0ull; // nothing of this tile is this wave's
-            if (PF == 2) lane_loads<ITER>(buf, cn, sub_off_n, lane, have_n);
+            if (n_held == 0 || kLaneBatchMax == 1) lane_count<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, held[0]);
+            else if (n_held == 1 || kLaneBatchMax == 2) lane_count<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, held[kLaneBatchMax > 1 ? 1 : 0]);
+            else lane_count<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, held[kLaneBatchMax > 2 ? 2 : 0]);
+            n_held++;
+        } else if (lane == 0) {
+            a.desc[d] = 0ull; // nothing of this tile is this wave's
+        }
+        if (PF == 2) lane_loads<ITER>(buf, cn, sub_off_n, lane, have_n);
+        if (n_held >= kLaneBatchMax || (!next && n_held)) {
+            lane_flush<ITER>(a, lane, held, n_held);
+            n_held = 0;
         }
         if (!next) break;
         t = tn;

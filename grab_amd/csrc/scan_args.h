@@ -8,7 +8,10 @@
 
 namespace gscan {
 
-constexpr int kShards = 64; // record-buffer regions, each with its own reservation counter.  Every WAVE reserves its run with one atomic
+#ifndef GSCAN_SHARDS
+#define GSCAN_SHARDS 64
+#endif
+constexpr int kShards = GSCAN_SHARDS; // record-buffer regions, each with its own reservation counter.  Every WAVE reserves its run with one atomic
                             // (descriptor d uses shard d & 63): with 8 counters the dense patterns queued up on them -- same-address
                             // atomics are served one at a time, ~90 ns each (profiles/r02_d_kernel_sweep_per_wave_8_shards.txt)
 // The counters sit one per 128-byte line: returning atomics on the SAME cache line are served one after the other by that
