@@ -120,17 +120,34 @@ __device__ __forceinline__ TileS tile_scalars(const ScanArgs &a, const TileDesc 
     return r;
 }
 
-// the wave's ITER + 1 loads of one sub-tile (the last one the halo: lane 0 only); valid == false: the same loads, far out
-// of range -- zeros, no memory traffic
+// the wave's loads of one sub-tile: the halo first (the 16 bytes behind the sub-tile, ONE byte each to lanes 0-15 -- see
+// lane_halo), then ITER 16-byte pieces per lane; valid == false: the same loads, far out of range -- zeros, no memory traffic
 template <int ITER>
-__device__ __forceinline__ void lane_loads(u32x4 (&buf)[ITER + 1], const TileS &s, int sub_off, uint32_t lane, bool valid)
+__device__ __forceinline__ void lane_loads(u32x4 (&buf)[ITER], uint32_t &halo, const TileS &s, int sub_off, uint32_t lane, bool valid)
 {
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)s.ahi << 32) | s.alo), 0, (int)((s.len + 15u) & ~15u), 0x00020000);
+    halo = __builtin_amdgcn_raw_buffer_load_b8(rsrc, valid && lane < 16 ? sub_off + ITER * 1024 + (int)lane : 0x7ffffff0, 0, 0);
     const int v0 = valid ? sub_off + (int)lane * 16 : 0x7ffffff0;
 #pragma unroll
     for (int k = 0; k < ITER; k++) buf[k] = load16<true>(rsrc, valid ? v0 + k * 1024 : 0x7ffffff0);
-    buf[ITER] = load16<false>(rsrc, valid && lane == 0 ? v0 + ITER * 1024 : 0x7ffffff0);
+}
+// The class masks of the 16 halo bytes (what lane 0 of a step past the sub-tile would hold).  Lane j < 16 holds byte j and
+// its table entry at dword position 0 (class c at bit 8c for two classes, 4c for four): one look-up, and a ballot per class
+// is that class's 16 positions -- instead of 16 look-ups and a merge whose other 63 lanes nobody reads.
+template <int NCLS>
+__device__ __forceinline__ void lane_halo(uint32_t eh, uint32_t &p01, uint32_t &p23)
+{
+    constexpr uint32_t sh = NCLS == 2 ? 8u : 4u;
+    const uint32_t c0 = (uint32_t)__builtin_amdgcn_ballot_w64((eh & 1u) != 0) & 0xffffu;
+    const uint32_t c1 = (uint32_t)__builtin_amdgcn_ballot_w64((eh & (1u << sh)) != 0) & 0xffffu;
+    p01 = c0 | (c1 << 16);
+    p23 = 0u;
+    if (NCLS == 4) {
+        const uint32_t c2 = (uint32_t)__builtin_amdgcn_ballot_w64((eh & (1u << 8)) != 0) & 0xffffu;
+        const uint32_t c3 = (uint32_t)__builtin_amdgcn_ballot_w64((eh & (1u << 12)) != 0) & 0xffffu;
+        p23 = c2 | (c3 << 16);
+    }
 }
 
 // Epilogue of one wave's sub-tile: xp = the wave's strip, xp[k * 64 + lane] = step k's 16-bit candidate mask of `lane`,
@@ -142,6 +159,12 @@ __device__ __forceinline__ void lane_loads(u32x4 (&buf)[ITER + 1], const TileS &
 // the difference between the identifier scan and the same kernel without records) is paid once per 24 KiB instead of once
 // per 12.  (Tried and measured slower, profiles/r03_p_lane_reserve_ahead_sweep.txt: reserving by a guess AHEAD of a tile's
 // loads -- the answer then queues in front of the loads -- and, r03_c: the next tile's loads behind the atomic.)
+// What the record path costs, measured by taking it away (identifier scan, 16 GiB, same box, interleaved runs; profiles/
+// r03_w_lane_record_path_experiments.txt, r03_v_*, r03_x_*): no stores at all 5.66 - 5.82 TB/s, no reservation (fixed slices)
+// 5.71 - 5.73, records staged in the strip and stored 64 at a time 5.65 - 5.68, as here 5.68 - 5.80 -- all one number; [0-9]{16},
+// which has no records, 6.35.  The identifier scan's distance to it is its second run's arithmetic, not its records.  Rolling
+// refill (piece k of the next tile requested the moment piece k of this one is looked up: a sub-tile in flight all the time) was
+// SLOWER, 5.1 and 6.1 TB/s: the kernel does not wait for memory latency that more loads in flight would hide.
 template <int NWORD>
 struct LaneCounted {
     uint32_t y[NWORD]; // group starts of this lane's 32 * NWORD positions
@@ -311,8 +334,9 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
     TileS c = tile_scalars(a, tiles, t, kTile);
     int sub_off = c.toff + (int)(wave * ITER * 1024);
     bool have = c.len >= a.m && sub_off < (int)c.len; // some of this tile is this wave's (wave-uniform)
-    u32x4 buf[ITER + 1];
-    if (PF) lane_loads<ITER>(buf, c, sub_off, lane, have);
+    u32x4 buf[ITER];
+    uint32_t halo = 0;
+    if (PF) lane_loads<ITER>(buf, halo, c, sub_off, lane, have);
     uint16_t *xp = s_xp + wave * (ITER * 64);
     LaneCounted<ITER / 2> held[kLaneBatchMax]; // counted sub-tiles whose records are not written yet
     int n_held = 0;
@@ -328,17 +352,20 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
             have_n = cn.len >= a.m && sub_off_n < (int)cn.len;
         }
         const uint32_t d = t * kLNW + wave;
-        if (!PF && have) lane_loads<ITER>(buf, c, sub_off, lane, true);
+        if (!PF && have) lane_loads<ITER>(buf, halo, c, sub_off, lane, true);
         if (have) {
             uint32_t e[16];
             uint32_t pa, qa, pb, qb; // class masks of step k (pa, qa) and of step k + 1 (pb, qb)
+            uint32_t hp, hq; // the halo's masks (wave-uniform)
+            lane_halo<NCLS>(GL_LUT(halo, 0u), hp, hq);
             GL_LOOKUPS(buf[0]);
             GL_MERGE(pa, qa);
             GL_LOOKUPS(buf[1]);
 #pragma unroll
             for (int k = 0; k < ITER; k++) {
-                GL_MERGE(pb, qb);                          // step k + 1 (k + 1 == ITER: the halo; only lane 0 of it is looked at)
-                if (k + 2 <= ITER) GL_LOOKUPS(buf[k + 2]); // in flight while step k is computed
+                if (k + 1 < ITER) GL_MERGE(pb, qb);       // step k + 1
+                else pb = hp, qb = hq;                    // ... of the last step: the halo (only lane 0 of it is looked at)
+                if (k + 2 < ITER) GL_LOOKUPS(buf[k + 2]); // in flight while step k is computed
                 // the next lane's masks (lane 63: lane 0 of the next step)
                 const uint32_t a01 = down1(pa, __builtin_amdgcn_readfirstlane(pb));
                 uint32_t cand;
@@ -371,7 +398,7 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
             }
         }
         // the next tile's text, requested before (PF 1) or inside (PF 2) this tile's epilogue
-        if (PF == 1) lane_loads<ITER>(buf, cn, sub_off_n, lane, have_n);
+        if (PF == 1) lane_loads<ITER>(buf, halo, cn, sub_off_n, lane, have_n);
         if (have) {
             if (n_held == 0 || kLaneBatchMax == 1) lane_count<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, held[0]);
             else if (n_held == 1 || kLaneBatchMax == 2) lane_count<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, held[kLaneBatchMax > 1 ? 1 : 0]);
@@ -380,7 +407,7 @@ __global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const T
         } else if (lane == 0) {
             a.desc[d] = 0ull; // nothing of this tile is this wave's
         }
-        if (PF == 2) lane_loads<ITER>(buf, cn, sub_off_n, lane, have_n);
+        if (PF == 2) lane_loads<ITER>(buf, halo, cn, sub_off_n, lane, have_n);
         if (n_held >= kLaneBatchMax || (!next && n_held)) {
             lane_flush<ITER>(a, lane, held, n_held);
             n_held = 0;
@@ -403,33 +430,22 @@ void launch_one(const ScanArgs &a, dim3 g, hipStream_t st)
 }
 
 // (experiment switch GSCAN_LANE_PF=0|1|2 for the two benchmark programs: the identifier scan and [0-9]{16})
-int lane_iter_experiment()
-{
-    static const int it = getenv("GSCAN_LANE_ITER") ? atoi(getenv("GSCAN_LANE_ITER")) : 0;
-    return it == 16 ? 16 : 0;
-}
-
 template <int NCLS, int NR, int S0, int S1>
 bool launch_pf_experiment(const ScanArgs &a, dim3 g, hipStream_t st)
 {
     static const int pf = getenv("GSCAN_LANE_PF") ? atoi(getenv("GSCAN_LANE_PF")) : -1;
-    const bool i16 = lane_iter_experiment() == 16;
-    if (pf < 0 && !i16) return false;
-    const int mode = (pf < 0 ? kLanePF : pf) + (i16 ? 3 : 0);
-    switch (mode) {
+    if (pf < 0) return false;
+    switch (pf) {
     case 0: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 0>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
     case 1: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 1>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
-    case 2: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 2>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
-    case 3: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 0, 16>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
-    case 4: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 1, 16>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
-    default: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 2, 16>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
+    default: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 2>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
     }
     return true;
 }
 
 } // namespace
 
-uint32_t k2_lane_tile_bytes() { return (uint32_t)(kLNW * (lane_iter_experiment() ? lane_iter_experiment() : kLIter) * 1024); }
+uint32_t k2_lane_tile_bytes() { return (uint32_t)(kLNW * kLIter * 1024); }
 uint32_t k2_lane_waves() { return (uint32_t)kLNW; }
 
 // Doubling steps a run of n positions takes: 1 -> 2 -> 4 ... while it fits, one overlapping step for the rest.
