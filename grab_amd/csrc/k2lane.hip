@@ -160,11 +160,16 @@ __device__ __forceinline__ void lane_halo(uint32_t eh, uint32_t &p01, uint32_t &
 // per 12.  (Tried and measured slower, profiles/r03_p_lane_reserve_ahead_sweep.txt: reserving by a guess AHEAD of a tile's
 // loads -- the answer then queues in front of the loads -- and, r03_c: the next tile's loads behind the atomic.)
 // What the record path costs, measured by taking it away (identifier scan, 16 GiB, same box, interleaved runs; profiles/
-// r03_w_lane_record_path_experiments.txt, r03_v_*, r03_x_*): no stores at all 5.66 - 5.82 TB/s, no reservation (fixed slices)
-// 5.71 - 5.73, records staged in the strip and stored 64 at a time 5.65 - 5.68, as here 5.68 - 5.80 -- all one number; [0-9]{16},
-// which has no records, 6.35.  The identifier scan's distance to it is its second run's arithmetic, not its records.  Rolling
-// refill (piece k of the next tile requested the moment piece k of this one is looked up: a sub-tile in flight all the time) was
-// SLOWER, 5.1 and 6.1 TB/s: the kernel does not wait for memory latency that more loads in flight would hide.
+// r03_y_lane_neither_reservation_nor_stores.txt, r03_w_*, r03_z_*): as here 5.2 - 5.7 TB/s; no reservation (fixed slices) but the
+// stores 5.3 - 5.8; the reservation but no stores 5.7 - 5.8; NEITHER 6.0 - 6.1 -- which is what the same arithmetic runs at on a
+// pattern without a match ([A-Za-z_][0-9]{15,}: 6.2 - 6.3; [0-9]{16}: 6.3).  So records cost the identifier scan ~10 %, the
+// returning atomic and the store loops each about half of it, and not additively.  Two cheaper-looking writers were slower:
+// records staged in the strip and stored 64 at a time (5.65 - 5.68 against 5.68 - 5.80), and a loop-free one for runs of <= 64
+// records (rank -> source lane by a running maximum over marks in the strip, the source's 192 bits by ds_bpermute, one store:
+// 65 instructions against ~130, but 5.1 - 5.3 against 5.6) -- with four waves per SIMD it is the length of a wave's dependent
+// chain (LDS round trips) that counts, not its instruction count.  For the same reason rolling refill (piece k of the next tile
+// requested the moment piece k of this one is looked up: a sub-tile in flight all the time) was SLOWER, 5.1 and 6.1 TB/s
+// (r03_x_*): the kernel is not waiting for memory latency that more loads in flight would hide.
 template <int NWORD>
 struct LaneCounted {
     uint32_t y[NWORD]; // group starts of this lane's 32 * NWORD positions
