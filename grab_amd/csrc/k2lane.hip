@@ -30,7 +30,13 @@ namespace gscan {
 namespace {
 
 constexpr int kLIter = 12; // KiB per wave sub-tile
-constexpr int kLNW = 8;    // waves per workgroup (64 KiB table + 12 KiB of strips: two workgroups per CU)
+#ifndef GSCAN_LANE_WAVES
+#define GSCAN_LANE_WAVES 8
+#endif
+constexpr int kLNW = GSCAN_LANE_WAVES;    // waves per workgroup (64 KiB table + 12 KiB of strips: two workgroups per CU)
+                           // (10 -- five waves per SIMD, the kernel fits 96 VGPRs and 2 x 79 KiB of LDS -- measured: identifier scan
+                           // 4.9 against 5.15 TB/s, [0-9]{16} the same, [a-z][0-9][A-Z]{3} 5.6 against 5.2, [a-z]{2,5} 2.85 against 3.0;
+                           // profiles/r03_aa_lane_ten_waves_per_workgroup.txt)
 constexpr int kLanePF = 0; // where the next tile's loads go (k2_lane_scan's PF).  Measured, same box, 16 GiB, identifier scan / [0-9]{16}
                            // (profiles/r03_c_lane_prefetch_and_subtile_sweep.txt): 0 (none) 5.70 / 6.41 TB/s, 1 (before the epilogue)
                            // 5.13 / 6.46, 2 (behind the atomic) 5.45 / 6.23; 16 KiB per wave: 5.17 / 6.29, 5.45 / 6.40, 4.40 / 4.74.
@@ -285,7 +291,7 @@ __device__ __forceinline__ void lane_flush(const ScanArgs &a, uint32_t lane, con
 // PF: where the next tile's loads are issued -- 0: at the top of its own pass (no prefetch), 1: between this tile's last step
 // and its epilogue, 2: inside the epilogue, right behind the reserving atomic.
 template <int NCLS, int NR, int S0, int S1, int PF = 0, int ITER = kLIter>
-__global__ __launch_bounds__(kLNW * 64, 4) void k2_lane_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
+__global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     constexpr uint32_t kTile = kLNW * ITER * 1024;
     static_assert(NCLS == 2 || NCLS == 4, "two entry layouts");
