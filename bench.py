@@ -196,7 +196,7 @@ def live_traffic(patterns, gib, timeout_s=90):
             if len(names) != len(patterns):
                 return None
             for p, k in zip(patterns, names):
-                out.setdefault(p, {"kernel": k.split("(")[0][-70:]})[ctr + "_KiB"] = sum(per[k]) / len(per[k])
+                out.setdefault(p, {"kernel": k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-70:]})[ctr + "_KiB"] = sum(per[k]) / len(per[k])
         for p in out:
             out[p]["traffic_bytes"] = int(2 * out[p]["FETCH_SIZE_KiB"] * 1024 + out[p]["WRITE_SIZE_KiB"] * 1024)
         return out
