@@ -2980,7 +2980,13 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     // restart position, i.e. the pattern never looks behind the match start.  That is K3's cold path.
     const bool vm_dev = !db.exact && db.vm_ok && !db.dev_pre && vm_independent_of_subject_start(*db.tree) && !getenv("GSCAN_NO_VM");
 
-    if (db.alts.size() > 1) { // several alternatives: the bucket filter is the one kernel that takes them
+    // several alternatives: the bucket filter is the one kernel that takes them -- unless they all look the same to the device
+    // ([0-9]+\.[0-9]+ unfolds into two alternatives over the one window [0-9]\.[0-9]; what tells them apart is the host's
+    // business): one window is K1's or K2's
+    bool one_window = true;
+    for (const std::vector<uint8_t> &w : db.dev_windows) one_window = one_window && w == db.dev_windows[0];
+    if (getenv("GSCAN_SAME_WINDOW_K3")) one_window = db.alts.size() == 1; // (A/B switch: the round-2 choice)
+    if (!one_window) {
         db.tier = GSCAN_TIER_BUCKET;
         pg.vm_filter = vm_dev;
         if (vm_dev) fill_vm_pairs(db);

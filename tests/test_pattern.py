@@ -68,11 +68,12 @@ SUPPORTED = [
     (r"\bfoo\w*\b", engine.TIER_LITERAL, 3),
     ("(?m)^fo.*$", engine.TIER_LITERAL, 2),
     (r"a\b b", engine.TIER_LITERAL, 3),       # decided on the spot: always true
-    # one unbounded repeat in the middle ("gapped"): the kernels look for one repeat byte + the rest
-    ("a+b", engine.TIER_BUCKET, 2),
-    (r"\d+\.\d+", engine.TIER_BUCKET, 3),
+    # one unbounded repeat in the middle ("gapped"): the kernels look for one repeat byte + the rest.  Two alternatives (with
+    # the repeat in front of the window and without) -- over ONE device window where the repeat leads: K1's or K2's then
+    ("a+b", engine.TIER_LITERAL, 2),
+    (r"\d+\.\d+", engine.TIER_CLASSRUN, 3),
     ("foo.*bar", engine.TIER_BUCKET, 6),
-    (r"[a-z]+\b", engine.TIER_BUCKET, 1),
+    (r"[a-z]+\b", engine.TIER_CLASSRUN, 1),
     ("a*b", engine.TIER_BUCKET, 1),
     ("a{2,}b", engine.TIER_BUCKET, 3),
     ("fo.*$", engine.TIER_ANCHORED, 2),
