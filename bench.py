@@ -25,8 +25,9 @@ One JSON line on rank 0: the driver's contract fields, plus
                   the GRAB_DETACH=1 figure (teardown left to a child) beside it.  "scaling": "strong"
   "cpu_baseline"  the reference binary (oracle/_ref/grab_jit), or the oracle port, on this box's host cores over
                   that same on-disk corpus (N=1, rank 0 only): -n swept over {32, 64, 128, all}, best kept
-  "e2e_cfg3"      BASELINE configs[2] end to end: the first 16 GiB of the corpus, `grab -n 8 -r -O -l IDENT`, line
-                  count, sorted-output md5 against the reference on a 1 GiB subset, its own cpu_baseline
+  "e2e_cfg3"      BASELINE configs[2] end to end at its full size: the whole corpus, `grab -n 8 -r -O -l IDENT`, line count,
+                  the same on the first 16 GiB ("at_16GiB"), sorted-output md5 against the reference on a 1 GiB subset,
+                  its own cpu_baseline (the reference on a 4 GiB sample)
   "e2e_cfg5"      BASELINE configs[4] at 8 GiB: ONE file with dense planted needles incl. every chunk-boundary
                   case, `grab -O -l` byte-exact (md5) against the reference, its own single-core cpu_baseline
   "roofline.traffic"  HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately, counters
@@ -345,7 +346,7 @@ def run_timed(argv, env, reps, warm=True, count_only=False):
     return best
 
 
-def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=2, workers=None, detached=True, count_only=False):
+def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=2, workers=None, detached=True, count_only=False, warm=True):
     """`grab -n max(8, 4 N) -r` over the corpus directory on the first N devices (a worker submits, waits and prints in turn:
     several per device keep its three windows in flight)."""
     workers = max(8, 4 * n_gpus) if workers is None else workers
@@ -356,7 +357,7 @@ def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=
     devs = [x for x in vis.split(",") if x] if vis else [str(i) for i in range(torch.cuda.device_count())]
     env["HIP_VISIBLE_DEVICES"] = ",".join(devs[:n_gpus])
     argv = [bin_path(), "-n", str(workers), "-r"] + flags + [pattern, d]
-    got = run_timed(argv, env, reps, count_only=count_only)
+    got = run_timed(argv, env, reps, warm=warm, count_only=count_only)
     if got is None or got[0] is None:
         return {"error": (got[2] if got else b"")[-300:].decode("latin-1")}
     # `value` is the run as ONE process, start to exit.  GRAB_DETACH=1 (opt-in) runs the scan in a child that hands back its
@@ -461,8 +462,10 @@ def link_subset(d, dst, nfiles):
 
 
 def e2e_cfg3(d, nfiles, file_bytes, n_gpus, want_cpu):
-    """BASELINE configs[2] end to end on the first 16 GiB of the corpus: `grab -n 8 -r -O -l IDENT` (match ends from the
-    device: the walk never touches the text), sorted-output md5 against the reference on a 1 GiB subset."""
+    """BASELINE configs[2] end to end at the size it is quoted on -- the whole corpus, 1024 x 64 MiB: `grab -n 8 -r -O -l IDENT`
+    (match ends from the device: the walk never touches the text), line count from an untimed pass; the same command on the
+    first 16 GiB beside it (`at_16GiB`: a quarter of the work under the same 0.25 s of start-up and teardown); sorted-output
+    md5 against the reference on a 1 GiB subset."""
     ident = synth.IDENT_RE
     n16 = min(nfiles, (16 << 30) // file_bytes)
     n1 = min(n16, max(1, (1 << 30) // file_bytes))
@@ -470,7 +473,10 @@ def e2e_cfg3(d, nfiles, file_bytes, n_gpus, want_cpu):
     try:
         link_subset(d, d16, n16)
         link_subset(d, d1, n1)
-        e = e2e_measure(d16, n16, file_bytes, ident, ["-O", "-l"], n_gpus, None, reps=2, detached=False, count_only=True)
+        e = e2e_measure(d, nfiles, file_bytes, ident, ["-O", "-l"], n_gpus, None, reps=2, detached=False, count_only=True)
+        if n16 < nfiles and "value" in e:
+            q = e2e_measure(d16, n16, file_bytes, ident, ["-O", "-l"], n_gpus, None, reps=2, detached=False, count_only=True, warm=False)
+            e["at_16GiB"] = {k: q.get(k) for k in ("value", "bytes", "wall_s", "startup_s", "scan_phase_GBps", "frac", "error") if k in q}
         e["lines_ok"] = None
         ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
         got = sorted_md5([bin_path(), "-n", "8", "-r", "-O", "-l", ident, d1])
