@@ -707,10 +707,13 @@ def main():
                 continue
             pat2, cap2 = CONFIGS[name]
             db2 = engine.Database(pat2)
-            wall, tot2, ovf2, kms2, nl2, _ = time_kernel(ctx, db2, arena, segs, stream, nbytes, cap2, max(3, a.steps // 2), 1, device)
+            # (as many launches as the headline kernel gets, behind as many warm-up ones: over 5 launches the figure followed the
+            # GPU's clock state more than the kernel -- profiles/r03_af_rate_vs_run_length_and_clocks.txt)
+            steps2, warm2 = max(3, a.steps), max(1, a.warmup)
+            wall, tot2, ovf2, kms2, nl2, _ = time_kernel(ctx, db2, arena, segs, stream, nbytes, cap2, steps2, warm2, device)
             blk = roofline_block(name, nbytes, tot2, kms2, nl2, live)
             blk.update({"pattern": pat2, "kernel": KERNEL_NAMES.get(db2.info.tier, "?"), "records_per_launch": int(tot2), "overflow": bool(ovf2),
-                        "value": round(nbytes / (wall / max(3, a.steps // 2)) / 1e9, 2)})
+                        "steps": steps2, "warmup": warm2, "value": round(nbytes / (wall / steps2) / 1e9, 2)})
             others[name] = blk
         if rank == 0:
             line["kernels"] = others
