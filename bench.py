@@ -707,13 +707,20 @@ def main():
                 continue
             pat2, cap2 = CONFIGS[name]
             db2 = engine.Database(pat2)
-            # (as many launches as the headline kernel gets, behind as many warm-up ones: over 5 launches the figure followed the
-            # GPU's clock state more than the kernel -- profiles/r03_af_rate_vs_run_length_and_clocks.txt)
-            steps2, warm2 = max(3, a.steps), max(1, a.warmup)
-            wall, tot2, ovf2, kms2, nl2, _ = time_kernel(ctx, db2, arena, segs, stream, nbytes, cap2, steps2, warm2, device)
+            # half the headline's launches behind one warm-up launch (as in rounds 1 and 2), then the same kernel back to back for
+            # twice the headline's launches ("sustained": does the figure depend on the length of the run?  On the boxes measured
+            # so far it did not -- 0.684 / 0.684, profiles/r03_ah_* -- while the same kernel differs by +-5 % from box to box and
+            # from one process to the next on one box: it is the one that draws the most power, 1.1 - 1.3 kW of the 1.4 kW cap at
+            # 2.0 - 2.4 GHz, profiles/r03_ae_*, r03_af_*)
+            steps2 = max(3, a.steps // 2)
+            wall, tot2, ovf2, kms2, nl2, _ = time_kernel(ctx, db2, arena, segs, stream, nbytes, cap2, steps2, 1, device)
             blk = roofline_block(name, nbytes, tot2, kms2, nl2, live)
             blk.update({"pattern": pat2, "kernel": KERNEL_NAMES.get(db2.info.tier, "?"), "records_per_launch": int(tot2), "overflow": bool(ovf2),
-                        "steps": steps2, "warmup": warm2, "value": round(nbytes / (wall / steps2) / 1e9, 2)})
+                        "steps": steps2, "warmup": 1, "value": round(nbytes / (wall / steps2) / 1e9, 2)})
+            steps3 = 2 * a.steps
+            _, tot3, _, kms3, nl3, _ = time_kernel(ctx, db2, arena, segs, stream, nbytes, cap2, steps3, 0, device)
+            sus = roofline_block(name, nbytes, tot3, kms3, nl3, None)
+            blk["sustained"] = {"launches": nl3, "kernel_ms": sus["kernel_ms"], "achieved": sus["achieved"], "frac": sus["frac"]}
             others[name] = blk
         if rank == 0:
             line["kernels"] = others
