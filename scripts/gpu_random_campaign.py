@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""One-off differential campaign on the GPU box: random patterns of the supported grammar (tests/test_fuzz.py's generator)
+through `grab` against the oracle (libpcre under the reference's loop) on one file -- tests/test_gpu_filegrep.py's
+test_random_patterns_cli_vs_oracle with other seeds and a time budget instead of 45 patterns.
+
+    python scripts/gpu_random_campaign.py --seed 31337 --seconds 170 [--lead-repeat]
+
+--lead-repeat: every pattern gets a leading unbounded repeat in front of it (the shapes whose alternatives share one device
+window and have been K1's / K2's since round 3).  Prints one JSON line; exit status 1 on any difference."""
+import argparse
+import json
+import os
+import random
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def run(exe, args, cwd):
+    r = subprocess.run([exe] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, GRAB_DIAG="1"))
+    return r.returncode, r.stdout, r.stderr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=31337)
+    ap.add_argument("--seconds", type=float, default=170)
+    ap.add_argument("--lead-repeat", action="store_true")
+    a = ap.parse_args()
+    from grab_amd import build, engine
+    from test_fuzz import gen
+
+    oracle = os.path.join(ROOT, "oracle", "grab_oracle")
+    rng = random.Random(a.seed)
+    nrng = np.random.default_rng(a.seed)
+    alpha = np.frombuffer(b"abcxA01 .\n\nab  ", np.uint8)
+    data = alpha[nrng.integers(0, alpha.size, 300_000)]
+    data[1000:1003] = np.frombuffer(b"abc", np.uint8)
+    tiers, done, skipped, bad = {}, 0, 0, []
+    with tempfile.TemporaryDirectory() as d:
+        data.tofile(os.path.join(d, "f"))
+        t0 = time.time()
+        while time.time() - t0 < a.seconds:
+            pat = gen(rng)
+            if a.lead_repeat:
+                pat = rng.choice(["a+", "[ab]+", r"\w+", "[a-c0-9]+", "x*", r"\d+", ".+"]) + pat
+            try:
+                db = engine.Database(pat)
+            except ValueError:
+                skipped += 1
+                continue
+            if db.minlen < 0:
+                skipped += 1
+                continue
+            flags = [["-O", "-l"], ["-O"], []][done % 3]
+            orc, oout, oerr = run(oracle, flags + [pat, "f"], d)
+            if orc != 0:
+                skipped += 1
+                continue
+            rc, out, err = run(build.bin_path(), flags + [pat, "f"], d)
+            if b"gave up" in oerr or b"abandoned" in err:
+                skipped += 1
+                continue
+            key = "tier%d%s" % (db.info.tier, "+vm" if db.info.vm else "")
+            tiers[key] = tiers.get(key, 0) + 1
+            if rc != 0 or out != oout:
+                bad.append({"pattern": pat, "flags": flags, "rc": rc, "lines": out.count(b"\n"), "oracle_lines": oout.count(b"\n"), "err": err[-200:].decode("latin-1")})
+            done += 1
+    print(json.dumps({"seed": a.seed, "lead_repeat": a.lead_repeat, "compared": done, "skipped": skipped, "by_tier": tiers, "differences": bad}))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
