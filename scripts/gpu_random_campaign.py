@@ -34,7 +34,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=170)
     ap.add_argument("--lead-repeat", action="store_true")
     a = ap.parse_args()
-    from grab_amd import build, engine
+    from grab_amd import engine
+    from grab_amd.build import bin_path
     from test_fuzz import gen
 
     oracle = os.path.join(ROOT, "oracle", "grab_oracle")
@@ -64,7 +65,7 @@ def main():
             if orc != 0:
                 skipped += 1
                 continue
-            rc, out, err = run(build.bin_path(), flags + [pat, "f"], d)
+            rc, out, err = run(bin_path(), flags + [pat, "f"], d)
             if b"gave up" in oerr or b"abandoned" in err:
                 skipped += 1
                 continue
