@@ -28,6 +28,8 @@ One JSON line on rank 0: the driver's contract fields, plus
   "e2e_cfg3"      BASELINE configs[2] end to end at its full size: the whole corpus, `grab -n 8 -r -O -l IDENT`, line count,
                   the same on the first 16 GiB ("at_16GiB"), sorted-output md5 against the reference on a 1 GiB subset,
                   its own cpu_baseline (the reference on a 4 GiB sample)
+  "e2e_cfg4"      BASELINE configs[3] at 16 GiB: 32 768 files of 512 KiB in a 64 x 64 directory tree, one needle each,
+                  `grab -n 8 -r -O -l`, line count == file count, sorted md5 against the reference, its own cpu_baseline
   "e2e_cfg5"      BASELINE configs[4] at 8 GiB: ONE file with dense planted needles incl. every chunk-boundary
                   case, `grab -O -l` byte-exact (md5) against the reference, its own single-core cpu_baseline
   "roofline.traffic"  HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately, counters
@@ -500,6 +502,40 @@ def e2e_cfg3(d, nfiles, file_bytes, n_gpus, want_cpu):
         shutil.rmtree(d1, ignore_errors=True)
 
 
+def e2e_cfg4(base, gib, n_gpus, want_cpu):
+    """BASELINE configs[3] at `gib` GiB: a tree of 2048 x gib files of 512 KiB in 64 x 64 directories, one needle per file
+    (scripts/fullsize_parity.py gen_files: the full-size script's generator); `grab -n 8 -r -O -l` -- the parallel walk, the
+    queue, small files batched 32 to a launch -- line count == file count, sorted output md5 against the reference."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fullsize_parity
+
+    d = os.path.join(base, "grab_bench_cfg4_%d" % os.getpid())
+    while gib > 1 and shutil.disk_usage(base).free < (gib << 30) * 1.2:
+        gib //= 2
+    files, fb = gib * 2048, 512 << 10
+    try:
+        os.makedirs(d)
+        t0 = time.perf_counter()
+        fullsize_parity.gen_files(d, files, fb, 1, tree=(64, 64, 32))
+        gen_s = time.perf_counter() - t0
+        needle = synth.NEEDLE.decode()
+        e = e2e_measure(d, files, fb, needle, ["-O", "-l"], n_gpus, files, reps=2, detached=False)
+        e["corpus_write_s"] = round(gen_s, 1)
+        e["tree"] = "%d files x 512 KiB in 64 x 64 directories" % files
+        ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
+        got = sorted_md5([bin_path(), "-n", "8", "-r", "-O", "-l", needle, d])
+        if os.path.exists(ref):
+            want = sorted_md5([ref, "-n", str(min(64, usable_cores())), "-r", "-O", "-l", needle, d])
+            e["sorted_md5"], e["reference_sorted_md5"], e["same_as_reference"] = got[0], want[0], got == want and got[0] is not None
+            if want_cpu:
+                e["cpu_baseline"] = cpu_baseline(d, files, fb, needle, ["-O", "-l"], threads=sorted(set([min(32, usable_cores()), min(64, usable_cores())])), reps=1, warm=False)
+                if e["cpu_baseline"] and "value" in e:
+                    e["vs_cpu_baseline"] = round(e["value"] / e["cpu_baseline"]["value"], 3)
+        return e
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def e2e_cfg5(base, gib, want_cpu):
     """BASELINE configs[4] at `gib` GiB: one file, ~31 250 seeded needles per GiB + one in every 4 KiB overlap window, across
     every chunk end, ending exactly at a chunk end, at every chunk start and in the last 18 bytes
@@ -556,7 +592,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the other two kernels' roofline blocks")
-    ap.add_argument("--no-e2e-extra", action="store_true", help="skip the e2e_cfg3 / e2e_cfg5 blocks")
+    ap.add_argument("--no-e2e-extra", action="store_true", help="skip the e2e_cfg3 / e2e_cfg4 / e2e_cfg5 blocks")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of rocprofv3 passes in this run")
     ap.add_argument("--e2e-gib", type=int, default=64, help="corpus written to /dev/shm for the end-to-end block")
     a = ap.parse_args()
@@ -752,7 +788,8 @@ def main():
                     # the other two end-to-end BASELINE configurations, each with its own parity check and CPU baseline
                     if not a.no_e2e_extra:
                         for key, fn in (("e2e_cfg3", lambda: e2e_cfg3(d, nfiles, file_bytes, world, want_cpu)),
-                                        ("e2e_cfg5", lambda: e2e_cfg5(os.path.dirname(d), min(8, max(2, use >> 33)), want_cpu))):
+                                        ("e2e_cfg5", lambda: e2e_cfg5(os.path.dirname(d), min(8, max(2, use >> 33)), want_cpu)),
+                                        ("e2e_cfg4", lambda: e2e_cfg4(os.path.dirname(d), min(16, max(2, use >> 32)), world, want_cpu))):
                             try:
                                 line[key] = fn()
                             except Exception as ex:
