@@ -229,6 +229,73 @@ def time_kernel(ctx, db, arena, segs, stream, nbytes, cap_per_gib, steps, warmup
     return wall, total, overflow, kern_ms, launches, res
 
 
+def check_launch(ctx, res, arena, pattern, files, file_bytes, plants, total, overflow, planted_only):
+    """What the timed launch left in HBM, checked on the first and the last file of the arena: the records of a file's first
+    and last 4 MiB against the candidate set the oracle (oracle/scan_oracle.py: Python's re, no product code) finds in those
+    bytes -- ascending, candidates only, every start of a group of consecutive candidates present (include/gscan.h,
+    gscan_wait) --, and for the planted literals the exact offsets and the exact total.  The oracle is the checker here,
+    nothing of it is timed."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import scan_oracle as so
+
+    if overflow:
+        return "record buffer overflow"
+    if planted_only and total != NEEDLES_PER_FILE * files:
+        return "expected %d matches, got %d" % (NEEDLES_PER_FILE * files, total)
+    span, halo = min(4 << 20, file_bytes), 4096
+    for i in sorted(set((0, files - 1))):
+        got = ctx.dev_fetch(res, i).astype(np.int64)
+        if got.size and np.any(np.diff(got) <= 0):
+            return "records of file %d are not ascending" % i
+        if planted_only and not np.array_equal(got, plants[i]):
+            return "planted offsets differ in file %d" % i
+        base = i * file_bytes
+        for lo, hi in ((0, span), (file_bytes - span, file_bytes)):
+            a, b = max(0, lo - halo), min(file_bytes, hi + halo)  # (a candidate is a function of the bytes AT it: the halo settles the window's edges)
+            text = arena[base + a:base + b].cpu().numpy().tobytes()
+            cands = so.all_starts(pattern.encode("latin-1"), text) + a
+            cset = np.zeros(b - a + 1, bool)
+            cset[cands - a] = True
+            g = got[(got >= lo) & (got < hi)]
+            if g.size and not np.all(cset[g - a]):
+                return "file %d: a reported offset in [%d, %d) is not a candidate" % (i, lo, hi)
+            c = cands[(cands >= lo) & (cands < hi)]
+            heads = c[(c == a) | ~cset[np.maximum(c - a - 1, 0)]] if c.size else c  # candidates whose predecessor is none (c == a only at the file's first byte)
+            if heads.size and not np.all(np.isin(heads, g)):
+                return "file %d: the start of a candidate group in [%d, %d) is missing" % (i, lo, hi)
+    return "ok"
+
+
+def clocks_snapshot():
+    """The device's shader clock (MHz) and socket power (W) right now, from sysfs / rocm-smi's sources: the kernels' rates
+    follow the clock the power management grants (*Clock and power*), so every kernel block carries them."""
+    import glob
+
+    out = {}
+    try:
+        for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+            f = os.path.join(card, "pp_dpm_sclk")
+            if not os.path.exists(f):
+                continue
+            for ln in open(f).read().splitlines():
+                if ln.rstrip().endswith("*"):
+                    out["sclk_mhz"] = int(re.search(r"(\d+)\s*Mhz", ln, re.I).group(1))
+            for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
+                for name in ("power1_average", "power1_input"):
+                    pf = os.path.join(hw, name)
+                    if os.path.exists(pf):
+                        try:
+                            out["power_w"] = round(int(open(pf).read().strip()) / 1e6, 1)
+                        except (OSError, ValueError):
+                            pass
+                        break
+            if out:
+                break
+    except Exception:
+        pass
+    return out or None
+
+
 def roofline_block(config, nbytes, total, kern_ms, launches, live=None):
     alg_bytes = nbytes + REC_BYTES * total  # per launch: every input byte once + one u32 per candidate
     kern_avg_ms = kern_ms / max(launches, 1)
@@ -433,7 +500,7 @@ def cpu_baseline(d, nfiles, file_bytes, pattern, flags, threads=None, reps=2, wa
     dt, out, t, argv = best
     return {"value": round(nbytes / dt / 1e9, 3), "unit": "GB/s", "cores": t, "kind": kind, "GBps_by_threads": tried,
             "sample": "%s of the same corpus under %s (%.0f GiB), '%s', warm cache, min of %d" % (
-                ("%d x %d MiB files" % (nfiles, file_bytes >> 20)) if os.path.isdir(d) else "one %d MiB file" % (nbytes >> 20),
+                ("%d x %s files" % (nfiles, "%d MiB" % (file_bytes >> 20) if file_bytes >= 1 << 20 else "%d KiB" % (file_bytes >> 10))) if os.path.isdir(d) else "one %d MiB file" % (nbytes >> 20),
                 os.path.dirname(d), nbytes / (1 << 30), " ".join(os.path.basename(a) if a == binary else a for a in argv[:-1]), reps),
             "lines": out.count(b"\n") if out is not None else None, "matches_per_s": out is not None and round(out.count(b"\n") / dt, 1), "wall_s": round(dt, 4),
             "engine": "libpcre 8.39 JIT (pcre_exec); the -H hyperscan path does not exist in the mounted reference"}
@@ -696,16 +763,10 @@ def main():
     elapsed = reduce_max(elapsed, world, device)
     matches_all = reduce_sum(float(total), world, device)
 
-    # sanity: the planted needles are exactly what came back (first and last file of this rank)
-    check = "ok"
-    if overflow:
-        check = "record buffer overflow"
-    elif a.config != "cfg3":
-        if total != NEEDLES_PER_FILE * a.files:
-            check = "expected %d matches, got %d" % (NEEDLES_PER_FILE * a.files, total)
-        for i in (0, a.files - 1):
-            if not np.array_equal(ctx.dev_fetch(res, i).astype(np.int64), plants[i]):
-                check = "planted offsets differ in file %d" % i
+    # the timed launch's output: planted needles exactly (literal configs), and the records of the first and last file against
+    # the oracle's candidate set (every config)
+    clk_after = clocks_snapshot()
+    check = check_launch(ctx, res, arena, pattern, a.files, file_bytes, plants, total, overflow, a.config != "cfg3")
 
     # HBM traffic per launch, measured in this run (rank 0 of a one-GPU run; the PMC passes run the native harness next to
     # this process: same kernels, an arena of the same size)
@@ -732,29 +793,42 @@ def main():
             "matches_per_s": round(matches_all / (elapsed / a.steps), 1),
             "check": check,
             "roofline": roofline_block(a.config, nbytes, total, kern_ms, launches, live),
+            "clocks": clk_after,
         }
 
     # the other two kernels on the same arena, same process (outside the timed region above): every rank runs them so that
     # the ranks stay in step, rank 0 reports its own
     if not a.no_kernels:
+        # Three interleaved passes (cfg3, alt, cfg3, alt, ...), each a warm-up launch + half the headline's launches: the
+        # block's figure is the MEDIAN pass, min / max and every pass's clock + power beside it -- the same kernel differs by
+        # +-5 % from box to box and from one process to the next (it is the one that draws the most power, 1.1 - 1.3 kW of the
+        # 1.4 kW cap at 2.0 - 2.4 GHz, profiles/r03_ae_*), and one number cannot say which of the two moved.  Then the same
+        # kernel back to back for twice the headline's launches ("sustained").
+        names = [n for n in sorted(CONFIGS) if n != a.config]
+        dbs = {n: engine.Database(CONFIGS[n][0]) for n in names}
+        steps2 = max(3, a.steps // 2)
+        passes = {n: [] for n in names}
+        checks = {}
+        for k in range(3):
+            for name in names:
+                pat2, cap2 = CONFIGS[name]
+                wall, tot2, ovf2, kms2, nl2, res2 = time_kernel(ctx, dbs[name], arena, segs, stream, nbytes, cap2, steps2, 1, device)
+                blk = roofline_block(name, nbytes, tot2, kms2, nl2, live)
+                blk.update({"records_per_launch": int(tot2), "overflow": bool(ovf2), "value": round(nbytes / (wall / steps2) / 1e9, 2), "clocks": clocks_snapshot()})
+                passes[name].append(blk)
+                if k == 0:
+                    checks[name] = check_launch(ctx, res2, arena, pat2, a.files, file_bytes, plants, tot2, ovf2, name != "cfg3")
         others = {}
-        for name in sorted(CONFIGS):
-            if name == a.config:
-                continue
+        for name in names:
             pat2, cap2 = CONFIGS[name]
-            db2 = engine.Database(pat2)
-            # half the headline's launches behind one warm-up launch (as in rounds 1 and 2), then the same kernel back to back for
-            # twice the headline's launches ("sustained": does the figure depend on the length of the run?  On the boxes measured
-            # so far it did not -- 0.684 / 0.684, profiles/r03_ah_* -- while the same kernel differs by +-5 % from box to box and
-            # from one process to the next on one box: it is the one that draws the most power, 1.1 - 1.3 kW of the 1.4 kW cap at
-            # 2.0 - 2.4 GHz, profiles/r03_ae_*, r03_af_*)
-            steps2 = max(3, a.steps // 2)
-            wall, tot2, ovf2, kms2, nl2, _ = time_kernel(ctx, db2, arena, segs, stream, nbytes, cap2, steps2, 1, device)
-            blk = roofline_block(name, nbytes, tot2, kms2, nl2, live)
-            blk.update({"pattern": pat2, "kernel": KERNEL_NAMES.get(db2.info.tier, "?"), "records_per_launch": int(tot2), "overflow": bool(ovf2),
-                        "steps": steps2, "warmup": 1, "value": round(nbytes / (wall / steps2) / 1e9, 2)})
+            by_frac = sorted(passes[name], key=lambda b: b["frac"])
+            blk = dict(by_frac[len(by_frac) // 2])
+            blk.update({"pattern": pat2, "kernel": KERNEL_NAMES.get(dbs[name].info.tier, "?"), "steps": steps2, "warmup": 1, "check": checks[name],
+                        "frac_min": by_frac[0]["frac"], "frac_max": by_frac[-1]["frac"],
+                        "passes": [{"frac": b["frac"], "kernel_ms": b["kernel_ms"], "clocks": b["clocks"]} for b in passes[name]],
+                        "records_same_every_pass": len(set(b["records_per_launch"] for b in passes[name])) == 1})
             steps3 = 2 * a.steps
-            _, tot3, _, kms3, nl3, _ = time_kernel(ctx, db2, arena, segs, stream, nbytes, cap2, steps3, 0, device)
+            _, tot3, _, kms3, nl3, _ = time_kernel(ctx, dbs[name], arena, segs, stream, nbytes, cap2, steps3, 0, device)
             sus = roofline_block(name, nbytes, tot3, kms3, nl3, None)
             blk["sustained"] = {"launches": nl3, "kernel_ms": sus["kernel_ms"], "achieved": sus["achieved"], "frac": sus["frac"]}
             others[name] = blk

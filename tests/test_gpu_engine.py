@@ -205,11 +205,16 @@ SIZES = [0, 1, 2, 3, 4, 5, 15, 16, 17, 18, 19, 31, 32, 33, 63, 64, 65, 1023, 102
          16383, 16384, 16385, 16400, 32767, 32768, 32769, 65535, 65536, 65537, 65553, 131071, 131072, 131073, 200000]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
-def test_ragged_sizes(ctx, variant):
-    """Every length around lane / wave-step / sub-tile / tile boundaries; matches planted at the very end."""
+_RAGGED_WANT = {}  # libpcre's answers, shared by the variants
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, DEFAULT_VARIANT])
+def test_ragged_sizes(ctx, liboracle, variant):
+    """Every length around lane / wave-step / sub-tile / tile boundaries; matches planted at the very end (an identifier
+    and a digit run too: the lane-table form's tail masking and halo see every ragged end).  Against the database's tables
+    and -- all six patterns are exact and context-free -- against libpcre itself."""
     ctx.set_option("variant", variant)
-    pats = ["foo", "foobardoesnotexist", "[a-z]{2,5}", "[A-Za-z_][A-Za-z0-9_]{15,}", "[0-9a-f]{32}", "e+"]
+    pats = ["foo", "foobardoesnotexist", "[a-z]{2,5}", "[A-Za-z_][A-Za-z0-9_]{15,}", "[0-9a-f]{32}", "e+", "[0-9]{17}", "[a-z][0-9][A-Z]{3}"]
     dbs = [engine.Database(p) for p in pats]
     base = sample(200_000, 2)
     for n in SIZES:
@@ -217,13 +222,28 @@ def test_ragged_sizes(ctx, variant):
         if n >= 40:
             data[n - 3:] = np.frombuffer(b"foo", np.uint8)
             data[n - 40:n - 22] = np.frombuffer(b"foobardoesnotexist", np.uint8)
+        if n >= 120:
+            data[n - 64:n - 47] = np.frombuffer(b"01234567890123456", np.uint8)  # exactly 17 digits ...
+            data[n - 47] = ord(" ")
+            data[n - 100:n - 95] = np.frombuffer(b"q7XYZ", np.uint8)
         for db, p in zip(dbs, pats):
-            if db.minlen > n and n > 0:
-                # shorter than the window: the host never submits it; the engine must still answer "nothing"
-                pass
+            # (shorter than the window: the host never submits it; the engine must still answer "nothing")
             got = ctx.scan(db, data)
             want = table_candidates(db, data)
             assert same(got, want), (p, n, variant)
+            if n:
+                if (p, n, 0) not in _RAGGED_WANT:
+                    _RAGGED_WANT[(p, n, 0)] = pcre_starts(liboracle, p, data)
+                assert same(got, _RAGGED_WANT[(p, n, 0)]), (p, n, variant, "libpcre")
+        if n >= 64:  # the window that ENDS with the chunk: an identifier / a digit run in the last bytes
+            tail = data.copy()
+            tail[n - 17:] = np.frombuffer(b"01234567890123456", np.uint8)
+            tail[n - 18] = ord(" ")
+            for db, p in zip(dbs, pats):
+                got = ctx.scan(db, tail)
+                if (p, n, 1) not in _RAGGED_WANT:
+                    _RAGGED_WANT[(p, n, 1)] = pcre_starts(liboracle, p, tail)
+                assert same(got, _RAGGED_WANT[(p, n, 1)]), (p, n, variant, "tail")
     ctx.set_option("variant", DEFAULT_VARIANT)
 
 
@@ -294,8 +314,9 @@ def test_pattern_switch(ctx):
             assert same(ctx.scan(db, data), table_candidates(db, data))
 
 
-def test_device_resident_segments(ctx):
-    """gscan_scan_device over an arena of ragged, 16-byte aligned segments == per-segment oracle."""
+def test_device_resident_segments(ctx, liboracle):
+    """gscan_scan_device over an arena of ragged, 16-byte aligned segments == per-segment oracle (the path bench.py times):
+    every variant incl. the shipped one, against the tables and against libpcre."""
     import torch
 
     lens = [0, 5, 17, 1000, 65536, 65537, 70001, 300000, 16, 131072, 1]
@@ -308,9 +329,10 @@ def test_device_resident_segments(ctx):
     arena = torch.from_numpy(host).cuda()
     segs = list(zip(offs, lens))
     ctx.set_capacity(1 << 20)
-    for pattern in ["foo", "[a-z]{2,5}", "[A-Za-z_][A-Za-z0-9_]{15,}"]:
+    for pattern in ["foo", "[a-z]{2,5}", "[A-Za-z_][A-Za-z0-9_]{15,}", "[0-9]{17}", "[a-z][0-9][A-Z]{3}", "foobardoesnotexist|Linus|555-1234"]:
         db = engine.Database(pattern)
-        for variant in (0, 1, 2):
+        wants = [pcre_starts(liboracle, pattern, host[o:o + ln]) if ln else np.zeros(0, np.int64) for o, ln in segs]
+        for variant in (0, 1, 2, DEFAULT_VARIANT):
             ctx.set_option("variant", variant)
             res = ctx.scan_device(db, arena.data_ptr(), segs)
             total, overflow = ctx.dev_sync(res)
@@ -320,6 +342,7 @@ def test_device_resident_segments(ctx):
                 got = ctx.dev_fetch(res, i)
                 want = table_candidates(db, host[o:o + ln])
                 assert same(got, want), (pattern, variant, i)
+                assert same(got, wants[i]), (pattern, variant, i, "libpcre")
                 n += len(got)
             assert n == total
     ctx.set_option("variant", DEFAULT_VARIANT)
@@ -406,7 +429,7 @@ def test_submit_fd_ranges(ctx, tmp_path):
         os.close(fd)
 
 
-def test_submit_batch_segments(ctx):
+def test_submit_batch_segments(ctx, liboracle):
     """gscan_acquire + gscan_submit_segs: many small inputs in one pinned block, one launch; every segment behaves
     like a chunk of its own (matches never cross a segment boundary, ragged and empty segments)."""
     rng = np.random.default_rng(33)
@@ -420,9 +443,10 @@ def test_submit_batch_segments(ctx):
     parts[10][:3] = np.frombuffer(b"bar", np.uint8)   # ... and the next one starts with another word
     parts[12][-2:] = np.frombuffer(b"fo", np.uint8)   # "fo" + "o...": must NOT match across the boundary
     parts[13][0] = ord("o")
-    for pattern in ["foo", "foobardoesnotexist", "[a-z]{2,5}", "[A-Za-z_][A-Za-z0-9_]{15,}", "foo|bar", "e+"]:
+    for pattern in ["foo", "foobardoesnotexist", "[a-z]{2,5}", "[A-Za-z_][A-Za-z0-9_]{15,}", "foo|bar", "e+", "[0-9]{17}", "[a-z][0-9][A-Z]{3}"]:
         db = engine.Database(pattern)
-        for variant in (1, 6):
+        wants = [pcre_starts(liboracle, pattern, part) if len(part) else np.zeros(0, np.int64) for part in parts]
+        for variant in (1, 6, DEFAULT_VARIANT):
             ctx.set_option("variant", variant)
             segs = ctx.submit_batch(db, parts, tag=7)
             assert all(o % 16 == 0 for o, _ in segs)
@@ -430,6 +454,7 @@ def test_submit_batch_segments(ctx):
             assert tag == 7 and has_content and len(per_seg) == len(parts)
             for i, (part, got) in enumerate(zip(parts, per_seg)):
                 assert same(got, table_candidates(db, part)), (pattern, variant, i, len(part))
+                assert same(got, wants[i]), (pattern, variant, i, len(part), "libpcre")
     ctx.set_option("variant", DEFAULT_VARIANT)
     # thousands of tiny segments (more tiles than len / tile size), and an empty batch
     tiny = [base[i * 37:i * 37 + int(rng.integers(0, 37))].copy() for i in range(3000)]
@@ -522,7 +547,7 @@ def test_line_extents_on_device(ctx):
         for pattern in ["foobardoesnotexist", "foo", "[A-Za-z_][A-Za-z0-9_]{15,}", "[0-9A-F]{6}[a-z]", "e+", "[a-z]{2,5}"]:
             db = engine.Database(pattern)
             assert db.info.lines_ok
-            for variant in (1, 6):
+            for variant in (1, 6, DEFAULT_VARIANT):
                 ctx.set_option("variant", variant)
                 starts = ctx.scan(db, data)
                 ext = ctx.last_ext(len(starts))
