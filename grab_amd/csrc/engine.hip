@@ -24,6 +24,7 @@
 //   gscan_submit      a caller buffer: registered and DMA'd in place (>= 1 MiB) or staged
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
 #include <pthread.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -147,6 +148,15 @@ struct ReadGroup {
     int rc = 0;                           // what `finish` came to (a GSCAN_* code) ...
     std::string msg;                      // ... and its text
 };
+// One small file of a batch (gscan_submit_files): where it comes from and where its bytes go inside the batch's text.
+struct FileItem {
+    std::string path; // opened by the reader with `oflags` and closed after the read; empty: `fd` is the caller's
+    int fd = -1;
+    int oflags = 0;
+    uint32_t len = 0;
+    uint64_t dst_off = 0; // 16-byte aligned offset of the segment in the batch
+    int err = 0;          // errno of open / pread, -1: the file is shorter than len
+};
 struct ReadTask {
     int fd;
     off_t off;
@@ -154,6 +164,10 @@ struct ReadTask {
     uint8_t *dst;       // device
     hipStream_t stream; // one of the submitting context's copy streams
     ReadGroup *grp;
+    // a piece made of whole small files (gscan_submit_files): items[0..nitems) land at their dst_off - items[0].dst_off
+    // inside the block, n covers them all, ONE DMA carries the lot
+    FileItem *items = nullptr;
+    uint32_t nitems = 0;
 };
 
 // "0-31,64-95" -> CPU numbers (the format of sysfs cpulist files)
@@ -188,10 +202,48 @@ int pci_cpulist(const char *root, const char *busid, char *buf, size_t cap)
     return (int)n;
 }
 
+// GSCAN_VIRTUAL_DEVICES=N (tests): the engine presents N device indices on a box that has fewer -- index v runs
+// on HIP device v mod (the real count) but is a device of its own in every other respect: its own reader pool, pinned
+// blocks, shared streams and placement (bus id 0000:XX:00.0 with XX = 0x0c + 0x10 v, looked up under $GSCAN_SYSFS_PCI like a
+// real one) -- so that `grab -n` over an 8-GPU node's worth of device indices, and one file's windows dealt over 8 contexts,
+// run for real on the one-GPU boxes there are.  GSCAN_VIRTUAL_FAIL_OPEN=v makes gscan_open fail for index v (a device that
+// is busy or out of memory).
+int virtual_devices()
+{
+    static const int n = [] {
+        const char *e = getenv("GSCAN_VIRTUAL_DEVICES");
+        const int v = e && *e ? atoi(e) : 0;
+        return v > 0 ? std::min(v, 64) : 0;
+    }();
+    return n;
+}
+int real_device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+int device_count()
+{
+    const int real = real_device_count();
+    return real > 0 && virtual_devices() ? virtual_devices() : real;
+}
+int hip_device_of(int device)
+{
+    if (!virtual_devices()) return device;
+    const int real = real_device_count();
+    return real > 0 ? device % real : device;
+}
+
 int device_cpulist(int device, char *buf, size_t cap)
 {
     char id[64] = {0};
-    if (hipDeviceGetPCIBusId(id, (int)sizeof id, device) != hipSuccess) {
+    if (virtual_devices()) {
+        snprintf(id, sizeof id, "0000:%02X:00.0", 0x0c + 0x10 * (device & 15));
+    } else if (hipDeviceGetPCIBusId(id, (int)sizeof id, device) != hipSuccess) {
         (void)hipGetLastError();
         return GSCAN_EHIP;
     }
@@ -263,7 +315,7 @@ public:
         std::lock_guard<std::mutex> lk(m_);
         if ((int)shared_.size() <= k) shared_.resize((size_t)k + 1, nullptr);
         if (!shared_[(size_t)k]) {
-            (void)hipSetDevice(device_);
+            (void)hipSetDevice(hip_device_of(device_));
             if (hipStreamCreateWithFlags(&shared_[(size_t)k], hipStreamNonBlocking) != hipSuccess) return shared_[(size_t)k] = nullptr;
         }
         return shared_[(size_t)k];
@@ -316,7 +368,7 @@ private:
         if (readers_ <= 0) { // auto: as many as the CPUs this device can count on allow
             int sharing = 1, ndev = 0;
             char mine[1024], other[1024];
-            if (numa_cpus_ > 0 && device_cpulist(device, mine, sizeof mine) > 0 && hipGetDeviceCount(&ndev) == hipSuccess) {
+            if (numa_cpus_ > 0 && device_cpulist(device, mine, sizeof mine) > 0 && (ndev = device_count()) > 0) {
                 sharing = 0;
                 for (int d = 0; d < ndev; d++)
                     if (d == device || (device_cpulist(d, other, sizeof other) > 0 && !strcmp(mine, other))) sharing++;
@@ -336,7 +388,7 @@ private:
             cv_tasks_.notify_all();
         }
         for (std::thread &t : threads_) t.join();
-        (void)hipSetDevice(device_);
+        (void)hipSetDevice(hip_device_of(device_));
         for (PinBlock *b : busy_) free_block(b, true);
         for (PinBlock *b : free_) free_block(b, false);
         for (PinBlock *b : slot_free_) free_block(b, false);
@@ -356,7 +408,7 @@ private:
     {
         PinBlock *b = new (std::nothrow) PinBlock();
         if (!b) return nullptr;
-        (void)hipSetDevice(device_);
+        (void)hipSetDevice(hip_device_of(device_));
         if (ingest_cfg().slab) { // one pinned allocation for all the blocks of the device (big pages under the DMA)
             std::lock_guard<std::mutex> lk(slab_m_);
             const size_t each = block_bytes() + kPad, total = each * (cap_ + 8);
@@ -424,7 +476,7 @@ private:
     void reader_main()
     {
         if (have_mask_) (void)pthread_setaffinity_np(pthread_self(), sizeof mask_, &mask_);
-        (void)hipSetDevice(device_);
+        (void)hipSetDevice(hip_device_of(device_));
         for (;;) {
             ReadTask t;
             double t0 = timing_ ? now() : 0;
@@ -443,7 +495,29 @@ private:
                 err = -2;
             } else {
                 size_t got = 0;
-                if (ingest_cfg().read_mode == 1 && (t.off & 4095) == 0 && t.n >= (1u << 20)) {
+                if (t.items) {
+                    // whole small files, each opened, read and closed here: the worker that queued them has long gone on to the
+                    // next batch.  A file that cannot be opened or has shrunk leaves its segment zero-filled and says so in
+                    // its own err (gscan_last_file_errors): the batch goes on.
+                    const uint64_t base = t.items[0].dst_off;
+                    for (uint32_t k = 0; k < t.nitems; k++) {
+                        FileItem &it = t.items[k];
+                        char *at = (char *)b->p + (it.dst_off - base);
+                        const int fd = it.path.empty() ? it.fd : open(it.path.c_str(), it.oflags);
+                        size_t have = 0;
+                        if (fd < 0) it.err = errno ? errno : EIO;
+                        while (fd >= 0 && have < it.len && !it.err) {
+                            const ssize_t r = pread(fd, at + have, it.len - have, (off_t)have);
+                            if (r > 0) have += (size_t)r;
+                            else if (r == 0) it.err = -1;
+                            else if (errno != EINTR) it.err = errno;
+                        }
+                        if (have < it.len) memset(at + have, 0, it.len - have);
+                        if (fd >= 0 && !it.path.empty()) close(fd);
+                    }
+                    got = t.n;
+                }
+                if (ingest_cfg().read_mode == 1 && !t.items && (t.off & 4095) == 0 && t.n >= (1u << 20)) {
                     // the piece through a mapping, copied with non-temporal stores (hostcopy.cc).  A file that is shorter
                     // than the range (it shrank) would fault beyond its end: checked first; anything odd falls back to pread
                     struct stat st;
@@ -456,7 +530,7 @@ private:
                         }
                     }
                 }
-                if (ingest_cfg().read_mode == 2) {
+                if (ingest_cfg().read_mode == 2 && !t.items) {
                     // pread into a buffer that stays in this core's L2, stream it out to the block past the caches
                     constexpr size_t kBounce = 256u << 10;
                     static thread_local char *bounce = nullptr;
@@ -596,7 +670,10 @@ struct Slot {
     void *ext_reg = nullptr;    // ... registered with the runtime for direct DMA until the scan is done
     PinBlock *blk = nullptr; // pool block serving as this slot's pinned buffer (acquires of <= block_bytes() bytes)
     bool no_content = false;    // gscan_submit_fd: the bytes never sat in a host buffer of ours
-    // multi-segment chunks (gscan_submit_segs)
+    // a batch of small files read by the device's readers (gscan_submit_files): segment i is file i
+    std::vector<FileItem> files;
+    std::vector<int> file_err; // per segment, filled by gscan_wait_segs (gscan_last_file_errors)
+    // multi-segment chunks (gscan_submit_segs, gscan_submit_files)
     std::vector<gscan_seg> segs;
     std::vector<uint32_t> tile_first; // first tile of segment i; [nseg] = n_tiles
     std::vector<size_t> seg_first;    // result: first record of segment i in `sorted`; [nseg] = total
@@ -620,7 +697,8 @@ struct EvPair {
 } // namespace
 
 struct gscan_ctx {
-    int device = 0;
+    int device = 0;  // the index gscan_open was given (what the caller counts in)
+    int hip_dev = 0; // the HIP device behind it (the same, unless GSCAN_VIRTUAL_DEVICES maps several indices onto one)
     int cus = 256;
     size_t max_chunk = 0;
     hipStream_t copy = nullptr, compute = nullptr;
@@ -655,7 +733,7 @@ struct gscan_ctx {
     size_t dense_cap = 0; // words
     uint8_t *h_gather = nullptr; // valid until the next gscan_wait* on this context
     size_t h_gather_cap = 0;
-    size_t hint_total = 0, hint_gather = 0; // what recent chunks produced (records, gathered bytes): sizes the speculative readback
+    std::atomic<size_t> hint_total{0}, hint_gather{0}; // what recent chunks produced (records, gathered bytes): sizes the speculative readback (written by the owner in gscan_wait, read by whichever thread launches: relaxed)
     // GSCAN_TIMING: where gscan_wait's time goes (seconds, this context)
     double tw_reads = 0, tw_scan = 0, tw_dense = 0, tw_gather = 0, tw_merge = 0, tw_alloc = 0;
     size_t tw_n = 0, tw_dense_bytes = 0, tw_gather_bytes = 0;
@@ -748,13 +826,14 @@ int slot_reserve_pinned(gscan_ctx *c, Slot &s, size_t len)
 int slot_reserve_device(gscan_ctx *c, Slot &s, size_t len)
 {
     if (len > s.d_text_cap || (c->line_extents && !s.gather_in_text)) {
+        const size_t had = s.d_text_cap; // (a slot that is only re-made for the gather half keeps the size it had)
         if (s.d_text) hipFree(s.d_text);
         if (s.d_gather && !s.gather_in_text) hipFree(s.d_gather);
         s.d_text = nullptr;
         s.d_gather = nullptr;
         s.d_text_cap = s.gather_cap = 0;
         s.gather_in_text = false;
-        size_t cap = std::max<size_t>((std::max(len, s.d_text_cap) + kPad + 0xfffff) & ~(size_t)0xfffff, 1u << 20);
+        size_t cap = std::max<size_t>((std::max(len, had) + kPad + 0xfffff) & ~(size_t)0xfffff, 1u << 20);
         // with the line pass on, the window's gather buffer (the printed lines never overlap: their text fits the window) comes
         // out of the same allocation: hipMalloc is not cheap and every slot of every context would make a second one
         HIPCHK(c, hipMalloc((void **)&s.d_text, c->line_extents ? 2 * cap : cap));
@@ -846,6 +925,16 @@ int slot_build_tiles(gscan_ctx *c, Slot &s, uint32_t tile_bytes)
     return 0;
 }
 
+// A free slot for a new chunk.  The slot the last gscan_wait* handed out still backs what the caller was given (starts, line
+// extents, gathered text live in its pinned buffers): it is the last choice.
+Slot *free_slot_for_submit(gscan_ctx *c)
+{
+    Slot *s = nullptr;
+    for (Slot &x : c->slot)
+        if (x.state == FREE && (!s || s == c->last_waited)) s = &x;
+    return s;
+}
+
 int slot_launch(gscan_ctx *c, Slot &s)
 {
     const Database &db = s.db->db;
@@ -925,7 +1014,8 @@ int slot_launch(gscan_ctx *c, Slot &s)
         HIPCHK(c, hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)s.n_tiles * nw * 8, hipMemcpyDeviceToHost, c->compute));
     s.spec_n = s.gspec_n = 0;
     if (s.ordered) { // the head of the ordered result: kSpecRecs records (enough for any sparse one), or what the last chunks suggest
-        const size_t want = std::min<size_t>(s.rec_cap, c->hint_total + c->hint_total / 4);
+        const size_t hint_t = c->hint_total.load(std::memory_order_relaxed), hint_g = c->hint_gather.load(std::memory_order_relaxed);
+        const size_t want = std::min<size_t>(s.rec_cap, hint_t + hint_t / 4);
         if (want > kSpecRecs) {
             if (want > s.big_recs) {
                 if (s.h_big) hipHostFree(s.h_big);
@@ -943,8 +1033,8 @@ int slot_launch(gscan_ctx *c, Slot &s)
             HIPCHK(c, hipMemcpyAsync(s.h_spec, s.d_sorted, s.spec_n * 4, hipMemcpyDeviceToHost, c->compute));
             if (s.has_ext) HIPCHK(c, hipMemcpyAsync(s.h_ext_spec, s.d_sorted + s.rec_cap, s.spec_n * 4 * s.ext_words, hipMemcpyDeviceToHost, c->compute));
         }
-        if (s.ext_words == 4 && c->hint_gather) { // ... and of the gathered line text
-            const size_t gw = std::min<size_t>(std::min<size_t>(s.gather_cap, kGatherPinnedMax), c->hint_gather + c->hint_gather / 4);
+        if (s.ext_words == 4 && hint_g) { // ... and of the gathered line text
+            const size_t gw = std::min<size_t>(std::min<size_t>(s.gather_cap, kGatherPinnedMax), hint_g + hint_g / 4);
             if (gw > s.gspec_cap) {
                 if (s.h_gspec) hipHostFree(s.h_gspec);
                 s.h_gspec = nullptr;
@@ -1102,12 +1192,7 @@ int gscan_db_alt_class(const gscan_db *db, int alt, int pos, uint8_t table[256],
 
 int gscan_db_class(const gscan_db *db, int pos, uint8_t table[256]) { return gscan_db_alt_class(db, 0, pos, table, nullptr); }
 
-int gscan_device_count(void)
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
+int gscan_device_count(void) { return device_count(); }
 
 int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
 {
@@ -1124,23 +1209,28 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
             t0 = t1;
         }
     };
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GSCAN_EHIP; // no device: there is no CPU path
+    const int n = device_count();
+    if (n <= 0) return GSCAN_EHIP; // no device: there is no CPU path
     lap("hipGetDeviceCount (runtime init)");
     if (hip_device < 0 || hip_device >= n) return GSCAN_EINVAL;
+    if (virtual_devices()) {
+        const char *f = getenv("GSCAN_VIRTUAL_FAIL_OPEN");
+        if (f && *f && atoi(f) == hip_device) return GSCAN_EHIP;
+    }
     gscan_ctx *c = new (std::nothrow) gscan_ctx();
     if (!c) return GSCAN_ENOMEM;
     c->device = hip_device;
+    c->hip_dev = hip_device_of(hip_device);
     c->max_chunk = max_chunk;
     auto bail = [&](int rc) {
         gscan_close(c);
         return rc;
     };
-    if (hipSetDevice(hip_device) != hipSuccess) return bail(GSCAN_EHIP);
+    if (hipSetDevice(c->hip_dev) != hipSuccess) return bail(GSCAN_EHIP);
     lap("hipSetDevice");
     c->ingest = Ingest::acquire(hip_device);
     int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && cus > 0) c->cus = cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->hip_dev) == hipSuccess && cus > 0) c->cus = cus;
     lap("device attribute");
     // Creating a stream takes the runtime ~6 ms and the runtime does them one at a time: eight workers opening their contexts
     // together would ALL be ready only when the last stream exists (+0.1 s).  One context at a time: the first one is scanning
@@ -1212,7 +1302,7 @@ void gscan_close(gscan_ctx *c)
     if (getenv("GSCAN_TIMING") && c->tw_n)
         fprintf(stderr, "[gscan timing] context on device %d: %zu waits | reads still arriving %.3f s  scan + fixed readback %.3f s  dense records %.3f s (%.1f MB, of which pinned (re)allocation %.3f s)  gathered lines %.3f s (%.1f MB)  merge %.3f s\n",
                 c->device, c->tw_n, c->tw_reads, c->tw_scan, c->tw_dense, c->tw_dense_bytes / 1e6, c->tw_alloc, c->tw_gather, c->tw_gather_bytes / 1e6, c->tw_merge);
-    hipSetDevice(c->device);
+    hipSetDevice(c->hip_dev);
     hipDeviceSynchronize();
     for (Slot &s : c->slot) free_slot(c, s);
     if (c->d_arena) hipFree(c->d_arena);
@@ -1260,13 +1350,11 @@ int gscan_acquire(gscan_ctx *c, size_t len, void **pinned)
 {
     if (!c || !pinned) return GSCAN_EINVAL;
     if (len > c->max_chunk) return fail(c, GSCAN_ETOOBIG, "chunk of %zu bytes exceeds max_chunk %zu", len, c->max_chunk);
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipSetDevice(c->hip_dev));
     Slot *s = nullptr;
     for (Slot &x : c->slot)
         if (x.state == ACQUIRED) s = &x; // re-acquire: same slot
-    if (!s)
-        for (Slot &x : c->slot)
-            if (x.state == FREE && !s) s = &x;
+    if (!s) s = free_slot_for_submit(c);
     if (!s) return fail(c, GSCAN_EBUSY, "all %d slots in flight", GSCAN_SLOTS);
     int rc = slot_pinned_for(c, *s, len, pinned);
     if (rc) return rc;
@@ -1311,14 +1399,13 @@ int gscan_submit(gscan_ctx *c, const gscan_db *db, const void *host_bytes, size_
     if (!c || !db || (!host_bytes && len)) return GSCAN_EINVAL;
     if (db->db.tier == GSCAN_TIER_NULL || db->db.tier == GSCAN_TIER_ANCHORED) return fail(c, GSCAN_EINVAL, "nothing to scan for this pattern (it matches \"\", or only at the restart position / chunk end)");
     if (len > c->max_chunk) return fail(c, GSCAN_ETOOBIG, "chunk of %zu bytes exceeds max_chunk %zu", len, c->max_chunk);
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipSetDevice(c->hip_dev));
     Slot *s = nullptr;
     for (Slot &x : c->slot)
         if (x.state == ACQUIRED) s = &x;
     const bool own = s && slot_owns(*s, host_bytes);
     if (!s) {
-        for (Slot &x : c->slot)
-            if (x.state == FREE && !s) s = &x;
+        s = free_slot_for_submit(c);
         if (!s) return fail(c, GSCAN_EBUSY, "all %d slots in flight", GSCAN_SLOTS);
     } else if (own && len > (host_bytes == s->pinned ? s->pinned_cap : block_bytes())) {
         return fail(c, GSCAN_EINVAL, "submitted %zu bytes into a smaller acquired buffer", len);
@@ -1330,6 +1417,7 @@ int gscan_submit(gscan_ctx *c, const gscan_db *db, const void *host_bytes, size_
     s->ext = nullptr;
     s->no_content = false;
     s->segs.clear();
+    s->files.clear();
     if (own) {
         s->ext = host_bytes;
         if (len) HIPCHK(c, hipMemcpyAsync(s->d_text, host_bytes, len, hipMemcpyHostToDevice, c->copy));
@@ -1378,7 +1466,7 @@ int gscan_submit_segs(gscan_ctx *c, const gscan_db *db, const void *pinned, cons
 {
     if (!c || !db || !pinned || (!segs && nseg)) return GSCAN_EINVAL;
     if (db->db.tier == GSCAN_TIER_NULL || db->db.tier == GSCAN_TIER_ANCHORED) return fail(c, GSCAN_EINVAL, "nothing to scan for this pattern (it matches \"\", or only at the restart position / chunk end)");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipSetDevice(c->hip_dev));
     Slot *s = nullptr;
     for (Slot &x : c->slot)
         if (x.state == ACQUIRED && slot_owns(x, pinned)) s = &x;
@@ -1396,6 +1484,7 @@ int gscan_submit_segs(gscan_ctx *c, const gscan_db *db, const void *pinned, cons
     if (rc) return rc;
     s->ext = pinned;
     s->no_content = false;
+    s->files.clear();
     s->segs.assign(segs, segs + nseg);
     if (nseg == 0) s->segs.push_back({0, 0, 0}); // keeps the chunk on the multi-segment path with one empty segment
     {
@@ -1422,10 +1511,8 @@ int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off
     if (!c || !db || fd < 0 || file_off < 0) return GSCAN_EINVAL;
     if (db->db.tier == GSCAN_TIER_NULL || db->db.tier == GSCAN_TIER_ANCHORED) return fail(c, GSCAN_EINVAL, "nothing to scan for this pattern (it matches \"\", or only at the restart position / chunk end)");
     if (len > c->max_chunk) return fail(c, GSCAN_ETOOBIG, "chunk of %zu bytes exceeds max_chunk %zu", len, c->max_chunk);
-    HIPCHK(c, hipSetDevice(c->device));
-    Slot *s = nullptr;
-    for (Slot &x : c->slot)
-        if (x.state == FREE && !s) s = &x;
+    HIPCHK(c, hipSetDevice(c->hip_dev));
+    Slot *s = free_slot_for_submit(c);
     if (!s) return fail(c, GSCAN_EBUSY, "no free slot (all in flight, or one is acquired)");
     int rc = ensure_prog(c, db, c->compute);
     if (rc) return rc;
@@ -1447,6 +1534,7 @@ int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off
     s->ext = nullptr;
     s->no_content = true;
     s->segs.clear();
+    s->files.clear();
     s->db = db;
     s->len = len;
     s->tag = tag;
@@ -1464,6 +1552,87 @@ int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off
     for (size_t o = 0; o < len; o += blk, k++) {
         const int which = (int)(k % (size_t)c->n_copy);
         tasks.push_back(ReadTask{fd, (off_t)(file_off + (long long)o), std::min(blk, len - o), s->d_text + o, which ? c->copy_x[which - 1] : c->copy, &g});
+    }
+    c->ingest->read(tasks.data(), tasks.size());
+    return GSCAN_OK;
+}
+
+int gscan_submit_files(gscan_ctx *c, const gscan_db *db, const gscan_file *files, size_t n, uint64_t tag)
+{
+    if (!c || !db || (!files && n)) return GSCAN_EINVAL;
+    if (db->db.tier == GSCAN_TIER_NULL || db->db.tier == GSCAN_TIER_ANCHORED) return fail(c, GSCAN_EINVAL, "nothing to scan for this pattern (it matches \"\", or only at the restart position / chunk end)");
+    const size_t blk = block_bytes();
+    size_t used = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!files[i].path && files[i].fd < 0) return fail(c, GSCAN_EINVAL, "file %zu has neither a path nor a descriptor", i);
+        if (files[i].len > blk) return fail(c, GSCAN_ETOOBIG, "file %zu is larger than a staging block (%zu bytes): hand it over with gscan_submit_fd", i, blk);
+        used = ((used + 15) & ~size_t(15)) + files[i].len;
+    }
+    if (used > c->max_chunk) return fail(c, GSCAN_ETOOBIG, "batch of %zu bytes exceeds max_chunk %zu", used, c->max_chunk);
+    HIPCHK(c, hipSetDevice(c->hip_dev));
+    Slot *s = free_slot_for_submit(c);
+    if (!s) return fail(c, GSCAN_EBUSY, "no free slot (all in flight, or one is acquired)");
+    int rc = ensure_prog(c, db, c->compute);
+    if (rc) return rc;
+    rc = slot_reserve_device(c, *s, used);
+    if (rc) return rc;
+    s->files.resize(n);
+    s->segs.resize(n);
+    size_t at = 0;
+    for (size_t i = 0; i < n; i++) {
+        at = (at + 15) & ~size_t(15);
+        FileItem &it = s->files[i];
+        if (files[i].path) it.path = files[i].path;
+        else it.path.clear();
+        it.fd = files[i].fd;
+        it.oflags = files[i].oflags;
+        it.len = files[i].len;
+        it.dst_off = at;
+        it.err = 0;
+        s->segs[i] = {(uint64_t)at, files[i].len, 0};
+        at += files[i].len;
+    }
+    if (n == 0) s->segs.push_back({0, 0, 0}); // keeps the chunk on the multi-segment path with one empty segment
+    {
+        uint32_t tb = 0, nw = 1;
+        gscan::scan_geometry(db->db.tier, c->variant, db->db.prog, &tb, &nw);
+        rc = slot_build_tiles(c, *s, tb); // (the tile table goes out on the copy stream, ahead of the pieces)
+    }
+    if (rc) return rc;
+    if (!s->grp) s->grp.reset(new (std::nothrow) ReadGroup());
+    if (!s->grp) return fail(c, GSCAN_ENOMEM, "out of memory");
+    ReadGroup &g = *s->grp;
+    // pieces: runs of consecutive files that fit one staging block -- one reader fills the block, one DMA carries it
+    std::vector<ReadTask> tasks;
+    for (size_t i = 0; i < n;) {
+        size_t j = i + 1;
+        const uint64_t base = s->files[i].dst_off;
+        while (j < n && s->files[j].dst_off + s->files[j].len - base <= blk) j++;
+        const int which = (int)(tasks.size() % (size_t)c->n_copy);
+        ReadTask t{-1, 0, (size_t)(s->files[j - 1].dst_off + s->files[j - 1].len - base), s->d_text + base, which ? c->copy_x[which - 1] : c->copy, &g};
+        t.items = &s->files[i];
+        t.nitems = (uint32_t)(j - i);
+        tasks.push_back(t);
+        i = j;
+    }
+    g.pending = tasks.size();
+    g.err = 0;
+    g.rc = 0;
+    g.msg.clear();
+    g.finish = fd_finish;
+    g.ctx = c;
+    g.slot = s;
+    s->ext = nullptr;
+    s->no_content = true;
+    s->db = db;
+    s->len = used;
+    s->tag = tag;
+    s->seq = c->next_seq++;
+    s->state = INFLIGHT;
+    g.finished = false;
+    if (tasks.empty()) { // nothing to read (no files, or empty ones only... an empty file still is a task): launch right away
+        fd_finish(&g);
+        return GSCAN_OK;
     }
     c->ingest->read(tasks.data(), tasks.size());
     return GSCAN_OK;
@@ -1500,7 +1669,7 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
         s->grp->rc = 0;
         return rc;
     }
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipSetDevice(c->hip_dev));
     HIPCHK(c, hipEventSynchronize(s->done));
     if (tw_on) c->tw_scan += tnow() - tw0, tw0 = tnow();
     slot_unregister(*s); // the DMA out of the caller's buffer is over (the text stays in HBM for a possible rescan)
@@ -1550,7 +1719,10 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     const bool ordered = s->ordered && struck == 0;
     if (ordered && s->h_counter[K * kCS + 3] != total) return fail(c, GSCAN_EHIP, "ordered copy holds %u records, the shard counters %zu", s->h_counter[K * kCS + 3], total);
     if (ordered) {
-        c->hint_total = std::max(total, c->hint_total - c->hint_total / 8); // (follows a growing result at once, a shrinking one slowly)
+        {
+            const size_t h = c->hint_total.load(std::memory_order_relaxed);
+            c->hint_total.store(std::max(total, h - h / 8), std::memory_order_relaxed); // (follows a growing result at once, a shrinking one slowly)
+        }
         if (total <= s->spec_n) { // it came in with the counters: a sparse result, or one the last chunks foretold
             const bool big = s->spec_n > kSpecRecs;
             dense = big ? s->h_big : s->h_spec;
@@ -1584,7 +1756,10 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     s->out_gather = nullptr;
     if (s->ext_words == 4) { // the printed lines' text: the used part of the gather buffer, into pinned memory
         const size_t used = std::min<size_t>(s->h_counter[K * kCS + 2], s->gather_cap);
-        c->hint_gather = std::max(used, c->hint_gather - c->hint_gather / 8);
+        {
+            const size_t h = c->hint_gather.load(std::memory_order_relaxed);
+            c->hint_gather.store(std::max(used, h - h / 8), std::memory_order_relaxed);
+        }
         if (s->ordered && used <= s->gspec_n) { // it came in with the counters
             s->gather_ok = true;
             s->gather_bytes = used;
@@ -1659,6 +1834,8 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
         s->out_starts = s->sorted.data();
         s->out_ext = s->has_ext ? s->sorted_ext.data() : nullptr;
     }
+    s->file_err.clear();
+    for (const FileItem &it : s->files) s->file_err.push_back(it.err);
     if (tag) *tag = s->tag;
     *starts = s->out_starts;
     *seg_first = s->seg_first.data();
@@ -1683,6 +1860,14 @@ const uint8_t *gscan_last_gather(const gscan_ctx *c, size_t *bytes)
     if (!c || !c->last_waited || c->last_waited->ext_words != 4 || !c->last_waited->gather_ok) return nullptr;
     if (bytes) *bytes = c->last_waited->gather_bytes;
     return c->last_waited->out_gather ? c->last_waited->out_gather : (const uint8_t *)"";
+}
+
+const int *gscan_last_file_errors(const gscan_ctx *c, size_t *n)
+{
+    if (n) *n = 0;
+    if (!c || !c->last_waited || c->last_waited->file_err.empty()) return nullptr;
+    if (n) *n = c->last_waited->file_err.size();
+    return c->last_waited->file_err.data();
 }
 
 const uint32_t *gscan_last_ends(const gscan_ctx *c)
@@ -1742,7 +1927,7 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
 {
     if (!c || !db || !res || (!segs && nseg)) return GSCAN_EINVAL;
     if (db->db.tier == GSCAN_TIER_NULL || db->db.tier == GSCAN_TIER_ANCHORED) return fail(c, GSCAN_EINVAL, "nothing to scan for this pattern (it matches \"\", or only at the restart position / chunk end)");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipSetDevice(c->hip_dev));
     hipStream_t st = stream ? (hipStream_t)stream : c->compute;
     c->dv_stream = st;
     int rc = ensure_prog(c, db, st);
@@ -1839,7 +2024,7 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
 int gscan_dev_sync(gscan_ctx *c, gscan_dev_result *res)
 {
     if (!c || !res) return GSCAN_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipSetDevice(c->hip_dev));
     hipStream_t st = c->dv_stream ? c->dv_stream : c->compute;
     uint32_t h[kCounterWords] = {0};
     HIPCHK(c, hipMemcpyAsync(h, c->dv_counter, sizeof h, hipMemcpyDeviceToHost, st));
@@ -1855,7 +2040,7 @@ long gscan_dev_fetch(gscan_ctx *c, const gscan_dev_result *res, size_t seg, uint
 {
     if (!c || !res) return GSCAN_EINVAL;
     if (seg + 1 >= c->dv_tile_first_h.size()) return fail(c, GSCAN_EINVAL, "segment index out of range");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipSetDevice(c->hip_dev));
     hipStream_t st = c->dv_stream ? c->dv_stream : c->compute;
     HIPCHK(c, hipStreamSynchronize(st));
     const size_t t0 = (size_t)c->dv_tile_first_h[seg] * c->dv_last_nw, t1 = (size_t)c->dv_tile_first_h[seg + 1] * c->dv_last_nw; // descriptors of the segment
@@ -1884,7 +2069,7 @@ long gscan_dev_fetch(gscan_ctx *c, const gscan_dev_result *res, size_t seg, uint
 int gscan_kernel_time(gscan_ctx *c, double *sum_ms, uint64_t *launches, int reset)
 {
     if (!c) return GSCAN_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipSetDevice(c->hip_dev));
     double sum = 0;
     for (size_t i = 0; i < c->ev_used; i++) {
         float ms = 0;

@@ -46,8 +46,9 @@ constexpr off_t kOverlap = 0x1000; // consecutive chunks share 4 KiB (grab.cc:15
 
 const char kInvOn[] = "\33[7m", kInvOff[] = "\33[27m"; // grab.cc:66-67
 
-// Files up to batch_max_ bytes (config key "batch", default 2 MiB, 0 = off) are read(2) into one pinned
-// block and scanned in one launch over a segment table, instead of paying one copy + launch + readback each.
+// Files up to batch_max_ bytes (config key "batch", default 2 MiB, 0 = off) are scanned many to a launch over a segment
+// table, instead of paying one copy + launch + readback each: the worker only QUEUES them (path + size from the walk's
+// stat), the device's reader threads open, read and close them (gscan_submit_files).
 constexpr size_t kBatchMaxFiles = 4096;
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -200,6 +201,11 @@ FileGrep::FileGrep() : uid_(geteuid())
     timing_ = getenv("GRAB_TIMING") != nullptr;
     const char *ing = getenv("GRAB_INGEST");
     ingest_register_ = ing && !strcmp(ing, "register");
+    // GRAB_BATCH_READ=worker (A/B runs): round 3's small-file path -- the worker itself read(2)s every file into a pinned
+    // block and hands the block over (gscan_acquire + gscan_submit_segs)
+    const char *br = getenv("GRAB_BATCH_READ");
+    batch_by_worker_ = br && !strcmp(br, "worker");
+    if (const char *bm = getenv("GRAB_BATCH_MIB")) batch_bytes_ = (size_t)std::max(1, atoi(bm)) << 20;
 }
 
 FileGrep::~FileGrep()
@@ -214,8 +220,8 @@ void FileGrep::report_timing()
 {
     if (timing_ && !timing_reported_) {
         timing_reported_ = true;
-        fprintf(stderr, "[grab timing] device %d: files %zu launches %zu bytes %zu | open %.3f s  read(batch) %.3f s  submit %.3f s  wait %.3f s  map+report %.3f s (of which writing it out, lock included: %.3f s)  close %.3f s\n",
-                device_, t_files_, t_chunks_, t_bytes_, t_map_, t_read_, t_submit_, t_wait_, t_report_, t_emit_, t_unmap_);
+        fprintf(stderr, "[grab timing] device %d: files %zu launches %zu bytes %zu | open %.3f s  read(batch) %.3f s  submit %.3f s  wait %.3f s  map+report %.3f s (of which writing it out, lock included: %.3f s; mapping small files that had something to print: %.3f s, %zu files)  close %.3f s\n",
+                device_, t_files_, t_chunks_, t_bytes_, t_map_, t_read_, t_submit_, t_wait_, t_report_, t_emit_, t_text_, t_text_files_, t_unmap_);
         fprintf(stderr, "[grab timing] printed so far (all workers): %llu via the device's line pass + gathered text, %llu via the pass with text from the window, %llu by the host's loop\n",
                 g_lines_gathered.load(), g_lines_window.load(), g_lines_loop.load());
         for (size_t k = 0; k < ctxs_.size(); k++) // what each device was handed: the work queue's balance (bench.py --mode e2e sums these)
@@ -237,6 +243,7 @@ void FileGrep::config(const std::map<std::string, size_t> &kv)
     if (has("out_fd")) out_fd_ = (int)kv.at("out_fd");
     if (has("batch")) batch_max_ = kv.at("batch");
     if (has("devices")) devices_ = std::max<size_t>(1, kv.at("devices"));
+    if (has("silent_errors")) silent_errors_ = kv.at("silent_errors") != 0;
 }
 
 unsigned FileGrep::report_flags() const
@@ -424,6 +431,7 @@ void FileGrep::emit(std::string &text)
 // ------------------------------------------------------------------------------------
 struct FileGrep::FileRef { // what the report needs to know about a file after find() has returned
     std::string path;
+    int oflags = 0;    // batched small files: how the readers open it (and the report, if the file has something to print)
     int fd = -1;       // big files: kept open until the last window has been printed (the report maps from it)
     bool done = false; // -s: a chunk of this file has printed, the rest of it stays silent (grab.cc:232-233)
     ~FileRef()
@@ -496,12 +504,46 @@ int FileGrep::retire_oldest(bool print)
             }
         }
     } else { // a batch: every segment is a whole small file, i.e. its one and only chunk
+        size_t nerr = 0;
+        const int *ferr = gscan_last_file_errors(ctx, &nerr);
+        const uint32_t *ext = gscan_last_ext(ctx), *ends = gscan_last_ends(ctx);
+        const uint8_t *gather = gscan_last_gather(ctx, nullptr);
         for (size_t i = 0; i < job.files.size(); i++) {
-            if (first[i + 1] == first[i] && !context_) continue;
-            const uint32_t *ext = gscan_last_ext(ctx), *ends = gscan_last_ends(ctx);
-            grab_report_chunk(db_, minlen_, rflags, job.files[i]->path.c_str(), (const char *)bytes + job.segs[i].offset, job.segs[i].len, 0,
-                              starts + first[i], first[i + 1] - first[i], text, ext ? ext + 4 * first[i] : nullptr, ends ? ends + first[i] : nullptr,
-                              gscan_last_gather(ctx, nullptr));
+            const char *path = job.files[i]->path.c_str();
+            if (ferr && i < nerr && ferr[i]) { // the readers could not open or read it: this file's error, the batch goes on (grab.cc:267-268)
+                err_ = ferr[i] == -1 ? std::string("FileGrep::find::read: file shrank while reading") : std::string("FileGrep::find::open: ") + strerror(ferr[i]);
+                file_error(path);
+                status = recursive_ ? status : -1;
+                continue;
+            }
+            const size_t n_i = first[i + 1] - first[i];
+            if (n_i == 0 && !context_) continue;
+            const uint32_t *ext_i = ext ? ext + 4 * first[i] : nullptr, *ends_i = ends ? ends + first[i] : nullptr;
+            const size_t len = job.segs[i].len;
+            const char *chunk = bytes ? (const char *)bytes + job.segs[i].offset : nullptr;
+            void *map = nullptr;
+            int fd = -1;
+            if (!chunk && report_needs_text(rflags, n_i, ext_i, ends_i, gather)) {
+                // the bytes went through the readers' blocks and are gone: a file that has something to print is mapped like the
+                // reference maps it (grab.cc:137-169) -- only the pages the report looks at are touched
+                const double tm = timing_ ? now_s() : 0;
+                fd = open(path, job.files[i]->oflags);
+                map = fd >= 0 && len ? mmap(nullptr, len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, fd, 0) : MAP_FAILED;
+                if (timing_) t_text_ += now_s() - tm, t_text_files_++;
+                if (map == MAP_FAILED) {
+                    err_ = std::string(fd < 0 ? "FileGrep::find::open: " : "FileGrep::find::mmap: ") + strerror(errno);
+                    if (fd >= 0) close(fd);
+                    file_error(path);
+                    status = recursive_ ? status : -1;
+                    continue;
+                }
+                chunk = (const char *)map;
+            }
+            grab_report_chunk(db_, minlen_, rflags, path, chunk, len, 0, starts + first[i], n_i, text, ext_i, ends_i, gather);
+            if (map) {
+                munmap(map, len);
+                close(fd);
+            }
         }
         if (!text.empty()) emit(text); // one lock per batch; per-file output stays contiguous and in order
     }
@@ -519,9 +561,20 @@ int FileGrep::submit_batch()
     batch_buf_ = nullptr;
     batch_used_ = 0;
     double t = timing_ ? now_s() : 0;
-    if (gscan_submit_segs(ctx_, db_, buf, job.segs.data(), job.segs.size(), 0) != GSCAN_OK) {
-        err_ = std::string("FileGrep::find::gscan_submit_segs: ") + gscan_strerror(ctx_);
-        return -1;
+    if (batch_by_worker_) {
+        if (gscan_submit_segs(ctx_, db_, buf, job.segs.data(), job.segs.size(), 0) != GSCAN_OK) {
+            err_ = std::string("FileGrep::find::gscan_submit_segs: ") + gscan_strerror(ctx_);
+            return -1;
+        }
+    } else {
+        if (make_room(0) < 0) return -1; // a slot has to be free for the batch
+        std::vector<gscan_file> list(job.files.size());
+        for (size_t i = 0; i < job.files.size(); i++) list[i] = gscan_file{job.files[i]->path.c_str(), -1, job.files[i]->oflags, job.segs[i].len};
+        t = timing_ ? now_s() : 0;
+        if (gscan_submit_files(ctx_, db_, list.data(), list.size(), 0) != GSCAN_OK) {
+            err_ = std::string("FileGrep::find::gscan_submit_files: ") + gscan_strerror(ctx_);
+            return -1;
+        }
     }
     if (timing_) t_submit_ += now_s() - t, t_chunks_++;
     inflight_[0]++;
@@ -541,8 +594,15 @@ int FileGrep::make_room(int ctx)
 // names it) and carry on with the current one, as the reference reports per file and keeps walking (grab.cc:267-268).
 void FileGrep::deferred_error()
 {
+    if (silent_errors_) return;
     if (recursive_) std::cerr << err_ << std::endl;
     else deferred_ = err_; // explicit paths: find(path) returns it
+}
+
+void FileGrep::idle()
+{
+    if (batch_by_worker_ || batch_files_.empty() || !ctx_) return;
+    if (inflight_[0] == 0 || batch_used_ >= (size_t(8) << 20)) (void)submit_batch();
 }
 
 // Everything handed over so far is scanned and printed when this returns.
@@ -556,8 +616,29 @@ int FileGrep::flush()
     return status;
 }
 
-// A small file joins the open batch: read(2) straight into the engine's pinned block.
-int FileGrep::batch_add(const char *path, int fd, size_t size)
+// A small file joins the open batch.  Nothing is opened or read here: the batch is a list of names that the device's reader
+// threads work off (gscan_submit_files) while this thread is already queueing the next one -- the reference's workers open,
+// map and scan each file themselves (main.cc:86-100, grab.cc:137-169); here that is the readers' job, eight to a device.
+int FileGrep::batch_add(const char *path, const struct stat *st, int oflags)
+{
+    const size_t size = (size_t)st->st_size;
+    const size_t cap = std::min(batch_bytes_, chunk_size_);
+    const size_t at = (batch_used_ + 15) & ~size_t(15);
+    if (!batch_files_.empty() && (at + size > cap || batch_files_.size() >= kBatchMaxFiles) && submit_batch() < 0) return -1;
+    const size_t off = (batch_used_ + 15) & ~size_t(15);
+    auto ref = std::make_shared<FileRef>();
+    ref->path = path;
+    ref->oflags = oflags;
+    batch_files_.push_back(std::move(ref));
+    batch_segs_.push_back({(uint64_t)off, (uint32_t)size, 0});
+    batch_used_ = off + size;
+    ctx_bytes_[0] += size;
+    if (timing_) t_bytes_ += size, t_files_++;
+    return 0;
+}
+
+// GRAB_BATCH_READ=worker: the worker read(2)s the file into the engine's pinned block itself (round 3's path, kept for A/B runs)
+int FileGrep::batch_add_read(const char *path, int fd, size_t size)
 {
     const size_t cap = gscan_block_size();
     const size_t at = (batch_used_ + 15) & ~size_t(15);
@@ -586,6 +667,35 @@ int FileGrep::batch_add(const char *path, int fd, size_t size)
     return 0;
 }
 
+// Does the walk over one chunk's records look at the chunk's bytes?  Not when every record it will print was settled on the
+// device: -O -l with the match ends (k_ends), the line modes with every printed line gathered (k_lines).
+bool FileGrep::report_needs_text(unsigned rflags, size_t n, const uint32_t *ext, const uint32_t *ends, const uint8_t *gather) const
+{
+    if (context_) return true; // (matches at the restart position / chunk end are the host's to find, list or no list)
+    if (n == 0) return false;
+    if (ends && (rflags & GRAB_NOLINE) && (rflags & GRAB_OFFSETS)) {
+        for (size_t i = 0; i < n; i++)
+            if (ends[i] == 0) return true;
+        return false;
+    }
+    if (ext && gather && !(rflags & GRAB_NOLINE)) {
+        for (size_t i = 0; i < n; i++)
+            if (ext[4 * i] != 0 && (ext[4 * i + 1] == 0xffffffffu || ext[4 * i + 3] == 0xffffffffu)) return true;
+        return false;
+    }
+    return true;
+}
+
+// An error that belongs to ONE file of a batch, found long after find() returned for it: said the way the walk says it
+// (grab.cc:267-268 prints "path: why" and goes on; the -n workers ignore per-file errors, main.cc:97), or kept for
+// find(path) to return.
+void FileGrep::file_error(const char *path)
+{
+    if (silent_errors_) return;
+    if (recursive_) std::cerr << path << ": " << err_ << std::endl;
+    else deferred_ = err_;
+}
+
 // Replaces grab.cc:131-239.  Geometry is the reference's: windows of chunk_size bytes that
 // advance by chunk_size - 4 KiB, files shorter than minlen skipped unopened, per-chunk output
 // flushed atomically and in file order, -s ends the file after the first chunk that printed.
@@ -603,6 +713,8 @@ int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
 #ifdef __linux__
     if (st->st_uid == uid_ || uid_ == 0) oflags |= O_NOATIME; // do not dirty the inode (grab.cc:139-143)
 #endif
+    const bool small = !anchored_ && (size_t)size <= batch_max_ && (size_t)size <= gscan_block_size() && (size_t)size <= chunk_size_;
+    if (small && !batch_by_worker_) return batch_add(path, st, oflags); // queued by name: the device's readers open and read it
     const int fd = open(path, oflags);
     if (fd < 0) {
         err_ = std::string("FileGrep::find::open: ") + strerror(errno);
@@ -634,8 +746,8 @@ int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
                 if (single_) break;
             }
         }
-    } else if ((size_t)size <= batch_max_ && (size_t)size <= gscan_block_size() && (size_t)size <= chunk_size_) {
-        status = batch_add(path, fd, (size_t)size);
+    } else if (small) {
+        status = batch_add_read(path, fd, (size_t)size);
     } else {
         if (submit_batch() < 0) status = -1; // keeps the submission order == walk order
         auto ref = std::make_shared<FileRef>();
@@ -650,8 +762,9 @@ int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
                 if (retire_oldest(true) < 0) deferred_error();
         // a file of several windows is dealt out over the configured devices (contexts opened on first need)
         const size_t nwin = (size_t)((size + stride - 1) / stride);
-        const size_t use = single_ ? 1 : std::min(devices_, nwin);
+        size_t use = single_ ? 1 : std::min(devices_, nwin);
         if (status == 0 && use > ctxs_.size() && want_contexts(use) < 0) status = -1;
+        use = std::max<size_t>(1, std::min(use, ctxs_.size())); // (a further device that could not be opened is left out: want_contexts)
         for (off_t off = 0; off < size && status == 0 && !ref->done; off += stride) {
             const size_t len = (size_t)std::min<off_t>(size - off, (off_t)chunk_size_);
             const int k = use > 1 ? (int)(next_ctx_++ % use) : 0;

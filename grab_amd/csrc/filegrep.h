@@ -62,6 +62,10 @@ public:
     // while this one is on the GPU; small files wait for their batch to fill).  flush() scans and prints
     // whatever is pending; find(string), find_recursive() and the destructor call it themselves.
     int flush();
+    // The caller has nothing to hand over right now (the work queue is empty): small files waiting for their batch to fill are
+    // handed to the device if it has nothing of this instance's in flight, or if they are a fair launch's worth (8 MiB).
+    // Nothing is waited for.
+    void idle();
     // GRAB_TIMING=1: this instance's time and byte totals on stderr, once (the destructor's job; a caller that leaves
     // without destroying the instance -- the command line does -- asks for them itself)
     void report_timing();
@@ -77,7 +81,10 @@ private:
     int want_contexts(size_t n);  // open contexts on further devices up to n (lazily: a multi-window file asks)
     void deferred_error();        // a window of an EARLIER file failed while this one was being handed over
     int submit_batch();
-    int batch_add(const char *path, int fd, size_t size);
+    int batch_add(const char *path, const struct stat *st, int oflags);
+    int batch_add_read(const char *path, int fd, size_t size);
+    bool report_needs_text(unsigned rflags, size_t n, const uint32_t *ext, const uint32_t *ends, const uint8_t *gather) const;
+    void file_error(const char *path); // an error of ONE file of a batch, found when the batch retires
     unsigned report_flags() const;
     int read_chunk(int fd, void *dst, size_t len, off_t at);
     void emit(std::string &text);
@@ -97,7 +104,8 @@ private:
     // GRAB_TIMING=1 in the environment: per-instance wall-clock split, printed to stderr by the destructor
     bool timing_ = false, timing_reported_ = false;
     size_t t_files_ = 0, t_chunks_ = 0, t_bytes_ = 0;
-    double t_map_ = 0, t_read_ = 0, t_submit_ = 0, t_wait_ = 0, t_report_ = 0, t_unmap_ = 0, t_emit_ = 0;
+    double t_map_ = 0, t_read_ = 0, t_submit_ = 0, t_wait_ = 0, t_report_ = 0, t_unmap_ = 0, t_emit_ = 0, t_text_ = 0;
+    size_t t_text_files_ = 0;
     // pipeline state
     std::deque<Job> flight_;
     std::vector<gscan_ctx *> ctxs_;   // [0] == ctx_; further devices for the windows of one big file ("devices")
@@ -110,7 +118,10 @@ private:
     bool ingest_register_ = false;    // GRAB_INGEST=register (experiment): windows are mapped, registered and DMA'd in place
     std::string report_buf_;
     size_t batch_max_ = size_t(2) << 20; // files up to this size are batched ("batch" config key; 0 = never)
-    void *batch_buf_ = nullptr;          // the engine's pinned block being filled
+    size_t batch_bytes_ = size_t(32) << 20; // a batch is handed over when it holds this much (GRAB_BATCH_MIB), or kBatchMaxFiles files
+    bool batch_by_worker_ = false;       // GRAB_BATCH_READ=worker (A/B): the worker reads the files into a pinned block itself
+    bool silent_errors_ = false;         // config "silent_errors": per-file errors found after find() returned are not printed (the -n workers: main.cc:97)
+    void *batch_buf_ = nullptr;          // ... that block, being filled
     size_t batch_used_ = 0;
     std::vector<std::shared_ptr<FileRef>> batch_files_;
     std::vector<gscan_seg> batch_segs_;

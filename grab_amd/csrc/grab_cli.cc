@@ -133,6 +133,15 @@ public:
         q_.push_back(std::move(j));
         ready_.notify_one();
     }
+    bool try_pop(Job &out) // false: nothing there right now
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        room_.notify_one();
+        return true;
+    }
     bool pop(Job &out)
     {
         std::unique_lock<std::mutex> lk(m_);
@@ -257,6 +266,7 @@ int run_workers(const Options &o)
             {
             auto cfg = o.cfg;
             cfg["device"] = size_t(device);
+            cfg["silent_errors"] = 1; // per-file errors are ignored in this mode (main.cc:97), also the ones that surface after find() returned
             g.config(cfg);
             g.recurse();
             if (g.prepare(o.regex) < 0) { // the pattern is fine (checked above): the device could not be opened
@@ -269,7 +279,13 @@ int run_workers(const Options &o)
                 mark("worker 0: context open");
                 mark_memory("worker 0 open");
             }
-            for (Job j; queue.pop(j);) g.find(j.path.c_str(), &j.st, FTW_F); // per-file errors ignored (main.cc:97)
+            for (Job j;;) { // per-file errors ignored (main.cc:97)
+                if (!queue.try_pop(j)) {
+                    g.idle(); // the walkers are behind: a half-filled batch of small files goes out now rather than when it is full
+                    if (!queue.pop(j)) break;
+                }
+                g.find(j.path.c_str(), &j.st, FTW_F);
+            }
             g.flush(); // what is still in flight or waiting in a half-filled batch
             g.report_timing();
             if (i == 0) mark("worker 0: everything retired");

@@ -21,7 +21,7 @@ SLOTS = 2
 SYMBOLS = [
     "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_match_info", "gscan_next_match", "gscan_tail_positions", "gscan_db_dev_window",
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
-    "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_gather", "gscan_last_ends", "gscan_next_listed",
+    "gscan_acquire", "gscan_block_size", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_submit_files", "gscan_last_file_errors", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_gather", "gscan_last_ends", "gscan_next_listed",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
     "gscan_set_option", "gscan_kernel_time", "gscan_resource_errors",
     "gscan_ingest_info", "gscan_auto_readers", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
@@ -43,6 +43,11 @@ class Cursor(C.Structure):
 
 class Seg(C.Structure):
     _fields_ = [("offset", C.c_uint64), ("len", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class File(C.Structure):
+    """gscan_file (include/gscan.h): one small file of a gscan_submit_files batch."""
+    _fields_ = [("path", C.c_char_p), ("fd", C.c_int), ("oflags", C.c_int), ("len", C.c_uint32)]
 
 
 class DevResult(C.Structure):
@@ -106,6 +111,9 @@ def lib():
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.gscan_submit_segs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Seg), C.c_size_t, C.c_uint64]
         L.gscan_submit_fd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_size_t, C.c_uint64]
+        L.gscan_submit_files.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(File), C.c_size_t, C.c_uint64]
+        L.gscan_last_file_errors.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        L.gscan_last_file_errors.restype = C.POINTER(C.c_int)
         L.gscan_wait_segs.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint32)),
                                       C.POINTER(C.POINTER(C.c_size_t)), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         L.gscan_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Seg), C.c_size_t, C.c_void_p,
@@ -320,6 +328,24 @@ class Context:
     def submit_fd(self, db, fd, offset, length, tag=0):
         """A range of an open file, read by the engine's reader threads straight into pinned blocks (gscan_submit_fd)."""
         self._chk(lib().gscan_submit_fd(self._h, db._h, fd, offset, length, tag), "gscan_submit_fd")
+
+    def submit_files(self, db, files, tag=0):
+        """Small files by name (or open descriptor), read by the engine's reader threads, one launch over all of them
+        (gscan_submit_files).  files: (path | fd, length) pairs."""
+        arr = (File * max(1, len(files)))()
+        for i, (src, ln) in enumerate(files):
+            if isinstance(src, int):
+                arr[i].path, arr[i].fd = None, src
+            else:
+                arr[i].path, arr[i].fd = os.fsencode(src), -1
+            arr[i].oflags, arr[i].len = os.O_RDONLY, ln
+        self._chk(lib().gscan_submit_files(self._h, db._h, arr, len(files), tag), "gscan_submit_files")
+
+    def last_file_errors(self):
+        """Per-segment status of the file batch the last wait_segs() returned (None: it was not one)."""
+        n = C.c_size_t()
+        p = lib().gscan_last_file_errors(self._h, C.byref(n))
+        return [p[i] for i in range(n.value)] if p else None
 
     def submit_batch(self, db, parts, tag=0):
         """Several small inputs (bytes-like) packed into the slot's pinned block at 16-byte aligned offsets and

@@ -101,6 +101,16 @@ typedef struct gscan_seg {
     uint32_t _pad;
 } gscan_seg;
 
+/* one small file of a batch handed over by NAME (gscan_submit_files) */
+typedef struct gscan_file {
+    const char *path; /* opened by the device's reader threads with `oflags` (O_RDONLY | O_NOATIME ...) and closed after the
+                         read; the string is copied at submit.  NULL: read from `fd` instead */
+    int fd;           /* path == NULL: an open descriptor, the caller's; it must stay open until gscan_wait_segs has
+                         returned the batch */
+    int oflags;
+    uint32_t len;     /* bytes to read from offset 0 (st_size as the tree walk saw it); at most gscan_block_size() */
+} gscan_file;
+
 /* result of a device-resident scan: everything stays in HBM */
 typedef struct gscan_dev_result {
     const uint32_t *recs;  /* device: candidate group starts (see gscan_wait), segment-relative; runs of ascending offsets */
@@ -218,6 +228,15 @@ long gscan_parse_cpulist(const char *list, int *cpus, size_t cap);
  *                      gscan_wait has returned the chunk; read errors surface there (GSCAN_EIO).
  *                      No host copy is kept: gscan_wait gives *content = NULL and the caller maps
  *                      the file itself if it has matches to print.
+ *   gscan_submit_files MANY small files by name (the reference opens and maps every file on the
+ *                      worker thread, src/main.cc:86-100 -> src/grab.cc:137-169): the caller only queues them.  The
+ *                      device's reader threads open, read and close them -- runs of consecutive files that fit one
+ *                      pinned block are read by one reader and leave in ONE DMA --, segment i is file i, packed at
+ *                      16-byte aligned offsets in the order given; the reader that finishes the last piece launches
+ *                      ONE scan over the segment table.  ASYNCHRONOUS like gscan_submit_fd, *content = NULL.  A
+ *                      file that cannot be opened, or is shorter than `len`, does not fail the batch: its segment is
+ *                      scanned zero-filled and gscan_last_file_errors says which -- the caller must ignore that
+ *                      segment's records.  The batch as a whole (16-byte padding included) must fit max_chunk.
  *   gscan_acquire +    the caller fills the slot's pinned buffer (gscan_block_size() bytes come
  *   gscan_submit[_segs] from the pinned pool; more is allocated for the slot): one chunk, or MANY
  *                      small files packed at 16-byte aligned offsets and described by a segment
@@ -242,16 +261,23 @@ int gscan_submit_segs(gscan_ctx *ctx, const gscan_db *db, const void *pinned, co
                       size_t nseg, uint64_t tag);
 int gscan_submit_fd(gscan_ctx *ctx, const gscan_db *db, int fd, long long file_off, size_t len,
                     uint64_t tag);
+int gscan_submit_files(gscan_ctx *ctx, const gscan_db *db, const gscan_file *files, size_t n, uint64_t tag);
+/* per-segment status of the gscan_submit_files batch the last gscan_wait_segs handed out: 0 the file was read in full, an
+ * errno from open(2) / pread(2), -1 the file was shorter than `len`.  *n = number of segments; NULL (and *n = 0) if that
+ * chunk was not such a batch.  Same lifetime as its starts. */
+const int *gscan_last_file_errors(const gscan_ctx *ctx, size_t *n);
 /* starts[0..n), ascending: the START of every group of consecutive candidate offsets of the
  * chunk (offsets p at which the pattern matches), possibly with further candidates of the
  * same groups in between.  That is all pcre_exec's "leftmost match at or after s" needs:
  *     gscan_match_at(db, content, clen, s) ? s : first starts[i] > s
  * (if s is a candidate it is the answer; if not, the next candidate after s begins a group).
  * *content is the chunk's bytes on the host: the buffer the chunk was submitted from, NULL after
- * gscan_submit_fd.  starts (and gscan_last_ext / _ends / _gather) stay valid until the next gscan_wait* on this context (a
- * dense list is handed out in the context's pinned staging buffer, exactly as the device put it together: in text order,
- * one linear transfer, no merge on the host); a pinned *content until the second gscan_acquire / gscan_submit* after this
- * call reuses the slot. */
+ * gscan_submit_fd / gscan_submit_files.  starts (and gscan_last_ext / _ends / _gather / _file_errors) stay valid until the
+ * next gscan_wait*, gscan_submit* or gscan_acquire on this context, whichever comes first: they live in the pinned buffers of
+ * the slot the chunk ran in (a dense list is handed out exactly as the device put it together: in text order, one linear
+ * transfer, no merge on the host), and a new chunk may take that slot (it does so only when no other slot is free).
+ * Consume a chunk's result before handing over the next one -- FileGrep does.  A pinned *content stays until the second
+ * gscan_acquire / gscan_submit* after this call reuses the slot. */
 int gscan_wait(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, size_t *n,
                const void **content);
 /*

@@ -473,6 +473,106 @@ def test_submit_batch_segments(ctx, liboracle):
     assert ctx.wait_segs()[0] == 1 and ctx.wait()[0] == 2
 
 
+def test_submit_files(ctx, liboracle, tmp_path):
+    """gscan_submit_files: small files handed over by NAME -- the device's reader threads open, read and close them, runs of
+    files that fit one staging block travel in one DMA, the last reader launches ONE scan over the segment table.  Ragged
+    and empty files, a batch of several pieces (> one block), a file that does not exist and one that is shorter than
+    announced in the MIDDLE of a batch (their own errors; every other segment intact), descriptors instead of names, an
+    empty batch, a batch beyond max_chunk, and batches in flight together with other submits."""
+    import errno
+
+    blk = engine.lib().gscan_block_size()
+    rng = np.random.default_rng(77)
+    lens = [0, 1, 2, 15, 16, 17, 31, 33, 1000, 4095, 4096, 4097, 70001, 0, 300000, 5, 49151, 49152, 49153, 98304, 3]
+    lens += [int(x) for x in rng.integers(200_000, 900_000, 32)]
+    base = sample(sum(lens) + 64, 23)
+    assert sum(lens) > blk, "the batch spans more than one staging block: several pieces"
+    parts, pos = [], 0
+    for ln in lens:
+        parts.append(base[pos:pos + ln].copy())
+        pos += ln
+    parts[9][-3:] = np.frombuffer(b"foo", np.uint8)   # ends a file ...
+    parts[10][:3] = np.frombuffer(b"bar", np.uint8)   # ... and the next one starts with another word
+    parts[11][-2:] = np.frombuffer(b"fo", np.uint8)   # "fo" + "o...": must NOT match across the boundary
+    parts[12][0] = ord("o")
+    paths = []
+    for i, part in enumerate(parts):
+        f = tmp_path / ("f%03d.bin" % i)
+        part.tofile(str(f))
+        paths.append(str(f))
+    files = list(zip(paths, lens))
+    for pattern in ["foo", "foobardoesnotexist", "[a-z]{2,5}", "[A-Za-z_][A-Za-z0-9_]{15,}", "foo|bar", "[0-9]{17}"]:
+        db = engine.Database(pattern)
+        wants = [pcre_starts(liboracle, pattern, part) if 0 < len(part) <= 100_000 else None for part in parts]
+        for variant in (1, DEFAULT_VARIANT):
+            ctx.set_option("variant", variant)
+            ctx.submit_files(db, files, tag=5)
+            tag, per_seg, has_content = ctx.wait_segs()
+            assert tag == 5 and not has_content and len(per_seg) == len(parts)
+            assert ctx.last_file_errors() == [0] * len(parts)
+            for i, (part, got) in enumerate(zip(parts, per_seg)):
+                assert same(got, table_candidates(db, part)), (pattern, variant, i, len(part))
+                if wants[i] is not None:
+                    assert same(got, wants[i]), (pattern, variant, i, "libpcre")
+    ctx.set_option("variant", DEFAULT_VARIANT)
+    db = engine.Database("[a-z]{2,5}")
+    # a file that is not there, one that is shorter than the walk said, one that is longer (the first `len` bytes count)
+    broken = list(files)
+    broken[25] = (str(tmp_path / "gone.bin"), 12345)
+    broken[30] = (paths[30], lens[30] + 1000)
+    broken[31] = (paths[31], lens[31] - 777)
+    ctx.submit_files(db, broken, tag=6)
+    tag, per_seg, _ = ctx.wait_segs()
+    errs = ctx.last_file_errors()
+    assert tag == 6 and errs[25] == errno.ENOENT and errs[30] == -1 and sum(1 for e in errs if e) == 2
+    for i, (part, got) in enumerate(zip(parts, per_seg)):
+        if i == 31:
+            assert same(got, table_candidates(db, part[:lens[31] - 777]))
+        elif i not in (25, 30):
+            assert same(got, table_candidates(db, part)), i
+    # open descriptors instead of names (the caller keeps them open until the batch is back)
+    fds = [os.open(p, os.O_RDONLY) for p in paths[:12]]
+    try:
+        ctx.submit_files(db, list(zip(fds, lens[:12])), tag=7)
+        tag, per_seg, _ = ctx.wait_segs()
+        assert tag == 7 and ctx.last_file_errors() == [0] * 12
+        for part, got in zip(parts[:12], per_seg):
+            assert same(got, table_candidates(db, part))
+    finally:
+        for fd in fds:
+            os.close(fd)
+    # thousands of tiny files, an empty batch, a batch that cannot fit
+    tiny = []
+    for i in range(1500):
+        ln = int(rng.integers(0, 37))
+        f = tmp_path / ("t%04d" % i)
+        base[i * 37:i * 37 + ln].tofile(str(f))
+        tiny.append((str(f), ln))
+    ctx.submit_files(db, tiny)
+    _, per_seg, _ = ctx.wait_segs()
+    assert len(per_seg) == 1500
+    for i, got in enumerate(per_seg):
+        assert same(got, table_candidates(db, base[i * 37:i * 37 + tiny[i][1]]))
+    ctx.submit_files(db, [])
+    _, per_seg, _ = ctx.wait_segs()
+    assert len(per_seg) == 1 and per_seg[0].size == 0 and ctx.last_file_errors() is None
+    with pytest.raises(engine.EngineError):
+        ctx.submit_files(db, [(paths[0], blk + 1)])  # larger than a staging block: gscan_submit_fd's business
+    # three in flight, of three kinds, back in submission order; the error array belongs to the batch only
+    fd = os.open(paths[-1], os.O_RDONLY)
+    try:
+        ctx.submit_files(db, files[:8], tag=1)
+        ctx.submit_fd(db, fd, 0, lens[-1], tag=2)
+        ctx.submit(db, base[:5000], tag=3)
+        t1, s1, _ = ctx.wait_segs()
+        assert t1 == 1 and len(s1) == 8 and ctx.last_file_errors() == [0] * 8
+        t2, s2, _ = ctx.wait_segs()
+        assert t2 == 2 and ctx.last_file_errors() is None and same(s2[0], table_candidates(db, parts[-1]))
+        assert ctx.wait()[0] == 3
+    finally:
+        os.close(fd)
+
+
 def test_shared_buckets_second_pass(ctx):
     """More than 8 alternatives share K3's 8 filter buckets: the tables alone would accept cross-products of a bucket's
     alternatives ("alota" from alpha + iota).  The second pass (k3_settle) strikes them out; also with a record buffer

@@ -110,6 +110,19 @@ def test_default_chunk_geometry(pattern, big_file, built, oracle_built):
         rc, out, err = _run(built.bin_path(), argv, d, {"GRAB_DEVICES": "3", "GRAB_TIMING": "1"})
         assert rc == 0 and out == one, err
         assert err.count(b"[grab bytes] device") == 3, err  # three contexts took windows
+    # ... and over EIGHT device indices (GSCAN_VIRTUAL_DEVICES: every index has its own reader pool, pinned blocks and
+    # streams, all on the one GPU there is; the file has 3 windows at 1 GiB, 11 at -L -L): identical bytes; and with
+    # device index 1 refusing to open (busy / out of memory on a real node): a warning, then the same bytes from fewer contexts
+    for flags in (["-O", "-l"], ["-L", "-L", "-O"]):
+        argv = flags + [pattern, "big.bin"]
+        _, one, _ = _run(built.bin_path(), argv, d, {"GRAB_DEVICES": "1"})
+        rc, out, err = _run(built.bin_path(), argv, d, {"GSCAN_VIRTUAL_DEVICES": "8", "GRAB_TIMING": "1"})
+        assert rc == 0 and out == one, err
+        devs = set(int(x) for x in __import__("re").findall(rb"\[grab bytes\] device (\d+): [1-9]", err))
+        assert devs == set(range(3 if flags[0] == "-O" else 8)), (flags, sorted(devs))
+        rc, out, err = _run(built.bin_path(), argv, d, {"GSCAN_VIRTUAL_DEVICES": "8", "GSCAN_VIRTUAL_FAIL_OPEN": "1"})
+        assert rc == 0 and out == one, err
+        assert b"HIP device 1 cannot be opened" in err
 
 
 def test_quartered_chunks_two_files(big_file, built, oracle_built):
@@ -194,5 +207,88 @@ def test_identifier_regex_16_files(tmp_path, built, oracle_built):
         a, b = sorted(out.splitlines()), sorted(oout.splitlines())
         assert len(a) == len(b) and len(a) > 2_000_000
         assert hashlib.md5(b"\n".join(a)).hexdigest() == hashlib.md5(b"\n".join(b)).hexdigest()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _fake_pci_tree(root):
+    """sysfs as an 8-GPU, two-socket node shows it, for the bus ids GSCAN_VIRTUAL_DEVICES gives its indices: devices 0-3 on the
+    first half of this box's CPUs, 4-7 on the second."""
+    cpus = sorted(os.sched_getaffinity(0))
+    half = len(cpus) // 2
+    lists = ["%d-%d" % (cpus[0], cpus[half - 1]), "%d-%d" % (cpus[half], cpus[-1])] if half and cpus == list(range(cpus[0], cpus[-1] + 1)) else [",".join(map(str, cpus))] * 2
+    for v in range(8):
+        d = os.path.join(root, "0000:%02x:00.0" % (0x0c + 0x10 * v))
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "local_cpulist"), "w") as f:
+            f.write(lists[v // 4] + "\n")
+    return root
+
+
+def test_queue_over_eight_device_indices(tmp_path, built, oracle_built):
+    """The `-n` work queue with MORE THAN ONE device index (VERDICT r3 task 5; /root/reference/src/main.cc:195-216 is the
+    thread pool it replaces): GSCAN_VIRTUAL_DEVICES=8 makes gscan_device_count() answer 8 on the one-GPU box -- every index
+    opens its own reader pool, pinned blocks and streams on device 0 and is placed from a faked two-socket sysfs tree --
+    so run_workers' per-device pools, placement and contexts run as they would on an 8-GPU node.  `grab -n 32 -r` over a
+    4096-file tree (small files: batches) and -n 16 over 16 x 64 MiB (file windows, identifier regex) == the oracle,
+    sorted; the bytes every device index was handed are within +-25 % of each other."""
+    import re
+
+    files, fbytes = 4096, 128 << 10
+    d = _scratch(tmp_path, files * fbytes + (20 << 26))
+    try:
+        env = {"GSCAN_VIRTUAL_DEVICES": "8", "GSCAN_SYSFS_PCI": _fake_pci_tree(os.path.join(d, "pci")), "GRAB_TIMING": "1"}
+        nd = np.frombuffer(synth.NEEDLE, np.uint8)
+        block = _torch_text(64 * fbytes, 9100)
+        for i in range(files):
+            sub = os.path.join(d, "t", "a%02d" % (i % 16), "b%02d" % ((i // 16) % 16))
+            os.makedirs(sub, exist_ok=True)
+            buf = np.roll(block[(i % 64) * fbytes:(i % 64 + 1) * fbytes], i * 131)
+            at = (i * 7919) % (fbytes - 64)
+            buf[at:at + nd.size] = nd
+            buf.tofile(os.path.join(sub, "f%05d.txt" % i))
+        workers = str(min(32, len(os.sched_getaffinity(0))))
+        for flags in (["-n", workers, "-r", "-O", "-l"], ["-n", workers, "-r"]):
+            argv = flags + [synth.NEEDLE.decode(), "t"]
+            rc, out, err = _run(built.bin_path(), argv, d, env)
+            orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), ["-n", "8"] + argv[2:], d)
+            assert rc == orc == 0, err
+            assert sorted(out.splitlines()) == sorted(oout.splitlines()), flags
+            per = {}
+            for m in re.finditer(rb"\[grab bytes\] device (\d+): (\d+)", err):
+                per[int(m.group(1))] = per.get(int(m.group(1)), 0) + int(m.group(2))
+            assert set(per) <= set(range(8)) and len(per) >= 2, per  # (2 GiB are gone before the last of 32 workers has its context: who gets how much is not the point here)
+            assert sum(per.values()) == files * fbytes
+        # BASELINE configs[1]'s shape at its full size for the price of 1 GiB: 16 distinct 64 MiB files, each under 64 names
+        # (hard links) = 1024 files, 64 GiB through the queue -- long enough for back-pressure to do the balancing: every
+        # device index within +-25 % of the mean.  Then the identifier regex over the 16 files themselves (dense output).
+        os.makedirs(os.path.join(d, "big", "x00"))
+        for i in range(16):
+            buf = _torch_text(64 << 20, 9200 + i)
+            synth.plant(buf, synth.NEEDLE, 8, i, gap=600)
+            buf.tofile(os.path.join(d, "big", "x00", "g%02d.txt" % i))
+        for k in range(1, 64):
+            os.makedirs(os.path.join(d, "big", "x%02d" % k))
+            for i in range(16):
+                os.link(os.path.join(d, "big", "x00", "g%02d.txt" % i), os.path.join(d, "big", "x%02d" % k, "g%02d.txt" % i))
+        argv = ["-n", workers, "-r", "-O", "-l", synth.NEEDLE.decode(), "big"]
+        rc, out, err = _run(built.bin_path(), argv, d, env)
+        orc, oout, _ = _run(_oracles(oracle_built)[-1], ["-n", str(min(32, len(os.sched_getaffinity(0))))] + argv[2:], d)
+        assert rc == orc == 0, err
+        assert len(out.splitlines()) == 1024 * 8 and sorted(out.splitlines()) == sorted(oout.splitlines())
+        per = {}
+        for m in re.finditer(rb"\[grab bytes\] device (\d+): (\d+)", err):
+            per[int(m.group(1))] = per.get(int(m.group(1)), 0) + int(m.group(2))
+        assert sorted(per) == list(range(8)) and sum(per.values()) == 1024 << 26, per
+        if int(workers) >= 32:
+            mean = sum(per.values()) / 8
+            assert all(abs(v - mean) <= 0.25 * mean for v in per.values()), per
+        argv = ["-n", str(min(16, len(os.sched_getaffinity(0)))), "-r", "-O", "-l", synth.IDENT_RE, os.path.join("big", "x00")]
+        rc, out, err = _run(built.bin_path(), argv, d, env)
+        orc, oout, _ = _run(_oracles(oracle_built)[-1], ["-n", "8"] + argv[2:], d)
+        assert rc == orc == 0, err
+        assert len(out) == len(oout) and hashlib.md5(b"\n".join(sorted(out.splitlines()))).digest() == hashlib.md5(b"\n".join(sorted(oout.splitlines()))).digest()
+        per = {int(m.group(1)) for m in re.finditer(rb"\[grab bytes\] device (\d+): [1-9]", err)}
+        assert len(per) >= 4, per  # (16 files over 16 workers on 8 device indices)
     finally:
         shutil.rmtree(d, ignore_errors=True)
