@@ -85,6 +85,22 @@ constexpr size_t kMaxChunk = (1ull << 30) + 4096;
 // 64 GiB corpus goes through at 44-47 GB/s whatever the block size (8/16/32 MiB), the number of copy streams, their
 // sharing, the flavour of the pinned memory or the way the readers copy; 8 readers are the best (more of them wait for
 // blocks longer than they save reading).  16 MiB is where the per-copy cost stops showing in the probe.
+// GSCAN_TRACE=1: a time line of the pipeline on stderr -- "[gscan trace] +seconds-since-load thread what" -- for the runs
+// that are over in a fraction of a second (where does a 256 MiB file's 0.1 s go?)
+const auto g_trace_t0 = std::chrono::steady_clock::now();
+const bool g_trace = getenv("GSCAN_TRACE") != nullptr;
+void trace(const char *fmt, ...)
+{
+    if (!g_trace) return;
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "[gscan trace] +%.4f s t%05ld %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_trace_t0).count(),
+            (long)(uintptr_t)pthread_self() % 100000, buf);
+}
+
 struct IngestCfg {
     size_t block;
     int readers;
@@ -96,6 +112,7 @@ struct IngestCfg {
     // contexts with two streams each were 0.1 s of start-up and 2 GB of resident memory for nothing: a 64 MiB window scans in
     // 15 us and the copies share one link.  So the contexts of a device share its streams by default.
     int shared_copy;    // GSCAN_SHARED_COPY (1): N = the contexts of a device share N copy streams; 0 = every context has its own
+    bool one_stream;    // GSCAN_ONE_STREAM (0): copies, scans and read-backs of a device all go down ONE stream (one HSA queue)
     int shared_compute; // GSCAN_SHARED_COMPUTE (2): N = they share N scan streams, dealt round robin; 0 = every context has its own
     bool slab;          // GSCAN_SLAB: the reader blocks of a device are carved from ONE pinned allocation instead of one each
     int read_mode;      // GSCAN_READ_MODE: 0 pread(2) into the block; 1 map the piece and copy it with non-temporal stores
@@ -118,6 +135,8 @@ const IngestCfg &ingest_cfg()
         v.numa = env("GSCAN_NUMA", 1, 0, 1) != 0;
         v.shared_copy = (int)env("GSCAN_SHARED_COPY", 1, 0, 4);
         v.shared_compute = (int)env("GSCAN_SHARED_COMPUTE", 2, 0, 4);
+        v.one_stream = env("GSCAN_ONE_STREAM", 0, 0, 1) != 0;
+        if (v.one_stream) v.shared_copy = 1;
         v.slab = env("GSCAN_SLAB", 0, 0, 1) != 0;
         v.read_mode = (int)env("GSCAN_READ_MODE", 0, 0, 2); // (1 and 2 measured and not adopted: profiles/r02_d_e2e_reader_modes.jsonl)
         const long pf = env("GSCAN_PIN_FLAGS", 0, 0, 2);
@@ -379,6 +398,31 @@ private:
         }
         cap_ = (size_t)readers_ * 2;
         timing_ = getenv("GSCAN_TIMING") != nullptr;
+        // The first blocks are made NOW, in the background, while the opener goes on creating its streams and sizing its
+        // first slot (30-50 ms): eight readers asking for their first block at the same moment would queue inside the
+        // runtime, the last one reading its first byte 25 ms late (GSCAN_PREALLOC=0: on demand only, as in round 3).
+        const char *pre = getenv("GSCAN_PREALLOC");
+        const int want = pre && *pre ? atoi(pre) : readers_ + 1;
+        if (want > 0) {
+            prealloc_ = std::thread([this, want] {
+                for (int i = 0; i < want; i++) {
+                    {
+                        std::lock_guard<std::mutex> lk(m_);
+                        if (stop_ || n_alloc_ >= cap_) return;
+                        n_alloc_++;
+                    }
+                    PinBlock *b = alloc_block();
+                    std::lock_guard<std::mutex> lk(m_);
+                    if (!b) {
+                        n_alloc_--;
+                        return;
+                    }
+                    free_.push_back(b);
+                    cv_blocks_.notify_one();
+                }
+                trace("ingest: %d pinned blocks made ahead", want);
+            });
+        }
     }
     ~Ingest()
     {
@@ -388,6 +432,7 @@ private:
             cv_tasks_.notify_all();
         }
         for (std::thread &t : threads_) t.join();
+        if (prealloc_.joinable()) prealloc_.join();
         (void)hipSetDevice(hip_device_of(device_));
         for (PinBlock *b : busy_) free_block(b, true);
         for (PinBlock *b : free_) free_block(b, false);
@@ -445,10 +490,19 @@ private:
                 free_.pop_back();
                 return b;
             }
+            // a block whose DMA is over is as good as a free one -- and a new block costs 3-4 ms of hipHostMalloc (0.22 s per GiB,
+            // one at a time inside the runtime) where a 16 MiB DMA takes 0.3 ms: the pool only grows while every block is busy
+            if (!busy_.empty() && hipEventQuery(busy_.front()->ev) == hipSuccess) {
+                PinBlock *b = busy_.front();
+                busy_.pop_front();
+                return b;
+            }
             if (n_alloc_ < cap_) {
                 n_alloc_++;
                 lk.unlock();
+                trace("reader: allocating a pinned block");
                 PinBlock *b = alloc_block();
+                trace("reader: pinned block allocated");
                 if (b) return b;
                 lk.lock();
                 n_alloc_--;
@@ -489,7 +543,9 @@ private:
             }
             double t1 = timing_ ? now() : 0;
             int err = 0;
+            trace("reader: task of %zu bytes taken", t.n);
             PinBlock *b = take_reader_block();
+            trace("reader: block in hand");
             double t2 = timing_ ? now() : 0, t3 = t2;
             if (!b) {
                 err = -2;
@@ -555,6 +611,7 @@ private:
                     else if (errno != EINTR) err = errno;
                 }
                 t3 = timing_ ? now() : 0;
+                trace("reader: %zu bytes read", t.n);
                 bool dma = false;
                 if (!err) {
                     if (hipMemcpyAsync(t.dst, b->p, t.n, hipMemcpyHostToDevice, t.stream) != hipSuccess ||
@@ -583,6 +640,7 @@ private:
                 if (err && !t.grp->err) t.grp->err = err;
                 last = --t.grp->pending == 0;
             }
+            trace("reader: piece queued for DMA%s", last ? " (last of its range: launching)" : "");
             if (last) t.grp->finish(t.grp); // every piece is on its copy stream: launch the scan behind them
         }
     }
@@ -611,6 +669,7 @@ private:
     std::deque<PinBlock *> busy_;
     std::deque<ReadTask> tasks_;
     std::vector<std::thread> threads_;
+    std::thread prealloc_;
     std::vector<hipStream_t> shared_;
     std::atomic<int> next_compute_{0};
     std::mutex slab_m_;
@@ -1166,6 +1225,7 @@ int gscan_db_info(const gscan_db *db, gscan_info *info)
     info->gapped = 0;
     for (const gscan::AltSeq &a : d.alts) info->gapped += a.gapped ? 1 : 0;
     info->ends_ok = (int)d.prog.ends_ok;
+    info->textfree = d.solitary && !d.alts.empty() && !d.alts[0].has_tail ? 1 : 0;
     info->exact = d.exact ? 1 : 0;
     info->vm = d.prog.vm_filter ? 1 : 0;
     return GSCAN_OK;
@@ -1238,7 +1298,10 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     static std::mutex open_order;
     std::unique_lock<std::mutex> one_at_a_time(open_order, std::defer_lock);
     if (!getenv("GSCAN_OPEN_UNORDERED")) one_at_a_time.lock(); // (the switch is for measuring the difference)
-    if (ingest_cfg().shared_compute > 0) { // (pool entries 0..3 are the copy streams, 4.. the scan streams)
+    if (ingest_cfg().one_stream) {
+        c->compute_shared = true;
+        if (!(c->compute = c->ingest->shared_stream(0))) return bail(GSCAN_EHIP);
+    } else if (ingest_cfg().shared_compute > 0) { // (pool entries 0..3 are the copy streams, 4.. the scan streams)
         c->compute_shared = true;
         if (!(c->compute = c->ingest->shared_stream(4 + c->ingest->next_compute() % ingest_cfg().shared_compute))) return bail(GSCAN_EHIP);
     } else if (hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) != hipSuccess) {
@@ -1514,10 +1577,13 @@ int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off
     HIPCHK(c, hipSetDevice(c->hip_dev));
     Slot *s = free_slot_for_submit(c);
     if (!s) return fail(c, GSCAN_EBUSY, "no free slot (all in flight, or one is acquired)");
+    trace("submit_fd: %zu bytes", len);
     int rc = ensure_prog(c, db, c->compute);
     if (rc) return rc;
+    trace("submit_fd: program on the device");
     rc = slot_reserve_device(c, *s, len);
     if (rc) return rc;
+    trace("submit_fd: slot sized");
     // fan the range out to the device's reader threads: every piece is DMA'd on one of this context's copy streams the
     // moment it is read, and whoever finishes the last piece launches the scan (fd_finish).  This thread goes on.
     if (!s->grp) s->grp.reset(new (std::nothrow) ReadGroup());
@@ -1661,7 +1727,9 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     static const bool tw_on = getenv("GSCAN_TIMING") != nullptr;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tw0 = tw_on ? tnow() : 0;
+    trace("wait: begin");
     slot_drain_reads(*s);
+    trace("wait: range read and launched");
     if (tw_on) c->tw_reads += tnow() - tw0, tw0 = tnow(), c->tw_n++;
     if (s->grp && s->grp->rc) {
         c->err = s->grp->msg;
@@ -1671,6 +1739,7 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
     }
     HIPCHK(c, hipSetDevice(c->hip_dev));
     HIPCHK(c, hipEventSynchronize(s->done));
+    trace("wait: scan done");
     if (tw_on) c->tw_scan += tnow() - tw0, tw0 = tnow();
     slot_unregister(*s); // the DMA out of the caller's buffer is over (the text stays in HBM for a possible rescan)
     const size_t K = gscan::kShards;

@@ -327,6 +327,7 @@ int FileGrep::prepare(const std::string &regex)
         context_ = info.has_context != 0;
         lines_ = info.lines_ok != 0;
         ends_ = info.ends_ok != 0;
+        textfree_ = info.textfree != 0;
     }
 
     flush();
@@ -673,6 +674,7 @@ bool FileGrep::report_needs_text(unsigned rflags, size_t n, const uint32_t *ext,
 {
     if (context_) return true; // (matches at the restart position / chunk end are the host's to find, list or no list)
     if (n == 0) return false;
+    if (textfree_ && (rflags & GRAB_NOLINE)) return false; // a fixed-length pattern all of whose candidates are listed: gscan_next_match walks the list alone
     if (ends && (rflags & GRAB_NOLINE) && (rflags & GRAB_OFFSETS)) {
         for (size_t i = 0; i < n; i++)
             if (ends[i] == 0) return true;

@@ -98,6 +98,7 @@ private:
     bool never_ = false;    // ... and not even there: the pattern's assertions contradict each other
     bool context_ = false;  // the pattern looks at the byte before / after its match
     bool lines_ = false;    // the device's line-extent pass applies to the pattern
+    bool textfree_ = false; // fixed length, every candidate listed: without line printing the walk never reads the chunk (gscan_info.textfree)
     bool ends_ = false;     // the device's match-end pass applies to the pattern (-O -l is then walked without the text)
     uid_t uid_;
     int device_ = 0, out_fd_ = 1;

@@ -90,6 +90,9 @@ typedef struct gscan_info {
                             host matcher at the listed offsets only */
     int gapped;          /* alternatives with one unbounded repeat in the middle (a+b, foo.*bar): the kernels list where the part BEHIND
                             the repeat begins (one repeat byte + the rest), gscan_next_match walks the run back to the match start */
+    int textfree;        /* 1: one plain alternative of fixed length whose window cannot match at two ADJACENT offsets (two neighbouring
+                            positions of it have no byte in common -- any literal that is not one repeated byte): every candidate is
+                            listed and ends where its window ends, so gscan_next_match never looks at `content` (it may be NULL) */
     int ends_ok;         /* 1 if the match-end pass applies (gscan_set_option "match_ends"): one plain alternative without context that
                             ends in an unbounded greedy repeat whose class contains the window's first class (gscan_next_listed) */
 } gscan_info;

@@ -291,8 +291,9 @@ def test_small_files_through_the_reader_pool(built, oracle_built, tmp_path):
         d.mkdir(parents=True, exist_ok=True)
         n = int(rng.choice([0, 1, 17, 18, 400, 5000, 70_000, 300_000, 524_288, 900_000])) if i % 40 else 3_000_000  # (3 MB: above the 2 MiB batching limit)
         buf = synth.text(n, 900 + i)
-        if n >= 400:
+        if n >= 5000:
             synth.plant(buf, b"foobardoesnotexist", 2, i, gap=100)
+        if n >= 400:
             buf[-18:] = np.frombuffer(b"foobardoesnotexist", np.uint8)  # ends with the file
         buf.tofile(str(d / ("f%03d.txt" % i)))
     for pattern in ["foobardoesnotexist", "[A-Za-z_][A-Za-z0-9_]{15,}", r"\bfoobardoesnotexist$|^[a-z]{4}\b"]:

@@ -152,6 +152,8 @@ def test_listed_literals_are_walked_without_reading_the_text(built):
             answers.append(got)
         assert len(answers[0]) >= 3, pattern
         assert (answers[0] == answers[1]) == (not reads_text), pattern
+        assert bool(db.info.textfree) == (not reads_text), pattern  # what FileGrep goes by when it decides whether a small file must be mapped for the report
+    assert not engine.Database("foo[a-z]*").info.textfree and not engine.Database(r"\bfoo").info.textfree and not engine.Database("foo|bar").info.textfree
 
 
 def test_long_lines_all_modes_match_libpcre(built, liboracle):
