@@ -570,9 +570,11 @@ def e2e_cfg3(d, nfiles, file_bytes, n_gpus, want_cpu):
 
 
 def e2e_cfg4(base, gib, n_gpus, want_cpu):
-    """BASELINE configs[3] at `gib` GiB: a tree of 2048 x gib files of 512 KiB in 64 x 64 directories, one needle per file
-    (scripts/fullsize_parity.py gen_files: the full-size script's generator); `grab -n 8 -r -O -l` -- the parallel walk, the
-    queue, small files batched 32 to a launch -- line count == file count, sorted output md5 against the reference."""
+    """BASELINE configs[3] at `gib` GiB (64: the size it is quoted on -- 131 072 files of 512 KiB in a 64 x 64 x 32 tree, one
+    needle per file; scripts/fullsize_parity.py gen_files is the generator): `grab -n W -r -O -l` -- the parallel walk, the
+    queue, small files queued by name and read by the device's reader pool, 64 to a launch -- line count == file count,
+    sorted output md5 against the reference; the same command over the first quarter of the tree beside it (`at_16GiB`:
+    hard links, the same 0.25 s of start-up and teardown under a quarter of the work)."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import fullsize_parity
 
@@ -580,6 +582,7 @@ def e2e_cfg4(base, gib, n_gpus, want_cpu):
     while gib > 1 and shutil.disk_usage(base).free < (gib << 30) * 1.2:
         gib //= 2
     files, fb = gib * 2048, 512 << 10
+    dq = d + "_quarter"
     try:
         os.makedirs(d)
         t0 = time.perf_counter()
@@ -589,6 +592,16 @@ def e2e_cfg4(base, gib, n_gpus, want_cpu):
         e = e2e_measure(d, files, fb, needle, ["-O", "-l"], n_gpus, files, reps=2, detached=False)
         e["corpus_write_s"] = round(gen_s, 1)
         e["tree"] = "%d files x 512 KiB in 64 x 64 directories" % files
+        if gib > 16:  # the first 16 of the 64 top-level directories: a quarter of the files under the same names
+            nq = 0
+            for a in sorted(os.listdir(d))[:16]:
+                for b in os.listdir(os.path.join(d, a)):
+                    os.makedirs(os.path.join(dq, a, b))
+                    for f in os.listdir(os.path.join(d, a, b)):
+                        os.link(os.path.join(d, a, b, f), os.path.join(dq, a, b, f))
+                        nq += 1
+            q = e2e_measure(dq, nq, fb, needle, ["-O", "-l"], n_gpus, nq, reps=2, detached=False, warm=False)
+            e["at_16GiB"] = {k: q.get(k) for k in ("value", "bytes", "wall_s", "startup_s", "scan_phase_GBps", "frac", "lines_ok", "error") if k in q}
         ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
         got = sorted_md5([bin_path(), "-n", "8", "-r", "-O", "-l", needle, d])
         if os.path.exists(ref):
@@ -600,45 +613,79 @@ def e2e_cfg4(base, gib, n_gpus, want_cpu):
                     e["vs_cpu_baseline"] = round(e["value"] / e["cpu_baseline"]["value"], 3)
         return e
     finally:
+        shutil.rmtree(dq, ignore_errors=True)
         shutil.rmtree(d, ignore_errors=True)
 
 
-def e2e_cfg5(base, gib, want_cpu):
-    """BASELINE configs[4] at `gib` GiB: one file, ~31 250 seeded needles per GiB + one in every 4 KiB overlap window, across
-    every chunk end, ending exactly at a chunk end, at every chunk start and in the last 18 bytes
-    (scripts/fullsize_parity.py gen_big); `grab -O -l` (1 GiB windows, dealt over the node's GPUs, printed in order)
-    byte-exact against the reference."""
+def one_file_block(argv_tail, path, size, what, want_cpu, reps=2, ref_reps=1):
+    """`grab <argv_tail> path` against `grab_jit <argv_tail> path` on ONE file: wall clock of the whole process (min of `reps`
+    after one untimed pass), output md5 against the reference's, the reference on one core as the CPU baseline (it scans
+    one file with one thread: main.cc:167-170)."""
     import hashlib
 
+    got = run_timed([bin_path()] + argv_tail + [path], None, reps)
+    if got is None or got[0] is None:
+        return {"error": (got[2] if got else b"")[-300:].decode("latin-1")}
+    dt, out, _ = got
+    e = {"value": round(size / dt / 1e9, 2), "unit": "GB/s", "bytes": size, "wall_s": round(dt, 4), "frac": round(size / dt / 1e9 / PCIE_PEAK_GBPS, 4),
+         "lines": out.count(b"\n"), "md5": hashlib.md5(out).hexdigest(),
+         "command": "grab %s <%s>, wall clock of the whole process, page cache warm, min of %d" % (" ".join(argv_tail), what, reps)}
+    ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
+    if os.path.exists(ref):
+        r = run_timed([ref] + argv_tail + [path], None, ref_reps, warm=ref_reps > 1)
+        if r and r[0]:
+            e["reference_md5"] = hashlib.md5(r[1]).hexdigest()
+            e["same_as_reference"] = e["reference_md5"] == e["md5"]
+            if want_cpu:
+                e["cpu_baseline"] = {"value": round(size / r[0] / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "reference", "wall_s": round(r[0], 4),
+                                     "sample": "the same file, 'grab_jit %s', one thread (the reference cannot use more on one file: main.cc:167-170), warm cache, min of %d" % (" ".join(argv_tail), ref_reps)}
+                e["vs_cpu_baseline"] = round(e["value"] / e["cpu_baseline"]["value"], 3)
+    return e
+
+
+def e2e_cfg5(base, gib, want_cpu):
+    """BASELINE configs[4] at `gib` GiB (32: the size it is quoted on): one file, ~31 250 seeded needles per GiB + one in every
+    4 KiB overlap window, across every chunk end, ending exactly at a chunk end, at every chunk start and in the last 18 bytes
+    (scripts/fullsize_parity.py gen_big); `grab -O -l` (1 GiB windows, dealt over the node's GPUs, printed in order)
+    byte-exact against the reference.  The same on an 8 GiB file beside it (`at_8GiB`)."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import fullsize_parity
 
-    path = os.path.join(base, "grab_bench_cfg5_%d.bin" % os.getpid())
+    needle = synth.NEEDLE.decode()
     while gib > 1 and shutil.disk_usage(base).free < (gib << 30) * 1.2:
         gib //= 2
-    size = gib << 30
+    out = None
+    for g in ([gib, 8] if gib > 8 else [gib]):
+        path = os.path.join(base, "grab_bench_cfg5_%d.bin" % os.getpid())
+        try:
+            t0 = time.perf_counter()
+            plants = fullsize_parity.gen_big(path, g << 30, 1 << 30, int(31250 * g))
+            gen_s = time.perf_counter() - t0
+            e = one_file_block(["-O", "-l", needle], path, g << 30, "one %d GiB file" % g, want_cpu and out is None)
+            e.update({"plants": int(plants), "corpus_write_s": round(gen_s, 1)})
+        finally:
+            if os.path.exists(path):
+                os.unlink(path)
+        if out is None:
+            out = e
+        else:
+            out["at_8GiB"] = {k: e.get(k) for k in ("value", "bytes", "wall_s", "frac", "lines", "same_as_reference", "error") if k in e}
+    return out
+
+
+def e2e_cfg1(base, device, want_cpu):
+    """BASELINE configs[0]: ONE 256 MiB file of synthetic text (seed k = 0), the literal that is not in it -- the
+    reference's own CPU-runnable case: `grab foobardoesnotexist <file>` against `grab_jit` on one core.  A run this short
+    is start-up and teardown of the HIP runtime more than anything else: the number is here whatever it says."""
+    path = os.path.join(base, "grab_bench_cfg1_%d.txt" % os.getpid())
+    size = 256 << 20
     try:
-        t0 = time.perf_counter()
-        plants = fullsize_parity.gen_big(path, size, 1 << 30, int(31250 * gib))
-        gen_s = time.perf_counter() - t0
-        needle = synth.NEEDLE.decode()
-        got = run_timed([bin_path(), "-O", "-l", needle, path], None, 2)
-        if got is None or got[0] is None:
-            return {"error": (got[2] if got else b"")[-300:].decode("latin-1")}
-        dt, out, _ = got
-        e = {"value": round(size / dt / 1e9, 2), "unit": "GB/s", "bytes": size, "wall_s": round(dt, 4), "frac": round(size / dt / 1e9 / PCIE_PEAK_GBPS, 4),
-             "lines": out.count(b"\n"), "plants": int(plants), "md5": hashlib.md5(out).hexdigest(), "corpus_write_s": round(gen_s, 1),
-             "command": "grab -O -l %s <one %d GiB file>, wall clock of the whole process, page cache warm, min of 2" % (needle, gib)}
-        ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
-        if os.path.exists(ref):
-            r = run_timed([ref, "-O", "-l", needle, path], None, 1, warm=False)
-            if r and r[0]:
-                e["reference_md5"] = hashlib.md5(r[1]).hexdigest()
-                e["same_as_reference"] = e["reference_md5"] == e["md5"]
-                if want_cpu:
-                    e["cpu_baseline"] = {"value": round(size / r[0] / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "reference", "wall_s": round(r[0], 4),
-                                         "sample": "the same %d GiB file, 'grab_jit -O -l %s', one thread (the reference cannot use more on one file: main.cc:167-170), warm cache, one run" % (gib, needle)}
-                    e["vs_cpu_baseline"] = round(e["value"] / e["cpu_baseline"]["value"], 3)
+        synth.torch_text(size, 0, device).cpu().numpy().tofile(path)
+        e = one_file_block([synth.NEEDLE.decode()], path, size, "one 256 MiB file", want_cpu, reps=5, ref_reps=5)
+        s = one_file_block(["-S", synth.NEEDLE.decode()], path, size, "one 256 MiB file", False, reps=3)
+        e["with_-S"] = {k: s.get(k) for k in ("value", "wall_s", "lines", "error") if k in s}
+        r = subprocess.run([bin_path(), synth.NEEDLE.decode(), path], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, GRAB_TIMING="1"))
+        e["marks_s"] = dict((m.group(2).decode(), float(m.group(1))) for m in re.finditer(rb"\[grab timing\] \+([0-9.]+) s ([^\n]+)", r.stderr))
         return e
     finally:
         if os.path.exists(path):
@@ -859,11 +906,19 @@ def main():
                         line["cpu_baseline"] = cpu_baseline(d, nfiles, file_bytes, pattern, flags)
                         if line["cpu_baseline"] and "value" in e:
                             e["vs_cpu_baseline"] = round(e["value"] / line["cpu_baseline"]["value"], 3)
-                    # the other two end-to-end BASELINE configurations, each with its own parity check and CPU baseline
+                    # the other end-to-end BASELINE configurations, each with its own parity check and CPU baseline.  cfg3 runs on
+                    # the cfg2 corpus; that corpus is removed before cfg5 (32 GiB) and cfg4 (64 GiB) write theirs
                     if not a.no_e2e_extra:
+                        base = os.path.dirname(d)
+                        full = nfiles * file_bytes >= (64 << 30)
+
+                        def drop_corpus():
+                            shutil.rmtree(d, ignore_errors=True)
+
                         for key, fn in (("e2e_cfg3", lambda: e2e_cfg3(d, nfiles, file_bytes, world, want_cpu)),
-                                        ("e2e_cfg5", lambda: e2e_cfg5(os.path.dirname(d), min(8, max(2, use >> 33)), want_cpu)),
-                                        ("e2e_cfg4", lambda: e2e_cfg4(os.path.dirname(d), min(16, max(2, use >> 32)), world, want_cpu))):
+                                        ("e2e_cfg1", lambda: (drop_corpus(), e2e_cfg1(base, device, want_cpu))[1]),
+                                        ("e2e_cfg5", lambda: e2e_cfg5(base, 32 if full else min(8, max(2, use >> 33)), want_cpu)),
+                                        ("e2e_cfg4", lambda: e2e_cfg4(base, 64 if full else min(16, max(2, use >> 32)), world, want_cpu))):
                             try:
                                 line[key] = fn()
                             except Exception as ex:

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--bytes", type=int, default=0)
     ap.add_argument("--env", action="append", default=[])
+    ap.add_argument("--sleep", type=float, default=0.0, help="seconds of quiet before every run (the previous process's teardown goes on in the kernel after its parent has seen it exit)")
     ap.add_argument("--interleave", action="store_true", help="round-robin over the environments instead of one after the other")
     ap.add_argument("cmd", nargs=argparse.REMAINDER)
     a = ap.parse_args()
@@ -32,6 +33,8 @@ def main():
         for kv in e.split():
             k, _, v = kv.partition("=")
             env[k] = v
+        if a.sleep:
+            time.sleep(a.sleep)
         with open("/dev/null", "wb") as out:
             t0 = time.perf_counter()
             r = subprocess.run(cmd, stdout=out, stderr=subprocess.PIPE, env=env)
