@@ -112,7 +112,9 @@ struct IngestCfg {
     // contexts with two streams each were 0.1 s of start-up and 2 GB of resident memory for nothing: a 64 MiB window scans in
     // 15 us and the copies share one link.  So the contexts of a device share its streams by default.
     int shared_copy;    // GSCAN_SHARED_COPY (1): N = the contexts of a device share N copy streams; 0 = every context has its own
-    bool one_stream;    // GSCAN_ONE_STREAM (0): copies, scans and read-backs of a device all go down ONE stream (one HSA queue)
+    bool one_stream;    // GSCAN_ONE_STREAM (1): copies, scans and read-backs of a device all go down ONE stream (one HSA queue): a
+                        // 64 MiB window scans in 15 us and the link carries one copy at a time anyway; every further stream is
+                        // 7 - 12 ms at start-up, 177 MB of wave-save area and 4 ms at exit (measured: profiles/r04_c_*)
     int shared_compute; // GSCAN_SHARED_COMPUTE (2): N = they share N scan streams, dealt round robin; 0 = every context has its own
     bool slab;          // GSCAN_SLAB: the reader blocks of a device are carved from ONE pinned allocation instead of one each
     int read_mode;      // GSCAN_READ_MODE: 0 pread(2) into the block; 1 map the piece and copy it with non-temporal stores
@@ -135,7 +137,9 @@ const IngestCfg &ingest_cfg()
         v.numa = env("GSCAN_NUMA", 1, 0, 1) != 0;
         v.shared_copy = (int)env("GSCAN_SHARED_COPY", 1, 0, 4);
         v.shared_compute = (int)env("GSCAN_SHARED_COMPUTE", 2, 0, 4);
-        v.one_stream = env("GSCAN_ONE_STREAM", 0, 0, 1) != 0;
+        // (the default unless the stream layout is spelled out: any of the three knobs above set means the caller wants that layout)
+        const bool layout_given = getenv("GSCAN_SHARED_COPY") || getenv("GSCAN_SHARED_COMPUTE") || getenv("GSCAN_COPY_STREAMS");
+        v.one_stream = env("GSCAN_ONE_STREAM", layout_given ? 0 : 1, 0, 1) != 0;
         if (v.one_stream) v.shared_copy = 1;
         v.slab = env("GSCAN_SLAB", 0, 0, 1) != 0;
         v.read_mode = (int)env("GSCAN_READ_MODE", 0, 0, 2); // (1 and 2 measured and not adopted: profiles/r02_d_e2e_reader_modes.jsonl)
@@ -398,11 +402,11 @@ private:
         }
         cap_ = (size_t)readers_ * 2;
         timing_ = getenv("GSCAN_TIMING") != nullptr;
-        // The first blocks are made NOW, in the background, while the opener goes on creating its streams and sizing its
-        // first slot (30-50 ms): eight readers asking for their first block at the same moment would queue inside the
-        // runtime, the last one reading its first byte 25 ms late (GSCAN_PREALLOC=0: on demand only, as in round 3).
+        // GSCAN_PREALLOC=n (measured and left off, profiles/r04_c_*): the first n blocks made in the background while the
+        // opener creates its streams and sizes its first slot.  The runtime serves one allocation at a time: the opener's
+        // own hipMalloc then queues behind these, and a 256 MiB file took 0.19 s instead of 0.13.
         const char *pre = getenv("GSCAN_PREALLOC");
-        const int want = pre && *pre ? atoi(pre) : readers_ + 1;
+        const int want = pre && *pre ? atoi(pre) : 0;
         if (want > 0) {
             prealloc_ = std::thread([this, want] {
                 for (int i = 0; i < want; i++) {
@@ -774,6 +778,9 @@ struct gscan_ctx {
     DevProgram *d_prog = nullptr;
     DevProgram *h_prog = nullptr; // pinned staging
     uint64_t prog_id = 0;
+    hipEvent_t prog_ev = nullptr;      // behind the last upload of the program ...
+    hipStream_t prog_stream = nullptr; // ... on this stream
+    bool prog_pending = false;
     // options
     // defaults from the sweeps under profiles/: 12 KiB per wave (110 VGPRs -> 4 waves/SIMD) with
     // nontemporal loads, one workgroup per tile
@@ -842,19 +849,31 @@ void slot_drain_reads(Slot &s);
 
 int ensure_prog(gscan_ctx *c, const gscan_db *db, hipStream_t st)
 {
-    if (c->prog_id == db->db.id) return 0;
+    if (c->prog_id == db->db.id) {
+        // uploaded on another stream and perhaps still on its way: this stream's kernels wait for it on the device
+        if (c->prog_pending && st != c->prog_stream) HIPCHK(c, hipStreamWaitEvent(st, c->prog_ev, 0));
+        return 0;
+    }
     // A file range submitted with ANOTHER database may still be on its way in: its scan is launched later, by the reader
     // that finishes its last piece, and reads c->d_prog then.  Let every such range arrive and launch first -- the device
     // program is one per context, not one per slot.
     for (Slot &s : c->slot)
         if (s.state == INFLIGHT) slot_drain_reads(s);
-    // The staging copy is overwritten: every earlier upload must have left it.  Uploads are
-    // rare (one per pattern), so a stream sync here costs nothing measurable.
-    HIPCHK(c, hipStreamSynchronize(c->compute));
-    if (c->dv_stream && c->dv_stream != c->compute) HIPCHK(c, hipStreamSynchronize(c->dv_stream));
+    if (c->prog_id != 0) {
+        // a pattern switch (rare: one per FileGrep::prepare): the staging copy is overwritten and so is the device copy that
+        // earlier scans may still be reading -- everything that uses either has to be over
+        if (c->prog_pending) HIPCHK(c, hipEventSynchronize(c->prog_ev));
+        HIPCHK(c, hipStreamSynchronize(c->compute));
+        if (c->dv_stream && c->dv_stream != c->compute) HIPCHK(c, hipStreamSynchronize(c->dv_stream));
+    }
     memcpy(c->h_prog, &db->db.prog, sizeof(DevProgram));
+    // NOT waited for: the scans that use it follow on the same stream (others wait for prog_ev on the device).  The first
+    // transfer of a process costs the runtime 12 - 25 ms of set-up (profiles/r04_b_*): it now runs while the caller sizes its
+    // slot and the readers read the first pieces of the file, instead of in front of them.
     HIPCHK(c, hipMemcpyAsync(c->d_prog, c->h_prog, sizeof(DevProgram), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipEventRecord(c->prog_ev, st));
+    c->prog_stream = st;
+    c->prog_pending = true;
     c->prog_id = db->db.id;
     return 0;
 }
@@ -1346,6 +1365,7 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
         }
         c->dv_counter = (uint32_t *)d;
     }
+    if (hipEventCreateWithFlags(&c->prog_ev, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
     for (Slot &s : c->slot) {
         if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
         if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
@@ -1368,6 +1388,7 @@ void gscan_close(gscan_ctx *c)
     hipSetDevice(c->hip_dev);
     hipDeviceSynchronize();
     for (Slot &s : c->slot) free_slot(c, s);
+    if (c->prog_ev) hipEventDestroy(c->prog_ev);
     if (c->d_arena) hipFree(c->d_arena);
     if (c->h_arena) hipHostFree(c->h_arena);
     if (c->h_dense) hipHostFree(c->h_dense);

@@ -426,6 +426,7 @@ int main(int argc, char **argv)
         const int code = rc & 255;
         (void)!write(status_fd, &code, sizeof code);
     }
+    if (const char *ms = getenv("GRAB_EXIT_SLEEP_MS")) usleep((useconds_t)atoi(ms) * 1000); // (diagnostic: what the exit costs against the process's age)
     if (getenv("GRAB_NORMAL_EXIT")) return rc & 255; // (profilers write their results from exit handlers)
     _exit(rc & 255);
 }

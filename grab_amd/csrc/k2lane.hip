@@ -191,10 +191,11 @@ __device__ __forceinline__ void lane_count(const ScanArgs &a, uint32_t d, int su
     constexpr int NWORD = ITER / 2;
     static_assert(ITER % 4 == 0, "the strip is read back in 8-byte pieces");
     // the wave's own LDS writes, then its reads: LDS operations of one wave execute in order; the fences only keep the
-    // compiler from moving them across each other
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // compiler from moving them across each other -- fences on the LDS address space alone: a plain workgroup fence also
+    // waits for every global store in flight (s_waitcnt vmcnt(0)), i.e. for the records the wave has just written
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     uint32_t x[NWORD];
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xp + lane * ITER);
 #pragma unroll
@@ -280,6 +281,41 @@ __device__ __forceinline__ void lane_flush(const ScanArgs &a, uint32_t lane, con
     if (kLaneBatchMax > 2 && n > 2) lane_write<ITER>(a, lane, p[kLaneBatchMax > 2 ? 2 : 0], base + p[0].wtot + p[kLaneBatchMax > 1 ? 1 : 0].wtot, over);
 }
 
+// The same in two halves with a whole tile between them (DEFER): lane_reserve() issues the returning atomic for ONE counted
+// sub-tile and leaves its answer in a register nobody reads yet; the wave goes on to request and scan its next sub-tile;
+// lane_commit() then takes the answer -- it came back long ago, behind it the next tile's loads have been waited for one
+// by one -- and writes descriptor and records.  The atomic's round trip, which lane_flush sits out with nothing else of
+// this wave in flight, disappears behind the next tile's HBM latency; one held sub-tile (10 VGPRs) instead of two.
+template <int ITER>
+__device__ __forceinline__ uint32_t lane_reserve(const ScanArgs &a, uint32_t lane, const LaneCounted<ITER / 2> &p)
+{
+    // (b stays undefined where no atomic is issued -- lane_commit reads lane 0's, and only when there are records: an
+    // initialising v_mov would have to wait for the register's previous atomic, i.e. for every store issued since)
+    uint32_t b;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+    if (p.wtot) {
+        if (lane == 0) b = atomicAdd(a.counter + (p.d & (kShards - 1)) * kCtrStride, p.wtot); // index inside the shard's region
+    }
+    return b;
+#pragma clang diagnostic pop
+}
+template <int ITER>
+__device__ __forceinline__ void lane_commit(const ScanArgs &a, uint32_t lane, const LaneCounted<ITER / 2> &p, uint32_t b)
+{
+    uint32_t base = 0;
+    bool over = false;
+    if (p.wtot) {
+        const uint32_t shard = p.d & (kShards - 1);
+        const uint32_t at = __builtin_amdgcn_readfirstlane(b);
+        over = (unsigned long long)at + p.wtot > (unsigned long long)a.cap_shard;
+        if (over && lane == 0) atomicOr(a.counter + kShards * kCtrStride, 1u);
+        base = shard * a.cap_shard + at;
+    }
+    lane_write<ITER>(a, lane, p, base, over);
+}
+
 // NCLS: 2 or 4 (table entry layout).  NR: runs of the program, sorted by their doubling steps -- 1 or 2 (two classes):
 // exactly that many, S0 / S1 steps; 3 or 4: exactly that many, the last one S1 steps, the others S0 (the most any of them
 // needs; zero shifts where one needs fewer) -- everything about them wave-uniform and decoded before the tile loop; 0: any
@@ -290,7 +326,10 @@ __device__ __forceinline__ void lane_flush(const ScanArgs &a, uint32_t lane, con
 // path (far out of range -- zeros, no traffic -- when there is no next tile or none of it is this wave's).
 // PF: where the next tile's loads are issued -- 0: at the top of its own pass (no prefetch), 1: between this tile's last step
 // and its epilogue, 2: inside the epilogue, right behind the reserving atomic.
-template <int NCLS, int NR, int S0, int S1, int PF = 0, int ITER = kLIter>
+#ifndef GSCAN_LANE_DEFER
+#define GSCAN_LANE_DEFER 1
+#endif
+template <int NCLS, int NR, int S0, int S1, int PF = 0, int ITER = kLIter, int DEFER = GSCAN_LANE_DEFER>
 __global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     constexpr uint32_t kTile = kLNW * ITER * 1024;
@@ -351,6 +390,8 @@ __global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, 
     uint16_t *xp = s_xp + wave * (ITER * 64);
     LaneCounted<ITER / 2> held[kLaneBatchMax]; // counted sub-tiles whose records are not written yet
     int n_held = 0;
+    uint32_t pend_b;      // DEFER: the reservation's answer for held[0] (lane 0's; undefined until one has been issued) ...
+    bool pending = false; // ... is on its way
     for (;;) {
         const uint32_t tn = t + gridDim.x;
         const bool next = tn < a.n_tiles;
@@ -410,6 +451,27 @@ __global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, 
         }
         // the next tile's text, requested before (PF 1) or inside (PF 2) this tile's epilogue
         if (PF == 1) lane_loads<ITER>(buf, halo, cn, sub_off_n, lane, have_n);
+        if (DEFER) {
+            // the sub-tile counted a pass ago: its reservation was issued before this pass's loads and has long been answered
+            if (pending) lane_commit<ITER>(a, lane, held[0], pend_b);
+            pending = false;
+            if (have) {
+                lane_count<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, held[0]);
+                pend_b = lane_reserve<ITER>(a, lane, held[0]);
+                pending = true;
+            } else if (lane == 0) {
+                a.desc[d] = 0ull; // nothing of this tile is this wave's
+            }
+            if (!next) {
+                if (pending) lane_commit<ITER>(a, lane, held[0], pend_b);
+                break;
+            }
+            t = tn;
+            c = cn;
+            sub_off = sub_off_n;
+            have = have_n;
+            continue;
+        }
         if (have) {
             if (n_held == 0 || kLaneBatchMax == 1) lane_count<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, held[0]);
             else if (n_held == 1 || kLaneBatchMax == 2) lane_count<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, held[kLaneBatchMax > 1 ? 1 : 0]);

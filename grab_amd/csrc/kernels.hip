@@ -135,9 +135,9 @@ __device__ __forceinline__ void emit_wave_t(const ScanArgs &a, uint32_t d, const
     const uint32_t shard = d & (kShards - 1);
     uint32_t b = 0;
     if (lane == 0) b = atomicAdd(a.counter + shard * kCtrStride, wtot);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     unsigned long long w[ITER / 4];
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xp + lane * ITER);
     uint32_t c = 0;
