@@ -388,6 +388,10 @@ def run_timed(argv, env, reps, warm=True, count_only=False):
     try:
         for it in range(0 if warm else 1, reps + 1):
             to_null = count_only and it > 0
+            # Half a second of quiet first: when a process that used the GPU has gone, the kernel is still taking its state
+            # apart, and the next process's hipInit waits for that -- 0.12 - 0.2 s instead of 0.05 (profiles/r04_c_*: the
+            # same command with and without the pause).  A one-shot command line is not started in another one's wake.
+            time.sleep(0.5)
             with open("/dev/null" if to_null else out_path, "wb") as out:
                 t0 = time.perf_counter()
                 r = subprocess.run(argv, stdout=out, stderr=subprocess.PIPE, env=env)

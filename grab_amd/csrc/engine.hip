@@ -73,7 +73,9 @@ constexpr size_t kCopyPiece = 32u << 20; // memcpy/H2D pipelining granule for fo
 constexpr size_t kMaxChunk = (1ull << 30) + 4096;
 
 // ---- ingest configuration (environment, read once) ----
-//   GSCAN_BLOCK_MIB     pinned pool block == read piece == one hipMemcpyAsync == batch buffer        (default 16)
+//   GSCAN_BLOCK_MIB     pinned pool block == read piece == one hipMemcpyAsync == batch buffer        (default 8: as fast as 16 in
+//                       the steady state, half the pinned memory -- every block costs 3-7 ms of hipHostMalloc while the pipe
+//                       fills and its share of the exit; profiles/r04_d_*)
 //   GSCAN_READERS       reader threads per device; 0 or unset = auto: 8, fewer when the device's NUMA node has few CPUs per
 //                       device (gscan_auto_readers: 8 GPUs x 8 readers must not outnumber the CPUs they are bound to)   (default auto)
 //   GSCAN_COPY_STREAMS  copy streams per context the pieces of a file range are spread over         (default 1)
@@ -129,7 +131,7 @@ const IngestCfg &ingest_cfg()
             long x = e && *e ? atol(e) : def;
             return std::max(lo, std::min(hi, x));
         };
-        v.block = (size_t)env("GSCAN_BLOCK_MIB", 16, 1, 64) << 20;
+        v.block = (size_t)env("GSCAN_BLOCK_MIB", 8, 1, 64) << 20;
         v.readers = (int)env("GSCAN_READERS", 0, 0, 64); // 0: auto, per device (Ingest's constructor)
         const long hw = (long)std::thread::hardware_concurrency();
         if (hw > 0 && v.readers > hw) v.readers = (int)hw;
@@ -914,7 +916,9 @@ int slot_reserve_device(gscan_ctx *c, Slot &s, size_t len)
         size_t cap = std::max<size_t>((std::max(len, had) + kPad + 0xfffff) & ~(size_t)0xfffff, 1u << 20);
         // with the line pass on, the window's gather buffer (the printed lines never overlap: their text fits the window) comes
         // out of the same allocation: hipMalloc is not cheap and every slot of every context would make a second one
+        trace("slot: text buffer, %zu MiB ...", (c->line_extents ? 2 * cap : cap) >> 20);
         HIPCHK(c, hipMalloc((void **)&s.d_text, c->line_extents ? 2 * cap : cap));
+        trace("slot: ... allocated");
         s.d_text_cap = cap - kPad;
         if (c->line_extents) {
             s.d_gather = s.d_text + cap;
@@ -932,7 +936,9 @@ int slot_reserve_device(gscan_ctx *c, Slot &s, size_t len)
         s.tiles_cap = 0;
         size_t cap = tiles + tiles / 4;
         HIPCHK(c, hipMalloc((void **)&s.d_desc, cap * 8));
+        trace("slot: descriptors on the device");
         HIPCHK(c, hipHostMalloc((void **)&s.h_desc, cap * 8, hipHostMallocDefault));
+        trace("slot: descriptors pinned (%zu KiB)", cap * 8 >> 10);
         s.tiles_cap = cap;
     }
     size_t want = std::max<size_t>((len / 64 + gscan::kShards - 1) / gscan::kShards * gscan::kShards, kSpecRecs);

@@ -287,19 +287,14 @@ __device__ __forceinline__ void lane_flush(const ScanArgs &a, uint32_t lane, con
 // by one -- and writes descriptor and records.  The atomic's round trip, which lane_flush sits out with nothing else of
 // this wave in flight, disappears behind the next tile's HBM latency; one held sub-tile (10 VGPRs) instead of two.
 template <int ITER>
-__device__ __forceinline__ uint32_t lane_reserve(const ScanArgs &a, uint32_t lane, const LaneCounted<ITER / 2> &p)
+__device__ __forceinline__ void lane_reserve(const ScanArgs &a, uint32_t lane, const LaneCounted<ITER / 2> &p, uint32_t &b)
 {
-    // (b stays undefined where no atomic is issued -- lane_commit reads lane 0's, and only when there are records: an
-    // initialising v_mov would have to wait for the register's previous atomic, i.e. for every store issued since)
-    uint32_t b;
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wuninitialized"
-#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+    // b is assigned by the atomic and by nothing else (it keeps its old value where none is issued; lane_commit reads lane
+    // 0's, and only when there are records): a v_mov that initialised it here would have to wait for the register's
+    // previous atomic first -- s_waitcnt vmcnt(0) -- and with it for every record store issued since
     if (p.wtot) {
         if (lane == 0) b = atomicAdd(a.counter + (p.d & (kShards - 1)) * kCtrStride, p.wtot); // index inside the shard's region
     }
-    return b;
-#pragma clang diagnostic pop
 }
 template <int ITER>
 __device__ __forceinline__ void lane_commit(const ScanArgs &a, uint32_t lane, const LaneCounted<ITER / 2> &p, uint32_t b)
@@ -390,7 +385,7 @@ __global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, 
     uint16_t *xp = s_xp + wave * (ITER * 64);
     LaneCounted<ITER / 2> held[kLaneBatchMax]; // counted sub-tiles whose records are not written yet
     int n_held = 0;
-    uint32_t pend_b;      // DEFER: the reservation's answer for held[0] (lane 0's; undefined until one has been issued) ...
+    uint32_t pend_b = 0;  // DEFER: the reservation's answer for held[0] (lane 0's) ...
     bool pending = false; // ... is on its way
     for (;;) {
         const uint32_t tn = t + gridDim.x;
@@ -457,7 +452,7 @@ __global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, 
             pending = false;
             if (have) {
                 lane_count<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, held[0]);
-                pend_b = lane_reserve<ITER>(a, lane, held[0]);
+                lane_reserve<ITER>(a, lane, held[0], pend_b);
                 pending = true;
             } else if (lane == 0) {
                 a.desc[d] = 0ull; // nothing of this tile is this wave's
