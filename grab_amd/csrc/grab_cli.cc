@@ -188,6 +188,30 @@ std::vector<std::vector<int>> device_cpu_lists(int ndev)
     return out;
 }
 
+// The HIP runtime initialises every device it can see, whether or not anything is ever sent there (on an 8-GPU node that is
+// most of hipInit's time and of the exit's).  What the input can use is known before the first HIP call: explicit files of
+// one window each need ONE device; `-n N` with N below the device count needs the first N.  Narrow HIP_VISIBLE_DEVICES to
+// that -- within whatever list the caller has already set -- unless the caller chose devices itself (GRAB_DEVICE,
+// GRAB_DEVICES, GRAB_ALL_DEVICES=1).
+void narrow_visible_devices(size_t want)
+{
+    if (want == 0 || getenv("GRAB_DEVICE") || getenv("GRAB_DEVICES") || getenv("GRAB_ALL_DEVICES") || getenv("GSCAN_VIRTUAL_DEVICES")) return;
+    const char *have = getenv("HIP_VISIBLE_DEVICES");
+    std::string list;
+    if (have && *have) { // the first `want` entries of the caller's list
+        size_t n = 0;
+        for (const char *q = have; *q && n < want; q++) {
+            if (*q == ',' && ++n == want) break;
+            list += *q;
+        }
+    } else {
+        for (size_t i = 0; i < want; i++) list += (i ? "," : "") + std::to_string(i);
+    }
+    setenv("HIP_VISIBLE_DEVICES", list.c_str(), 1);
+    static const bool on = getenv("GRAB_TIMING") != nullptr;
+    if (on) fprintf(stderr, "[grab timing] visible devices narrowed to %s\n", list.c_str());
+}
+
 int run_workers(const Options &o)
 {
     if (!o.recursive) {
@@ -234,6 +258,7 @@ int run_workers(const Options &o)
         }
     }
 
+    narrow_visible_devices((size_t)o.workers); // worker i drives device i mod #devices: fewer workers than devices leave the rest idle
     JobQueue queue;
     // the walk starts at once, on its own threads; the workers open their devices meanwhile
     int walkers = 4;
@@ -320,6 +345,15 @@ int run_serial(const Options &o)
     } closer{gp};
     FileGrep &grep = *gp;
     auto cfg = o.cfg;
+    if (!o.recursive) { // explicit paths: how many windows can be in flight at once is known before the runtime is up
+        const size_t chunk = cfg.count("chunk_size") ? cfg.at("chunk_size") : (size_t(1) << 30), stride = chunk - 4096;
+        size_t most = 1;
+        for (const std::string &p : o.paths) {
+            struct stat st;
+            if (stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode)) most = std::max(most, ((size_t)st.st_size + stride - 1) / stride);
+        }
+        if (most <= 64) narrow_visible_devices(most);
+    }
     if (const char *dev = getenv("GRAB_DEVICE")) cfg["device"] = size_t(atoi(dev));
     // a file of several windows is spread over the node's GPUs (contexts beyond the first open when such a file turns up)
     if (const char *n = getenv("GRAB_DEVICES")) cfg["devices"] = size_t(std::max(1, atoi(n)));

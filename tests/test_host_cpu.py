@@ -200,3 +200,33 @@ def test_detached_parent_forwards_signals(built, tmp_path):
     time.sleep(0.3)
     out = subprocess.run(["pgrep", "-f", str(big)], capture_output=True, text=True).stdout.split()
     assert out == [], "a scanning child outlived its signalled parent: %s" % out
+
+
+def test_visible_devices_are_narrowed_before_the_runtime_starts(built, tmp_path):
+    """hipInit brings up every device it can see; what the input can use is known before the first HIP call (VERDICT r3 task
+    3c): explicit files of one window need one device, `-n N` the first N -- taken from the caller's own HIP_VISIBLE_DEVICES
+    list when there is one; GRAB_DEVICE / GRAB_DEVICES / GRAB_ALL_DEVICES leave the list alone.  (Runs without a device: the
+    mark is printed before the runtime is touched.)"""
+    f = tmp_path / "f.txt"
+    f.write_bytes(b"foo\n" * 10)
+    big = tmp_path / "big.bin"
+    with open(big, "wb") as fh:
+        fh.truncate((64 << 20) + 5)  # sparse: three 32 MiB windows under -L x 5
+
+    def narrowed(argv, **env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith(("HIP_VISIBLE", "GRAB_", "GSCAN_"))}
+        e.update(env, GRAB_TIMING="1")
+        r = subprocess.run([built.bin_path()] + argv, capture_output=True, text=True, env=e, cwd=str(tmp_path))
+        got = [ln.split("narrowed to ")[1] for ln in r.stderr.splitlines() if "visible devices narrowed to" in ln]
+        return got[0] if got else None
+
+    assert narrowed(["foo", "f.txt"]) == "0"
+    assert narrowed(["foo", "f.txt"], HIP_VISIBLE_DEVICES="3,5,7") == "3"
+    assert narrowed(["-L", "-L", "-L", "-L", "-L", "foo", "big.bin"]) == "0,1,2"
+    assert narrowed(["-L", "-L", "-L", "-L", "-L", "foo", "big.bin"], HIP_VISIBLE_DEVICES="4,5") == "4,5"
+    assert narrowed(["-n", "2", "-r", "foo", "."], HIP_VISIBLE_DEVICES="3,5,7") == "3,5"
+    assert narrowed(["-n", "2", "-r", "foo", "."]) == "0,1"
+    assert narrowed(["-r", "foo", "."]) is None  # a tree: how many windows it holds is not known up front
+    assert narrowed(["foo", "f.txt"], GRAB_DEVICES="2") is None
+    assert narrowed(["foo", "f.txt"], GRAB_DEVICE="1") is None
+    assert narrowed(["foo", "f.txt"], GRAB_ALL_DEVICES="1") is None
