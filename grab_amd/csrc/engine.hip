@@ -158,6 +158,7 @@ struct PinBlock {
     void *p = nullptr;
     hipEvent_t ev = nullptr;
     bool from_slab = false;
+    bool marked = false; // ev was recorded behind this block's DMA (only every GSCAN_MARK_EVERY-th block of a stream is: see Lane)
 };
 
 // One file range on its way to HBM (gscan_submit_fd): its pieces are read by the reader threads; whoever finishes the
@@ -402,7 +403,11 @@ private:
             if (cpus <= 0) cpus = have_mask_ ? CPU_COUNT(&mask_) : (int)std::thread::hardware_concurrency();
             readers_ = gscan_auto_readers(cpus, std::max(1, sharing));
         }
-        cap_ = (size_t)readers_ * 2;
+        {
+            const char *k = getenv("GSCAN_MARK_EVERY");
+            mark_every_ = std::max(1, std::min(16, k && *k ? atoi(k) : 4));
+        }
+        cap_ = (size_t)readers_ * 2 + (mark_every_ > 1 ? 2 * (size_t)mark_every_ : 0); // (blocks come back K at a time: K more per lane keep the readers busy meanwhile)
         timing_ = getenv("GSCAN_TIMING") != nullptr;
         // GSCAN_PREALLOC=n (measured and left off, profiles/r04_c_*): the first n blocks made in the background while the
         // opener creates its streams and sizes its first slot.  The runtime serves one allocation at a time: the opener's
@@ -440,7 +445,8 @@ private:
         for (std::thread &t : threads_) t.join();
         if (prealloc_.joinable()) prealloc_.join();
         (void)hipSetDevice(hip_device_of(device_));
-        for (PinBlock *b : busy_) free_block(b, true);
+        for (auto &l : lanes_)
+            for (PinBlock *b : l->fifo) free_block(b, false); // (every context is closed: gscan_close has waited for the device)
         for (PinBlock *b : free_) free_block(b, false);
         for (PinBlock *b : slot_free_) free_block(b, false);
         for (hipStream_t st : shared_)
@@ -487,6 +493,52 @@ private:
         return b;
     }
 
+    // DMA bookkeeping, one Lane per copy stream.  The blocks whose DMA has been queued on the stream sit in `fifo` in stream
+    // order (`order` makes "enqueue + push" one step).  An event is recorded behind every K-th of them only (K =
+    // GSCAN_MARK_EVERY, default 4): a stream is in order, so an event that has completed frees every block in front of it.
+    // An event after EVERY copy -- round 3's scheme -- made the runtime put a barrier packet between any two copies: the
+    // SDMA engine waits for the command processor to see copy k's signal before it may start copy k + 1, 26 us per 8 MiB
+    // piece in which the link carried nothing (46 GB/s in the pipeline where the same copies back to back move 53-57;
+    // profiles/r04_e_*, r04_f_*).
+    struct Lane {
+        hipStream_t st = nullptr;
+        std::mutex order;
+        std::deque<PinBlock *> fifo;
+        int since_mark = 0;
+        bool waiter = false; // a reader is blocked on one of this lane's events
+    };
+    Lane *lane_for(hipStream_t st) // (under m_)
+    {
+        for (auto &l : lanes_)
+            if (l->st == st) return l.get();
+        lanes_.emplace_back(new Lane());
+        lanes_.back()->st = st;
+        return lanes_.back().get();
+    }
+    // free every block in front of (and including) the last marked block whose event has completed (under m_)
+    size_t reap()
+    {
+        size_t freed = 0;
+        for (auto &l : lanes_) {
+            size_t upto = 0;
+            for (size_t i = 0; i < l->fifo.size(); i++) {
+                if (!l->fifo[i]->marked) continue;
+                if (hipEventQuery(l->fifo[i]->ev) != hipSuccess) {
+                    (void)hipGetLastError();
+                    break;
+                }
+                upto = i + 1;
+            }
+            for (size_t i = 0; i < upto; i++) {
+                l->fifo.front()->marked = false;
+                free_.push_back(l->fifo.front());
+                l->fifo.pop_front();
+            }
+            freed += upto;
+        }
+        return freed;
+    }
+
     PinBlock *take_reader_block()
     {
         std::unique_lock<std::mutex> lk(m_);
@@ -496,13 +548,9 @@ private:
                 free_.pop_back();
                 return b;
             }
-            // a block whose DMA is over is as good as a free one -- and a new block costs 3-4 ms of hipHostMalloc (0.22 s per GiB,
-            // one at a time inside the runtime) where a 16 MiB DMA takes 0.3 ms: the pool only grows while every block is busy
-            if (!busy_.empty() && hipEventQuery(busy_.front()->ev) == hipSuccess) {
-                PinBlock *b = busy_.front();
-                busy_.pop_front();
-                return b;
-            }
+            // a block whose DMA is over is as good as a free one -- and a new block costs 2-7 ms of hipHostMalloc (0.22 s per GiB,
+            // one at a time inside the runtime) where an 8 MiB DMA takes 0.15 ms: the pool only grows while every block is busy
+            if (reap()) continue;
             if (n_alloc_ < cap_) {
                 n_alloc_++;
                 lk.unlock();
@@ -512,23 +560,52 @@ private:
                 if (b) return b;
                 lk.lock();
                 n_alloc_--;
-                if (n_alloc_ == 0 && busy_.empty()) return nullptr; // no pinned memory at all
+                bool any = false;
+                for (auto &l : lanes_) any = any || !l->fifo.empty();
+                if (n_alloc_ == 0 && !any) return nullptr; // no pinned memory at all
                 continue;
             }
-            if (!busy_.empty()) { // the oldest DMA out of a block: wait for it outside the lock
-                PinBlock *b = busy_.front();
-                busy_.pop_front();
-                lk.unlock();
-                (void)hipEventSynchronize(b->ev);
-                return b;
+            // every block is on its way out: one reader per lane waits for that lane's next event (recording one behind the
+            // lane's last block if none is pending), the others for the blocks it will free
+            Lane *pick = nullptr;
+            for (auto &l : lanes_)
+                if (!l->fifo.empty() && !l->waiter && (!pick || l->fifo.size() > pick->fifo.size())) pick = l.get();
+            if (!pick) {
+                cv_blocks_.wait(lk);
+                continue;
             }
-            cv_blocks_.wait(lk);
+            PinBlock *target = nullptr;
+            for (PinBlock *x : pick->fifo)
+                if (x->marked) {
+                    target = x;
+                    break;
+                }
+            pick->waiter = true;
+            lk.unlock();
+            if (!target) { // nothing marked in flight: mark the lane's tail now (in stream order: under `order`)
+                std::lock_guard<std::mutex> ord(pick->order);
+                std::lock_guard<std::mutex> again(m_);
+                if (!pick->fifo.empty()) {
+                    target = pick->fifo.back();
+                    if (!target->marked) {
+                        if (hipEventRecord(target->ev, pick->st) != hipSuccess) (void)hipGetLastError();
+                        target->marked = true;
+                        pick->since_mark = 0;
+                    }
+                }
+            }
+            if (target) (void)hipEventSynchronize(target->ev);
+            lk.lock();
+            pick->waiter = false;
+            if (reap()) cv_blocks_.notify_all();
         }
     }
-    void give_reader_block(PinBlock *b, bool dma_pending)
+    // the block goes back: straight to the free list, or -- its DMA queued on `st` by the caller, who holds that lane's
+    // `order` -- to the tail of the lane
+    void give_reader_block(PinBlock *b, Lane *lane)
     {
         std::lock_guard<std::mutex> lk(m_);
-        if (dma_pending) busy_.push_back(b);
+        if (lane) lane->fifo.push_back(b);
         else free_.push_back(b);
         cv_blocks_.notify_one();
     }
@@ -618,18 +695,32 @@ private:
                 }
                 t3 = timing_ ? now() : 0;
                 trace("reader: %zu bytes read", t.n);
-                bool dma = false;
                 if (!err) {
-                    if (hipMemcpyAsync(t.dst, b->p, t.n, hipMemcpyHostToDevice, t.stream) != hipSuccess ||
-                        hipEventRecord(b->ev, t.stream) != hipSuccess) {
+                    Lane *lane;
+                    {
+                        std::lock_guard<std::mutex> lk(m_);
+                        lane = lane_for(t.stream);
+                    }
+                    std::lock_guard<std::mutex> ord(lane->order); // (enqueue + push: the lane's fifo is the stream's order)
+                    if (hipMemcpyAsync(t.dst, b->p, t.n, hipMemcpyHostToDevice, t.stream) != hipSuccess) {
                         (void)hipGetLastError();
                         (void)hipStreamSynchronize(t.stream);
                         err = -2;
+                        give_reader_block(b, nullptr);
                     } else {
-                        dma = true;
+                        if (++lane->since_mark >= mark_every_) {
+                            if (hipEventRecord(b->ev, t.stream) == hipSuccess) {
+                                b->marked = true;
+                                lane->since_mark = 0;
+                            } else {
+                                (void)hipGetLastError();
+                            }
+                        }
+                        give_reader_block(b, lane);
                     }
+                } else {
+                    give_reader_block(b, nullptr);
                 }
-                give_reader_block(b, dma);
             }
             if (timing_) {
                 const double t4 = now();
@@ -672,7 +763,8 @@ private:
     std::mutex m_;
     std::condition_variable cv_blocks_, cv_tasks_;
     std::vector<PinBlock *> free_, slot_free_;
-    std::deque<PinBlock *> busy_;
+    std::vector<std::unique_ptr<Lane>> lanes_;
+    int mark_every_ = 4;
     std::deque<ReadTask> tasks_;
     std::vector<std::thread> threads_;
     std::thread prealloc_;

@@ -322,7 +322,7 @@ __device__ __forceinline__ void lane_commit(const ScanArgs &a, uint32_t lane, co
 // PF: where the next tile's loads are issued -- 0: at the top of its own pass (no prefetch), 1: between this tile's last step
 // and its epilogue, 2: inside the epilogue, right behind the reserving atomic.
 #ifndef GSCAN_LANE_DEFER
-#define GSCAN_LANE_DEFER 1
+#define GSCAN_LANE_DEFER 0
 #endif
 template <int NCLS, int NR, int S0, int S1, int PF = 0, int ITER = kLIter, int DEFER = GSCAN_LANE_DEFER>
 __global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
