@@ -114,9 +114,12 @@ struct IngestCfg {
     // contexts with two streams each were 0.1 s of start-up and 2 GB of resident memory for nothing: a 64 MiB window scans in
     // 15 us and the copies share one link.  So the contexts of a device share its streams by default.
     int shared_copy;    // GSCAN_SHARED_COPY (1): N = the contexts of a device share N copy streams; 0 = every context has its own
-    bool one_stream;    // GSCAN_ONE_STREAM (1): copies, scans and read-backs of a device all go down ONE stream (one HSA queue): a
-                        // 64 MiB window scans in 15 us and the link carries one copy at a time anyway; every further stream is
-                        // 7 - 12 ms at start-up, 177 MB of wave-save area and 4 ms at exit (measured: profiles/r04_c_*)
+    bool one_stream;    // GSCAN_ONE_STREAM (1): no stream of their own for the scans and read-backs -- they ride on the device's first
+                        // copy stream (a 64 MiB window scans in 15 us); every further stream is 7 - 12 ms at start-up, 177 MB of
+                        // wave-save area and 4 ms at exit (profiles/r04_c_*).  The pieces of a window alternate between TWO copy
+                        // streams (GSCAN_ONE_STREAM_COPIES): with the readers no longer short of blocks it is the DMA side that
+                        // sets the pace, and a second stream's copy runs in the first one's gaps -- 46.7 -> 49.2 GB/s through the
+                        // pipe at 64 GiB; a third adds nothing (profiles/r04_f_*)
     int shared_compute; // GSCAN_SHARED_COMPUTE (2): N = they share N scan streams, dealt round robin; 0 = every context has its own
     bool slab;          // GSCAN_SLAB: the reader blocks of a device are carved from ONE pinned allocation instead of one each
     int read_mode;      // GSCAN_READ_MODE: 0 pread(2) into the block; 1 map the piece and copy it with non-temporal stores
@@ -142,7 +145,7 @@ const IngestCfg &ingest_cfg()
         // (the default unless the stream layout is spelled out: any of the three knobs above set means the caller wants that layout)
         const bool layout_given = getenv("GSCAN_SHARED_COPY") || getenv("GSCAN_SHARED_COMPUTE") || getenv("GSCAN_COPY_STREAMS");
         v.one_stream = env("GSCAN_ONE_STREAM", layout_given ? 0 : 1, 0, 1) != 0;
-        if (v.one_stream) v.shared_copy = 1;
+        if (v.one_stream) v.shared_copy = (int)env("GSCAN_ONE_STREAM_COPIES", 2, 1, 4); // (the scans ride on the first of them)
         v.slab = env("GSCAN_SLAB", 0, 0, 1) != 0;
         v.read_mode = (int)env("GSCAN_READ_MODE", 0, 0, 2); // (1 and 2 measured and not adopted: profiles/r02_d_e2e_reader_modes.jsonl)
         const long pf = env("GSCAN_PIN_FLAGS", 0, 0, 2);
@@ -405,7 +408,7 @@ private:
         }
         {
             const char *k = getenv("GSCAN_MARK_EVERY");
-            mark_every_ = std::max(1, std::min(16, k && *k ? atoi(k) : 4));
+            mark_every_ = std::max(1, std::min(16, k && *k ? atoi(k) : 1));
         }
         cap_ = (size_t)readers_ * 2 + (mark_every_ > 1 ? 2 * (size_t)mark_every_ : 0); // (blocks come back K at a time: K more per lane keep the readers busy meanwhile)
         timing_ = getenv("GSCAN_TIMING") != nullptr;
@@ -494,12 +497,10 @@ private:
     }
 
     // DMA bookkeeping, one Lane per copy stream.  The blocks whose DMA has been queued on the stream sit in `fifo` in stream
-    // order (`order` makes "enqueue + push" one step).  An event is recorded behind every K-th of them only (K =
-    // GSCAN_MARK_EVERY, default 4): a stream is in order, so an event that has completed frees every block in front of it.
-    // An event after EVERY copy -- round 3's scheme -- made the runtime put a barrier packet between any two copies: the
-    // SDMA engine waits for the command processor to see copy k's signal before it may start copy k + 1, 26 us per 8 MiB
-    // piece in which the link carried nothing (46 GB/s in the pipeline where the same copies back to back move 53-57;
-    // profiles/r04_e_*, r04_f_*).
+    // order (`order` makes "enqueue + push" one step).  An event is recorded behind every K-th of them (K = GSCAN_MARK_EVERY,
+    // default 1): a stream is in order, so an event that has completed frees every block in front of it.  K = 4 and 8 were
+    // built to test whether the barrier packet an event puts between two copies is what keeps the pipe at 46-48 GB/s where
+    // the same copies back to back move 53-57: it is not -- 46.1 / 46.7 / 47.2 GB/s for K = 1 / 4 / 8 (profiles/r04_g_*).
     struct Lane {
         hipStream_t st = nullptr;
         std::mutex order;
