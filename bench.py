@@ -18,20 +18,25 @@ One JSON line on rank 0: the driver's contract fields, plus
                   launch stream, vs the 8 TB/s HBM peak
   "kernels"       the same block for the OTHER two kernels (cfg3 = BASELINE configs[2], alt), timed in the same
                   process on the same arena, outside the headline's timed region
+  "kernels"       (every block: "check" -- the launch's records of the first and last file against the oracle's candidate set --,
+                  three interleaved passes with the median reported, min / max and every pass's clock and power beside it)
   "e2e"           the drop-in binary end to end (PCIe-inclusive): the same corpus written to /dev/shm once (pages
-                  interleaved over the NUMA nodes), `grab -n max(8, 4 N) -r` over the first N devices -- one walk, one
-                  queue, files sharded over the GPUs -- wall clock of the whole (ONE) process, output line count
-                  checked, fraction of the 63 GB/s-per-GPU PCIe Gen5 x16 roofline, bytes each device was handed;
-                  the GRAB_DETACH=1 figure (teardown left to a child) beside it.  "scaling": "strong"
+                  interleaved over the NUMA nodes), `grab -n 4 N (>= 8) -r` over the first N devices -- one walk, one
+                  queue, files sharded over the GPUs -- wall clock of the whole (ONE) process after half a second of quiet,
+                  output line count checked, fraction of the 63 GB/s-per-GPU PCIe Gen5 x16 roofline, start-up / scan phase /
+                  exit split, bytes each device was handed; the GRAB_DETACH=1 figure beside it.  "scaling": "strong"
   "cpu_baseline"  the reference binary (oracle/_ref/grab_jit), or the oracle port, on this box's host cores over
                   that same on-disk corpus (N=1, rank 0 only): -n swept over {32, 64, 128, all}, best kept
   "e2e_cfg3"      BASELINE configs[2] end to end at its full size: the whole corpus, `grab -n 8 -r -O -l IDENT`, line count,
                   the same on the first 16 GiB ("at_16GiB"), sorted-output md5 against the reference on a 1 GiB subset,
                   its own cpu_baseline (the reference on a 4 GiB sample)
-  "e2e_cfg4"      BASELINE configs[3] at 16 GiB: 32 768 files of 512 KiB in a 64 x 64 directory tree, one needle each,
-                  `grab -n 8 -r -O -l`, line count == file count, sorted md5 against the reference, its own cpu_baseline
-  "e2e_cfg5"      BASELINE configs[4] at 8 GiB: ONE file with dense planted needles incl. every chunk-boundary
-                  case, `grab -O -l` byte-exact (md5) against the reference, its own single-core cpu_baseline
+  "e2e_cfg1"      BASELINE configs[0]: ONE 256 MiB file, the literal that is not in it, `grab` against `grab_jit` on one core
+  "e2e_cfg5"      BASELINE configs[4] at its full size: ONE 32 GiB file with a million planted needles incl. every
+                  chunk-boundary case, `grab -O -l` byte-exact (md5) against the reference, its own single-core
+                  cpu_baseline; the same on an 8 GiB file ("at_8GiB")
+  "e2e_cfg4"      BASELINE configs[3] at its full size: 131 072 files of 512 KiB in a 64 x 64 x 32 tree, one needle each,
+                  `grab -n 8 -r -O -l`, line count == file count, sorted md5 against the reference, its own cpu_baseline;
+                  the same over a quarter of the tree ("at_16GiB")
   "roofline.traffic"  HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately, counters
                   only) run by this script over the native harness (grab_amd/bin/gscan_sweep, same kernels, same
                   arena size); falls back to the committed profile, labelled, if rocprofv3 cannot run
@@ -419,10 +424,18 @@ def run_timed(argv, env, reps, warm=True, count_only=False):
     return best
 
 
+def pick_workers(n_gpus):
+    """`-n` for N devices: FOUR workers per device, at least eight.  One worker keeps a device's pipe full (three
+    windows in flight: `grab -r`, -n 4 and -n 8 move the literal corpus at the same rate, profiles/r04_e_*); what needs more
+    is formatting: BASELINE configs[2] prints 172.9 M lines during a scan phase of 1.4 / N seconds, 123 M x N lines per
+    second, and a worker formats 30-60 M per second with the match ends from the device (15 ns per line + the sink:
+    profiles/r04_c_report_probe.txt) -- 2 to 4 per device.  Eight on a lone device cost nothing (same rate as four)."""
+    return max(8, 4 * n_gpus)
+
+
 def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=2, workers=None, detached=True, count_only=False, warm=True):
-    """`grab -n max(8, 4 N) -r` over the corpus directory on the first N devices (a worker submits, waits and prints in turn:
-    several per device keep its three windows in flight)."""
-    workers = max(8, 4 * n_gpus) if workers is None else workers
+    """`grab -n pick_workers(N) -r` over the corpus directory on the first N devices."""
+    workers = pick_workers(n_gpus) if workers is None else workers
     allowed = len(os.sched_getaffinity(0))
     workers = max(1, min(workers, allowed))
     env = dict(os.environ, GRAB_TIMING="1")
@@ -454,6 +467,9 @@ def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=
             "detached_wall_s": det_s and round(det_s, 4), "detached_GBps": det_s and round(nbytes / det_s / 1e9, 2),
             "scan_phase_s": scan_s and round(scan_s, 4), "scan_phase_GBps": scan_s and round(nbytes / scan_s / 1e9, 2),
             "scan_phase_frac": scan_s and round(nbytes / scan_s / 1e9 / (PCIE_PEAK_GBPS * n_gpus), 4),
+            # what of the run is neither: exec + hipInit in front ("startup_s"), and from the last window printed to the
+            # moment the caller has the exit status (the kernel taking the process's GPU state apart)
+            "exit_s": t_done is not None and round(dt - t_done, 4), "fixed_s": t_up is not None and t_done is not None and round(dt - (t_done - t_up), 4),
             "pcie_peak": PCIE_PEAK_GBPS * n_gpus, "frac": round(rate / (PCIE_PEAK_GBPS * n_gpus), 4),
             "lines": lines, "lines_expected": want_lines, "lines_ok": lines == want_lines,
             "matches_per_s": lines is not None and round(lines / dt, 1),
@@ -562,7 +578,7 @@ def e2e_cfg3(d, nfiles, file_bytes, n_gpus, want_cpu):
             d4, n4 = d + "_cfg3c", min(n16, max(1, (4 << 30) // file_bytes))
             try:
                 link_subset(d, d4, n4)
-                e["cpu_baseline"] = cpu_baseline(d4, n4, file_bytes, ident, ["-O", "-l"], threads=sorted(set([min(64, usable_cores()), usable_cores()])), reps=1, warm=False, count_only=True)
+                e["cpu_baseline"] = cpu_baseline(d4, n4, file_bytes, ident, ["-O", "-l"], threads=sorted(set([min(64, usable_cores()), usable_cores()])), reps=2, warm=False, count_only=True)
             finally:
                 shutil.rmtree(d4, ignore_errors=True)
             if e["cpu_baseline"] and "value" in e:
@@ -688,6 +704,7 @@ def e2e_cfg1(base, device, want_cpu):
         e = one_file_block([synth.NEEDLE.decode()], path, size, "one 256 MiB file", want_cpu, reps=5, ref_reps=5)
         s = one_file_block(["-S", synth.NEEDLE.decode()], path, size, "one 256 MiB file", False, reps=3)
         e["with_-S"] = {k: s.get(k) for k in ("value", "wall_s", "lines", "error") if k in s}
+        time.sleep(0.5)
         r = subprocess.run([bin_path(), synth.NEEDLE.decode(), path], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, GRAB_TIMING="1"))
         e["marks_s"] = dict((m.group(2).decode(), float(m.group(1))) for m in re.finditer(rb"\[grab timing\] \+([0-9.]+) s ([^\n]+)", r.stderr))
         return e
