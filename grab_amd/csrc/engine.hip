@@ -506,7 +506,6 @@ private:
         std::mutex order;
         std::deque<PinBlock *> fifo;
         int since_mark = 0;
-        bool waiter = false; // a reader is blocked on one of this lane's events
     };
     Lane *lane_for(hipStream_t st) // (under m_)
     {
@@ -566,39 +565,50 @@ private:
                 if (n_alloc_ == 0 && !any) return nullptr; // no pinned memory at all
                 continue;
             }
-            // every block is on its way out: one reader per lane waits for that lane's next event (recording one behind the
-            // lane's last block if none is pending), the others for the blocks it will free
+            // Every block is on its way out: wait for the next event of the lane with the most blocks in flight.  The waiter
+            // TAKES the blocks up to and including the marked one out of the lane first: while it sleeps on that event no
+            // other thread can query it, free the block or -- after a round through the free list -- record the event again
+            // (two threads on one hipEvent_t at a time is not something the runtime promises to survive).
             Lane *pick = nullptr;
             for (auto &l : lanes_)
-                if (!l->fifo.empty() && !l->waiter && (!pick || l->fifo.size() > pick->fifo.size())) pick = l.get();
+                if (!l->fifo.empty() && (!pick || l->fifo.size() > pick->fifo.size())) pick = l.get();
             if (!pick) {
-                cv_blocks_.wait(lk);
+                cv_blocks_.wait(lk); // (other waiters hold every block in flight: they will bring some back)
                 continue;
             }
-            PinBlock *target = nullptr;
-            for (PinBlock *x : pick->fifo)
-                if (x->marked) {
-                    target = x;
-                    break;
-                }
-            pick->waiter = true;
-            lk.unlock();
-            if (!target) { // nothing marked in flight: mark the lane's tail now (in stream order: under `order`)
-                std::lock_guard<std::mutex> ord(pick->order);
-                std::lock_guard<std::mutex> again(m_);
-                if (!pick->fifo.empty()) {
-                    target = pick->fifo.back();
-                    if (!target->marked) {
-                        if (hipEventRecord(target->ev, pick->st) != hipSuccess) (void)hipGetLastError();
-                        target->marked = true;
+            size_t upto = 0;
+            for (size_t i = 0; i < pick->fifo.size() && !upto; i++)
+                if (pick->fifo[i]->marked) upto = i + 1;
+            if (!upto) {
+                // nothing marked in flight (GSCAN_MARK_EVERY > 1): mark the lane's tail now -- in stream order, i.e. under
+                // `order`, which is taken BEFORE m_ everywhere
+                lk.unlock();
+                {
+                    std::lock_guard<std::mutex> ord(pick->order);
+                    std::lock_guard<std::mutex> again(m_);
+                    if (!pick->fifo.empty() && !pick->fifo.back()->marked) {
+                        if (hipEventRecord(pick->fifo.back()->ev, pick->st) != hipSuccess) (void)hipGetLastError();
+                        pick->fifo.back()->marked = true;
                         pick->since_mark = 0;
                     }
                 }
+                lk.lock();
+                continue;
             }
-            if (target) (void)hipEventSynchronize(target->ev);
+            std::vector<PinBlock *> mine(pick->fifo.begin(), pick->fifo.begin() + (long)upto);
+            pick->fifo.erase(pick->fifo.begin(), pick->fifo.begin() + (long)upto);
+            lk.unlock();
+            (void)hipEventSynchronize(mine.back()->ev); // a stream is in order: everything in front of it is over as well
             lk.lock();
-            pick->waiter = false;
-            if (reap()) cv_blocks_.notify_all();
+            PinBlock *take = mine.back();
+            take->marked = false;
+            mine.pop_back();
+            for (PinBlock *x : mine) {
+                x->marked = false;
+                free_.push_back(x);
+            }
+            if (!mine.empty()) cv_blocks_.notify_all();
+            return take;
         }
     }
     // the block goes back: straight to the free list, or -- its DMA queued on `st` by the caller, who holds that lane's
