@@ -3,10 +3,13 @@
 through `grab` against the oracle (libpcre under the reference's loop) on one file -- tests/test_gpu_filegrep.py's
 test_random_patterns_cli_vs_oracle with other seeds and a time budget instead of 45 patterns.
 
-    python scripts/gpu_random_campaign.py --seed 31337 --seconds 170 [--lead-repeat]
+    python scripts/gpu_random_campaign.py --seed 31337 --seconds 170 [--lead-repeat] [--tree]
 
 --lead-repeat: every pattern gets a leading unbounded repeat in front of it (the shapes whose alternatives share one device
-window and have been K1's / K2's since round 3).  Prints one JSON line; exit status 1 on any difference."""
+window and have been K1's / K2's since round 3).  --tree (round 4): the text is cut into 40 files of ragged sizes in a small
+tree and searched with `-r` (byte-exact: the serial walk is nftw's order) and `-n 3 -r` (sorted) alternately -- every pattern
+goes through the small-file path (names queued, the device's readers open and read them, one launch per batch).
+Prints one JSON line; exit status 1 on any difference."""
 import argparse
 import json
 import os
@@ -33,6 +36,7 @@ def main():
     ap.add_argument("--seed", type=int, default=31337)
     ap.add_argument("--seconds", type=float, default=170)
     ap.add_argument("--lead-repeat", action="store_true")
+    ap.add_argument("--tree", action="store_true")
     a = ap.parse_args()
     from grab_amd import engine
     from grab_amd.build import bin_path
@@ -47,6 +51,14 @@ def main():
     tiers, done, skipped, bad = {}, 0, 0, []
     with tempfile.TemporaryDirectory() as d:
         data.tofile(os.path.join(d, "f"))
+        if a.tree:
+            os.remove(os.path.join(d, "f"))
+            cuts = sorted(set([0, data.size] + [int(x) for x in nrng.integers(0, data.size, 37)] + [1000, 1001]))  # (1000..1001: a one-byte file)
+            for i, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+                sub = os.path.join(d, "f", "d%d" % (i % 4), "s%d" % (i % 3))
+                os.makedirs(sub, exist_ok=True)
+                data[lo:hi].tofile(os.path.join(sub, "p%02d" % i))
+            open(os.path.join(d, "f", "empty"), "wb").close()
         t0 = time.time()
         while time.time() - t0 < a.seconds:
             pat = gen(rng)
@@ -61,6 +73,9 @@ def main():
                 skipped += 1
                 continue
             flags = [["-O", "-l"], ["-O"], []][done % 3]
+            threaded = a.tree and done % 2 == 1
+            if a.tree:
+                flags = (["-n", "3"] if threaded else []) + ["-r"] + flags
             orc, oout, oerr = run(oracle, flags + [pat, "f"], d)
             if orc != 0:
                 skipped += 1
@@ -71,10 +86,19 @@ def main():
                 continue
             key = "tier%d%s" % (db.info.tier, "+vm" if db.info.vm else "")
             tiers[key] = tiers.get(key, 0) + 1
-            if rc != 0 or out != oout:
+            if threaded and "-O" in flags and "-l" not in flags:  # (offset line + text line belong together: compare 2-line records)
+                def recs(b):
+                    ls = b.split(b"\n")
+                    return sorted(zip(ls[0:-1:2], ls[1::2]))
+                same = len(out) == len(oout) and recs(out) == recs(oout)
+            elif threaded:
+                same = sorted(out.splitlines()) == sorted(oout.splitlines())
+            else:
+                same = out == oout
+            if rc != 0 or not same:
                 bad.append({"pattern": pat, "flags": flags, "rc": rc, "lines": out.count(b"\n"), "oracle_lines": oout.count(b"\n"), "err": err[-200:].decode("latin-1")})
             done += 1
-    print(json.dumps({"seed": a.seed, "lead_repeat": a.lead_repeat, "compared": done, "skipped": skipped, "by_tier": tiers, "differences": bad}))
+    print(json.dumps({"seed": a.seed, "lead_repeat": a.lead_repeat, "tree": a.tree, "compared": done, "skipped": skipped, "by_tier": tiers, "differences": bad}))
     return 1 if bad else 0
 
 
