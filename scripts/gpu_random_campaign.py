@@ -86,15 +86,20 @@ def main():
                 continue
             key = "tier%d%s" % (db.info.tier, "+vm" if db.info.vm else "")
             tiers[key] = tiers.get(key, 0) + 1
-            if threaded and "-O" in flags and "-l" not in flags:  # (offset line + text line belong together: compare 2-line records)
-                def recs(b):
-                    ls = b.split(b"\n")
-                    return sorted(zip(ls[0:-1:2], ls[1::2]))
-                same = len(out) == len(oout) and recs(out) == recs(oout)
-            elif threaded:
-                same = sorted(out.splitlines()) == sorted(oout.splitlines())
-            else:
-                same = out == oout
+            if threaded and "-O" in flags and "-l" not in flags:
+                # offset line + text belong together, and the text may hold newlines of its own (a match of [^a] or \s):
+                # a file's output is written in one piece (one chunk per file here), so cut the stream where a record of
+                # ANOTHER file begins and compare file by file
+                def by_file(b):
+                    import re
+                    out_, cur_ = {}, None
+                    for ln in b.split(b"\n"):
+                        m_ = re.match(rb"^(f/[^:]+):Match at offset \d+$", ln)
+                        if m_:
+                            cur_ = m_.group(1)
+                        out_.setdefault(cur_, []).append(ln)
+                    return out_
+                same = len(out) == len(oout) and by_file(out) == by_file(oout)
             if rc != 0 or not same:
                 bad.append({"pattern": pat, "flags": flags, "rc": rc, "lines": out.count(b"\n"), "oracle_lines": oout.count(b"\n"), "err": err[-200:].decode("latin-1")})
             done += 1
