@@ -100,6 +100,10 @@ def main():
                         out_.setdefault(cur_, []).append(ln)
                     return out_
                 same = len(out) == len(oout) and by_file(out) == by_file(oout)
+            elif threaded:
+                same = sorted(out.splitlines()) == sorted(oout.splitlines())
+            else:
+                same = out == oout
             if rc != 0 or not same:
                 bad.append({"pattern": pat, "flags": flags, "rc": rc, "lines": out.count(b"\n"), "oracle_lines": oout.count(b"\n"), "err": err[-200:].decode("latin-1")})
             done += 1
