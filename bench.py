@@ -234,6 +234,23 @@ def time_kernel(ctx, db, arena, segs, stream, nbytes, cap_per_gib, steps, warmup
     return wall, total, overflow, kern_ms, launches, res
 
 
+def check_span(got, text, a, lo, hi, pattern, so):
+    """The records `got` (ascending offsets of one segment) inside [lo, hi) against the oracle's candidate set of `text` =
+    the segment's bytes [a, a + len(text)), a <= lo: every one a candidate, every start of a group of consecutive
+    candidates present.  None if so, else what is wrong."""
+    cands = so.all_starts(pattern.encode("latin-1"), text) + a
+    cset = np.zeros(len(text) + 1, bool)
+    cset[cands - a] = True
+    g = got[(got >= lo) & (got < hi)]
+    if g.size and not np.all(cset[g - a]):
+        return "a reported offset in [%d, %d) is not a candidate" % (lo, hi)
+    c = cands[(cands >= lo) & (cands < hi)]
+    heads = c[(c == a) | ~cset[np.maximum(c - a - 1, 0)]] if c.size else c  # candidates whose predecessor is none (c == a only at the segment's first byte)
+    if heads.size and not np.all(np.isin(heads, g)):
+        return "the start of a candidate group in [%d, %d) is missing" % (lo, hi)
+    return None
+
+
 def check_launch(ctx, res, arena, pattern, files, file_bytes, plants, total, overflow, planted_only):
     """What the timed launch left in HBM, checked on the first and the last file of the arena: the records of a file's first
     and last 4 MiB against the candidate set the oracle (oracle/scan_oracle.py: Python's re, no product code) finds in those
@@ -257,17 +274,9 @@ def check_launch(ctx, res, arena, pattern, files, file_bytes, plants, total, ove
         base = i * file_bytes
         for lo, hi in ((0, span), (file_bytes - span, file_bytes)):
             a, b = max(0, lo - halo), min(file_bytes, hi + halo)  # (a candidate is a function of the bytes AT it: the halo settles the window's edges)
-            text = arena[base + a:base + b].cpu().numpy().tobytes()
-            cands = so.all_starts(pattern.encode("latin-1"), text) + a
-            cset = np.zeros(b - a + 1, bool)
-            cset[cands - a] = True
-            g = got[(got >= lo) & (got < hi)]
-            if g.size and not np.all(cset[g - a]):
-                return "file %d: a reported offset in [%d, %d) is not a candidate" % (i, lo, hi)
-            c = cands[(cands >= lo) & (cands < hi)]
-            heads = c[(c == a) | ~cset[np.maximum(c - a - 1, 0)]] if c.size else c  # candidates whose predecessor is none (c == a only at the file's first byte)
-            if heads.size and not np.all(np.isin(heads, g)):
-                return "file %d: the start of a candidate group in [%d, %d) is missing" % (i, lo, hi)
+            bad = check_span(got, arena[base + a:base + b].cpu().numpy().tobytes(), a, lo, hi, pattern, so)
+            if bad:
+                return "file %d: %s" % (i, bad)
     return "ok"
 
 

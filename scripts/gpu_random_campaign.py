@@ -93,7 +93,7 @@ def main():
                 def by_file(b):
                     import re
                     out_, cur_ = {}, None
-                    for ln in b.split(b"\n"):
+                    for ln in (b[:-1] if b.endswith(b"\n") else b).split(b"\n"):
                         m_ = re.match(rb"^(f/[^:]+):Match at offset \d+$", ln)
                         if m_:
                             cur_ = m_.group(1)

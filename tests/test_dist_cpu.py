@@ -65,3 +65,29 @@ def test_gpus_must_match_world(monkeypatch):
     monkeypatch.setenv("RANK", "0")
     with pytest.raises(SystemExit):
         bench.dist_setup(2)
+
+
+def test_bench_checker_and_worker_rule():
+    """bench.py's own checker (check_span: the timed launch's records against the oracle's candidate set) says "ok" for what the
+    contract allows -- group starts, with or without further members of the groups -- and names what is wrong otherwise; the
+    `-n` rule is four workers per device, at least eight."""
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bench
+    import scan_oracle as so
+
+    text = b"xx abcdefghijklmnopqrstu  yy_0123456789abcdefgh zz short_id x" + b"q" * 40 + b" end"
+    pat = "[A-Za-z_][A-Za-z0-9_]{15,}"
+    cands = so.all_starts(pat.encode(), text)
+    heads = so.group_starts(cands)
+    assert len(heads) == 3 and len(cands) > len(heads)
+    n = len(text)
+    assert bench.check_span(heads, text, 0, 0, n, pat, so) is None
+    assert bench.check_span(cands, text, 0, 0, n, pat, so) is None              # more of a group is allowed
+    assert "missing" in bench.check_span(heads[1:], text, 0, 0, n, pat, so)     # a group start left out
+    assert "not a candidate" in bench.check_span(np.sort(np.append(heads, 1)), text, 0, 0, n, pat, so)
+    # a window cut out of a longer segment: text begins at a = 1000, the span checked is [1010, 1000 + n)
+    assert bench.check_span(heads + 1000, text, 1000, 1010, 1000 + n, pat, so) in (None,) or heads[0] + 1000 < 1010
+    assert [bench.pick_workers(k) for k in (1, 2, 4, 8)] == [8, 8, 16, 32]
