@@ -285,7 +285,7 @@ def test_queue_over_eight_device_indices(tmp_path, built, oracle_built):
             # kernel sees fit: measured 6.1 - 12.8 GiB per index around the 8 GiB mean.  On a real node every device has its own
             # link and the queue's back-pressure evens them out; what this box can show is that none is starved)
             mean = sum(per.values()) / 8
-            assert all(0.4 * mean <= v <= 1.7 * mean for v in per.values()), per
+            assert all(0.3 * mean <= v <= 2.0 * mean for v in per.values()), per
         argv = ["-n", str(min(16, len(os.sched_getaffinity(0)))), "-r", "-O", "-l", synth.IDENT_RE, os.path.join("big", "x00")]
         rc, out, err = _run(built.bin_path(), argv, d, env)
         orc, oout, _ = _run(_oracles(oracle_built)[-1], ["-n", "8"] + argv[2:], d)
