@@ -324,6 +324,9 @@ __device__ __forceinline__ void lane_commit(const ScanArgs &a, uint32_t lane, co
 #ifndef GSCAN_LANE_DEFER
 #define GSCAN_LANE_DEFER 0
 #endif
+#ifndef GSCAN_LANE_SCHED
+#define GSCAN_LANE_SCHED 0
+#endif
 template <int NCLS, int NR, int S0, int S1, int PF = 0, int ITER = kLIter, int DEFER = GSCAN_LANE_DEFER>
 __global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
@@ -413,6 +416,15 @@ __global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, 
                 if (k + 1 < ITER) GL_MERGE(pb, qb);       // step k + 1
                 else pb = hp, qb = hq;                    // ... of the last step: the halo (only lane 0 of it is looked at)
                 if (k + 2 < ITER) GL_LOOKUPS(buf[k + 2]); // in flight while step k is computed
+#if GSCAN_LANE_SCHED
+                // ... and (GSCAN_LANE_SCHED=1) made to stay there: left to itself the scheduler sinks half of the look-ups down
+                // to their first use (the next pass's merge) to save registers -- the disassembly shows an s_waitcnt lgkmcnt
+                // right behind eight freshly issued ds_reads.  With this line all sixteen are issued above step k's arithmetic
+                // (99 VGPRs instead of 88).  Measured, interleaved, one box (profiles/r04_o_*): identifier scan 5.36 against
+                // 5.41 TB/s, [0-9]{16} 6.20 against 6.14 -- inside the box's own +-4 %: four waves per SIMD cover the LDS
+                // round trip either way.  Off.
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 // the next lane's masks (lane 63: lane 0 of the next step)
                 const uint32_t a01 = down1(pa, __builtin_amdgcn_readfirstlane(pb));
                 uint32_t cand;
