@@ -103,6 +103,20 @@ void trace(const char *fmt, ...)
             (long)(uintptr_t)pthread_self() % 100000, buf);
 }
 
+// Staging memory made ready BEFORE the HIP runtime is up (gscan_prefault): the command line knows it is going to scan the
+// moment it starts, hipInit takes 50 ms, and a pinned block from hipHostMalloc costs 1.5 - 2 ms while the pipe fills (the
+// runtime serves one at a time: a 256 MiB file spends 25 of its 30 ms of transfer waiting for blocks).  So a helper thread
+// maps anonymous memory (huge pages where the kernel gives them) and touches it while the runtime starts; a block is then
+// taken from there and only REGISTERED with the runtime (pages present, nothing to zero).
+struct Prefault {
+    char *base = nullptr;
+    size_t stride = 0, count = 0;
+    std::atomic<size_t> next{0};
+    std::unique_ptr<std::atomic<bool>[]> touched;
+    std::vector<std::thread> th;
+};
+Prefault g_prefault;
+
 struct IngestCfg {
     size_t block;
     int readers;
@@ -161,6 +175,7 @@ struct PinBlock {
     void *p = nullptr;
     hipEvent_t ev = nullptr;
     bool from_slab = false;
+    bool registered = false; // p comes from the prefaulted arena and was hipHostRegister'ed (not hipHostMalloc'ed)
     bool marked = false; // ev was recorded behind this block's DMA (only every GSCAN_MARK_EVERY-th block of a stream is: see Lane)
 };
 
@@ -460,7 +475,8 @@ private:
     {
         if (wait) (void)hipEventSynchronize(b->ev);
         if (b->ev) (void)hipEventDestroy(b->ev);
-        if (b->p && !b->from_slab) (void)hipHostFree(b->p);
+        if (b->p && b->registered) (void)hipHostUnregister(b->p);
+        else if (b->p && !b->from_slab) (void)hipHostFree(b->p);
         delete b;
     }
 
@@ -484,6 +500,23 @@ private:
                 (void)hipGetLastError();
                 delete b;
                 return nullptr;
+            }
+        }
+        // a block that was mapped and touched while the runtime started (gscan_prefault): only registered here
+        if (g_prefault.base && g_prefault.stride >= block_bytes() + kPad) {
+            const size_t k = g_prefault.next.fetch_add(1, std::memory_order_relaxed);
+            if (k < g_prefault.count) {
+                while (!g_prefault.touched[k].load(std::memory_order_acquire)) std::this_thread::yield();
+                void *p = g_prefault.base + k * g_prefault.stride;
+                if (hipHostRegister(p, block_bytes() + kPad, hipHostRegisterDefault) == hipSuccess) {
+                    if (hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) == hipSuccess) {
+                        b->p = p;
+                        b->registered = true;
+                        return b;
+                    }
+                    (void)hipHostUnregister(p);
+                }
+                (void)hipGetLastError(); // (registration refused: the runtime's own allocator below)
             }
         }
         if (hipHostMalloc(&b->p, block_bytes() + kPad, ingest_cfg().pin_flags) != hipSuccess ||
@@ -1556,6 +1589,37 @@ int gscan_acquire(gscan_ctx *c, size_t len, void **pinned)
 }
 
 size_t gscan_block_size(void) { return block_bytes(); }
+
+int gscan_prefault(size_t blocks)
+{
+    if (g_prefault.base || blocks == 0) return GSCAN_OK; // once per process
+    if (const char *e = getenv("GSCAN_PREFAULT"))
+        if (atoi(e) == 0) return GSCAN_OK;
+    blocks = std::min<size_t>(blocks, 64);
+    const size_t huge = size_t(2) << 20;
+    const size_t stride = (block_bytes() + kPad + huge - 1) / huge * huge;
+    void *m = mmap(nullptr, stride * blocks + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) return GSCAN_ENOMEM;
+    char *base = (char *)(((uintptr_t)m + huge - 1) & ~(uintptr_t)(huge - 1));
+    (void)madvise(base, stride * blocks, MADV_HUGEPAGE);
+    g_prefault.stride = stride;
+    g_prefault.count = blocks;
+    g_prefault.touched.reset(new std::atomic<bool>[blocks]);
+    for (size_t k = 0; k < blocks; k++) g_prefault.touched[k].store(false, std::memory_order_relaxed);
+    g_prefault.base = base;
+    const size_t nth = std::min<size_t>(4, blocks);
+    const size_t used = block_bytes() + kPad;
+    for (size_t t = 0; t < nth; t++)
+        g_prefault.th.emplace_back([t, nth, blocks, base, stride, used] {
+            for (size_t k = t; k < blocks; k += nth) { // (block k is handed out k-th: the early ones first)
+                for (size_t o = 0; o < used; o += 4096) base[k * stride + o] = 0;
+                g_prefault.touched[k].store(true, std::memory_order_release);
+            }
+        });
+    for (std::thread &th : g_prefault.th) th.detach();
+    g_prefault.th.clear();
+    return GSCAN_OK;
+}
 
 // Reader threads for one device whose NUMA node offers `local_cpus` CPUs to this process and is shared by `devices_sharing`
 // devices: 8 where there are CPUs to spare (the measured optimum on a one-GPU box: more of them only wait for blocks), half

@@ -442,6 +442,20 @@ int main(int argc, char **argv)
             }
         }
     }
+    // staging memory is mapped and touched by helper threads while the HIP runtime starts (no HIP call in there; behind the fork above: threads do not survive one): as many
+    // blocks as the input can keep busy -- a tree: the reader pool's worth; explicit files: what their bytes fill
+    {
+        size_t blocks = 18;
+        if (!o.recursive && o.workers <= 1) {
+            unsigned long long total = 0;
+            for (const std::string &p : o.paths) {
+                struct stat st;
+                if (stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode)) total += (unsigned long long)st.st_size;
+            }
+            blocks = (size_t)std::min<unsigned long long>(18, total / gscan_block_size() + 1);
+        }
+        gscan_prefault(blocks);
+    }
     const int rc = o.workers > 1 ? run_workers(o) : run_serial(o);
     mark("scan done");
     std::cout.flush();

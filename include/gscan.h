@@ -252,6 +252,11 @@ long gscan_parse_cpulist(const char *list, int *cpus, size_t cap);
 #define GSCAN_SLOTS 3
 int gscan_acquire(gscan_ctx *ctx, size_t len, void **pinned);
 size_t gscan_block_size(void);
+/* Optional, before the first other call of a process that is about to scan (the command line calls it first thing in main):
+ * helper threads map and touch `blocks` staging blocks' worth of memory WHILE the HIP runtime starts; the reader pool then
+ * only registers them with the runtime instead of allocating pinned memory block by block while the pipe fills (1.5 - 2 ms
+ * each, one at a time).  No HIP call is made here.  GSCAN_PREFAULT=0 in the environment turns it into a no-op. */
+int gscan_prefault(size_t blocks);
 /* the ingest configuration in force (environment: GSCAN_BLOCK_MIB, GSCAN_READERS; copy streams: GSCAN_SHARED_COPY per device,
  * or GSCAN_COPY_STREAMS per context when GSCAN_SHARED_COPY=0); any pointer may be NULL */
 void gscan_ingest_info(size_t *block_bytes, int *readers, int *copy_streams);
