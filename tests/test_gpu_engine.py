@@ -725,3 +725,49 @@ def test_match_ends_on_device(ctx):
     finally:
         ctx.set_option("match_ends", 0)
         ctx.set_option("variant", DEFAULT_VARIANT)
+
+
+def test_prefaulted_staging_blocks(built, tmp_path):
+    """gscan_prefault: staging memory mapped and touched before the runtime is up, then registered by the reader pool instead of
+    allocated -- more blocks wanted than were made ahead (the pool falls back to the runtime's allocator for the rest), file
+    ranges of several pieces, a batch of small files; and GSCAN_PREFAULT=0 (a no-op).  In a process of its own: the arena
+    is made once per process, before anything else."""
+    import subprocess
+
+    driver = (
+        "import os, sys\n"
+        "import numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "from grab_amd import engine, synth\n"
+        "from inputs import db_candidates\n"
+        "sys.path.insert(0, os.path.join(%r, 'oracle'))\n"
+        "import scan_oracle as so\n"
+        "assert engine.lib().gscan_prefault(3) == 0\n"
+        "assert engine.lib().gscan_prefault(5) == 0  # once per process: the second call changes nothing\n"
+        "blk = engine.lib().gscan_block_size()\n"
+        "data = synth.text(5 * blk + 12345, 77)\n"
+        "data[blk - 9:blk + 9] = np.frombuffer(b'foobardoesnotexist', np.uint8)\n"
+        "d = sys.argv[1]\n"
+        "data.tofile(os.path.join(d, 'f.bin'))\n"
+        "small = []\n"
+        "for i in range(12):\n"
+        "    part = data[i * 70001:(i + 1) * 70001]\n"
+        "    part.tofile(os.path.join(d, 's%%02d' %% i))\n"
+        "    small.append((os.path.join(d, 's%%02d' %% i), part.size))\n"
+        "ctx = engine.Context(0, 1 << 30)\n"
+        "fd = os.open(os.path.join(d, 'f.bin'), os.O_RDONLY)\n"
+        "for pattern in ('foobardoesnotexist', '[A-Za-z_][A-Za-z0-9_]{15,}'):\n"
+        "    db = engine.Database(pattern)\n"
+        "    for rep in range(3):\n"
+        "        ctx.submit_fd(db, fd, 0, data.size, tag=1)\n"
+        "        ctx.submit_files(db, small, tag=2)\n"
+        "        ctx.submit_fd(db, fd, 4096, 2 * blk + 5, tag=3)\n"
+        "        t, s, _ = ctx.wait_segs(); assert t == 1 and so.check_reported(s[0], db_candidates(db, data))\n"
+        "        t, s, _ = ctx.wait_segs(); assert t == 2 and all(so.check_reported(s[i], db_candidates(db, data[i * 70001:(i + 1) * 70001])) for i in range(12))\n"
+        "        t, s, _ = ctx.wait_segs(); assert t == 3 and so.check_reported(s[0], db_candidates(db, data[4096:4096 + 2 * blk + 5]))\n"
+        "ctx.close()\n"
+        "print('PREFAULT OK')\n"
+    ) % (ROOT, ROOT, ROOT)
+    for env in ({}, {"GSCAN_PREFAULT": "0"}, {"GSCAN_READERS": "2"}):
+        r = subprocess.run([sys.executable, "-c", driver, str(tmp_path)], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "PREFAULT OK" in r.stdout, (env, r.stdout[-300:], r.stderr[-800:])
