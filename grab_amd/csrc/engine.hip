@@ -1595,9 +1595,9 @@ int gscan_prefault(size_t blocks)
     if (g_prefault.base || blocks == 0) return GSCAN_OK; // once per process
     if (const char *e = getenv("GSCAN_PREFAULT"))
         if (atoi(e) == 0) return GSCAN_OK;
-    blocks = std::min<size_t>(blocks, 64);
     const size_t huge = size_t(2) << 20;
     const size_t stride = (block_bytes() + kPad + huge - 1) / huge * huge;
+    blocks = std::min<size_t>(std::min<size_t>(blocks, 64), std::max<size_t>(1, (size_t(256) << 20) / stride)); // (at most 256 MiB touched ahead, whatever GSCAN_BLOCK_MIB says)
     void *m = mmap(nullptr, stride * blocks + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (m == MAP_FAILED) return GSCAN_ENOMEM;
     char *base = (char *)(((uintptr_t)m + huge - 1) & ~(uintptr_t)(huge - 1));
