@@ -1590,21 +1590,6 @@ int gscan_acquire(gscan_ctx *c, size_t len, void **pinned)
 
 size_t gscan_block_size(void) { return block_bytes(); }
 
-namespace {
-__global__ void k_nothing(int *p)
-{
-    if (p) p[0] = 0;
-}
-} // namespace
-// (diagnostic, not in gscan.h: GRAB_EXIT_KICK=1 makes the command line launch one empty kernel and wait for it right before it
-// leaves -- does a GPU that has just run something let its process go faster?  DESIGN.md 9)
-void gscan_debug_kick(int hip_device)
-{
-    if (hipSetDevice(hip_device_of(hip_device)) != hipSuccess) return;
-    hipLaunchKernelGGL(k_nothing, dim3(1), dim3(64), 0, nullptr, (int *)nullptr);
-    (void)hipDeviceSynchronize();
-}
-
 int gscan_prefault(size_t blocks)
 {
     if (g_prefault.base || blocks == 0) return GSCAN_OK; // once per process

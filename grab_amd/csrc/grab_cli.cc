@@ -47,8 +47,6 @@
 #include "placement.h"
 #include "walk.h"
 
-extern "C" void gscan_debug_kick(int hip_device); // (diagnostic, libgscan.so; not part of the ABI)
-
 namespace {
 
 // GRAB_TIMING=1: wall-clock marks of the run on stderr (startup cost is a large part of a sub-second scan)
@@ -477,10 +475,6 @@ int main(int argc, char **argv)
         (void)!write(status_fd, &code, sizeof code);
     }
     if (const char *ms = getenv("GRAB_EXIT_SLEEP_MS")) usleep((useconds_t)atoi(ms) * 1000); // (diagnostic: what the exit costs against the process's age)
-    if (getenv("GRAB_EXIT_KICK")) { // (diagnostic: one empty kernel right before leaving)
-        gscan_debug_kick(0);
-        mark("kicked");
-    }
     if (getenv("GRAB_NORMAL_EXIT")) return rc & 255; // (profilers write their results from exit handlers)
     _exit(rc & 255);
 }
