@@ -112,8 +112,7 @@ struct Prefault {
     char *base = nullptr;
     size_t stride = 0, count = 0;
     std::atomic<size_t> next{0};
-    std::unique_ptr<std::atomic<bool>[]> touched;
-    std::vector<std::thread> th;
+    std::atomic<bool> *touched = nullptr; // (never freed: the helper threads are detached and may outlive static destruction)
 };
 Prefault g_prefault;
 
@@ -1604,20 +1603,23 @@ int gscan_prefault(size_t blocks)
     (void)madvise(base, stride * blocks, MADV_HUGEPAGE);
     g_prefault.stride = stride;
     g_prefault.count = blocks;
-    g_prefault.touched.reset(new std::atomic<bool>[blocks]);
+    g_prefault.touched = new (std::nothrow) std::atomic<bool>[blocks];
+    if (!g_prefault.touched) {
+        munmap(m, stride * blocks + huge);
+        return GSCAN_ENOMEM;
+    }
     for (size_t k = 0; k < blocks; k++) g_prefault.touched[k].store(false, std::memory_order_relaxed);
     g_prefault.base = base;
     const size_t nth = std::min<size_t>(4, blocks);
     const size_t used = block_bytes() + kPad;
+    std::atomic<bool> *const touched = g_prefault.touched;
     for (size_t t = 0; t < nth; t++)
-        g_prefault.th.emplace_back([t, nth, blocks, base, stride, used] {
+        std::thread([t, nth, blocks, base, stride, used, touched] {
             for (size_t k = t; k < blocks; k += nth) { // (block k is handed out k-th: the early ones first)
                 for (size_t o = 0; o < used; o += 4096) base[k * stride + o] = 0;
-                g_prefault.touched[k].store(true, std::memory_order_release);
+                touched[k].store(true, std::memory_order_release);
             }
-        });
-    for (std::thread &th : g_prefault.th) th.detach();
-    g_prefault.th.clear();
+        }).detach();
     return GSCAN_OK;
 }
 
