@@ -848,8 +848,9 @@ struct Slot {
     // first gspec_n bytes of gathered line text, sized by what this context's last chunks produced (+25 %).  A chunk whose
     // result fits needs no transfer after its scan at all -- fetching it then costs a blocking round trip of ~2-3 ms behind
     // the 64 MiB window copies that are always in flight.
-    uint32_t *h_big = nullptr; // pinned: [big_recs] records, then [big_recs * 4] extras
+    uint32_t *h_big = nullptr; // pinned: [big_recs] records, then [big_recs * big_ew] extras
     size_t big_recs = 0, spec_n = 0;
+    uint32_t big_ew = 0; // extras per record h_big has room for
     uint8_t *h_gspec = nullptr; // pinned
     size_t gspec_cap = 0, gspec_n = 0;
     const uint8_t *out_gather = nullptr;
@@ -1236,13 +1237,15 @@ int slot_launch(gscan_ctx *c, Slot &s)
         const size_t hint_t = c->hint_total.load(std::memory_order_relaxed), hint_g = c->hint_gather.load(std::memory_order_relaxed);
         const size_t want = std::min<size_t>(s.rec_cap, hint_t + hint_t / 4);
         if (want > kSpecRecs) {
-            if (want > s.big_recs) {
+            if (want > s.big_recs || s.ext_words > s.big_ew) { // (sized for the extras this context asks for: 1 word for match ends, 4 for line extents, none otherwise -- not for the most there could be)
+                const size_t had = s.big_recs;
                 if (s.h_big) hipHostFree(s.h_big);
                 s.h_big = nullptr;
                 s.big_recs = 0;
-                const size_t cap = want + want / 4;
-                HIPCHK(c, hipHostMalloc((void **)&s.h_big, cap * 4 * 5, hipHostMallocDefault));
+                const size_t cap = std::max(want + want / 4, had);
+                HIPCHK(c, hipHostMalloc((void **)&s.h_big, cap * 4 * (1 + (size_t)s.ext_words), hipHostMallocDefault));
                 s.big_recs = cap;
+                s.big_ew = s.ext_words;
             }
             s.spec_n = want;
             HIPCHK(c, hipMemcpyAsync(s.h_big, s.d_sorted, want * 4, hipMemcpyDeviceToHost, c->compute));
