@@ -437,8 +437,8 @@ def pick_workers(n_gpus):
     """`-n` for N devices: FOUR workers per device, at least eight.  One worker keeps a device's pipe full (three
     windows in flight: `grab -r`, -n 4 and -n 8 move the literal corpus at the same rate, profiles/r04_e_*); what needs more
     is formatting: BASELINE configs[2] prints 172.9 M lines during a scan phase of 1.4 / N seconds, 123 M x N lines per
-    second, and a worker formats 30-60 M per second with the match ends from the device (15 ns per line + the sink:
-    profiles/r04_c_report_probe.txt) -- 2 to 4 per device.  Eight on a lone device cost nothing (same rate as four)."""
+    second, and a worker formats 50-100 M per second with the match ends from the device (9 ns per line + the sink:
+    profiles/r04_y_report_probe_after_fast_offsets_formatter.txt) -- 2 to 3 per device; four leave room.  Eight on a lone device cost nothing (same rate as four)."""
     return max(8, 4 * n_gpus)
 
 
