@@ -282,3 +282,18 @@ def test_line_pass_with_resync(built):
                     noga = ext.copy()
                     noga[:, 3] = 0xFFFFFFFF
                     assert filegrep.report_chunk_ext(db, f, "d/f", data, 0, starts, noga, None) == want, (pattern, trial, ask_rate, f)
+
+
+def test_offsets_formatter_digits(built):
+    """The -O -l offsets loop (match ends from the device) writes its numbers two digits at a time: every digit count from 1 to
+    19, with and without a path prefix, more lines than its 64 KiB buffer holds -- against Python's own formatting."""
+    db = engine.Database(r"foo\w*")
+    assert db.info.ends_ok
+    data = np.frombuffer(b"foo1 " * 5000, np.uint8)
+    starts = np.arange(0, data.size, 5, dtype=np.uint32)
+    ends = starts + 4
+    for off in [0, 3, 7, 96, 995, 9_996, 99_997, 999_998, 10 ** 7 - 1, 10 ** 8, 10 ** 9 + 1, 2 ** 32 - 2, 2 ** 32 + 5, 10 ** 12, 10 ** 15 + 3, 2 ** 62]:
+        for flags, prefix in ((filegrep.OFFSETS | filegrep.NOLINE, b""), (filegrep.OFFSETS | filegrep.NOLINE | filegrep.PREFIX, b"some/dir/file.txt:")):
+            got = filegrep.report_chunk(db, flags, "some/dir/file.txt", None, off, starts, ends=ends, clen=data.size)
+            want = b"".join(prefix + b"Match at offset %d\n" % (off + int(p)) for p in starts)
+            assert got == want, (off, flags)
