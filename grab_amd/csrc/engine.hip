@@ -595,6 +595,7 @@ private:
                 bool any = false;
                 for (auto &l : lanes_) any = any || !l->fifo.empty();
                 if (n_alloc_ == 0 && !any) return nullptr; // no pinned memory at all
+                if (n_alloc_ > 0) cap_ = n_alloc_;         // the runtime has no more to give: the pool stays as big as it is (no retry per piece)
                 continue;
             }
             // Every block is on its way out: wait for the next event of the lane with the most blocks in flight.  The waiter
