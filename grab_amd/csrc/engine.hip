@@ -4,9 +4,9 @@
 // Data flow of the host-chunk path (what FileGrep::find drives, replacing the
 // mmap -> pcre_exec loop of /root/reference/src/grab.cc:154-215):
 //
-//   read(2) into slot.pinned ──copy stream: hipMemcpyAsync──► slot.d_text (HBM)
-//        event `copied` ──compute stream waits──► scan kernel ──► d_recs/d_desc/d_counter
-//        ──compute stream: async D2H of counter + descriptors + first records──► event `done`
+//   reader threads: pread(2) into pinned blocks ──the device's copy streams: hipMemcpyAsync──► slot.d_text (HBM)
+//        scan kernel on the first copy stream (behind its pieces there, after an event of every further copy stream)
+//        ──► d_recs/d_desc/d_counter ──same stream: async D2H of counter + descriptors + first records──► event `done`
 //   gscan_wait: sync `done`, fetch the rest if needed, stitch runs in tile order.
 //
 // With GSCAN_SLOTS = 3 the read + copy of chunk k+2 overlaps the scan of chunk k+1 and the report of chunk k.
@@ -74,23 +74,30 @@ constexpr size_t kMaxChunk = (1ull << 30) + 4096;
 
 // ---- ingest configuration (environment, read once) ----
 //   GSCAN_BLOCK_MIB     pinned pool block == read piece == one hipMemcpyAsync == batch buffer        (default 8: as fast as 16 in
-//                       the steady state, half the pinned memory -- every block costs 3-7 ms of hipHostMalloc while the pipe
-//                       fills and its share of the exit; profiles/r04_d_*)
+//                       the steady state, half the pinned memory; profiles/r04_d_*)
 //   GSCAN_READERS       reader threads per device; 0 or unset = auto: 8, fewer when the device's NUMA node has few CPUs per
-//                       device (gscan_auto_readers: 8 GPUs x 8 readers must not outnumber the CPUs they are bound to)   (default auto)
-//   GSCAN_COPY_STREAMS  copy streams per context the pieces of a file range are spread over         (default 1)
+//                       device (gscan_auto_readers: 8 GPUs x 8 readers must not outnumber the CPUs they are bound to)
+//   GSCAN_COPY_STREAMS  copy streams per DEVICE, shared by its contexts; the scans ride on the first (default 2: a second
+//                       stream's copy runs in the first one's gaps, 46.7 -> 49.2 GB/s; a third adds nothing, profiles/r04_f_*)
 //   GSCAN_NUMA          0: readers inherit the process's CPU mask; else the CPUs local to the device (default 1)
-// and, measured and left off: GSCAN_SHARED_COPY (device-wide copy streams), GSCAN_SLAB (one pinned allocation),
-// GSCAN_PIN_FLAGS (non-coherent / write-combined blocks), GSCAN_READ_MODE (mapping or bounce buffer + non-temporal copy).
-// What the round-2 sweeps on the MI355X boxes say (profiles/r02_a_e2e_ingest_sweep.jsonl, r02_b_dma_probe.txt, r02_b..e_e2e_*):
-// the link itself moves 57 GB/s in any piece size >= 16 MiB, also next to 16 busy pread threads; inside the pipeline the
-// 64 GiB corpus goes through at 44-47 GB/s whatever the block size (8/16/32 MiB), the number of copy streams, their
-// sharing, the flavour of the pinned memory or the way the readers copy; 8 readers are the best (more of them wait for
-// blocks longer than they save reading).  16 MiB is where the per-copy cost stops showing in the probe.
+//   GSCAN_NT_COPY       readers pread into a cache-sized bounce buffer and stream it into the block with non-temporal stores
+//                       (hostcopy.cc): one DRAM crossing less per byte (no write-allocate).  -1 (default) = by device count:
+//                       on from five devices up, where the host's DRAM and not the links sets the pace; 0 / 1 force
+// Test hooks (tests/test_gpu_pool.py): GSCAN_POOL_CAP caps the reader pool's blocks, GSCAN_FAIL_ALLOC_AFTER=n makes every
+// allocation of a staging block after the n-th fail.  GSCAN_DIAG (measurements only -- the results are NOT scan results, said
+// on stderr): 1 = the readers fill their blocks and give them straight back, no DMA, no scan (the host's page cache -> pinned
+// ceiling); 2 = the readers do not read, the blocks go out as they are (the DMA side on its own).
+// What the sweeps of rounds 2 - 4 on the MI355X boxes say (profiles/r02_a_e2e_ingest_sweep.jsonl, r02_b_dma_probe.txt,
+// r04_e_* .. r04_k_*): the link itself moves 57 GB/s in any piece size >= 16 MiB, also next to 16 busy pread threads; inside the
+// pipeline the 64 GiB corpus goes through at 49-52 GB/s whatever the block size, the flavour of the pinned memory, the way the
+// readers copy or how often an event is recorded behind a DMA; 8 readers are the best (more of them wait for blocks longer
+// than they save reading).  The alternates those sweeps went through (per-context streams, a slab allocation, write-combined
+// blocks, blocks made ahead, an event per k-th DMA, a mapped copy) are gone from the code; their numbers are in profiles/.
 // GSCAN_TRACE=1: a time line of the pipeline on stderr -- "[gscan trace] +seconds-since-load thread what" -- for the runs
 // that are over in a fraction of a second (where does a 256 MiB file's 0.1 s go?)
 const auto g_trace_t0 = std::chrono::steady_clock::now();
 const bool g_trace = getenv("GSCAN_TRACE") != nullptr;
+const bool g_timing = getenv("GSCAN_TIMING") != nullptr; // where the readers' and gscan_wait's time goes, printed when a context closes
 void trace(const char *fmt, ...)
 {
     if (!g_trace) return;
@@ -119,24 +126,19 @@ Prefault g_prefault;
 struct IngestCfg {
     size_t block;
     int readers;
+    // A HIP stream is an HSA queue, and on this part a queue comes with ~177 MB of wave-save area that the runtime allocates
+    // AND touches: 7-12 ms to create, ~4 ms of the process's exit, per stream (profiles/r02_r_resident_memory.txt, r04_c_*).
+    // So the contexts of a device share the device's copy streams, and the scans and read-backs ride on the first of them
+    // (a 64 MiB window scans in 15 us).
     int copy_streams;
     bool numa;
-    unsigned pin_flags; // hipHostMalloc flags of the staging blocks (GSCAN_PIN_FLAGS: 0 default, 1 non-coherent, 2 write-combined)
-    // A HIP stream is an HSA queue, and on this part a queue comes with ~177 MB of wave-save area that the runtime allocates
-    // AND touches: 7-12 ms to create, ~4 ms of the process's exit, per stream (profiles/r02_r_resident_memory.txt).  Eight
-    // contexts with two streams each were 0.1 s of start-up and 2 GB of resident memory for nothing: a 64 MiB window scans in
-    // 15 us and the copies share one link.  So the contexts of a device share its streams by default.
-    int shared_copy;    // GSCAN_SHARED_COPY (1): N = the contexts of a device share N copy streams; 0 = every context has its own
-    bool one_stream;    // GSCAN_ONE_STREAM (1): no stream of their own for the scans and read-backs -- they ride on the device's first
-                        // copy stream (a 64 MiB window scans in 15 us); every further stream is 7 - 12 ms at start-up, 177 MB of
-                        // wave-save area and 4 ms at exit (profiles/r04_c_*).  The pieces of a window alternate between TWO copy
-                        // streams (GSCAN_ONE_STREAM_COPIES): with the readers no longer short of blocks it is the DMA side that
-                        // sets the pace, and a second stream's copy runs in the first one's gaps -- 46.7 -> 49.2 GB/s through the
-                        // pipe at 64 GiB; a third adds nothing (profiles/r04_f_*)
-    int shared_compute; // GSCAN_SHARED_COMPUTE (2): N = they share N scan streams, dealt round robin; 0 = every context has its own
-    bool slab;          // GSCAN_SLAB: the reader blocks of a device are carved from ONE pinned allocation instead of one each
-    int read_mode;      // GSCAN_READ_MODE: 0 pread(2) into the block; 1 map the piece and copy it with non-temporal stores
-                        // (hostcopy.cc); 2 pread into a cache-sized bounce buffer, non-temporal copy from there
+    int nt_copy;          // -1: by device count (Ingest's constructor), 0 / 1
+    long pool_cap;        // GSCAN_POOL_CAP (test hook): 0 = two blocks per reader
+    long fail_alloc_after; // GSCAN_FAIL_ALLOC_AFTER (test hook): -1 = never
+    int diag;             // GSCAN_DIAG: 0, 1 (no DMA, no scan), 2 (no read)
+    int virtual_devices;  // GSCAN_VIRTUAL_DEVICES (below)
+    int virtual_fail_open; // GSCAN_VIRTUAL_FAIL_OPEN: gscan_open fails for this index (-1: none)
+    bool prefault;        // GSCAN_PREFAULT=0 switches gscan_prefault off
 };
 const IngestCfg &ingest_cfg()
 {
@@ -151,18 +153,16 @@ const IngestCfg &ingest_cfg()
         v.readers = (int)env("GSCAN_READERS", 0, 0, 64); // 0: auto, per device (Ingest's constructor)
         const long hw = (long)std::thread::hardware_concurrency();
         if (hw > 0 && v.readers > hw) v.readers = (int)hw;
-        v.copy_streams = (int)env("GSCAN_COPY_STREAMS", 1, 1, 4);
+        v.copy_streams = (int)env("GSCAN_COPY_STREAMS", 2, 1, 4);
         v.numa = env("GSCAN_NUMA", 1, 0, 1) != 0;
-        v.shared_copy = (int)env("GSCAN_SHARED_COPY", 1, 0, 4);
-        v.shared_compute = (int)env("GSCAN_SHARED_COMPUTE", 2, 0, 4);
-        // (the default unless the stream layout is spelled out: any of the three knobs above set means the caller wants that layout)
-        const bool layout_given = getenv("GSCAN_SHARED_COPY") || getenv("GSCAN_SHARED_COMPUTE") || getenv("GSCAN_COPY_STREAMS");
-        v.one_stream = env("GSCAN_ONE_STREAM", layout_given ? 0 : 1, 0, 1) != 0;
-        if (v.one_stream) v.shared_copy = (int)env("GSCAN_ONE_STREAM_COPIES", 2, 1, 4); // (the scans ride on the first of them)
-        v.slab = env("GSCAN_SLAB", 0, 0, 1) != 0;
-        v.read_mode = (int)env("GSCAN_READ_MODE", 0, 0, 2); // (1 and 2 measured and not adopted: profiles/r02_d_e2e_reader_modes.jsonl)
-        const long pf = env("GSCAN_PIN_FLAGS", 0, 0, 2);
-        v.pin_flags = pf == 1 ? hipHostMallocNonCoherent : pf == 2 ? hipHostMallocWriteCombined : hipHostMallocDefault;
+        v.nt_copy = (int)env("GSCAN_NT_COPY", -1, -1, 1);
+        v.pool_cap = env("GSCAN_POOL_CAP", 0, 0, 4096);
+        v.fail_alloc_after = env("GSCAN_FAIL_ALLOC_AFTER", -1, -1, 1 << 20);
+        v.diag = (int)env("GSCAN_DIAG", 0, 0, 2);
+        v.virtual_devices = (int)env("GSCAN_VIRTUAL_DEVICES", 0, 0, 64);
+        v.virtual_fail_open = (int)env("GSCAN_VIRTUAL_FAIL_OPEN", -1, -1, 64);
+        v.prefault = env("GSCAN_PREFAULT", 1, 0, 1) != 0;
+        if (v.diag) fprintf(stderr, "gscan: GSCAN_DIAG=%d -- a measurement of the ingest pipe, NOT a scan: whatever is reported is meaningless\n", v.diag);
         return v;
     }();
     return c;
@@ -173,9 +173,7 @@ inline size_t block_bytes() { return ingest_cfg().block; }
 struct PinBlock {
     void *p = nullptr;
     hipEvent_t ev = nullptr;
-    bool from_slab = false;
     bool registered = false; // p comes from the prefaulted arena and was hipHostRegister'ed (not hipHostMalloc'ed)
-    bool marked = false; // ev was recorded behind this block's DMA (only every GSCAN_MARK_EVERY-th block of a stream is: see Lane)
 };
 
 // One file range on its way to HBM (gscan_submit_fd): its pieces are read by the reader threads; whoever finishes the
@@ -251,15 +249,7 @@ int pci_cpulist(const char *root, const char *busid, char *buf, size_t cap)
 // real one) -- so that `grab -n` over an 8-GPU node's worth of device indices, and one file's windows dealt over 8 contexts,
 // run for real on the one-GPU boxes there are.  GSCAN_VIRTUAL_FAIL_OPEN=v makes gscan_open fail for index v (a device that
 // is busy or out of memory).
-int virtual_devices()
-{
-    static const int n = [] {
-        const char *e = getenv("GSCAN_VIRTUAL_DEVICES");
-        const int v = e && *e ? atoi(e) : 0;
-        return v > 0 ? std::min(v, 64) : 0;
-    }();
-    return n;
-}
+int virtual_devices() { return ingest_cfg().virtual_devices; }
 int real_device_count()
 {
     int n = 0;
@@ -352,10 +342,11 @@ public:
         else cv_tasks_.notify_all();
     }
     int readers() const { return readers_; }
-    // device-wide copy streams (GSCAN_SHARED_COPY): created on first use, destroyed with the pool
+    // the device's copy streams: created on first use (one at a time per device; devices do not wait for each other),
+    // destroyed with the pool
     hipStream_t shared_stream(int k)
     {
-        std::lock_guard<std::mutex> lk(m_);
+        std::lock_guard<std::mutex> lk(streams_m_);
         if ((int)shared_.size() <= k) shared_.resize((size_t)k + 1, nullptr);
         if (!shared_[(size_t)k]) {
             (void)hipSetDevice(hip_device_of(device_));
@@ -363,10 +354,9 @@ public:
         }
         return shared_[(size_t)k];
     }
-    int next_compute() { return next_compute_++; }
     void report_if_timing()
     {
-        if (timing_ && n_pieces_) report();
+        if (g_timing && n_pieces_) report();
     }
 
 private:
@@ -420,37 +410,9 @@ private:
             if (cpus <= 0) cpus = have_mask_ ? CPU_COUNT(&mask_) : (int)std::thread::hardware_concurrency();
             readers_ = gscan_auto_readers(cpus, std::max(1, sharing));
         }
-        {
-            const char *k = getenv("GSCAN_MARK_EVERY");
-            mark_every_ = std::max(1, std::min(16, k && *k ? atoi(k) : 1));
-        }
-        cap_ = (size_t)readers_ * 2 + (mark_every_ > 1 ? 2 * (size_t)mark_every_ : 0); // (blocks come back K at a time: K more per lane keep the readers busy meanwhile)
-        timing_ = getenv("GSCAN_TIMING") != nullptr;
-        // GSCAN_PREALLOC=n (measured and left off, profiles/r04_c_*): the first n blocks made in the background while the
-        // opener creates its streams and sizes its first slot.  The runtime serves one allocation at a time: the opener's
-        // own hipMalloc then queues behind these, and a 256 MiB file took 0.19 s instead of 0.13.
-        const char *pre = getenv("GSCAN_PREALLOC");
-        const int want = pre && *pre ? atoi(pre) : 0;
-        if (want > 0) {
-            prealloc_ = std::thread([this, want] {
-                for (int i = 0; i < want; i++) {
-                    {
-                        std::lock_guard<std::mutex> lk(m_);
-                        if (stop_ || n_alloc_ >= cap_) return;
-                        n_alloc_++;
-                    }
-                    PinBlock *b = alloc_block();
-                    std::lock_guard<std::mutex> lk(m_);
-                    if (!b) {
-                        n_alloc_--;
-                        return;
-                    }
-                    free_.push_back(b);
-                    cv_blocks_.notify_one();
-                }
-                trace("ingest: %d pinned blocks made ahead", want);
-            });
-        }
+        cap_ = ingest_cfg().pool_cap > 0 ? (size_t)ingest_cfg().pool_cap : (size_t)readers_ * 2;
+        // one DRAM crossing less per byte where the host's DRAM is what N devices share: from five devices up
+        nt_copy_ = ingest_cfg().nt_copy >= 0 ? ingest_cfg().nt_copy != 0 : device_count() >= 5;
     }
     ~Ingest()
     {
@@ -460,7 +422,6 @@ private:
             cv_tasks_.notify_all();
         }
         for (std::thread &t : threads_) t.join();
-        if (prealloc_.joinable()) prealloc_.join();
         (void)hipSetDevice(hip_device_of(device_));
         for (auto &l : lanes_)
             for (PinBlock *b : l->fifo) free_block(b, false); // (every context is closed: gscan_close has waited for the device)
@@ -468,14 +429,13 @@ private:
         for (PinBlock *b : slot_free_) free_block(b, false);
         for (hipStream_t st : shared_)
             if (st) (void)hipStreamDestroy(st);
-        if (slab_) (void)hipHostFree(slab_);
     }
     void free_block(PinBlock *b, bool wait)
     {
         if (wait) (void)hipEventSynchronize(b->ev);
         if (b->ev) (void)hipEventDestroy(b->ev);
         if (b->p && b->registered) (void)hipHostUnregister(b->p);
-        else if (b->p && !b->from_slab) (void)hipHostFree(b->p);
+        else if (b->p) (void)hipHostFree(b->p);
         delete b;
     }
 
@@ -484,22 +444,9 @@ private:
         PinBlock *b = new (std::nothrow) PinBlock();
         if (!b) return nullptr;
         (void)hipSetDevice(hip_device_of(device_));
-        if (ingest_cfg().slab) { // one pinned allocation for all the blocks of the device (big pages under the DMA)
-            std::lock_guard<std::mutex> lk(slab_m_);
-            const size_t each = block_bytes() + kPad, total = each * (cap_ + 8);
-            if (!slab_ && hipHostMalloc(&slab_, total, ingest_cfg().pin_flags) != hipSuccess) {
-                (void)hipGetLastError();
-                slab_ = nullptr;
-            }
-            if (slab_ && slab_used_ + each <= total) {
-                b->p = (char *)slab_ + slab_used_;
-                slab_used_ += each;
-                b->from_slab = true;
-                if (hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) == hipSuccess) return b;
-                (void)hipGetLastError();
-                delete b;
-                return nullptr;
-            }
+        if (ingest_cfg().fail_alloc_after >= 0 && n_made_.fetch_add(1) >= ingest_cfg().fail_alloc_after) { // (test hook: the runtime has no more pinned memory to give)
+            delete b;
+            return nullptr;
         }
         // a block that was mapped and touched while the runtime started (gscan_prefault): only registered here
         if (g_prefault.base && g_prefault.stride >= block_bytes() + kPad) {
@@ -518,7 +465,7 @@ private:
                 (void)hipGetLastError(); // (registration refused: the runtime's own allocator below)
             }
         }
-        if (hipHostMalloc(&b->p, block_bytes() + kPad, ingest_cfg().pin_flags) != hipSuccess ||
+        if (hipHostMalloc(&b->p, block_bytes() + kPad, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             if (b->p) hipHostFree(b->p);
@@ -529,15 +476,14 @@ private:
     }
 
     // DMA bookkeeping, one Lane per copy stream.  The blocks whose DMA has been queued on the stream sit in `fifo` in stream
-    // order (`order` makes "enqueue + push" one step).  An event is recorded behind every K-th of them (K = GSCAN_MARK_EVERY,
-    // default 1): a stream is in order, so an event that has completed frees every block in front of it.  K = 4 and 8 were
-    // built to test whether the barrier packet an event puts between two copies is what keeps the pipe at 46-48 GB/s where
-    // the same copies back to back move 53-57: it is not -- 46.1 / 46.7 / 47.2 GB/s for K = 1 / 4 / 8 (profiles/r04_g_*).
+    // order (`order` makes "enqueue + event + push" one step), each with its event recorded right behind its DMA: a stream is
+    // in order, so an event that has completed frees every block in front of it.  (An event behind every 4th / 8th DMA only:
+    // 46.1 / 46.7 / 47.2 GB/s for K = 1 / 4 / 8 -- the event packets are not what keeps the pipe below the link's rate,
+    // profiles/r04_g_*; taken out again.)
     struct Lane {
         hipStream_t st = nullptr;
         std::mutex order;
         std::deque<PinBlock *> fifo;
-        int since_mark = 0;
     };
     Lane *lane_for(hipStream_t st) // (under m_)
     {
@@ -547,14 +493,13 @@ private:
         lanes_.back()->st = st;
         return lanes_.back().get();
     }
-    // free every block in front of (and including) the last marked block whose event has completed (under m_)
+    // free every block up to the last one of each lane whose event has completed (under m_)
     size_t reap()
     {
         size_t freed = 0;
         for (auto &l : lanes_) {
             size_t upto = 0;
             for (size_t i = 0; i < l->fifo.size(); i++) {
-                if (!l->fifo[i]->marked) continue;
                 if (hipEventQuery(l->fifo[i]->ev) != hipSuccess) {
                     (void)hipGetLastError();
                     break;
@@ -562,7 +507,6 @@ private:
                 upto = i + 1;
             }
             for (size_t i = 0; i < upto; i++) {
-                l->fifo.front()->marked = false;
                 free_.push_back(l->fifo.front());
                 l->fifo.pop_front();
             }
@@ -592,55 +536,29 @@ private:
                 if (b) return b;
                 lk.lock();
                 n_alloc_--;
-                bool any = false;
-                for (auto &l : lanes_) any = any || !l->fifo.empty();
-                if (n_alloc_ == 0 && !any) return nullptr; // no pinned memory at all
-                if (n_alloc_ > 0) cap_ = n_alloc_;         // the runtime has no more to give: the pool stays as big as it is (no retry per piece)
+                cv_blocks_.notify_all();               // (readers asleep below count on allocations still under way)
+                if (n_alloc_ == 0) return nullptr;     // no pinned memory at all (and no other allocation under way)
+                cap_ = n_alloc_;                       // the runtime has no more to give: the pool stays as big as it is (no retry per piece)
                 continue;
             }
-            // Every block is on its way out: wait for the next event of the lane with the most blocks in flight.  The waiter
-            // TAKES the blocks up to and including the marked one out of the lane first: while it sleeps on that event no
-            // other thread can query it, free the block or -- after a round through the free list -- record the event again
-            // (two threads on one hipEvent_t at a time is not something the runtime promises to survive).
+            // Every block is on its way out: wait for the oldest event of the lane with the most blocks in flight.  The waiter
+            // TAKES that block out of the lane first: while it sleeps on the event no other thread can query it, free the
+            // block or -- after a round through the free list -- record the event again (two threads on one hipEvent_t at a
+            // time is not something the runtime promises to survive).
             Lane *pick = nullptr;
             for (auto &l : lanes_)
                 if (!l->fifo.empty() && (!pick || l->fifo.size() > pick->fifo.size())) pick = l.get();
             if (!pick) {
-                cv_blocks_.wait(lk); // (other waiters hold every block in flight: they will bring some back)
+                if (n_alloc_ == 0) return nullptr; // not one staging block to be had, and nobody is trying any more
+                n_waits_cv_++;
+                cv_blocks_.wait(lk); // (other waiters hold every block in flight, or readers hold them all: they will bring some back)
                 continue;
             }
-            size_t upto = 0;
-            for (size_t i = 0; i < pick->fifo.size() && !upto; i++)
-                if (pick->fifo[i]->marked) upto = i + 1;
-            if (!upto) {
-                // nothing marked in flight (GSCAN_MARK_EVERY > 1): mark the lane's tail now -- in stream order, i.e. under
-                // `order`, which is taken BEFORE m_ everywhere
-                lk.unlock();
-                {
-                    std::lock_guard<std::mutex> ord(pick->order);
-                    std::lock_guard<std::mutex> again(m_);
-                    if (!pick->fifo.empty() && !pick->fifo.back()->marked) {
-                        if (hipEventRecord(pick->fifo.back()->ev, pick->st) != hipSuccess) (void)hipGetLastError();
-                        pick->fifo.back()->marked = true;
-                        pick->since_mark = 0;
-                    }
-                }
-                lk.lock();
-                continue;
-            }
-            std::vector<PinBlock *> mine(pick->fifo.begin(), pick->fifo.begin() + (long)upto);
-            pick->fifo.erase(pick->fifo.begin(), pick->fifo.begin() + (long)upto);
+            PinBlock *take = pick->fifo.front();
+            pick->fifo.pop_front();
+            n_waits_ev_++;
             lk.unlock();
-            (void)hipEventSynchronize(mine.back()->ev); // a stream is in order: everything in front of it is over as well
-            lk.lock();
-            PinBlock *take = mine.back();
-            take->marked = false;
-            mine.pop_back();
-            for (PinBlock *x : mine) {
-                x->marked = false;
-                free_.push_back(x);
-            }
-            if (!mine.empty()) cv_blocks_.notify_all();
+            (void)hipEventSynchronize(take->ev);
             return take;
         }
     }
@@ -658,9 +576,10 @@ private:
     {
         if (have_mask_) (void)pthread_setaffinity_np(pthread_self(), sizeof mask_, &mask_);
         (void)hipSetDevice(hip_device_of(device_));
+        const int diag = ingest_cfg().diag;
         for (;;) {
             ReadTask t;
-            double t0 = timing_ ? now() : 0;
+            double t0 = g_timing ? now() : 0;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_tasks_.wait(lk, [&] { return !tasks_.empty() || stop_; });
@@ -668,12 +587,12 @@ private:
                 t = tasks_.front();
                 tasks_.pop_front();
             }
-            double t1 = timing_ ? now() : 0;
+            double t1 = g_timing ? now() : 0;
             int err = 0;
             trace("reader: task of %zu bytes taken", t.n);
             PinBlock *b = take_reader_block();
             trace("reader: block in hand");
-            double t2 = timing_ ? now() : 0, t3 = t2;
+            double t2 = g_timing ? now() : 0, t3 = t2;
             if (!b) {
                 err = -2;
             } else {
@@ -700,21 +619,10 @@ private:
                     }
                     got = t.n;
                 }
-                if (ingest_cfg().read_mode == 1 && !t.items && (t.off & 4095) == 0 && t.n >= (1u << 20)) {
-                    // the piece through a mapping, copied with non-temporal stores (hostcopy.cc).  A file that is shorter
-                    // than the range (it shrank) would fault beyond its end: checked first; anything odd falls back to pread
-                    struct stat st;
-                    if (fstat(t.fd, &st) == 0 && (off_t)(t.off + (off_t)t.n) <= st.st_size) {
-                        void *map = mmap(nullptr, t.n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, t.fd, t.off);
-                        if (map != MAP_FAILED) {
-                            gscan::nt_copy(b->p, map, t.n);
-                            munmap(map, t.n);
-                            got = t.n;
-                        }
-                    }
-                }
-                if (ingest_cfg().read_mode == 2 && !t.items) {
-                    // pread into a buffer that stays in this core's L2, stream it out to the block past the caches
+                if (diag == 2) got = t.n; // (GSCAN_DIAG=2: nothing is read, the block goes out as it is)
+                if (nt_copy_ && !t.items) {
+                    // pread into a buffer that stays in this core's L2, stream it out to the block past the caches: the block's
+                    // lines are never read into a cache for ownership (one DRAM crossing less per byte)
                     constexpr size_t kBounce = 256u << 10;
                     static thread_local char *bounce = nullptr;
                     if (!bounce && posix_memalign((void **)&bounce, 4096, kBounce) != 0) bounce = nullptr;
@@ -737,36 +645,28 @@ private:
                     else if (r == 0) err = -1;
                     else if (errno != EINTR) err = errno;
                 }
-                t3 = timing_ ? now() : 0;
+                t3 = g_timing ? now() : 0;
                 trace("reader: %zu bytes read", t.n);
-                if (!err) {
+                if (!err && diag != 1) {
                     Lane *lane;
                     {
                         std::lock_guard<std::mutex> lk(m_);
                         lane = lane_for(t.stream);
                     }
-                    std::lock_guard<std::mutex> ord(lane->order); // (enqueue + push: the lane's fifo is the stream's order)
-                    if (hipMemcpyAsync(t.dst, b->p, t.n, hipMemcpyHostToDevice, t.stream) != hipSuccess) {
+                    std::lock_guard<std::mutex> ord(lane->order); // (enqueue + event + push: the lane's fifo is the stream's order)
+                    if (hipMemcpyAsync(t.dst, b->p, t.n, hipMemcpyHostToDevice, t.stream) != hipSuccess || hipEventRecord(b->ev, t.stream) != hipSuccess) {
                         (void)hipGetLastError();
-                        (void)hipStreamSynchronize(t.stream);
+                        (void)hipStreamSynchronize(t.stream); // (whatever did get queued out of the block is over before it is reused)
                         err = -2;
                         give_reader_block(b, nullptr);
                     } else {
-                        if (++lane->since_mark >= mark_every_) {
-                            if (hipEventRecord(b->ev, t.stream) == hipSuccess) {
-                                b->marked = true;
-                                lane->since_mark = 0;
-                            } else {
-                                (void)hipGetLastError();
-                            }
-                        }
                         give_reader_block(b, lane);
                     }
                 } else {
-                    give_reader_block(b, nullptr);
+                    give_reader_block(b, nullptr); // (a failed read, or GSCAN_DIAG=1: the block is filled and given straight back)
                 }
             }
-            if (timing_) {
+            if (g_timing) {
                 const double t4 = now();
                 ns_idle_ += (uint64_t)((t1 - t0) * 1e9);
                 ns_block_ += (uint64_t)((t2 - t1) * 1e9);
@@ -788,13 +688,12 @@ private:
 
     // GSCAN_TIMING=1: where the reader threads spend their time, printed when a context closes
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    bool timing_ = false;
     std::atomic<uint64_t> ns_idle_{0}, ns_block_{0}, ns_read_{0}, ns_hip_{0}, n_pieces_{0}, n_bytes_{0};
     void report()
     {
-        fprintf(stderr, "[gscan timing] device %d readers %d (%d local CPUs) block %zu MiB: pieces %llu bytes %llu | per reader: idle %.3f s  wait-for-block %.3f s  pread %.3f s  hip calls %.3f s\n",
-                device_, readers_, numa_cpus_, block_bytes() >> 20, (unsigned long long)n_pieces_.load(), (unsigned long long)n_bytes_.load(), ns_idle_ / 1e9 / readers_,
-                ns_block_ / 1e9 / readers_, ns_read_ / 1e9 / readers_, ns_hip_ / 1e9 / readers_);
+        fprintf(stderr, "[gscan timing] device %d readers %d (%d local CPUs) block %zu MiB pool %zu of %zu: pieces %llu bytes %llu | per reader: idle %.3f s  wait-for-block %.3f s  pread %.3f s  hip calls %.3f s | waits on an event %llu, on other readers %llu\n",
+                device_, readers_, numa_cpus_, block_bytes() >> 20, n_alloc_, cap_, (unsigned long long)n_pieces_.load(), (unsigned long long)n_bytes_.load(), ns_idle_ / 1e9 / readers_,
+                ns_block_ / 1e9 / readers_, ns_read_ / 1e9 / readers_, ns_hip_ / 1e9 / readers_, (unsigned long long)n_waits_ev_, (unsigned long long)n_waits_cv_);
     }
     int device_;
     int refs_ = 1;
@@ -802,21 +701,29 @@ private:
     int numa_cpus_ = 0; // CPUs of the device's NUMA node the readers are bound to (0: not bound by NUMA)
     cpu_set_t mask_;
     bool have_mask_ = false;
+    bool nt_copy_ = false;
     size_t cap_ = 16, n_alloc_ = 0;
+    std::atomic<long> n_made_{0};           // staging blocks asked of the runtime so far (GSCAN_FAIL_ALLOC_AFTER)
+    uint64_t n_waits_ev_ = 0, n_waits_cv_ = 0; // (under m_) how often the pool's slow paths ran: slept on a block's event / on the other readers
     bool started_ = false, stop_ = false;
-    std::mutex m_;
+    std::mutex m_, streams_m_;
     std::condition_variable cv_blocks_, cv_tasks_;
     std::vector<PinBlock *> free_, slot_free_;
     std::vector<std::unique_ptr<Lane>> lanes_;
-    int mark_every_ = 4;
     std::deque<ReadTask> tasks_;
     std::vector<std::thread> threads_;
-    std::thread prealloc_;
     std::vector<hipStream_t> shared_;
-    std::atomic<int> next_compute_{0};
-    std::mutex slab_m_;
-    void *slab_ = nullptr;
-    size_t slab_used_ = 0;
+
+public:
+    // how often the pool's slow paths have run on this device (gscan_pool_stats: the tests that force them check that they did)
+    void stats(uint64_t out[4])
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        out[0] = n_alloc_;
+        out[1] = cap_;
+        out[2] = n_waits_ev_;
+        out[3] = n_waits_cv_;
+    }
 };
 
 enum SlotState { FREE = 0, ACQUIRED, INFLIGHT };
@@ -881,8 +788,8 @@ struct Slot {
     std::vector<size_t> seg_first;    // result: first record of segment i in `sorted`; [nseg] = total
     gscan::TileDesc *d_tiles = nullptr, *h_tiles = nullptr;
     size_t seg_tiles_cap = 0;
-    hipEvent_t copied = nullptr, done = nullptr;
-    hipEvent_t copied_x[3] = {nullptr, nullptr, nullptr}; // the further copy streams of a file range
+    hipEvent_t done = nullptr;
+    hipEvent_t copied_x[3] = {nullptr, nullptr, nullptr}; // behind a file range's pieces on the further copy streams (the scan rides on the first)
     std::unique_ptr<ReadGroup> grp;                       // gscan_submit_fd: the range's pieces (finished == true when idle)
     uint64_t tag = 0;
     size_t len = 0;
@@ -903,11 +810,11 @@ struct gscan_ctx {
     int hip_dev = 0; // the HIP device behind it (the same, unless GSCAN_VIRTUAL_DEVICES maps several indices onto one)
     int cus = 256;
     size_t max_chunk = 0;
+    // the device's streams (they belong to its Ingest, not to this context): GSCAN_COPY_STREAMS copy streams, the scans and
+    // read-backs on the first of them
     hipStream_t copy = nullptr, compute = nullptr;
-    hipStream_t copy_x[3] = {nullptr, nullptr, nullptr}; // further copy streams (GSCAN_COPY_STREAMS - 1 of them)
+    hipStream_t copy_x[3] = {nullptr, nullptr, nullptr};
     int n_copy = 1;
-    bool compute_shared = false; // the scan stream is one of the device's (GSCAN_SHARED_COMPUTE)
-    bool copy_shared = false; // the copy streams belong to the device's Ingest (GSCAN_SHARED_COPY), not to this context
     Ingest *ingest = nullptr;
     Slot slot[GSCAN_SLOTS];
     uint64_t next_seq = 1;
@@ -1298,7 +1205,6 @@ void free_slot(gscan_ctx *c, Slot &s)
     if (s.d_recs) hipFree(s.d_recs);
     if (s.d_desc) hipFree(s.d_desc);
     if (s.h_desc) hipHostFree(s.h_desc);
-    if (s.copied) hipEventDestroy(s.copied);
     for (hipEvent_t e : s.copied_x)
         if (e) hipEventDestroy(e);
     if (s.done) hipEventDestroy(s.done);
@@ -1320,8 +1226,17 @@ void fd_finish(ReadGroup *g)
             if (g->err == -2) return fail(c, GSCAN_EHIP, "staging block or DMA failed");
             return fail(c, GSCAN_EIO, "%s", strerror(g->err));
         }
-        HIPCHK(c, hipEventRecord(s.copied, c->copy));
-        HIPCHK(c, hipStreamWaitEvent(c->compute, s.copied, 0));
+        if (ingest_cfg().diag == 1) { // nothing went to the device: an empty result behind whatever the stream still holds
+            memset(s.h_counter, 0, kCounterWords * 4);
+            s.n_tiles = 0;
+            s.nw = 1;
+            s.ordered = s.has_ext = false;
+            s.ext_words = 0;
+            s.spec_n = s.gspec_n = 0;
+            HIPCHK(c, hipEventRecord(s.done, c->compute));
+            return 0;
+        }
+        // (the pieces on the first copy stream are in front of the scan as it is: the scans ride on that stream)
         for (int k = 1; k < c->n_copy; k++) {
             HIPCHK(c, hipEventRecord(s.copied_x[k - 1], c->copy_x[k - 1]));
             HIPCHK(c, hipStreamWaitEvent(c->compute, s.copied_x[k - 1], 0));
@@ -1423,7 +1338,7 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     if (!out) return GSCAN_EINVAL;
     *out = nullptr;
     if (max_chunk == 0 || max_chunk > kMaxChunk) return GSCAN_ETOOBIG;
-    const bool tm = getenv("GSCAN_TIMING") != nullptr;
+    const bool tm = g_timing;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     auto lap = [&](const char *what) {
@@ -1437,10 +1352,7 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     if (n <= 0) return GSCAN_EHIP; // no device: there is no CPU path
     lap("hipGetDeviceCount (runtime init)");
     if (hip_device < 0 || hip_device >= n) return GSCAN_EINVAL;
-    if (virtual_devices()) {
-        const char *f = getenv("GSCAN_VIRTUAL_FAIL_OPEN");
-        if (f && *f && atoi(f) == hip_device) return GSCAN_EHIP;
-    }
+    if (virtual_devices() && ingest_cfg().virtual_fail_open == hip_device) return GSCAN_EHIP;
     gscan_ctx *c = new (std::nothrow) gscan_ctx();
     if (!c) return GSCAN_ENOMEM;
     c->device = hip_device;
@@ -1456,34 +1368,15 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->hip_dev) == hipSuccess && cus > 0) c->cus = cus;
     lap("device attribute");
-    // Creating a stream takes the runtime ~6 ms and the runtime does them one at a time: eight workers opening their contexts
-    // together would ALL be ready only when the last stream exists (+0.1 s).  One context at a time: the first one is scanning
-    // after two creations while the others queue here.
-    static std::mutex open_order;
-    std::unique_lock<std::mutex> one_at_a_time(open_order, std::defer_lock);
-    if (!getenv("GSCAN_OPEN_UNORDERED")) one_at_a_time.lock(); // (the switch is for measuring the difference)
-    if (ingest_cfg().one_stream) {
-        c->compute_shared = true;
-        if (!(c->compute = c->ingest->shared_stream(0))) return bail(GSCAN_EHIP);
-    } else if (ingest_cfg().shared_compute > 0) { // (pool entries 0..3 are the copy streams, 4.. the scan streams)
-        c->compute_shared = true;
-        if (!(c->compute = c->ingest->shared_stream(4 + c->ingest->next_compute() % ingest_cfg().shared_compute))) return bail(GSCAN_EHIP);
-    } else if (hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) != hipSuccess) {
-        return bail(GSCAN_EHIP);
-    }
-    if (ingest_cfg().shared_copy > 0) {
-        c->copy_shared = true;
-        c->n_copy = ingest_cfg().shared_copy;
-        if (!(c->copy = c->ingest->shared_stream(0))) return bail(GSCAN_EHIP);
-        for (int k = 1; k < c->n_copy; k++)
-            if (!(c->copy_x[k - 1] = c->ingest->shared_stream(k))) return bail(GSCAN_EHIP);
-    } else {
-        if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
-        c->n_copy = ingest_cfg().copy_streams;
-        for (int k = 1; k < c->n_copy; k++)
-            if (hipStreamCreateWithFlags(&c->copy_x[k - 1], hipStreamNonBlocking) != hipSuccess) return bail(GSCAN_EHIP);
-    }
-    if (one_at_a_time.owns_lock()) one_at_a_time.unlock();
+    // The device's streams (Ingest::shared_stream): the first context of a device creates them -- ~6 ms each, one at a time
+    // per DEVICE -- the others find them there.  Contexts on different devices do not wait for each other (until round 5 one
+    // process-wide lock put every open in line: on an eight-GPU node the eighth device's first byte waited for fifteen
+    // stream creations that were none of its business).
+    c->n_copy = ingest_cfg().copy_streams;
+    if (!(c->copy = c->ingest->shared_stream(0))) return bail(GSCAN_EHIP);
+    for (int k = 1; k < c->n_copy; k++)
+        if (!(c->copy_x[k - 1] = c->ingest->shared_stream(k))) return bail(GSCAN_EHIP);
+    c->compute = c->copy; // the scans and read-backs ride on the first copy stream
     lap("streams");
     // one pinned allocation for every small host-side buffer of the context (each hipHostMalloc costs about a millisecond)
     const size_t kHead = (kCounterWords * 4 + 63) & ~size_t(63); // the slot's counter words
@@ -1512,7 +1405,6 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     }
     if (hipEventCreateWithFlags(&c->prog_ev, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
     for (Slot &s : c->slot) {
-        if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
         if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
         for (int k = 1; k < c->n_copy; k++)
             if (hipEventCreateWithFlags(&s.copied_x[k - 1], hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
@@ -1527,7 +1419,7 @@ void gscan_close(gscan_ctx *c)
     if (!c) return;
     for (Slot &s : c->slot) slot_drain_reads(s); // a file range still being read: its last piece launches into this context
     if (c->ingest) c->ingest->report_if_timing();
-    if (getenv("GSCAN_TIMING") && c->tw_n)
+    if (g_timing && c->tw_n)
         fprintf(stderr, "[gscan timing] context on device %d: %zu waits | reads still arriving %.3f s  scan + fixed readback %.3f s  dense records %.3f s (%.1f MB, of which pinned (re)allocation %.3f s)  gathered lines %.3f s (%.1f MB)  merge %.3f s\n",
                 c->device, c->tw_n, c->tw_reads, c->tw_scan, c->tw_dense, c->tw_dense_bytes / 1e6, c->tw_alloc, c->tw_gather, c->tw_gather_bytes / 1e6, c->tw_merge);
     hipSetDevice(c->hip_dev);
@@ -1545,12 +1437,6 @@ void gscan_close(gscan_ctx *c)
         hipEventDestroy(e.a);
         hipEventDestroy(e.b);
     }
-    if (!c->copy_shared) {
-        if (c->copy) hipStreamDestroy(c->copy);
-        for (hipStream_t st : c->copy_x)
-            if (st) hipStreamDestroy(st);
-    }
-    if (c->compute && !c->compute_shared) hipStreamDestroy(c->compute);
     if (c->ingest) Ingest::release(c->ingest); // the last context of the device: reader threads joined, pinned pool freed
     delete c;
 }
@@ -1596,8 +1482,7 @@ size_t gscan_block_size(void) { return block_bytes(); }
 int gscan_prefault(size_t blocks)
 {
     if (g_prefault.base || blocks == 0) return GSCAN_OK; // once per process
-    if (const char *e = getenv("GSCAN_PREFAULT"))
-        if (atoi(e) == 0) return GSCAN_OK;
+    if (!ingest_cfg().prefault) return GSCAN_OK;
     const size_t huge = size_t(2) << 20;
     const size_t stride = (block_bytes() + kPad + huge - 1) / huge * huge;
     blocks = std::min<size_t>(std::min<size_t>(blocks, 64), std::max<size_t>(1, (size_t(256) << 20) / stride)); // (at most 256 MiB touched ahead, whatever GSCAN_BLOCK_MIB says)
@@ -1641,7 +1526,14 @@ void gscan_ingest_info(size_t *block_bytes_out, int *readers, int *copy_streams)
 {
     if (block_bytes_out) *block_bytes_out = ingest_cfg().block;
     if (readers) *readers = ingest_cfg().readers; // (0: auto -- gscan_auto_readers per device)
-    if (copy_streams) *copy_streams = ingest_cfg().shared_copy > 0 ? ingest_cfg().shared_copy : ingest_cfg().copy_streams;
+    if (copy_streams) *copy_streams = ingest_cfg().copy_streams;
+}
+
+int gscan_pool_stats(const gscan_ctx *c, uint64_t out[4])
+{
+    if (!c || !c->ingest || !out) return GSCAN_EINVAL;
+    c->ingest->stats(out);
+    return GSCAN_OK;
 }
 
 long gscan_parse_cpulist(const char *list, int *cpus, size_t cap)
@@ -1712,8 +1604,6 @@ int gscan_submit(gscan_ctx *c, const gscan_db *db, const void *host_bytes, size_
             }
         }
     }
-    HIPCHK(c, hipEventRecord(s->copied, c->copy));
-    HIPCHK(c, hipStreamWaitEvent(c->compute, s->copied, 0));
     s->db = db;
     s->len = len;
     s->tag = tag;
@@ -1757,8 +1647,6 @@ int gscan_submit_segs(gscan_ctx *c, const gscan_db *db, const void *pinned, cons
     }
     if (rc) return rc;
     if (used) HIPCHK(c, hipMemcpyAsync(s->d_text, pinned, used, hipMemcpyHostToDevice, c->copy));
-    HIPCHK(c, hipEventRecord(s->copied, c->copy));
-    HIPCHK(c, hipStreamWaitEvent(c->compute, s->copied, 0));
     s->db = db;
     s->len = used;
     s->tag = tag;
@@ -1924,7 +1812,7 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
             }
         }
     } release{s};
-    static const bool tw_on = getenv("GSCAN_TIMING") != nullptr;
+    const bool tw_on = g_timing;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tw0 = tw_on ? tnow() : 0;
     trace("wait: begin");

@@ -259,8 +259,6 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
 FileGrep::FileGrep() : uid_(geteuid())
 {
     timing_ = getenv("GRAB_TIMING") != nullptr;
-    const char *ing = getenv("GRAB_INGEST");
-    ingest_register_ = ing && !strcmp(ing, "register");
     // GRAB_BATCH_READ=worker (A/B runs): round 3's small-file path -- the worker itself read(2)s every file into a pinned
     // block and hands the block over (gscan_acquire + gscan_submit_segs)
     const char *br = getenv("GRAB_BATCH_READ");
@@ -507,7 +505,6 @@ struct FileGrep::Job {
     std::shared_ptr<FileRef> file;
     off_t off = 0;
     size_t len = 0;
-    void *map = nullptr; // GRAB_INGEST=register: the window's mapping, registered with the runtime and DMA'd in place
     // batch: segment i is file i
     std::vector<std::shared_ptr<FileRef>> files;
     std::vector<gscan_seg> segs;
@@ -532,13 +529,9 @@ int FileGrep::retire_oldest(bool print)
         const std::string &whose = job.file ? job.file->path : (job.files.empty() ? std::string("?") : job.files.front()->path + " (+ the rest of its batch)");
         err_ = std::string(rc == GSCAN_EIO ? "FileGrep::find::read: " : "FileGrep::find::gscan_wait: ") + gscan_strerror(ctx) + " [" + whose + "]";
         if (rc != GSCAN_EIO) failed_ = true;
-        if (job.map) munmap(job.map, job.len);
         return -1;
     }
-    if (!print) {
-        if (job.map) munmap(job.map, job.len);
-        return 0;
-    }
+    if (!print) return 0;
     const unsigned rflags = report_flags();
     std::string &text = report_buf_; // kept across jobs: dense outputs are tens of MB per window, no point in growing it anew each time
     text.clear();
@@ -548,9 +541,8 @@ int FileGrep::retire_oldest(bool print)
         // no candidate start at all -> nothing is printed (a match at s = 0 would head a group and be in the list),
         // and the file's bytes are never touched by the host.  Not so for patterns with context (\b ^ $ ...): a match
         // at offset 0 or at the very end of the window is the host's to find
-        if (job.map && (f.done || !(first[nseg] > 0 || context_))) munmap(job.map, job.len);
         if (!f.done && (first[nseg] > 0 || context_)) {
-            void *map = job.map ? job.map : mmap(nullptr, job.len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, f.fd, job.off); // grab.cc:161 (MAP_POPULATE: no gain, measured)
+            void *map = mmap(nullptr, job.len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, f.fd, job.off); // grab.cc:161 (MAP_POPULATE: no gain, measured)
             if (map == MAP_FAILED) {
                 err_ = std::string("FileGrep::find::mmap: ") + strerror(errno);
                 status = -1;
@@ -622,18 +614,26 @@ int FileGrep::submit_batch()
     batch_buf_ = nullptr;
     batch_used_ = 0;
     double t = timing_ ? now_s() : 0;
+    // A batch that cannot be handed over is not one file's error: its files have left batch_files_ and would never be scanned
+    // or reported.  The instance is marked failed -- every later find() fails, and the -n workers (which ignore per-file
+    // errors, main.cc:97) report it when they are done: failed() / why().
     if (batch_by_worker_) {
         if (gscan_submit_segs(ctx_, db_, buf, job.segs.data(), job.segs.size(), 0) != GSCAN_OK) {
-            err_ = std::string("FileGrep::find::gscan_submit_segs: ") + gscan_strerror(ctx_);
+            err_ = std::string("FileGrep::find::gscan_submit_segs: ") + gscan_strerror(ctx_) + " [" + job.files.front()->path + " (+ the rest of its batch)]";
+            failed_ = true;
             return -1;
         }
     } else {
-        if (make_room(0) < 0) return -1; // a slot has to be free for the batch
+        if (make_room(0) < 0) { // a slot has to be free for the batch (make_room fails on a device error only: failed_ is set)
+            err_ += " [then " + job.files.front()->path + " (+ the rest of its batch) could not be handed over]";
+            return -1;
+        }
         std::vector<gscan_file> list(job.files.size());
         for (size_t i = 0; i < job.files.size(); i++) list[i] = gscan_file{job.files[i]->path.c_str(), -1, job.files[i]->oflags, job.segs[i].len};
         t = timing_ ? now_s() : 0;
         if (gscan_submit_files(ctx_, db_, list.data(), list.size(), 0) != GSCAN_OK) {
-            err_ = std::string("FileGrep::find::gscan_submit_files: ") + gscan_strerror(ctx_);
+            err_ = std::string("FileGrep::find::gscan_submit_files: ") + gscan_strerror(ctx_) + " [" + job.files.front()->path + " (+ the rest of its batch)]";
+            failed_ = true;
             return -1;
         }
     }
@@ -835,17 +835,10 @@ int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
                 break;
             }
             double t = timing_ ? now_s() : 0;
-            void *reg_map = nullptr;
-            if (ingest_register_) {
-                // experiment (GRAB_INGEST=register): no copy on the host at all -- the window is mapped as the reference maps
-                // it (grab.cc:161), the mapping registered with the runtime and DMA'd straight out of the page cache
-                reg_map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, fd, off);
-                if (reg_map == MAP_FAILED) reg_map = nullptr;
-            }
-            const int src = reg_map ? gscan_submit(ctxs_[(size_t)k], db_, reg_map, len, (uint64_t)off)
-                                    : gscan_submit_fd(ctxs_[(size_t)k], db_, fd, (long long)off, len, (uint64_t)off);
+            // (mapping the window, registering the mapping and DMA-ing it in place -- no copy on the host at all -- was built and
+            // measured in round 2: registration serialises inside the runtime, 55 ms per GiB per thread; taken out again)
+            const int src = gscan_submit_fd(ctxs_[(size_t)k], db_, fd, (long long)off, len, (uint64_t)off);
             if (src != GSCAN_OK) {
-                if (reg_map) munmap(reg_map, len);
                 err_ = std::string("FileGrep::find::read: ") + gscan_strerror(ctxs_[(size_t)k]);
                 status = -1;
                 break;
@@ -854,7 +847,6 @@ int FileGrep::find(const char *path, const struct stat *st, int /*typeflag*/)
             ctx_bytes_[(size_t)k] += len;
             Job job;
             job.ctx = k;
-            job.map = reg_map;
             job.file = ref;
             job.off = off;
             job.len = len;
@@ -878,7 +870,10 @@ int FileGrep::find(const std::string &path)
     }
     if (S_ISREG(st.st_mode)) {
         const int rc = find(path.c_str(), &st, FTW_F);
-        if (flush() < 0) return -1; // an explicit path is done when this returns, like the reference's
+        if (flush() < 0) { // an explicit path is done when this returns, like the reference's
+            deferred_.clear(); // (err_ says what failed: a per-file error noted on the way must not be handed to the NEXT find())
+            return -1;
+        }
         if (!deferred_.empty()) { // a window of an earlier explicit path failed while this one was handed over
             err_.swap(deferred_);
             deferred_.clear();

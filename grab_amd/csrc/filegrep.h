@@ -40,6 +40,9 @@ public:
     FileGrep &operator=(const FileGrep &) = delete;
 
     const char *why() { return err_.c_str(); }
+    // a DEVICE error has happened (not a per-file one): nothing can be scanned any more and files handed over since may not
+    // have been; why() says which.  Callers that ignore find()'s per-file results (the -n workers) ask this when they are done.
+    bool failed() const { return failed_; }
     void recurse() { recursive_ = true; }
     void show_path(bool on) { show_path_ = on; }
 
@@ -116,7 +119,6 @@ private:
     size_t devices_ = 1;              // config "devices"
     size_t next_ctx_ = 0;             // round-robin cursor over the contexts a big file uses
     bool failed_ = false;             // a device error: every later find() fails at once with why() saying so
-    bool ingest_register_ = false;    // GRAB_INGEST=register (experiment): windows are mapped, registered and DMA'd in place
     std::string report_buf_;
     size_t batch_max_ = size_t(2) << 20; // files up to this size are batched ("batch" config key; 0 = never)
     size_t batch_bytes_ = size_t(32) << 20; // a batch is handed over when it holds this much (GRAB_BATCH_MIB), or kBatchMaxFiles files

@@ -197,6 +197,7 @@ void narrow_visible_devices(size_t want)
 {
     if (want == 0 || getenv("GRAB_DEVICE") || getenv("GRAB_DEVICES") || getenv("GRAB_ALL_DEVICES") || getenv("GSCAN_VIRTUAL_DEVICES")) return;
     const char *have = getenv("HIP_VISIBLE_DEVICES");
+    if (!have || !*have) have = getenv("CUDA_VISIBLE_DEVICES"); // (the runtime honours it when the HIP one is unset: narrow within the caller's choice)
     std::string list;
     if (have && *have) { // the first `want` entries of the caller's list
         size_t n = 0;
@@ -258,7 +259,6 @@ int run_workers(const Options &o)
         }
     }
 
-    narrow_visible_devices((size_t)o.workers); // worker i drives device i mod #devices: fewer workers than devices leave the rest idle
     JobQueue queue;
     // the walk starts at once, on its own threads; the workers open their devices meanwhile
     int walkers = 4;
@@ -312,6 +312,10 @@ int run_workers(const Options &o)
                 g.find(j.path.c_str(), &j.st, FTW_F);
             }
             g.flush(); // what is still in flight or waiting in a half-filled batch
+            if (g.failed()) { // a device error (per-file errors are ignored in this mode, a device that stopped scanning is not)
+                std::lock_guard<std::mutex> lk(err_lock);
+                if (first_error.empty()) first_error = g.why();
+            }
             g.report_timing();
             if (i == 0) mark("worker 0: everything retired");
             }
@@ -345,15 +349,6 @@ int run_serial(const Options &o)
     } closer{gp};
     FileGrep &grep = *gp;
     auto cfg = o.cfg;
-    if (!o.recursive) { // explicit paths: how many windows can be in flight at once is known before the runtime is up
-        const size_t chunk = cfg.count("chunk_size") ? cfg.at("chunk_size") : (size_t(1) << 30), stride = chunk - 4096;
-        size_t most = 1;
-        for (const std::string &p : o.paths) {
-            struct stat st;
-            if (stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode)) most = std::max(most, ((size_t)st.st_size + stride - 1) / stride);
-        }
-        if (most <= 64) narrow_visible_devices(most);
-    }
     if (const char *dev = getenv("GRAB_DEVICE")) cfg["device"] = size_t(atoi(dev));
     // a file of several windows is spread over the node's GPUs (contexts beyond the first open when such a file turns up)
     if (const char *n = getenv("GRAB_DEVICES")) cfg["devices"] = size_t(std::max(1, atoi(n)));
@@ -441,6 +436,20 @@ int main(int argc, char **argv)
                 close(pfd[1]);
             }
         }
+    }
+    // Devices the input cannot use stay out of sight (narrow_visible_devices) -- decided here, before any helper thread exists
+    // (setenv next to running threads is not safe): `-n N`: worker i drives device i mod #devices, fewer workers than devices
+    // leave the rest idle; explicit paths: as many windows as the largest file has can be in flight at once.
+    if (o.workers > 1) {
+        if (o.recursive) narrow_visible_devices((size_t)o.workers);
+    } else if (!o.recursive) {
+        const size_t chunk = o.cfg.count("chunk_size") ? o.cfg.at("chunk_size") : (size_t(1) << 30), stride = chunk - 4096;
+        size_t most = 1;
+        for (const std::string &p : o.paths) {
+            struct stat st;
+            if (stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode)) most = std::max(most, ((size_t)st.st_size + stride - 1) / stride);
+        }
+        if (most <= 64) narrow_visible_devices(most);
     }
     // staging memory is mapped and touched by helper threads while the HIP runtime starts (no HIP call in there; behind the fork above: threads do not survive one): as many
     // blocks as the input can keep busy -- a tree: the reader pool's worth; explicit files: what their bytes fill

@@ -15,7 +15,7 @@ OK, UNSUPPORTED = 0, 1
 EINVAL, ENOMEM, EHIP, EBUSY, EEMPTY, ETOOBIG, EIO = -1, -2, -3, -4, -5, -6, -7
 LITERAL = 1
 TIER_NULL, TIER_LITERAL, TIER_CLASSRUN, TIER_BUCKET, TIER_ANCHORED = 0, 1, 2, 3, 4
-SLOTS = 2
+SLOTS = 3  # GSCAN_SLOTS (include/gscan.h): chunks one context keeps in flight
 
 # every symbol include/gscan.h declares
 SYMBOLS = [
@@ -24,7 +24,7 @@ SYMBOLS = [
     "gscan_acquire", "gscan_block_size", "gscan_prefault", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_submit_files", "gscan_last_file_errors", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_gather", "gscan_last_ends", "gscan_next_listed",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
     "gscan_set_option", "gscan_kernel_time", "gscan_resource_errors",
-    "gscan_ingest_info", "gscan_auto_readers", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
+    "gscan_ingest_info", "gscan_pool_stats", "gscan_auto_readers", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
     "gscan_vm_verdict", "gscan_vm_filter", "gscan_vm_pair", "gscan_prefix_viable",
 ]
 
@@ -129,6 +129,7 @@ def lib():
         L.gscan_resource_errors.restype = C.c_uint64
         L.gscan_ingest_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gscan_ingest_info.restype = None
+        L.gscan_pool_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.gscan_device_cpulist.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.gscan_pci_cpulist.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
         L.gscan_parse_cpulist.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_size_t]
@@ -410,6 +411,12 @@ class Context:
         if n2 < 0:
             self._chk(int(n2), "gscan_dev_fetch")
         return out[:n2]
+
+    def pool_stats(self):
+        """{allocated, cap, event_waits, reader_waits} of the device's staging-block pool (gscan_pool_stats)."""
+        out = (C.c_uint64 * 4)()
+        self._chk(lib().gscan_pool_stats(self._h, out), "gscan_pool_stats")
+        return {"allocated": out[0], "cap": out[1], "event_waits": out[2], "reader_waits": out[3]}
 
     def kernel_time(self, reset=True):
         s = C.c_double()

@@ -257,9 +257,13 @@ size_t gscan_block_size(void);
  * only registers them with the runtime instead of allocating pinned memory block by block while the pipe fills (1.5 - 2 ms
  * each, one at a time).  No HIP call is made here.  GSCAN_PREFAULT=0 in the environment turns it into a no-op. */
 int gscan_prefault(size_t blocks);
-/* the ingest configuration in force (environment: GSCAN_BLOCK_MIB, GSCAN_READERS; copy streams: GSCAN_SHARED_COPY per device,
- * or GSCAN_COPY_STREAMS per context when GSCAN_SHARED_COPY=0); any pointer may be NULL */
+/* the ingest configuration in force (environment: GSCAN_BLOCK_MIB, GSCAN_READERS, GSCAN_COPY_STREAMS = the copy streams of a
+ * DEVICE, shared by its contexts); any pointer may be NULL */
 void gscan_ingest_info(size_t *block_bytes, int *readers, int *copy_streams);
+/* the staging-block pool of the context's device, for tests and diagnostics: out[0] blocks allocated, out[1] the pool's cap,
+ * out[2] how often a reader had to sleep on a block's DMA event because every block was in flight, out[3] how often it had
+ * to sleep until another reader brought a block back.  (tests/test_gpu_pool.py forces these slow paths and checks they ran.) */
+int gscan_pool_stats(const gscan_ctx *ctx, uint64_t out[4]);
 /* reader threads a device gets when GSCAN_READERS is unset (*readers == 0 above): 8, fewer when the device's share of its
  * NUMA node's CPUs (local_cpus / devices_sharing that node) is small; exported for tests */
 int gscan_auto_readers(int local_cpus, int devices_sharing);

@@ -116,8 +116,8 @@ def test_ingest_configuration(built):
     info = engine.ingest_info()
     assert info["block_bytes"] % (1 << 20) == 0 and (1 << 20) <= info["block_bytes"] <= (64 << 20)
     assert 0 <= info["readers"] <= 64 and 1 <= info["copy_streams"] <= 4  # readers 0: auto, per device (gscan_auto_readers)
-    # copy streams: the device's shared ones (GSCAN_SHARED_COPY, the default), or per context (GSCAN_COPY_STREAMS) when sharing is off
-    for extra, want in (({"GSCAN_SHARED_COPY": "0", "GSCAN_COPY_STREAMS": "4"}, 4), ({"GSCAN_SHARED_COPY": "2", "GSCAN_COPY_STREAMS": "4"}, 2), ({}, 2), ({"GSCAN_ONE_STREAM_COPIES": "1"}, 1)):
+    # copy streams: per DEVICE, shared by its contexts (GSCAN_COPY_STREAMS, default 2; the scans ride on the first)
+    for extra, want in (({"GSCAN_COPY_STREAMS": "4"}, 4), ({}, 2), ({"GSCAN_COPY_STREAMS": "1"}, 1), ({"GSCAN_COPY_STREAMS": "9"}, 4)):
         env = dict(os.environ, GSCAN_BLOCK_MIB="32", GSCAN_READERS="3", **extra)
         r = subprocess.run(["python", "-c", "from grab_amd import engine; print(engine.ingest_info())"], cwd=ROOT, env=env, capture_output=True, text=True)
         assert "'block_bytes': 33554432" in r.stdout and "'readers': 3" in r.stdout and "'copy_streams': %d" % want in r.stdout, r.stdout + r.stderr
