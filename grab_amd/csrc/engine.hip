@@ -661,6 +661,9 @@ private:
                         give_reader_block(b, nullptr);
                     } else {
                         give_reader_block(b, lane);
+                        if (g_timing && !first_dma_said_.exchange(true)) // (the ramp of a device: DESIGN.md 6's F(N) is made of these)
+                            fprintf(stderr, "[gscan timing] device %d: first piece queued for DMA at +%.4f s\n", device_,
+                                    std::chrono::duration<double>(std::chrono::steady_clock::now() - g_trace_t0).count());
                     }
                 } else {
                     give_reader_block(b, nullptr); // (a failed read, or GSCAN_DIAG=1: the block is filled and given straight back)
@@ -703,6 +706,7 @@ private:
     bool have_mask_ = false;
     bool nt_copy_ = false;
     size_t cap_ = 16, n_alloc_ = 0;
+    std::atomic<bool> first_dma_said_{false};
     std::atomic<long> n_made_{0};           // staging blocks asked of the runtime so far (GSCAN_FAIL_ALLOC_AFTER)
     uint64_t n_waits_ev_ = 0, n_waits_cv_ = 0; // (under m_) how often the pool's slow paths ran: slept on a block's event / on the other readers
     bool started_ = false, stop_ = false;

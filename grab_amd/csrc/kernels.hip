@@ -635,6 +635,7 @@ __device__ __forceinline__ uint32_t nonzero_bytes16(const uint32_t (&H)[4], bool
 // end of the sub-tile through the window tables and the pattern's backtracking VM (vm.h, program in LDS); a hit at which no
 // match can start is dropped instead of being recorded for the host's matcher (DevProgram::vm_filter).  The text is read
 // with the default cache policy in this form: the VM comes back to it.
+constexpr int kK3Queue = 192;
 __device__ __noinline__ bool vm_keep_hit_dev(const DevProgram *pg, const VmProg *vm, const uint8_t *seg, uint32_t slen, uint32_t q)
 {
     return vm_keep_hit(pg, vm, seg, slen, q);
@@ -652,6 +653,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
     __shared__ __attribute__((aligned(16))) uint8_t s_pos[kK3Confirm * 256];
     __shared__ uint8_t s_blen[kK3Buckets];
     __shared__ __attribute__((aligned(16))) uint32_t s_vm[VM ? sizeof(VmProg) / 4 : 1];
+    __shared__ uint16_t s_queue[VM ? NW * kK3Queue : 1]; // (VM) the waves' survivor queues (below): 192 entries each, three rounds of 64 lanes
     constexpr uint32_t kTile = NW * ITER * 1024;
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x / kWave;
@@ -833,7 +835,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
 #pragma unroll
             for (int j = 1; j < ITER; j++) buf[j] = load_step<ITER, NT, 1>(cn, sub_off_n, lane, j, have_n);
         }
-        if ((VM || !exact) && cur) { // the survivors of the sub-tile, word by word: confirm (+ VM), the lanes side by side
+        if (!VM && !exact && cur) { // the filter is not the pattern: the sub-tile's hits confirmed word by word, each lane working off its own
             cnt = 0;
 #pragma unroll
             for (int w = 0; w < (ITER + 1) / 2; w++) {
@@ -846,9 +848,64 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                     if (!confirm_hit(p)) keep &= ~(1u << b);
                 }
                 // keep group starts (within a lane's sixteen positions of one step) where the tables have the last word
-                if (!VM && confirm_exact) keep &= ~((keep << 1) & 0xfffefffeu);
+                if (confirm_exact) keep &= ~((keep << 1) & 0xfffefffeu);
                 hits[w] = keep;
                 cnt += (uint32_t)__popc(keep);
+            }
+        }
+        if (VM && cur) {
+            // The survivors of the sub-tile go through confirm (+ VM) from a WAVE-WIDE QUEUE (round 5): every lane writes the
+            // positions of its own hits into a strip of LDS at the rank a wave scan of the lanes' counts gives them, then lane i
+            // takes entry i (+ 64, + 128) -- 64 survivors run side by side whichever lanes they came from.  Until round 4 each
+            // lane worked off its own hits, word by word: with a hit every 150 bytes ([a-z]+\([a-z0-9, ]*\);) a word's loop
+            // ran as often as its fullest lane had hits with a fifth, then a fiftieth of the lanes active -- ~7 % of the lanes
+            // busy in the one part of the kernel that costs hundreds of instructions per hit (31 GB/s).  Verdicts come back
+            // through the same strip (a dropped entry is overwritten) and the owners clear their bits.
+            uint32_t mine = 0;
+#pragma unroll
+            for (int w = 0; w < (ITER + 1) / 2; w++) mine += (uint32_t)__popc(hits[w]);
+            const uint32_t incl = wave_scan(mine), excl = incl - mine;
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            volatile uint16_t *q = s_queue + wave * kK3Queue;
+            for (uint32_t base = 0; base < total; base += kK3Queue) { // (wave-uniform; one round unless a sub-tile has > kK3Queue survivors)
+                uint32_t idx = excl;
+#pragma unroll
+                for (int w = 0; w < (ITER + 1) / 2; w++) {
+                    uint32_t word = hits[w];
+                    while (word) {
+                        const uint32_t b = (uint32_t)__ffs((int)word) - 1u;
+                        word &= word - 1u;
+                        if (idx - base < (uint32_t)kK3Queue) q[idx - base] = (uint16_t)((2u * (uint32_t)w + (b >> 4)) * 1024u + lane * 16u + (b & 15u));
+                        idx++;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t n = min(total - base, (uint32_t)kK3Queue);
+                for (uint32_t i = lane; i < n; i += kWave) {
+                    const uint32_t e = q[i];
+                    if (!confirm_hit((uint32_t)sub_off + e - koff)) q[i] = 0xffffu;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                idx = excl;
+#pragma unroll
+                for (int w = 0; w < (ITER + 1) / 2; w++) {
+                    uint32_t word = hits[w], keep = word;
+                    while (word) {
+                        const uint32_t b = (uint32_t)__ffs((int)word) - 1u;
+                        word &= word - 1u;
+                        if (idx - base < (uint32_t)kK3Queue && q[idx - base] == 0xffffu) keep &= ~(1u << b);
+                        idx++;
+                    }
+                    hits[w] = keep;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            cnt = 0;
+#pragma unroll
+            for (int w = 0; w < (ITER + 1) / 2; w++) {
+                cnt += (uint32_t)__popc(hits[w]); // (no group-start compression: a real hit must not be dropped for following one the VM struck out)
             }
         }
         if (cur) emit_wave<ITER>(a, t * NW + wave, hits, cnt, sub_off, koff - a.report_shift, lane);

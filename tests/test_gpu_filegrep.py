@@ -356,3 +356,30 @@ def test_small_file_errors_surface_per_file(built, tmp_path):
             assert "FileGrep::find" not in r.stderr, r.stderr
         else:
             assert "FileGrep::find::read: file shrank" in rc_line or "FileGrep::find::open" in rc_line, rc_line
+
+
+def test_a_file_error_is_returned_once(built, tmp_path):
+    """an error that belongs to one explicit path is returned by the find() during which it surfaces and by no
+    later one -- the instance goes on with the next path as if nothing had happened."""
+    for n in ("bad", "good1", "good2"):
+        (tmp_path / n).write_bytes(b"x" * 100 + b"foo\n" + b"y" * 50)
+    driver = (
+        "import os, sys\n"
+        "from grab_amd import filegrep\n"
+        "d = sys.argv[1]\n"
+        "g = filegrep.FileGrep()\n"
+        "g.config({'offsets': 1, 'noline': 1, 'chunk_size': 1 << 30})\n"
+        "assert g.prepare('foo') == 0, g.why()\n"
+        "st = filegrep.c_stat(os.path.join(d, 'bad'))\n"
+        "open(os.path.join(d, 'bad'), 'wb').write(b'short')\n"   # shrank after it was stat()ed
+        "r0 = g.find3(os.path.join(d, 'bad'), st)\n"             # queued in a batch: nothing has looked at it yet
+        "r1 = g.find(os.path.join(d, 'good1')); w1 = g.why()\n"   # the batch retires here: bad's error comes out of THIS call
+        "r2 = g.find(os.path.join(d, 'good2'))\n"
+        "sys.stdout.flush()\n"
+        "print('RC', r0, r1, r2, repr(w1))\n"
+    )
+    r = subprocess.run([sys.executable, "-c", driver, str(tmp_path)], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rc_line = [ln for ln in r.stdout.splitlines() if ln.startswith("RC")][0]
+    assert rc_line.startswith("RC 0 -1 0 ") and "file shrank" in rc_line, r.stdout + r.stderr
+    assert r.stdout.count("Match at offset 100") == 2, r.stdout  # good1 (same batch as the bad file) and good2
