@@ -215,7 +215,8 @@ def live_traffic(patterns, gib, timeout_s=90):
 
 
 def time_kernel(ctx, db, arena, segs, stream, nbytes, cap_per_gib, steps, warmup, device):
-    """W untimed + K timed launches of one pattern over the arena; (wall seconds for K steps, records, overflow, kernel ms sum, launches, last result)."""
+    """W untimed + K timed launches of one pattern over the arena; (wall seconds for K steps, records, overflow, kernel ms sum,
+    launches, last result, clock + power sampled while the timed launches ran)."""
     ctx.set_capacity(max(1 << 16, int(cap_per_gib * nbytes / (1 << 30))))
     res = None
     for _ in range(warmup):
@@ -224,14 +225,16 @@ def time_kernel(ctx, db, arena, segs, stream, nbytes, cap_per_gib, steps, warmup
         ctx.dev_sync(res)
     ctx.kernel_time(reset=True)
     torch.cuda.synchronize(device)
+    sampler = ClockSampler().start()
     t0 = time.perf_counter()
     for _ in range(steps):
         res = ctx.scan_device(db, arena.data_ptr(), segs, stream)
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
+    clocks = sampler.stop()
     total, overflow = ctx.dev_sync(res)
     kern_ms, launches = ctx.kernel_time(reset=True)
-    return wall, total, overflow, kern_ms, launches, res
+    return wall, total, overflow, kern_ms, launches, res, clocks
 
 
 def check_span(got, text, a, lo, hi, pattern, so):
@@ -310,6 +313,45 @@ def clocks_snapshot():
     return out or None
 
 
+class ClockSampler:
+    """Shader clock and socket power sampled WHILE kernels run (a thread reading sysfs every 5 ms between start() and
+    stop()): the median is what the timed launches ran at.  A snapshot taken after the synchronize reads the idle state
+    (111 MHz, 240 W in round 4's records), which says nothing about the run."""
+
+    def __init__(self, period_s=0.005):
+        import threading
+
+        self.period = period_s
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            c = clocks_snapshot()
+            if c:
+                self.samples.append(c)
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._thread.join()
+        clk = sorted(c["sclk_mhz"] for c in self.samples if "sclk_mhz" in c)
+        pw = sorted(c["power_w"] for c in self.samples if "power_w" in c)
+        if not clk and not pw:
+            return None
+        out = {"samples": len(self.samples), "sampled": "every %d ms while the timed launches ran" % round(self.period * 1e3)}
+        if clk:
+            out.update({"sclk_mhz": clk[len(clk) // 2], "sclk_mhz_min": clk[0], "sclk_mhz_max": clk[-1]})
+        if pw:
+            out.update({"power_w": pw[len(pw) // 2], "power_w_max": pw[-1]})
+        return out
+
+
 def roofline_block(config, nbytes, total, kern_ms, launches, live=None):
     alg_bytes = nbytes + REC_BYTES * total  # per launch: every input byte once + one u32 per candidate
     kern_avg_ms = kern_ms / max(launches, 1)
@@ -381,21 +423,50 @@ def write_corpus(arena, d, nfiles, file_bytes):
 
 
 class Lines(int):
-    """Line count of an output that was not kept (run_timed(count_only=True)): answers .count(b"\\n") like the bytes would."""
+    """Line count of an output that was not kept (run_timed(count_only=True)): answers .count(b"\\n") like the bytes would;
+    .digest is the order-independent digest of its lines (line_digest)."""
+
+    digest = None
 
     def count(self, what):
         return int(self)
 
 
-def run_timed(argv, env, reps, warm=True, count_only=False):
+def line_digest(argv, env=None, stdin_bytes=None):
+    """(lines, digest, seconds) of a command's stdout through oracle/linesum -- the sum and the xor of a 64-bit hash of every
+    line + the byte count: equal for two outputs iff they hold the same multiset of lines, whatever their order (the `-n`
+    modes print files in no particular order; the reference's own check sorts, README.md:206-216 -- at 172.9 M lines a
+    digest is what one can afford to run on both sides at full size).  The checker's tool; nothing of it is timed as
+    the product.  stdin_bytes: digest these bytes instead of running argv."""
+    tool = os.path.join(ROOT, "oracle", "linesum")
+    if not os.path.exists(tool):
+        return None, None, None
+    t0 = time.perf_counter()
+    if stdin_bytes is not None:
+        r = subprocess.run([tool], input=stdin_bytes, capture_output=True)
+        rc = 0
+    else:
+        p1 = subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+        r = subprocess.run([tool], stdin=p1.stdout, capture_output=True)
+        p1.stdout.close()
+        rc = p1.wait()
+    dt = time.perf_counter() - t0
+    f = r.stdout.split()
+    if rc != 0 or r.returncode != 0 or len(f) != 4:
+        return None, None, dt
+    return int(f[0]), (b"%s:%s:%s" % (f[1], f[2], f[3])).decode(), dt
+
+
+def run_timed(argv, env, reps, warm=True, count_only=False, pause=0.5):
     """One untimed pass (warms the page cache; warm=False: the cache is known to be warm), then the min
     of `reps`; (seconds, stdout, stderr of the best).
 
     stdout goes to a file in /dev/shm, not to a pipe: with 10^8 output lines this process's own reading (and joining) of a
     pipe is a good part of a second that has nothing to do with the program under test.  count_only (cfg3 prints gigabytes):
     the TIMED runs write to /dev/null (SURVEY.md 8d's rule for the CPU baseline, applied to both sides: allocating 3.5 GB of
-    fresh tmpfs pages per run is the sink's cost, not the scanner's); the untimed pass writes the file and its lines are
-    counted in 16 MiB pieces and returned in stdout's place (None without such a pass)."""
+    fresh tmpfs pages per run is the sink's cost, not the scanner's); the untimed pass goes through the line digest
+    (line_digest: count + order-independent hash) and that is returned in stdout's place (None without such a pass).
+    pause: seconds of quiet before every run."""
     best = None
     lines = None
     out_path = "/dev/shm/grab_bench_out_%d.txt" % os.getpid()
@@ -405,7 +476,14 @@ def run_timed(argv, env, reps, warm=True, count_only=False):
             # Half a second of quiet first: when a process that used the GPU has gone, the kernel is still taking its state
             # apart, and the next process's hipInit waits for that -- 0.12 - 0.2 s instead of 0.05 (profiles/r04_c_*: the
             # same command with and without the pause).  A one-shot command line is not started in another one's wake.
-            time.sleep(0.5)
+            time.sleep(pause)
+            if count_only and not to_null:  # the untimed pass of an output too big to keep: through the digest, never on disk
+                n, dg, _ = line_digest(argv, env)
+                if n is None:
+                    return None, b"", b"linesum failed"
+                lines = Lines(n)
+                lines.digest = dg
+                continue
             with open("/dev/null" if to_null else out_path, "wb") as out:
                 t0 = time.perf_counter()
                 r = subprocess.run(argv, stdout=out, stderr=subprocess.PIPE, env=env)
@@ -414,13 +492,6 @@ def run_timed(argv, env, reps, warm=True, count_only=False):
             if not count_only:
                 with open(out_path, "rb") as f:
                     stdout = f.read()
-            elif not to_null and r.returncode == 0:
-                n = 0
-                with open(out_path, "rb") as f:
-                    for blk in iter(lambda: f.read(1 << 24), b""):
-                        n += blk.count(b"\n")
-                lines = Lines(n)
-                os.unlink(out_path)
             if r.returncode != 0:
                 return None, stdout, r.stderr
             if it > 0 and (best is None or dt < best[0]):
@@ -433,6 +504,17 @@ def run_timed(argv, env, reps, warm=True, count_only=False):
     return best
 
 
+def back_to_back_s(argv, env):
+    """Wall clock of the command started the moment a first run of it has gone (output discarded both times)."""
+    with open("/dev/null", "wb") as out:
+        if subprocess.run(argv, stdout=out, stderr=subprocess.DEVNULL, env=env).returncode != 0:
+            return None
+        t0 = time.perf_counter()
+        r = subprocess.run(argv, stdout=out, stderr=subprocess.DEVNULL, env=env)
+        dt = time.perf_counter() - t0
+    return dt if r.returncode == 0 else None
+
+
 def pick_workers(n_gpus):
     """`-n` for N devices: FOUR workers per device, at least eight.  One worker keeps a device's pipe full (three
     windows in flight: `grab -r`, -n 4 and -n 8 move the literal corpus at the same rate, profiles/r04_e_*); what needs more
@@ -442,7 +524,7 @@ def pick_workers(n_gpus):
     return max(8, 4 * n_gpus)
 
 
-def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=2, workers=None, detached=True, count_only=False, warm=True):
+def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=2, workers=None, detached=True, count_only=False, warm=True, back_to_back=True):
     """`grab -n pick_workers(N) -r` over the corpus directory on the first N devices."""
     workers = pick_workers(n_gpus) if workers is None else workers
     allowed = len(os.sched_getaffinity(0))
@@ -459,6 +541,9 @@ def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=
     # status and leaves the GPU teardown (0.1 - 0.2 s) behind the caller's back (grab_cli.cc): timed next to it.
     det = run_timed(argv, dict(env, GRAB_DETACH="1"), 1) if detached else None
     det_s = det[0] if det and det[0] else None
+    # ... and the same command started the moment the previous GPU process has gone (no half second of quiet): hipInit in
+    # another process's wake costs 0.12 - 0.2 s instead of 0.05 (profiles/r04_c_*); both figures belong in the record
+    b2b_s = back_to_back_s(argv, env) if back_to_back else None
     dt, out, err = got
     nbytes = nfiles * file_bytes
     lines = out.count(b"\n") if out is not None else None
@@ -480,8 +565,10 @@ def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=
             # moment the caller has the exit status (the kernel taking the process's GPU state apart)
             "exit_s": t_done is not None and round(dt - t_done, 4), "fixed_s": t_up is not None and t_done is not None and round(dt - (t_done - t_up), 4),
             "pcie_peak": PCIE_PEAK_GBPS * n_gpus, "frac": round(rate / (PCIE_PEAK_GBPS * n_gpus), 4),
+            "back_to_back_wall_s": b2b_s and round(b2b_s, 4), "back_to_back_GBps": b2b_s and round(nbytes / b2b_s / 1e9, 2),
             "lines": lines, "lines_expected": want_lines, "lines_ok": lines == want_lines,
-            "matches_per_s": lines is not None and round(lines / dt, 1),
+            "digest": getattr(out, "digest", None) if count_only else (line_digest(None, stdin_bytes=out)[1] if out is not None else None),
+            "matches_per_s": round(lines / dt, 1) if lines is not None else None,
             "per_device_bytes": {str(k): v for k, v in sorted(per_dev.items())},
             "ingest": engine.ingest_info(),
             "command": " ".join([os.path.basename(argv[0])] + argv[1:-1]) + " <dir>, wall clock of the whole (one) process, page cache warm, min of %d" % reps}
@@ -531,7 +618,8 @@ def cpu_baseline(d, nfiles, file_bytes, pattern, flags, threads=None, reps=2, wa
             "sample": "%s of the same corpus under %s (%.0f GiB), '%s', warm cache, min of %d" % (
                 ("%d x %s files" % (nfiles, "%d MiB" % (file_bytes >> 20) if file_bytes >= 1 << 20 else "%d KiB" % (file_bytes >> 10))) if os.path.isdir(d) else "one %d MiB file" % (nbytes >> 20),
                 os.path.dirname(d), nbytes / (1 << 30), " ".join(os.path.basename(a) if a == binary else a for a in argv[:-1]), reps),
-            "lines": out.count(b"\n") if out is not None else None, "matches_per_s": out is not None and round(out.count(b"\n") / dt, 1), "wall_s": round(dt, 4),
+            "lines": out.count(b"\n") if out is not None else None, "matches_per_s": round(out.count(b"\n") / dt, 1) if out is not None else None, "wall_s": round(dt, 4),
+            "digest": getattr(out, "digest", None) if count_only else (line_digest(None, stdin_bytes=out)[1] if out is not None else None),
             "engine": "libpcre 8.39 JIT (pcre_exec); the -H hyperscan path does not exist in the mounted reference"}
 
 
@@ -573,10 +661,16 @@ def e2e_cfg3(d, nfiles, file_bytes, n_gpus, want_cpu):
         link_subset(d, d1, n1)
         e = e2e_measure(d, nfiles, file_bytes, ident, ["-O", "-l"], n_gpus, None, reps=2, detached=False, count_only=True)
         if n16 < nfiles and "value" in e:
-            q = e2e_measure(d16, n16, file_bytes, ident, ["-O", "-l"], n_gpus, None, reps=2, detached=False, count_only=True, warm=False)
+            q = e2e_measure(d16, n16, file_bytes, ident, ["-O", "-l"], n_gpus, None, reps=2, detached=False, count_only=True, warm=False, back_to_back=False)
             e["at_16GiB"] = {k: q.get(k) for k in ("value", "bytes", "wall_s", "startup_s", "scan_phase_GBps", "frac", "error") if k in q}
-        e["lines_ok"] = None
         ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
+        # the WHOLE output against the reference's, at the size BASELINE quotes: count + order-independent digest of the
+        # 172.9 M lines on both sides (the reference needs ~25 s for its side; its sink here is the digest's pipe, so this run
+        # is not its timing -- cpu_baseline below is)
+        if os.path.exists(ref) and "value" in e:
+            n_ref, dg_ref, ref_s = line_digest([ref, "-n", str(min(64, usable_cores())), "-r", "-O", "-l", ident, d])
+            e.update({"lines_expected": n_ref, "reference_digest": dg_ref, "lines_ok": n_ref is not None and e.get("lines") == n_ref,
+                      "same_as_reference": dg_ref is not None and e.get("digest") == dg_ref, "reference_full_size_s": ref_s and round(ref_s, 1)})
         got = sorted_md5([bin_path(), "-n", "8", "-r", "-O", "-l", ident, d1])
         if os.path.exists(ref):
             want = sorted_md5([ref, "-n", str(min(64, usable_cores())), "-r", "-O", "-l", ident, d1])
@@ -629,7 +723,7 @@ def e2e_cfg4(base, gib, n_gpus, want_cpu):
                     for f in os.listdir(os.path.join(d, a, b)):
                         os.link(os.path.join(d, a, b, f), os.path.join(dq, a, b, f))
                         nq += 1
-            q = e2e_measure(dq, nq, fb, needle, ["-O", "-l"], n_gpus, nq, reps=2, detached=False, warm=False)
+            q = e2e_measure(dq, nq, fb, needle, ["-O", "-l"], n_gpus, nq, reps=2, detached=False, warm=False, back_to_back=False)
             e["at_16GiB"] = {k: q.get(k) for k in ("value", "bytes", "wall_s", "startup_s", "scan_phase_GBps", "frac", "lines_ok", "error") if k in q}
         ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
         got = sorted_md5([bin_path(), "-n", "8", "-r", "-O", "-l", needle, d])
@@ -637,7 +731,7 @@ def e2e_cfg4(base, gib, n_gpus, want_cpu):
             want = sorted_md5([ref, "-n", str(min(64, usable_cores())), "-r", "-O", "-l", needle, d])
             e["sorted_md5"], e["reference_sorted_md5"], e["same_as_reference"] = got[0], want[0], got == want and got[0] is not None
             if want_cpu:
-                e["cpu_baseline"] = cpu_baseline(d, files, fb, needle, ["-O", "-l"], threads=sorted(set([min(32, usable_cores()), min(64, usable_cores())])), reps=1, warm=False)
+                e["cpu_baseline"] = cpu_baseline(d, files, fb, needle, ["-O", "-l"], threads=sorted(set([min(32, usable_cores()), min(64, usable_cores())])), reps=2, warm=False)
                 if e["cpu_baseline"] and "value" in e:
                     e["vs_cpu_baseline"] = round(e["value"] / e["cpu_baseline"]["value"], 3)
         return e
@@ -656,12 +750,14 @@ def one_file_block(argv_tail, path, size, what, want_cpu, reps=2, ref_reps=1):
     if got is None or got[0] is None:
         return {"error": (got[2] if got else b"")[-300:].decode("latin-1")}
     dt, out, _ = got
+    b2b = back_to_back_s([bin_path()] + argv_tail + [path], None)
     e = {"value": round(size / dt / 1e9, 2), "unit": "GB/s", "bytes": size, "wall_s": round(dt, 4), "frac": round(size / dt / 1e9 / PCIE_PEAK_GBPS, 4),
+         "back_to_back_wall_s": b2b and round(b2b, 4),
          "lines": out.count(b"\n"), "md5": hashlib.md5(out).hexdigest(),
          "command": "grab %s <%s>, wall clock of the whole process, page cache warm, min of %d" % (" ".join(argv_tail), what, reps)}
     ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
     if os.path.exists(ref):
-        r = run_timed([ref] + argv_tail + [path], None, ref_reps, warm=ref_reps > 1)
+        r = run_timed([ref] + argv_tail + [path], None, ref_reps, warm=False)  # (the file is in the page cache: grab has just read it)
         if r and r[0]:
             e["reference_md5"] = hashlib.md5(r[1]).hexdigest()
             e["same_as_reference"] = e["reference_md5"] == e["md5"]
@@ -690,7 +786,7 @@ def e2e_cfg5(base, gib, want_cpu):
             t0 = time.perf_counter()
             plants = fullsize_parity.gen_big(path, g << 30, 1 << 30, int(31250 * g))
             gen_s = time.perf_counter() - t0
-            e = one_file_block(["-O", "-l", needle], path, g << 30, "one %d GiB file" % g, want_cpu and out is None)
+            e = one_file_block(["-O", "-l", needle], path, g << 30, "one %d GiB file" % g, want_cpu and out is None, ref_reps=2 if out is None else 1)
             e.update({"plants": int(plants), "corpus_write_s": round(gen_s, 1)})
         finally:
             if os.path.exists(path):
@@ -828,12 +924,14 @@ def main():
 
     barrier(world, device)
     torch.cuda.synchronize(device)
+    sampler = ClockSampler().start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = step()
     torch.cuda.synchronize(device)
     barrier(world, device)
     elapsed = time.perf_counter() - t0
+    clk_run = sampler.stop()
 
     total, overflow = ctx.dev_sync(res)
     kern_ms, launches = ctx.kernel_time(reset=True)
@@ -842,7 +940,6 @@ def main():
 
     # the timed launch's output: planted needles exactly (literal configs), and the records of the first and last file against
     # the oracle's candidate set (every config)
-    clk_after = clocks_snapshot()
     check = check_launch(ctx, res, arena, pattern, a.files, file_bytes, plants, total, overflow, a.config != "cfg3")
 
     # HBM traffic per launch, measured in this run (rank 0 of a one-GPU run; the PMC passes run the native harness next to
@@ -870,7 +967,7 @@ def main():
             "matches_per_s": round(matches_all / (elapsed / a.steps), 1),
             "check": check,
             "roofline": roofline_block(a.config, nbytes, total, kern_ms, launches, live),
-            "clocks": clk_after,
+            "clocks": clk_run,
         }
 
     # the other two kernels on the same arena, same process (outside the timed region above): every rank runs them so that
@@ -889,9 +986,9 @@ def main():
         for k in range(3):
             for name in names:
                 pat2, cap2 = CONFIGS[name]
-                wall, tot2, ovf2, kms2, nl2, res2 = time_kernel(ctx, dbs[name], arena, segs, stream, nbytes, cap2, steps2, 1, device)
+                wall, tot2, ovf2, kms2, nl2, res2, clk2 = time_kernel(ctx, dbs[name], arena, segs, stream, nbytes, cap2, steps2, 1, device)
                 blk = roofline_block(name, nbytes, tot2, kms2, nl2, live)
-                blk.update({"records_per_launch": int(tot2), "overflow": bool(ovf2), "value": round(nbytes / (wall / steps2) / 1e9, 2), "clocks": clocks_snapshot()})
+                blk.update({"records_per_launch": int(tot2), "overflow": bool(ovf2), "value": round(nbytes / (wall / steps2) / 1e9, 2), "clocks": clk2})
                 passes[name].append(blk)
                 if k == 0:
                     checks[name] = check_launch(ctx, res2, arena, pat2, a.files, file_bytes, plants, tot2, ovf2, name != "cfg3")
@@ -905,9 +1002,9 @@ def main():
                         "passes": [{"frac": b["frac"], "kernel_ms": b["kernel_ms"], "clocks": b["clocks"]} for b in passes[name]],
                         "records_same_every_pass": len(set(b["records_per_launch"] for b in passes[name])) == 1})
             steps3 = 2 * a.steps
-            _, tot3, _, kms3, nl3, _ = time_kernel(ctx, dbs[name], arena, segs, stream, nbytes, cap2, steps3, 0, device)
+            _, tot3, _, kms3, nl3, _, clk3 = time_kernel(ctx, dbs[name], arena, segs, stream, nbytes, cap2, steps3, 0, device)
             sus = roofline_block(name, nbytes, tot3, kms3, nl3, None)
-            blk["sustained"] = {"launches": nl3, "kernel_ms": sus["kernel_ms"], "achieved": sus["achieved"], "frac": sus["frac"]}
+            blk["sustained"] = {"launches": nl3, "kernel_ms": sus["kernel_ms"], "achieved": sus["achieved"], "frac": sus["frac"], "clocks": clk3}
             others[name] = blk
         if rank == 0:
             line["kernels"] = others
@@ -933,9 +1030,21 @@ def main():
                     line["e2e"] = e
                     want_cpu = world == 1 and not a.no_cpu_baseline
                     if want_cpu:
-                        line["cpu_baseline"] = cpu_baseline(d, nfiles, file_bytes, pattern, flags)
+                        line["cpu_baseline"] = cpu_baseline(d, nfiles, file_bytes, pattern, flags, count_only=a.config == "cfg3")
                         if line["cpu_baseline"] and "value" in e:
                             e["vs_cpu_baseline"] = round(e["value"] / line["cpu_baseline"]["value"], 3)
+                            e["reference_digest"] = line["cpu_baseline"].get("digest")
+                            e["same_as_reference"] = e.get("digest") is not None and e.get("digest") == e["reference_digest"]
+                    # the N = 8 model's terms that one GPU can measure: the fixed cost with eight device indices
+                    # through one runtime, the host's copy ceiling with the DMA stubbed out
+                    if world == 1 and not a.no_e2e_extra:
+                        try:
+                            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                            import n8_model
+
+                            line["n8_model"] = n8_model.measure(bin_path(), d, nfiles * file_bytes, pattern=synth.NEEDLE.decode(), reps=2)
+                        except Exception as ex:
+                            line["n8_model"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
                     # the other end-to-end BASELINE configurations, each with its own parity check and CPU baseline.  cfg3 runs on
                     # the cfg2 corpus; that corpus is removed before cfg5 (32 GiB) and cfg4 (64 GiB) write theirs
                     if not a.no_e2e_extra:

@@ -115,11 +115,27 @@ void trace(const char *fmt, ...)
 // runtime serves one at a time: a 256 MiB file spends 25 of its 30 ms of transfer waiting for blocks).  So a helper thread
 // maps anonymous memory (huge pages where the kernel gives them) and touches it while the runtime starts; a block is then
 // taken from there and only REGISTERED with the runtime (pages present, nothing to zero).
+// Round 5: the helpers can also FILL blocks with the first pieces of the files the command line names (gscan_prefault_files):
+// what a reader would pread after the runtime is up is read while it starts; the piece's reader then adopts the block as it
+// is -- registers it and queues the DMA.  A 256 MiB file used to crawl through the pipe's ramp in 29 ms, after the runtime's
+// 50 ms; now its bytes are in staging memory before the runtime answers its first call.
 struct Prefault {
     char *base = nullptr;
     size_t stride = 0, count = 0;
-    std::atomic<size_t> next{0};
-    std::atomic<bool> *touched = nullptr; // (never freed: the helper threads are detached and may outlive static destruction)
+    size_t ahead = 0;               // blocks [0, ahead) are read-ahead pieces, [ahead, count) plain touched blocks
+    std::atomic<size_t> next{0};    // plain blocks handed out so far
+    std::atomic<int> *state = nullptr; // per block: 0 not ready yet, 1 touched, 2 filled with its piece, 3 the read failed
+                                       // (never freed: the helper threads are detached and may outlive static destruction)
+    struct Piece {
+        std::string path;
+        dev_t dev = 0;
+        ino_t ino = 0;
+        off_t off = 0;
+        size_t n = 0;
+        std::atomic<bool> claimed{false};
+    };
+    Piece *piece = nullptr;         // [ahead]; dev / ino are written by the helper before state goes to 2
+    std::atomic<size_t> unclaimed{0};
 };
 Prefault g_prefault;
 
@@ -205,6 +221,7 @@ struct ReadTask {
     uint8_t *dst;       // device
     hipStream_t stream; // one of the submitting context's copy streams
     ReadGroup *grp;
+    int ahead = -1;     // >= 0: the piece was read ahead into this block of the prefaulted arena (gscan_prefault_files)
     // a piece made of whole small files (gscan_submit_files): items[0..nitems) land at their dst_off - items[0].dst_off
     // inside the block, n covers them all, ONE DMA carries the lot
     FileItem *items = nullptr;
@@ -450,9 +467,9 @@ private:
         }
         // a block that was mapped and touched while the runtime started (gscan_prefault): only registered here
         if (g_prefault.base && g_prefault.stride >= block_bytes() + kPad) {
-            const size_t k = g_prefault.next.fetch_add(1, std::memory_order_relaxed);
+            const size_t k = g_prefault.ahead + g_prefault.next.fetch_add(1, std::memory_order_relaxed);
             if (k < g_prefault.count) {
-                while (!g_prefault.touched[k].load(std::memory_order_acquire)) std::this_thread::yield();
+                while (!g_prefault.state[k].load(std::memory_order_acquire)) std::this_thread::yield();
                 void *p = g_prefault.base + k * g_prefault.stride;
                 if (hipHostRegister(p, block_bytes() + kPad, hipHostRegisterDefault) == hipSuccess) {
                     if (hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) == hipSuccess) {
@@ -472,6 +489,33 @@ private:
             delete b;
             return nullptr;
         }
+        return b;
+    }
+
+    // A piece that was read ahead while the runtime started (gscan_prefault_files): its block joins the pool as it is, filled.
+    // nullptr: the helper's read failed, or the runtime refuses the registration -- the piece is read the ordinary way.
+    PinBlock *adopt_ahead_block(int k)
+    {
+        while (!g_prefault.state[k].load(std::memory_order_acquire)) std::this_thread::yield();
+        if (g_prefault.state[k].load(std::memory_order_acquire) != 2) return nullptr;
+        PinBlock *b = new (std::nothrow) PinBlock();
+        if (!b) return nullptr;
+        void *p = g_prefault.base + (size_t)k * g_prefault.stride;
+        if (hipHostRegister(p, block_bytes() + kPad, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            delete b;
+            return nullptr;
+        }
+        if (hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostUnregister(p);
+            delete b;
+            return nullptr;
+        }
+        b->p = p;
+        b->registered = true;
+        std::lock_guard<std::mutex> lk(m_);
+        n_alloc_++; // (beyond cap_ if need be: the memory is there already; the block serves the pool from now on)
         return b;
     }
 
@@ -590,13 +634,15 @@ private:
             double t1 = g_timing ? now() : 0;
             int err = 0;
             trace("reader: task of %zu bytes taken", t.n);
-            PinBlock *b = take_reader_block();
+            PinBlock *b = t.ahead >= 0 ? adopt_ahead_block(t.ahead) : nullptr;
+            const bool filled = b != nullptr; // read ahead while the runtime started: nothing left to read
+            if (!b) b = take_reader_block();
             trace("reader: block in hand");
             double t2 = g_timing ? now() : 0, t3 = t2;
             if (!b) {
                 err = -2;
             } else {
-                size_t got = 0;
+                size_t got = filled ? t.n : 0;
                 if (t.items) {
                     // whole small files, each opened, read and closed here: the worker that queued them has long gone on to the
                     // next batch.  A file that cannot be opened or has shrunk leaves its segment zero-filled and says so in
@@ -1483,37 +1529,120 @@ int gscan_acquire(gscan_ctx *c, size_t len, void **pinned)
 
 size_t gscan_block_size(void) { return block_bytes(); }
 
-int gscan_prefault(size_t blocks)
+namespace {
+// the arena is bounded (at most 384 MiB whatever is asked), a helper thread that cannot be started leaves its
+// blocks to the runtime's own allocator instead of taking the process down, and nothing crosses the extern "C" boundary.
+struct AheadSrc {
+    std::string path;
+    off_t off;
+    size_t n;
+};
+int prefault_start(size_t plain, const std::vector<AheadSrc> &ahead_src)
 {
-    if (g_prefault.base || blocks == 0) return GSCAN_OK; // once per process
+    if (g_prefault.base || plain + ahead_src.size() == 0) return GSCAN_OK; // once per process
     if (!ingest_cfg().prefault) return GSCAN_OK;
     const size_t huge = size_t(2) << 20;
     const size_t stride = (block_bytes() + kPad + huge - 1) / huge * huge;
-    blocks = std::min<size_t>(std::min<size_t>(blocks, 64), std::max<size_t>(1, (size_t(256) << 20) / stride)); // (at most 256 MiB touched ahead, whatever GSCAN_BLOCK_MIB says)
+    const size_t most = std::max<size_t>(1, (size_t(384) << 20) / stride);
+    const size_t ahead = std::min(ahead_src.size(), most);
+    plain = std::min(std::min<size_t>(plain, 64), most - ahead);
+    const size_t blocks = ahead + plain;
+    if (blocks == 0) return GSCAN_OK;
     void *m = mmap(nullptr, stride * blocks + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (m == MAP_FAILED) return GSCAN_ENOMEM;
     char *base = (char *)(((uintptr_t)m + huge - 1) & ~(uintptr_t)(huge - 1));
     (void)madvise(base, stride * blocks, MADV_HUGEPAGE);
-    g_prefault.stride = stride;
-    g_prefault.count = blocks;
-    g_prefault.touched = new (std::nothrow) std::atomic<bool>[blocks];
-    if (!g_prefault.touched) {
+    std::atomic<int> *state = new (std::nothrow) std::atomic<int>[blocks];
+    Prefault::Piece *piece = ahead ? new (std::nothrow) Prefault::Piece[ahead] : nullptr;
+    if (!state || (ahead && !piece)) {
+        delete[] state;
+        delete[] piece;
         munmap(m, stride * blocks + huge);
         return GSCAN_ENOMEM;
     }
-    for (size_t k = 0; k < blocks; k++) g_prefault.touched[k].store(false, std::memory_order_relaxed);
+    for (size_t k = 0; k < blocks; k++) state[k].store(0, std::memory_order_relaxed);
+    for (size_t k = 0; k < ahead; k++) {
+        piece[k].path = ahead_src[k].path;
+        piece[k].off = ahead_src[k].off;
+        piece[k].n = ahead_src[k].n;
+    }
+    g_prefault.stride = stride;
+    g_prefault.count = blocks;
+    g_prefault.ahead = ahead;
+    g_prefault.state = state;
+    g_prefault.piece = piece;
+    g_prefault.unclaimed.store(ahead, std::memory_order_relaxed);
     g_prefault.base = base;
-    const size_t nth = std::min<size_t>(4, blocks);
+    const size_t nth = std::min<size_t>(ahead ? 8 : 4, blocks);
     const size_t used = block_bytes() + kPad;
-    std::atomic<bool> *const touched = g_prefault.touched;
-    for (size_t t = 0; t < nth; t++)
-        std::thread([t, nth, blocks, base, stride, used, touched] {
-            for (size_t k = t; k < blocks; k += nth) { // (block k is handed out k-th: the early ones first)
-                for (size_t o = 0; o < used; o += 4096) base[k * stride + o] = 0;
-                touched[k].store(true, std::memory_order_release);
+    for (size_t t = 0; t < nth; t++) {
+        auto work = [t, nth, blocks, ahead, base, stride, used, state, piece] {
+            int fd = -1;
+            const std::string *open_path = nullptr;
+            for (size_t k = t; k < blocks; k += nth) { // (block k is asked for k-th: the early ones first)
+                char *at = base + k * stride;
+                if (k >= ahead) {
+                    for (size_t o = 0; o < used; o += 4096) at[o] = 0;
+                    state[k].store(1, std::memory_order_release);
+                    continue;
+                }
+                Prefault::Piece &pc = piece[k];
+                if (!open_path || *open_path != pc.path) {
+                    if (fd >= 0) close(fd);
+                    fd = open(pc.path.c_str(), O_RDONLY | O_NOCTTY | O_CLOEXEC);
+                    open_path = &pc.path;
+                }
+                struct stat st;
+                bool ok = fd >= 0 && fstat(fd, &st) == 0;
+                size_t got = 0;
+                while (ok && got < pc.n) {
+                    const ssize_t r = pread(fd, at + got, pc.n - got, pc.off + (off_t)got);
+                    if (r > 0) got += (size_t)r;
+                    else if (r == 0 || errno != EINTR) ok = false;
+                }
+                if (ok) {
+                    pc.dev = st.st_dev;
+                    pc.ino = st.st_ino;
+                    for (size_t o = (pc.n + 4095) & ~size_t(4095); o < used; o += 4096) at[o] = 0; // (the slack behind the piece is staging memory too)
+                }
+                state[k].store(ok ? 2 : 3, std::memory_order_release);
             }
-        }).detach();
+            if (fd >= 0) close(fd);
+        };
+        try {
+            std::thread(work).detach();
+        } catch (...) { // no thread to be had: this one's blocks are never ready -- marked failed, the runtime's allocator serves instead
+            for (size_t k = t; k < blocks; k += nth) state[k].store(3, std::memory_order_release);
+        }
+    }
     return GSCAN_OK;
+}
+} // namespace
+
+int gscan_prefault(size_t blocks)
+{
+    try {
+        return prefault_start(blocks, {});
+    } catch (...) {
+        return GSCAN_ENOMEM;
+    }
+}
+
+int gscan_prefault_files(size_t blocks, const char *const *paths, size_t npaths)
+{
+    std::vector<AheadSrc> src;
+    const size_t blk = block_bytes();
+    try {
+        for (size_t i = 0; paths && i < npaths && src.size() < blocks; i++) {
+            struct stat st;
+            if (!paths[i] || stat(paths[i], &st) != 0 || !S_ISREG(st.st_mode)) continue;
+            for (off_t o = 0; o < st.st_size && src.size() < blocks; o += (off_t)blk)
+                src.push_back(AheadSrc{paths[i], o, (size_t)std::min<off_t>((off_t)blk, st.st_size - o)});
+        }
+        return prefault_start(blocks > src.size() ? blocks - src.size() : 0, src);
+    } catch (...) {
+        return GSCAN_ENOMEM;
+    }
 }
 
 // Reader threads for one device whose NUMA node offers `local_cpus` CPUs to this process and is shared by `devices_sharing`
@@ -1707,9 +1836,26 @@ int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off
     std::vector<ReadTask> tasks;
     tasks.reserve(g.pending);
     size_t k = 0;
+    // pieces that were read ahead while the runtime started (gscan_prefault_files): same file, same offset, same length
+    struct stat fst;
+    const bool look_ahead = g_prefault.unclaimed.load(std::memory_order_relaxed) > 0 && fstat(fd, &fst) == 0;
     for (size_t o = 0; o < len; o += blk, k++) {
         const int which = (int)(k % (size_t)c->n_copy);
         tasks.push_back(ReadTask{fd, (off_t)(file_off + (long long)o), std::min(blk, len - o), s->d_text + o, which ? c->copy_x[which - 1] : c->copy, &g});
+        if (look_ahead) {
+            ReadTask &t = tasks.back();
+            for (size_t a = 0; a < g_prefault.ahead; a++) {
+                Prefault::Piece &pc = g_prefault.piece[a];
+                if (pc.off != t.off || pc.n != t.n || pc.claimed.load(std::memory_order_relaxed)) continue;
+                // (dev / ino are the helper's to write: wait for it -- it has had the whole start of the runtime)
+                while (!g_prefault.state[a].load(std::memory_order_acquire)) std::this_thread::yield();
+                if (g_prefault.state[a].load(std::memory_order_acquire) != 2 || pc.dev != fst.st_dev || pc.ino != fst.st_ino) continue;
+                if (pc.claimed.exchange(true)) continue;
+                g_prefault.unclaimed.fetch_sub(1, std::memory_order_relaxed);
+                t.ahead = (int)a;
+                break;
+            }
+        }
     }
     c->ingest->read(tasks.data(), tasks.size());
     return GSCAN_OK;

@@ -452,18 +452,25 @@ int main(int argc, char **argv)
         if (most <= 64) narrow_visible_devices(most);
     }
     // staging memory is mapped and touched by helper threads while the HIP runtime starts (no HIP call in there; behind the fork above: threads do not survive one): as many
-    // blocks as the input can keep busy -- a tree: the reader pool's worth; explicit files: what their bytes fill
+    // blocks as the input can keep busy -- a tree: the reader pool's worth; explicit files: what their bytes fill, and the
+    // helpers READ the files' first pieces into them while they are at it (gscan_prefault_files): by the time the runtime
+    // answers its first call, a 256 MiB file sits in staging memory and only has to be registered and DMA'd
     {
-        size_t blocks = 18;
         if (!o.recursive && o.workers <= 1) {
             unsigned long long total = 0;
+            std::vector<const char *> names;
             for (const std::string &p : o.paths) {
                 struct stat st;
-                if (stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode)) total += (unsigned long long)st.st_size;
+                // (files up to the batching limit are queued by name and read by the reader pool as a batch: not these)
+                const unsigned long long batch = o.cfg.count("batch") ? o.cfg.at("batch") : (2ull << 20);
+                if (stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode) && (unsigned long long)st.st_size > batch) total += (unsigned long long)st.st_size, names.push_back(p.c_str());
             }
-            blocks = (size_t)std::min<unsigned long long>(18, total / gscan_block_size() + 1);
+            const size_t blocks = (size_t)std::min<unsigned long long>(36, total / gscan_block_size() + 2);
+            if (getenv("GRAB_NO_READ_AHEAD")) gscan_prefault(std::min<size_t>(18, blocks)); // (A/B runs)
+            else gscan_prefault_files(blocks, names.data(), names.size());
+        } else {
+            gscan_prefault(18);
         }
-        gscan_prefault(blocks);
     }
     const int rc = o.workers > 1 ? run_workers(o) : run_serial(o);
     mark("scan done");

@@ -643,7 +643,12 @@ __device__ __noinline__ bool vm_keep_hit_dev(const DevProgram *pg, const VmProg 
 
 // PF: the next tile's text is requested while this one is computed (see k2_classrun_scan).
 template <int ITER, bool NT, int DEPTH = 4, int NW = 8, bool VM = false, bool PF = false>
-__global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
+// (the VM form is bound by the latency of its cold path's dependent loads -- text, class bitmaps, the pair table, its stack in
+// scratch memory: asked to fit four waves per SIMD, 120 VGPRs instead of 135, a second workgroup shares the CU)
+#ifndef GSCAN_VM_WAVES
+#define GSCAN_VM_WAVES 4
+#endif
+__global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : VM ? GSCAN_VM_WAVES : 1) void k3_bucket_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     // The filter table, one copy PER LANE: entry b of lane l lives at byte address b << 8 | l << 2.  Both fields are whole
     // bytes, so ONE v_perm_b32 turns a text byte into its LDS address (with the 32-copy layout the address took a v_bfe
@@ -867,6 +872,9 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
             const uint32_t incl = wave_scan(mine), excl = incl - mine;
             const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
             volatile uint16_t *q = s_queue + wave * kK3Queue;
+            uint32_t keep[(ITER + 1) / 2]; // the verdicts; `hits` stays as it is until the last round: a survivor's rank is its rank among ALL hits
+#pragma unroll
+            for (int w = 0; w < (ITER + 1) / 2; w++) keep[w] = hits[w];
             for (uint32_t base = 0; base < total; base += kK3Queue) { // (wave-uniform; one round unless a sub-tile has > kK3Queue survivors)
                 uint32_t idx = excl;
 #pragma unroll
@@ -891,20 +899,20 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 1) void k3_bucket_scan(Scan
                 idx = excl;
 #pragma unroll
                 for (int w = 0; w < (ITER + 1) / 2; w++) {
-                    uint32_t word = hits[w], keep = word;
+                    uint32_t word = hits[w];
                     while (word) {
                         const uint32_t b = (uint32_t)__ffs((int)word) - 1u;
                         word &= word - 1u;
-                        if (idx - base < (uint32_t)kK3Queue && q[idx - base] == 0xffffu) keep &= ~(1u << b);
+                        if (idx - base < (uint32_t)kK3Queue && q[idx - base] == 0xffffu) keep[w] &= ~(1u << b);
                         idx++;
                     }
-                    hits[w] = keep;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
             cnt = 0;
 #pragma unroll
             for (int w = 0; w < (ITER + 1) / 2; w++) {
+                hits[w] = keep[w];
                 cnt += (uint32_t)__popc(hits[w]); // (no group-start compression: a real hit must not be dropped for following one the VM struck out)
             }
         }

@@ -21,7 +21,7 @@ SLOTS = 3  # GSCAN_SLOTS (include/gscan.h): chunks one context keeps in flight
 SYMBOLS = [
     "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_match_info", "gscan_next_match", "gscan_tail_positions", "gscan_db_dev_window",
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
-    "gscan_acquire", "gscan_block_size", "gscan_prefault", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_submit_files", "gscan_last_file_errors", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_gather", "gscan_last_ends", "gscan_next_listed",
+    "gscan_acquire", "gscan_block_size", "gscan_prefault", "gscan_prefault_files", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_submit_files", "gscan_last_file_errors", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_gather", "gscan_last_ends", "gscan_next_listed",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
     "gscan_set_option", "gscan_kernel_time", "gscan_resource_errors",
     "gscan_ingest_info", "gscan_pool_stats", "gscan_auto_readers", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
@@ -129,6 +129,7 @@ def lib():
         L.gscan_resource_errors.restype = C.c_uint64
         L.gscan_ingest_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gscan_ingest_info.restype = None
+        L.gscan_prefault_files.argtypes = [C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t]
         L.gscan_pool_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.gscan_device_cpulist.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.gscan_pci_cpulist.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]

@@ -257,6 +257,12 @@ size_t gscan_block_size(void);
  * only registers them with the runtime instead of allocating pinned memory block by block while the pipe fills (1.5 - 2 ms
  * each, one at a time).  No HIP call is made here.  GSCAN_PREFAULT=0 in the environment turns it into a no-op. */
 int gscan_prefault(size_t blocks);
+/* The same, and the helper threads FILL the first blocks with the first bytes of the files named (in the order given, piece by
+ * piece of gscan_block_size() bytes, `blocks` pieces at most): what the reader threads would pread once the runtime is up is
+ * read while it starts (hipInit takes 50 ms; 256 MiB are read in 10).  A gscan_submit_fd whose range holds such a piece --
+ * same file (device + inode), same offset, same length -- takes the block as it is: registered, DMA'd, nothing is read twice.
+ * For callers that know their input before the first HIP call (the command line with explicit paths: BASELINE configs[0]). */
+int gscan_prefault_files(size_t blocks, const char *const *paths, size_t npaths);
 /* the ingest configuration in force (environment: GSCAN_BLOCK_MIB, GSCAN_READERS, GSCAN_COPY_STREAMS = the copy streams of a
  * DEVICE, shared by its contexts); any pointer may be NULL */
 void gscan_ingest_info(size_t *block_bytes, int *readers, int *copy_streams);

@@ -383,3 +383,29 @@ def test_a_file_error_is_returned_once(built, tmp_path):
     rc_line = [ln for ln in r.stdout.splitlines() if ln.startswith("RC")][0]
     assert rc_line.startswith("RC 0 -1 0 ") and "file shrank" in rc_line, r.stdout + r.stderr
     assert r.stdout.count("Match at offset 100") == 2, r.stdout  # good1 (same batch as the bad file) and good2
+
+
+def test_read_ahead_while_the_runtime_starts(built, oracle_built, tmp_path):
+    """Explicit files are read into staging memory by helper threads WHILE hipInit runs (gscan_prefault_files) and their
+    pieces adopted by the reader pool: same bytes as without (GRAB_NO_READ_AHEAD=1) and as the oracle -- a file of three
+    pieces with a ragged last one, two files on one command line (the second one's pieces are beyond the arena), a file
+    that fills more than the arena holds, needles across piece boundaries."""
+    blk = 8 << 20
+    files = []
+    for i, n in enumerate((2 * blk + 3, 5 * blk, 45 * blk + 17)):
+        buf = synth.text(n, 600 + i)
+        synth.plant(buf, synth.NEEDLE, 40, i, gap=100)
+        for edge in range(blk, n - 20, blk):  # across and right behind every piece boundary
+            buf[edge - 7:edge - 7 + len(synth.NEEDLE)] = np.frombuffer(synth.NEEDLE, np.uint8)
+            buf[edge + 100:edge + 100 + len(synth.NEEDLE)] = np.frombuffer(synth.NEEDLE, np.uint8)
+        p = tmp_path / ("f%d.bin" % i)
+        buf.tofile(p)
+        files.append(p.name)
+    for pattern, flags in ((synth.NEEDLE.decode(), ["-O", "-l"]), (synth.NEEDLE.decode(), ["-O"]), (synth.IDENT_RE, ["-O", "-l"])):
+        for names in (files[:1], files[:2], files[2:], files):
+            argv = flags + [pattern] + names
+            orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), argv, str(tmp_path))
+            assert orc == 0
+            for env in ({}, {"GRAB_NO_READ_AHEAD": "1"}, {"GSCAN_BLOCK_MIB": "3"}):
+                r = subprocess.run([built.bin_path()] + argv, cwd=str(tmp_path), capture_output=True, env=dict(os.environ, **env))
+                assert r.returncode == 0 and r.stdout == oout, (pattern, flags, names, env, r.stderr[-300:])
