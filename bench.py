@@ -352,6 +352,18 @@ class ClockSampler:
         return out
 
 
+# The SQ counters of the three bench kernels (profiles/r04_w_sq_counters.txt: rocprofv3 --pmc passes over gscan_sweep, 4 GiB,
+# the kernels' code unchanged since): wave-level VALU instructions per input byte and the fraction of the SIMDs' VALU issue
+# slots taken (SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 4 waves per SIMD)).  With them a kernel time says what shader clock
+# the launch effectively ran at -- instructions / (time x 1024 SIMDs x issue fraction / 4 cycles per wave64 instruction) --
+# and how far that is from the part's 2.4 GHz: the table kernels draw the power cap, and their rate moves with the clock
+# the cap leaves them.
+SQ_PASS = {"cfg2": {"valu_insts_per_byte": 203661888 / (4 << 30), "valu_issue_frac": 0.669},
+           "cfg3": {"valu_insts_per_byte": 242272778 / (4 << 30), "valu_issue_frac": 0.722},
+           "alt": {"valu_insts_per_byte": 278997568 / (4 << 30), "valu_issue_frac": 0.895}}
+SIMDS, MAX_SCLK_GHZ = 256 * 4, 2.4
+
+
 def roofline_block(config, nbytes, total, kern_ms, launches, live=None):
     alg_bytes = nbytes + REC_BYTES * total  # per launch: every input byte once + one u32 per candidate
     kern_avg_ms = kern_ms / max(launches, 1)
@@ -362,9 +374,16 @@ def roofline_block(config, nbytes, total, kern_ms, launches, live=None):
         source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this script over grab_amd/bin/gscan_sweep (same kernel %s, %d GiB arena, 2 x FETCH_SIZE + WRITE_SIZE)" % (rec["kernel"], nbytes >> 30)
     else:
         traffic, source = measured_traffic(config, nbytes)
-    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": source,
-            "kernel_ms": round(kern_avg_ms, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(alg_bytes)}
+    sq = SQ_PASS.get(config)
+    extra = {}
+    if sq:
+        clk = sq["valu_insts_per_byte"] * nbytes / (kern_avg_ms * 1e-3 * SIMDS * sq["valu_issue_frac"] / 4.0) / 1e9
+        extra = {"valu_issue_frac": sq["valu_issue_frac"], "valu_issue_source": "profiles/r04_w_sq_counters.txt (SQ_ACTIVE_INST_VALU over SQ_WAVE_CYCLES / 4)",
+                 "implied_sclk_ghz": round(clk, 3), "frac_of_clock_scaled_ceiling": round(min(1.0, clk / MAX_SCLK_GHZ), 4),
+                 "frac_at_max_sclk": round(achieved / HBM_PEAK_GBPS * MAX_SCLK_GHZ / clk, 4) if config != "cfg2" else None}
+    return dict({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": source,
+                 "kernel_ms": round(kern_avg_ms, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(alg_bytes)}, **extra)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

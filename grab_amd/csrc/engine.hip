@@ -78,15 +78,19 @@ constexpr size_t kMaxChunk = (1ull << 30) + 4096;
 //   GSCAN_READERS       reader threads per device; 0 or unset = auto: 8, fewer when the device's NUMA node has few CPUs per
 //                       device (gscan_auto_readers: 8 GPUs x 8 readers must not outnumber the CPUs they are bound to)
 //   GSCAN_COPY_STREAMS  copy streams per DEVICE, shared by its contexts; the scans ride on the first (default 2: a second
-//                       stream's copy runs in the first one's gaps, 46.7 -> 49.2 GB/s; a third adds nothing, profiles/r04_f_*)
+//                       stream's copy runs in the first one's gaps, 46.7 -> 49.2 GB/s; a third adds nothing, profiles/r04_f_*).
+//                       The second one is made when the device has been handed GSCAN_SECOND_STREAM_MIB (1024) MiB, by a
+//                       helper thread: a stream costs 7-12 ms to create and its share of the exit, and a run that is over in
+//                       a tenth of a second -- one 256 MiB file: 0.101 against 0.123 s, profiles/r05_b_cfg1_* -- never needs it
 //   GSCAN_NUMA          0: readers inherit the process's CPU mask; else the CPUs local to the device (default 1)
-//   GSCAN_NT_COPY       readers pread into a cache-sized bounce buffer and stream it into the block with non-temporal stores
-//                       (hostcopy.cc): one DRAM crossing less per byte (no write-allocate).  -1 (default) = by device count:
-//                       on from five devices up, where the host's DRAM and not the links sets the pace; 0 / 1 force
+//   GSCAN_NT_COPY       1: readers pread into a cache-sized bounce buffer and stream it into the block with non-temporal
+//                       stores (hostcopy.cc: no write-allocate, one DRAM crossing less per byte).  Off by default: measured
+//                       slower than plain pread at one device AND under eight pools' load (profiles/r04_k_*, r05_a_n8_*)
 // Test hooks (tests/test_gpu_pool.py): GSCAN_POOL_CAP caps the reader pool's blocks, GSCAN_FAIL_ALLOC_AFTER=n makes every
 // allocation of a staging block after the n-th fail.  GSCAN_DIAG (measurements only -- the results are NOT scan results, said
 // on stderr): 1 = the readers fill their blocks and give them straight back, no DMA, no scan (the host's page cache -> pinned
-// ceiling); 2 = the readers do not read, the blocks go out as they are (the DMA side on its own).
+// ceiling); 2 = the readers do not read, the blocks go out as they are (the DMA side on its own); 3 = 2 without
+// the scans and read-backs (the copies alone).
 // What the sweeps of rounds 2 - 4 on the MI355X boxes say (profiles/r02_a_e2e_ingest_sweep.jsonl, r02_b_dma_probe.txt,
 // r04_e_* .. r04_k_*): the link itself moves 57 GB/s in any piece size >= 16 MiB, also next to 16 busy pread threads; inside the
 // pipeline the 64 GiB corpus goes through at 49-52 GB/s whatever the block size, the flavour of the pinned memory, the way the
@@ -147,11 +151,14 @@ struct IngestCfg {
     // So the contexts of a device share the device's copy streams, and the scans and read-backs ride on the first of them
     // (a 64 MiB window scans in 15 us).
     int copy_streams;
+    size_t second_after;  // bytes handed to a device before its second copy stream is made
+    bool scan_stream;     // GSCAN_SCAN_STREAM=1 (measurements): the scans and read-backs on a stream of their own
+    int ahead_threads;    // GSCAN_AHEAD_THREADS (measurements): helper threads of gscan_prefault_files
     bool numa;
-    int nt_copy;          // -1: by device count (Ingest's constructor), 0 / 1
+    int nt_copy;          // GSCAN_NT_COPY
     long pool_cap;        // GSCAN_POOL_CAP (test hook): 0 = two blocks per reader
     long fail_alloc_after; // GSCAN_FAIL_ALLOC_AFTER (test hook): -1 = never
-    int diag;             // GSCAN_DIAG: 0, 1 (no DMA, no scan), 2 (no read)
+    int diag;             // GSCAN_DIAG: 0, 1 (no DMA, no scan), 2 (no read), 3 (no read, no scan)
     int virtual_devices;  // GSCAN_VIRTUAL_DEVICES (below)
     int virtual_fail_open; // GSCAN_VIRTUAL_FAIL_OPEN: gscan_open fails for this index (-1: none)
     bool prefault;        // GSCAN_PREFAULT=0 switches gscan_prefault off
@@ -169,12 +176,15 @@ const IngestCfg &ingest_cfg()
         v.readers = (int)env("GSCAN_READERS", 0, 0, 64); // 0: auto, per device (Ingest's constructor)
         const long hw = (long)std::thread::hardware_concurrency();
         if (hw > 0 && v.readers > hw) v.readers = (int)hw;
-        v.copy_streams = (int)env("GSCAN_COPY_STREAMS", 2, 1, 4);
+        v.copy_streams = (int)env("GSCAN_COPY_STREAMS", 2, 1, 2);
+        v.second_after = (size_t)env("GSCAN_SECOND_STREAM_MIB", 1024, 0, 1 << 20) << 20;
+        v.scan_stream = env("GSCAN_SCAN_STREAM", 0, 0, 1) != 0;
+        v.ahead_threads = (int)env("GSCAN_AHEAD_THREADS", 8, 1, 32);
         v.numa = env("GSCAN_NUMA", 1, 0, 1) != 0;
-        v.nt_copy = (int)env("GSCAN_NT_COPY", -1, -1, 1);
+        v.nt_copy = (int)env("GSCAN_NT_COPY", 0, 0, 1);
         v.pool_cap = env("GSCAN_POOL_CAP", 0, 0, 4096);
         v.fail_alloc_after = env("GSCAN_FAIL_ALLOC_AFTER", -1, -1, 1 << 20);
-        v.diag = (int)env("GSCAN_DIAG", 0, 0, 2);
+        v.diag = (int)env("GSCAN_DIAG", 0, 0, 3);
         v.virtual_devices = (int)env("GSCAN_VIRTUAL_DEVICES", 0, 0, 64);
         v.virtual_fail_open = (int)env("GSCAN_VIRTUAL_FAIL_OPEN", -1, -1, 64);
         v.prefault = env("GSCAN_PREFAULT", 1, 0, 1) != 0;
@@ -359,8 +369,29 @@ public:
         else cv_tasks_.notify_all();
     }
     int readers() const { return readers_; }
-    // the device's copy streams: created on first use (one at a time per device; devices do not wait for each other),
-    // destroyed with the pool
+    // The second copy stream, if the device has one by now.  It is made once the device has been handed `second_after` bytes,
+    // by a helper thread (nobody waits for it: the pieces go on over the first stream until it is there).
+    hipStream_t second_stream(size_t more_bytes)
+    {
+        const size_t had = handed_.fetch_add(more_bytes, std::memory_order_relaxed);
+        if (ingest_cfg().copy_streams < 2) return nullptr;
+        hipStream_t st = second_.load(std::memory_order_acquire);
+        if (st || had + more_bytes < ingest_cfg().second_after) return st;
+        bool expected = false;
+        if (second_started_.compare_exchange_strong(expected, true)) {
+            try {
+                second_maker_ = std::thread([this] {
+                    hipStream_t s = shared_stream(1);
+                    second_.store(s, std::memory_order_release);
+                    trace("ingest: second copy stream made");
+                });
+            } catch (...) { // (no thread to be had: one stream it is)
+            }
+        }
+        return nullptr;
+    }
+    // the device's streams: created on first use (one at a time per device; devices do not wait for each other), destroyed
+    // with the pool
     hipStream_t shared_stream(int k)
     {
         std::lock_guard<std::mutex> lk(streams_m_);
@@ -425,11 +456,12 @@ private:
             }
             int cpus = numa_cpus_;
             if (cpus <= 0) cpus = have_mask_ ? CPU_COUNT(&mask_) : (int)std::thread::hardware_concurrency();
-            readers_ = gscan_auto_readers(cpus, std::max(1, sharing));
+            readers_ = gscan_auto_readers(cpus, std::max(1, sharing), std::max(1, ndev > 0 ? ndev : device_count()));
         }
         cap_ = ingest_cfg().pool_cap > 0 ? (size_t)ingest_cfg().pool_cap : (size_t)readers_ * 2;
-        // one DRAM crossing less per byte where the host's DRAM is what N devices share: from five devices up
-        nt_copy_ = ingest_cfg().nt_copy >= 0 ? ingest_cfg().nt_copy != 0 : device_count() >= 5;
+        // (measured under the load it was written for, round 5: eight reader pools, 8 .. 64 readers, no DMA -- the non-temporal
+        // copy is SLOWER than plain pread at every reader count, 69 / 99 / 73 / 55 against 83 / 116 / 99 / 64 GB/s; off unless asked for)
+        nt_copy_ = ingest_cfg().nt_copy > 0;
     }
     ~Ingest()
     {
@@ -439,6 +471,7 @@ private:
             cv_tasks_.notify_all();
         }
         for (std::thread &t : threads_) t.join();
+        if (second_maker_.joinable()) second_maker_.join();
         (void)hipSetDevice(hip_device_of(device_));
         for (auto &l : lanes_)
             for (PinBlock *b : l->fifo) free_block(b, false); // (every context is closed: gscan_close has waited for the device)
@@ -665,7 +698,7 @@ private:
                     }
                     got = t.n;
                 }
-                if (diag == 2) got = t.n; // (GSCAN_DIAG=2: nothing is read, the block goes out as it is)
+                if (diag >= 2) got = t.n; // (GSCAN_DIAG=2, 3: nothing is read, the block goes out as it is)
                 if (nt_copy_ && !t.items) {
                     // pread into a buffer that stays in this core's L2, stream it out to the block past the caches: the block's
                     // lines are never read into a cache for ownership (one DRAM crossing less per byte)
@@ -753,6 +786,10 @@ private:
     bool nt_copy_ = false;
     size_t cap_ = 16, n_alloc_ = 0;
     std::atomic<bool> first_dma_said_{false};
+    std::atomic<size_t> handed_{0};             // bytes handed to this device so far (second_stream)
+    std::atomic<hipStream_t> second_{nullptr};
+    std::atomic<bool> second_started_{false};
+    std::thread second_maker_;
     std::atomic<long> n_made_{0};           // staging blocks asked of the runtime so far (GSCAN_FAIL_ALLOC_AFTER)
     uint64_t n_waits_ev_ = 0, n_waits_cv_ = 0; // (under m_) how often the pool's slow paths ran: slept on a block's event / on the other readers
     bool started_ = false, stop_ = false;
@@ -839,7 +876,8 @@ struct Slot {
     gscan::TileDesc *d_tiles = nullptr, *h_tiles = nullptr;
     size_t seg_tiles_cap = 0;
     hipEvent_t done = nullptr;
-    hipEvent_t copied_x[3] = {nullptr, nullptr, nullptr}; // behind a file range's pieces on the further copy streams (the scan rides on the first)
+    hipEvent_t copied = nullptr, copied2 = nullptr; // behind a chunk's copies on the first copy stream (only when the scans have a stream of their own) / behind its pieces on the second
+    hipStream_t second = nullptr;                  // the second copy stream, if this chunk's pieces use it
     std::unique_ptr<ReadGroup> grp;                       // gscan_submit_fd: the range's pieces (finished == true when idle)
     uint64_t tag = 0;
     size_t len = 0;
@@ -863,8 +901,6 @@ struct gscan_ctx {
     // the device's streams (they belong to its Ingest, not to this context): GSCAN_COPY_STREAMS copy streams, the scans and
     // read-backs on the first of them
     hipStream_t copy = nullptr, compute = nullptr;
-    hipStream_t copy_x[3] = {nullptr, nullptr, nullptr};
-    int n_copy = 1;
     Ingest *ingest = nullptr;
     Slot slot[GSCAN_SLOTS];
     uint64_t next_seq = 1;
@@ -1255,8 +1291,8 @@ void free_slot(gscan_ctx *c, Slot &s)
     if (s.d_recs) hipFree(s.d_recs);
     if (s.d_desc) hipFree(s.d_desc);
     if (s.h_desc) hipHostFree(s.h_desc);
-    for (hipEvent_t e : s.copied_x)
-        if (e) hipEventDestroy(e);
+    if (s.copied) hipEventDestroy(s.copied);
+    if (s.copied2) hipEventDestroy(s.copied2);
     if (s.done) hipEventDestroy(s.done);
     s = Slot();
 }
@@ -1271,12 +1307,12 @@ void fd_finish(ReadGroup *g)
     int rc = [&]() -> int {
         if (g->err) {
             HIPCHK(c, hipStreamSynchronize(c->copy)); // pieces that did make it must not land after the slot is reused
-            for (int k = 1; k < c->n_copy; k++) HIPCHK(c, hipStreamSynchronize(c->copy_x[k - 1]));
+            if (s.second) HIPCHK(c, hipStreamSynchronize(s.second));
             if (g->err == -1) return fail(c, GSCAN_EIO, "file shrank while reading");
             if (g->err == -2) return fail(c, GSCAN_EHIP, "staging block or DMA failed");
             return fail(c, GSCAN_EIO, "%s", strerror(g->err));
         }
-        if (ingest_cfg().diag == 1) { // nothing went to the device: an empty result behind whatever the stream still holds
+        if (ingest_cfg().diag == 1 || ingest_cfg().diag == 3) { // nothing went to the device (or nothing is to be made of it): an empty result behind whatever the stream still holds
             memset(s.h_counter, 0, kCounterWords * 4);
             s.n_tiles = 0;
             s.nw = 1;
@@ -1286,10 +1322,14 @@ void fd_finish(ReadGroup *g)
             HIPCHK(c, hipEventRecord(s.done, c->compute));
             return 0;
         }
-        // (the pieces on the first copy stream are in front of the scan as it is: the scans ride on that stream)
-        for (int k = 1; k < c->n_copy; k++) {
-            HIPCHK(c, hipEventRecord(s.copied_x[k - 1], c->copy_x[k - 1]));
-            HIPCHK(c, hipStreamWaitEvent(c->compute, s.copied_x[k - 1], 0));
+        // (the pieces on the first copy stream are in front of the scan as it is when the scans ride on that stream)
+        if (c->compute != c->copy) {
+            HIPCHK(c, hipEventRecord(s.copied, c->copy));
+            HIPCHK(c, hipStreamWaitEvent(c->compute, s.copied, 0));
+        }
+        if (s.second) {
+            HIPCHK(c, hipEventRecord(s.copied2, s.second));
+            HIPCHK(c, hipStreamWaitEvent(c->compute, s.copied2, 0));
         }
         return slot_launch(c, s);
     }();
@@ -1422,11 +1462,9 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     // per DEVICE -- the others find them there.  Contexts on different devices do not wait for each other (until round 5 one
     // process-wide lock put every open in line: on an eight-GPU node the eighth device's first byte waited for fifteen
     // stream creations that were none of its business).
-    c->n_copy = ingest_cfg().copy_streams;
     if (!(c->copy = c->ingest->shared_stream(0))) return bail(GSCAN_EHIP);
-    for (int k = 1; k < c->n_copy; k++)
-        if (!(c->copy_x[k - 1] = c->ingest->shared_stream(k))) return bail(GSCAN_EHIP);
     c->compute = c->copy; // the scans and read-backs ride on the first copy stream
+    if (ingest_cfg().scan_stream && !(c->compute = c->ingest->shared_stream(2))) return bail(GSCAN_EHIP);
     lap("streams");
     // one pinned allocation for every small host-side buffer of the context (each hipHostMalloc costs about a millisecond)
     const size_t kHead = (kCounterWords * 4 + 63) & ~size_t(63); // the slot's counter words
@@ -1456,8 +1494,8 @@ int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out)
     if (hipEventCreateWithFlags(&c->prog_ev, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
     for (Slot &s : c->slot) {
         if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
-        for (int k = 1; k < c->n_copy; k++)
-            if (hipEventCreateWithFlags(&s.copied_x[k - 1], hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
+        if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
+        if (hipEventCreateWithFlags(&s.copied2, hipEventDisableTiming) != hipSuccess) return bail(GSCAN_EHIP);
     }
     lap("events");
     *out = c;
@@ -1573,7 +1611,7 @@ int prefault_start(size_t plain, const std::vector<AheadSrc> &ahead_src)
     g_prefault.piece = piece;
     g_prefault.unclaimed.store(ahead, std::memory_order_relaxed);
     g_prefault.base = base;
-    const size_t nth = std::min<size_t>(ahead ? 8 : 4, blocks);
+    const size_t nth = std::min<size_t>(ahead ? (size_t)ingest_cfg().ahead_threads : 4, blocks);
     const size_t used = block_bytes() + kPad;
     for (size_t t = 0; t < nth; t++) {
         auto work = [t, nth, blocks, ahead, base, stride, used, state, piece] {
@@ -1646,13 +1684,17 @@ int gscan_prefault_files(size_t blocks, const char *const *paths, size_t npaths)
 }
 
 // Reader threads for one device whose NUMA node offers `local_cpus` CPUs to this process and is shared by `devices_sharing`
-// devices: 8 where there are CPUs to spare (the measured optimum on a one-GPU box: more of them only wait for blocks), half
-// of the device's share of the node otherwise -- the other half is the workers' (report walk, batch reads) -- never below 2.
-int gscan_auto_readers(int local_cpus, int devices_sharing)
+// devices, on a node that drives `devices_total`: 8 where there are CPUs to spare (the measured optimum on a one-GPU box: more
+// of them only wait for blocks), half of the device's share of the node otherwise -- the other half is the workers' (report
+// walk, batch reads) -- and never more than the node's page cache can feed: the host's copy ceiling (page cache -> pinned,
+// no DMA) was measured with eight pools at 83 / 116 / 99 / 64 GB/s for 8 / 16 / 32 / 64 readers in all (profiles/r05_a_n8_*,
+// a two-socket EPYC 9575F): past ~24 readers they take bandwidth from each other.  Never below 2.
+int gscan_auto_readers(int local_cpus, int devices_sharing, int devices_total)
 {
-    if (local_cpus <= 0) return 8;
+    const int by_host = std::max(2, std::min(8, 24 / std::max(1, devices_total)));
+    if (local_cpus <= 0) return by_host;
     const int share = local_cpus / std::max(1, devices_sharing);
-    return std::max(2, std::min(8, share / 2));
+    return std::max(2, std::min(by_host, share / 2));
 }
 
 void gscan_ingest_info(size_t *block_bytes_out, int *readers, int *copy_streams)
@@ -1737,6 +1779,11 @@ int gscan_submit(gscan_ctx *c, const gscan_db *db, const void *host_bytes, size_
             }
         }
     }
+    if (c->compute != c->copy) {
+        HIPCHK(c, hipEventRecord(s->copied, c->copy));
+        HIPCHK(c, hipStreamWaitEvent(c->compute, s->copied, 0));
+    }
+    s->second = nullptr;
     s->db = db;
     s->len = len;
     s->tag = tag;
@@ -1780,6 +1827,11 @@ int gscan_submit_segs(gscan_ctx *c, const gscan_db *db, const void *pinned, cons
     }
     if (rc) return rc;
     if (used) HIPCHK(c, hipMemcpyAsync(s->d_text, pinned, used, hipMemcpyHostToDevice, c->copy));
+    if (c->compute != c->copy) {
+        HIPCHK(c, hipEventRecord(s->copied, c->copy));
+        HIPCHK(c, hipStreamWaitEvent(c->compute, s->copied, 0));
+    }
+    s->second = nullptr;
     s->db = db;
     s->len = used;
     s->tag = tag;
@@ -1839,9 +1891,9 @@ int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off
     // pieces that were read ahead while the runtime started (gscan_prefault_files): same file, same offset, same length
     struct stat fst;
     const bool look_ahead = g_prefault.unclaimed.load(std::memory_order_relaxed) > 0 && fstat(fd, &fst) == 0;
+    s->second = c->ingest->second_stream(len); // (nullptr until the device has been handed enough to be worth a second stream)
     for (size_t o = 0; o < len; o += blk, k++) {
-        const int which = (int)(k % (size_t)c->n_copy);
-        tasks.push_back(ReadTask{fd, (off_t)(file_off + (long long)o), std::min(blk, len - o), s->d_text + o, which ? c->copy_x[which - 1] : c->copy, &g});
+        tasks.push_back(ReadTask{fd, (off_t)(file_off + (long long)o), std::min(blk, len - o), s->d_text + o, (k & 1) && s->second ? s->second : c->copy, &g});
         if (look_ahead) {
             ReadTask &t = tasks.back();
             for (size_t a = 0; a < g_prefault.ahead; a++) {
@@ -1907,13 +1959,13 @@ int gscan_submit_files(gscan_ctx *c, const gscan_db *db, const gscan_file *files
     if (!s->grp) return fail(c, GSCAN_ENOMEM, "out of memory");
     ReadGroup &g = *s->grp;
     // pieces: runs of consecutive files that fit one staging block -- one reader fills the block, one DMA carries it
+    s->second = c->ingest->second_stream(used);
     std::vector<ReadTask> tasks;
     for (size_t i = 0; i < n;) {
         size_t j = i + 1;
         const uint64_t base = s->files[i].dst_off;
         while (j < n && s->files[j].dst_off + s->files[j].len - base <= blk) j++;
-        const int which = (int)(tasks.size() % (size_t)c->n_copy);
-        ReadTask t{-1, 0, (size_t)(s->files[j - 1].dst_off + s->files[j - 1].len - base), s->d_text + base, which ? c->copy_x[which - 1] : c->copy, &g};
+        ReadTask t{-1, 0, (size_t)(s->files[j - 1].dst_off + s->files[j - 1].len - base), s->d_text + base, (tasks.size() & 1) && s->second ? s->second : c->copy, &g};
         t.items = &s->files[i];
         t.nitems = (uint32_t)(j - i);
         tasks.push_back(t);

@@ -271,8 +271,9 @@ void gscan_ingest_info(size_t *block_bytes, int *readers, int *copy_streams);
  * to sleep until another reader brought a block back.  (tests/test_gpu_pool.py forces these slow paths and checks they ran.) */
 int gscan_pool_stats(const gscan_ctx *ctx, uint64_t out[4]);
 /* reader threads a device gets when GSCAN_READERS is unset (*readers == 0 above): 8, fewer when the device's share of its
- * NUMA node's CPUs (local_cpus / devices_sharing that node) is small; exported for tests */
-int gscan_auto_readers(int local_cpus, int devices_sharing);
+ * NUMA node's CPUs (local_cpus / devices_sharing that node) is small or when the node drives so many devices (devices_total)
+ * that 8 readers each would outrun what the host's page cache can feed (24 in all); exported for tests */
+int gscan_auto_readers(int local_cpus, int devices_sharing, int devices_total);
 int gscan_submit(gscan_ctx *ctx, const gscan_db *db, const void *host_bytes, size_t len,
                  uint64_t tag);
 int gscan_submit_segs(gscan_ctx *ctx, const gscan_db *db, const void *pinned, const gscan_seg *segs,

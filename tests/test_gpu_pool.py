@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _drive(tmp_path, env, mib, per_device=2):
-    e = dict(os.environ, GSCAN_VIRTUAL_DEVICES="4", GSCAN_BLOCK_MIB="1", GSCAN_READERS="16", **env)
+    # (GSCAN_SECOND_STREAM_MIB: every index's second copy stream is made after 16 MiB -- while pieces are in flight on the first)
+    e = dict(os.environ, GSCAN_VIRTUAL_DEVICES="4", GSCAN_BLOCK_MIB="1", GSCAN_READERS="16", GSCAN_SECOND_STREAM_MIB="16", **env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pool_driver.py"), "--dir", str(tmp_path), "--mib", str(mib), "--per-device", str(per_device)],
                        capture_output=True, text=True, env=e, timeout=900)
     assert r.stdout.strip(), r.stderr[-2000:]
@@ -62,7 +63,7 @@ def test_no_staging_block_at_all_is_an_error_not_a_hang(built, oracle_built, tmp
 
 
 def test_non_temporal_reader_copy(built, oracle_built, tmp_path):
-    """GSCAN_NT_COPY=1 (what a node with five or more devices runs by default): pread into a bounce buffer, non-temporal
+    """GSCAN_NT_COPY=1 (off by default: measured slower than pread at every reader count): pread into a bounce buffer, non-temporal
     copy into the block -- same results, through the same starved pool."""
     rec = _drive(tmp_path, {"GSCAN_POOL_CAP": "6", "GSCAN_NT_COPY": "1"}, 96)
     assert all(st["cap"] == 6 for st in rec["pool"].values())

@@ -116,8 +116,8 @@ def test_ingest_configuration(built):
     info = engine.ingest_info()
     assert info["block_bytes"] % (1 << 20) == 0 and (1 << 20) <= info["block_bytes"] <= (64 << 20)
     assert 0 <= info["readers"] <= 64 and 1 <= info["copy_streams"] <= 4  # readers 0: auto, per device (gscan_auto_readers)
-    # copy streams: per DEVICE, shared by its contexts (GSCAN_COPY_STREAMS, default 2; the scans ride on the first)
-    for extra, want in (({"GSCAN_COPY_STREAMS": "4"}, 4), ({}, 2), ({"GSCAN_COPY_STREAMS": "1"}, 1), ({"GSCAN_COPY_STREAMS": "9"}, 4)):
+    # copy streams: per DEVICE, shared by its contexts (GSCAN_COPY_STREAMS: 1, or 2 = a second one once the device has been handed 1 GiB; the scans ride on the first)
+    for extra, want in (({"GSCAN_COPY_STREAMS": "2"}, 2), ({}, 2), ({"GSCAN_COPY_STREAMS": "1"}, 1), ({"GSCAN_COPY_STREAMS": "9"}, 2)):
         env = dict(os.environ, GSCAN_BLOCK_MIB="32", GSCAN_READERS="3", **extra)
         r = subprocess.run(["python", "-c", "from grab_amd import engine; print(engine.ingest_info())"], cwd=ROOT, env=env, capture_output=True, text=True)
         assert "'block_bytes': 33554432" in r.stdout and "'readers': 3" in r.stdout and "'copy_streams': %d" % want in r.stdout, r.stdout + r.stderr
@@ -161,15 +161,16 @@ def test_reader_threads_scale_with_the_node(built):
     """GSCAN_READERS unset: 8 reader threads per device where the device's share of its NUMA node has CPUs to spare (the
     measured optimum on the one-GPU boxes), fewer on a node where 8 devices x 8 readers would outnumber the CPUs."""
     L = engine.lib()
-    assert L.gscan_auto_readers(128, 1) == 8      # the gpurun boxes: device 0 -> CPUs 0-63,128-191
-    assert L.gscan_auto_readers(128, 4) == 8      # 8-GPU node, 4 devices per socket: 32 CPUs each, half for readers -> capped at 8
-    assert L.gscan_auto_readers(32, 4) == 4       # a smaller host: 8 CPUs per device
-    assert L.gscan_auto_readers(8, 4) == 2        # never below 2
-    assert L.gscan_auto_readers(0, 1) == 8        # nothing known
+    assert L.gscan_auto_readers(128, 1, 1) == 8   # the gpurun boxes: device 0 -> CPUs 0-63,128-191
+    assert L.gscan_auto_readers(128, 2, 4) == 6   # four devices: 24 readers in all is what the page cache feeds (profiles/r05_a_n8_*)
+    assert L.gscan_auto_readers(128, 4, 8) == 3   # 8-GPU node, 4 devices per socket
+    assert L.gscan_auto_readers(32, 4, 4) == 4    # a smaller host: 8 CPUs per device, half for readers
+    assert L.gscan_auto_readers(8, 4, 4) == 2     # never below 2
+    assert L.gscan_auto_readers(0, 1, 1) == 8     # nothing known
     for cpus in (16, 64, 128, 256):
-        for sharing in (1, 2, 4, 8):
-            r = L.gscan_auto_readers(cpus, sharing)
-            assert 2 <= r <= 8 and (r == 2 or r * sharing * 2 <= cpus)  # readers of all devices of a node never exceed half its CPUs
+        for sharing, total in ((1, 1), (1, 2), (2, 2), (2, 4), (4, 8), (8, 8)):
+            r = L.gscan_auto_readers(cpus, sharing, total)
+            assert 2 <= r <= 8 and (r == 2 or (r * sharing * 2 <= cpus and r * total <= 24))  # never more than half the node's CPUs, nor than the host can feed
 
 
 def test_detached_parent_forwards_signals(built, tmp_path):
