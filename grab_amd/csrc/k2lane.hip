@@ -193,9 +193,9 @@ __device__ __forceinline__ void lane_count(const ScanArgs &a, uint32_t d, int su
     // the wave's own LDS writes, then its reads: LDS operations of one wave execute in order; the fences only keep the
     // compiler from moving them across each other -- fences on the LDS address space alone: a plain workgroup fence also
     // waits for every global store in flight (s_waitcnt vmcnt(0)), i.e. for the records the wave has just written
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    GS_LDS_FENCE(__ATOMIC_RELEASE);
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    GS_LDS_FENCE(__ATOMIC_ACQUIRE);
     uint32_t x[NWORD];
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xp + lane * ITER);
 #pragma unroll
@@ -255,10 +255,7 @@ __device__ __forceinline__ void lane_write(const ScanArgs &a, uint32_t lane, con
     }
 }
 
-#ifndef GSCAN_LANE_BATCH
-#define GSCAN_LANE_BATCH 2
-#endif
-constexpr int kLaneBatchMax = GSCAN_LANE_BATCH; // sub-tiles a wave holds counted but unwritten before it reserves for all of them (10 VGPRs each; 1..3)
+constexpr int kLaneBatchMax = 2; // sub-tiles a wave holds counted but unwritten before it reserves for all of them (10 VGPRs each; 1..3)
 
 // one reservation for the sub-tiles in p[0 .. n): their runs lie back to back in the shard of the first one's descriptor
 template <int ITER>
@@ -281,35 +278,12 @@ __device__ __forceinline__ void lane_flush(const ScanArgs &a, uint32_t lane, con
     if (kLaneBatchMax > 2 && n > 2) lane_write<ITER>(a, lane, p[kLaneBatchMax > 2 ? 2 : 0], base + p[0].wtot + p[kLaneBatchMax > 1 ? 1 : 0].wtot, over);
 }
 
-// The same in two halves with a whole tile between them (DEFER): lane_reserve() issues the returning atomic for ONE counted
-// sub-tile and leaves its answer in a register nobody reads yet; the wave goes on to request and scan its next sub-tile;
-// lane_commit() then takes the answer -- it came back long ago, behind it the next tile's loads have been waited for one
-// by one -- and writes descriptor and records.  The atomic's round trip, which lane_flush sits out with nothing else of
-// this wave in flight, disappears behind the next tile's HBM latency; one held sub-tile (10 VGPRs) instead of two.
-template <int ITER>
-__device__ __forceinline__ void lane_reserve(const ScanArgs &a, uint32_t lane, const LaneCounted<ITER / 2> &p, uint32_t &b)
-{
-    // b is assigned by the atomic and by nothing else (it keeps its old value where none is issued; lane_commit reads lane
-    // 0's, and only when there are records): a v_mov that initialised it here would have to wait for the register's
-    // previous atomic first -- s_waitcnt vmcnt(0) -- and with it for every record store issued since
-    if (p.wtot) {
-        if (lane == 0) b = atomicAdd(a.counter + (p.d & (kShards - 1)) * kCtrStride, p.wtot); // index inside the shard's region
-    }
-}
-template <int ITER>
-__device__ __forceinline__ void lane_commit(const ScanArgs &a, uint32_t lane, const LaneCounted<ITER / 2> &p, uint32_t b)
-{
-    uint32_t base = 0;
-    bool over = false;
-    if (p.wtot) {
-        const uint32_t shard = p.d & (kShards - 1);
-        const uint32_t at = __builtin_amdgcn_readfirstlane(b);
-        over = (unsigned long long)at + p.wtot > (unsigned long long)a.cap_shard;
-        if (over && lane == 0) atomicOr(a.counter + kShards * kCtrStride, 1u);
-        base = shard * a.cap_shard + at;
-    }
-    lane_write<ITER>(a, lane, p, base, over);
-}
+// (Round 4 built the same in two halves with a whole tile between them -- the returning atomic issued, the next sub-tile
+// requested and scanned, only then the answer taken and the records written; the disassembly showed no s_waitcnt vmcnt(0)
+// left between scan and stores -- and measured NOTHING on the identifier scan, -5 % on three classes and 1.68 against 3.0
+// TB/s on dense output (one reservation per sub-tile instead of per two): the atomic's latency is not what the kernel waits
+// for, profiles/r04_e_lane_deferred_reservation_vs_batched.txt.  The code is gone; so is a scheduling barrier that kept all
+// sixteen look-ups of a step above the step's arithmetic: 5.36 against 5.41 TB/s, r04_o_*.)
 
 // NCLS: 2 or 4 (table entry layout).  NR: runs of the program, sorted by their doubling steps -- 1 or 2 (two classes):
 // exactly that many, S0 / S1 steps; 3 or 4: exactly that many, the last one S1 steps, the others S0 (the most any of them
@@ -321,13 +295,7 @@ __device__ __forceinline__ void lane_commit(const ScanArgs &a, uint32_t lane, co
 // path (far out of range -- zeros, no traffic -- when there is no next tile or none of it is this wave's).
 // PF: where the next tile's loads are issued -- 0: at the top of its own pass (no prefetch), 1: between this tile's last step
 // and its epilogue, 2: inside the epilogue, right behind the reserving atomic.
-#ifndef GSCAN_LANE_DEFER
-#define GSCAN_LANE_DEFER 0
-#endif
-#ifndef GSCAN_LANE_SCHED
-#define GSCAN_LANE_SCHED 0
-#endif
-template <int NCLS, int NR, int S0, int S1, int PF = 0, int ITER = kLIter, int DEFER = GSCAN_LANE_DEFER>
+template <int NCLS, int NR, int S0, int S1, int PF = 0, int ITER = kLIter>
 __global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     constexpr uint32_t kTile = kLNW * ITER * 1024;
@@ -388,8 +356,6 @@ __global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, 
     uint16_t *xp = s_xp + wave * (ITER * 64);
     LaneCounted<ITER / 2> held[kLaneBatchMax]; // counted sub-tiles whose records are not written yet
     int n_held = 0;
-    uint32_t pend_b = 0;  // DEFER: the reservation's answer for held[0] (lane 0's) ...
-    bool pending = false; // ... is on its way
     for (;;) {
         const uint32_t tn = t + gridDim.x;
         const bool next = tn < a.n_tiles;
@@ -416,15 +382,6 @@ __global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, 
                 if (k + 1 < ITER) GL_MERGE(pb, qb);       // step k + 1
                 else pb = hp, qb = hq;                    // ... of the last step: the halo (only lane 0 of it is looked at)
                 if (k + 2 < ITER) GL_LOOKUPS(buf[k + 2]); // in flight while step k is computed
-#if GSCAN_LANE_SCHED
-                // ... and (GSCAN_LANE_SCHED=1) made to stay there: left to itself the scheduler sinks half of the look-ups down
-                // to their first use (the next pass's merge) to save registers -- the disassembly shows an s_waitcnt lgkmcnt
-                // right behind eight freshly issued ds_reads.  With this line all sixteen are issued above step k's arithmetic
-                // (99 VGPRs instead of 88).  Measured, interleaved, one box (profiles/r04_o_*): identifier scan 5.36 against
-                // 5.41 TB/s, [0-9]{16} 6.20 against 6.14 -- inside the box's own +-4 %: four waves per SIMD cover the LDS
-                // round trip either way.  Off.
-                __builtin_amdgcn_sched_barrier(0);
-#endif
                 // the next lane's masks (lane 63: lane 0 of the next step)
                 const uint32_t a01 = down1(pa, __builtin_amdgcn_readfirstlane(pb));
                 uint32_t cand;
@@ -458,27 +415,6 @@ __global__ __launch_bounds__(kLNW * 64, kLNW / 2) void k2_lane_scan(ScanArgs a, 
         }
         // the next tile's text, requested before (PF 1) or inside (PF 2) this tile's epilogue
         if (PF == 1) lane_loads<ITER>(buf, halo, cn, sub_off_n, lane, have_n);
-        if (DEFER) {
-            // the sub-tile counted a pass ago: its reservation was issued before this pass's loads and has long been answered
-            if (pending) lane_commit<ITER>(a, lane, held[0], pend_b);
-            pending = false;
-            if (have) {
-                lane_count<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, held[0]);
-                lane_reserve<ITER>(a, lane, held[0], pend_b);
-                pending = true;
-            } else if (lane == 0) {
-                a.desc[d] = 0ull; // nothing of this tile is this wave's
-            }
-            if (!next) {
-                if (pending) lane_commit<ITER>(a, lane, held[0], pend_b);
-                break;
-            }
-            t = tn;
-            c = cn;
-            sub_off = sub_off_n;
-            have = have_n;
-            continue;
-        }
         if (have) {
             if (n_held == 0 || kLaneBatchMax == 1) lane_count<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, held[0]);
             else if (n_held == 1 || kLaneBatchMax == 2) lane_count<ITER>(a, d, sub_off, (int)c.len - m, lane, xp, held[kLaneBatchMax > 1 ? 1 : 0]);
@@ -509,20 +445,6 @@ void launch_one(const ScanArgs &a, dim3 g, hipStream_t st)
     hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, kLanePF>), g, dim3(kLNW * 64), 0, st, a, a.tiles);
 }
 
-// (experiment switch GSCAN_LANE_PF=0|1|2 for the two benchmark programs: the identifier scan and [0-9]{16})
-template <int NCLS, int NR, int S0, int S1>
-bool launch_pf_experiment(const ScanArgs &a, dim3 g, hipStream_t st)
-{
-    static const int pf = getenv("GSCAN_LANE_PF") ? atoi(getenv("GSCAN_LANE_PF")) : -1;
-    if (pf < 0) return false;
-    switch (pf) {
-    case 0: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 0>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
-    case 1: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 1>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
-    default: hipLaunchKernelGGL((k2_lane_scan<NCLS, NR, S0, S1, 2>), g, dim3(kLNW * 64), 0, st, a, a.tiles); break;
-    }
-    return true;
-}
-
 } // namespace
 
 uint32_t k2_lane_tile_bytes() { return (uint32_t)(kLNW * kLIter * 1024); }
@@ -544,8 +466,6 @@ hipError_t launch_k2_lane(const ScanArgs &a, uint32_t grid, hipStream_t st)
     const dim3 g(grid);
     const uint32_t s0 = a.lane_steps[0], s1 = a.lane_steps[1];
     const bool four = a.n_classes > 2;
-    if (!four && a.nruns == 2 && s0 == 0 && s1 == 4 && launch_pf_experiment<2, 2, 0, 4>(a, g, st)) return hipGetLastError();
-    if (!four && a.nruns == 1 && s0 == 4 && launch_pf_experiment<2, 1, 4, 0>(a, g, st)) return hipGetLastError();
 #define GL_CASE(n_, r_, a_, b_) case (a_) * 8 + (b_): launch_one<n_, r_, a_, b_>(a, g, st); break;
 #define GL_SORTED(n_, r_)                                                                                                      \
     switch (s0 * 8 + s1) { /* fill_program() sorts the runs by their step counts: s0 <= s1 */                                  \

@@ -11,6 +11,16 @@ namespace gscan {
 
 namespace {
 
+// A fence on the LDS address space alone (the wave's own strip: written, then read back transposed).  The three-argument
+// form -- order, scope, address space -- exists from clang 19 (ROCm 6.3) on; the plain workgroup fence of older toolchains
+// does the job too, at a price: it is an s_waitcnt vmcnt(0) as well, i.e. it waits for the record stores the wave issued a
+// moment ago (-4 % on the identifier scan).  The Makefile's toolchain is ROCm 7.2 (clang 22).
+#if defined(__clang_major__) && __clang_major__ >= 19
+#define GS_LDS_FENCE(order_) __builtin_amdgcn_fence((order_), "workgroup", "local")
+#else
+#define GS_LDS_FENCE(order_) __builtin_amdgcn_fence((order_), "workgroup")
+#endif
+
 constexpr int kWave = 64;
 constexpr int kWG = 256;
 constexpr int kWaves = kWG / kWave;

@@ -135,9 +135,9 @@ __device__ __forceinline__ void emit_wave_t(const ScanArgs &a, uint32_t d, const
     const uint32_t shard = d & (kShards - 1);
     uint32_t b = 0;
     if (lane == 0) b = atomicAdd(a.counter + shard * kCtrStride, wtot);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    GS_LDS_FENCE(__ATOMIC_RELEASE);
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    GS_LDS_FENCE(__ATOMIC_ACQUIRE);
     unsigned long long w[ITER / 4];
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xp + lane * ITER);
     uint32_t c = 0;
@@ -322,16 +322,13 @@ __device__ __forceinline__ uint32_t run_one_flat(uint32_t d, uint32_t w0, uint32
 // first-tile loads in the same order: the compiler's vmcnt counts then come out exact -- with the refills trickling in step
 // by step it merged the loop with its preheader conservatively and made the tail steps of every tile wait for loads issued
 // two steps earlier.
-// LT (two-class form): instead of the pair table (one look-up per TWO text bytes, random 16-bit addresses: the text's bank
-// conflicts) a per-lane copy of a 256-entry table as K3 has it -- one look-up per byte at address byte << 8 | lane << 2 (ONE
-// v_perm_b32, never a conflict), entry = class 0 in bit 0, class 1 in bit 16, sixteen of them merged by sixteen
-// v_lshl_or_b32 straight into the lane's two 16-bit class masks.  12 VALU operations more per step, 8 conflicting look-ups
-// less.
-template <int ITER, bool NT, bool WIDE, bool PAIR, int NR = -1, int NW = (PAIR ? 8 : 4), bool PF = false, bool LT = false>
+// (A per-lane copy of a 256-entry table in this kernel -- round 2's "LT" form: one look-up per byte, never a conflict, sixteen
+// v_lshl_or_b32 to merge -- was built and measured: [0-9]{16} 5.60 -> 5.94 TB/s, the identifier scan 5.18 -> 4.87,
+// profiles/r02_k_kernel_sweep_lane_table.txt.  Round 3's lane-table kernel (k2lane.hip) is that idea done right; the form is gone.)
+template <int ITER, bool NT, bool WIDE, bool PAIR, int NR = -1, int NW = (PAIR ? 8 : 4), bool PF = false>
 __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) void k2_classrun_scan(ScanArgs a, const TileDesc *__restrict__ tiles)
 {
     static_assert(!PF || PAIR, "the prefetching form is the pair form's");
-    static_assert(!LT || PAIR, "the per-lane table is a form of the two-class kernel");
     static_assert(NR < 0 || (PAIR && !WIDE), "the flat run program is the two-class, 32-bit form's");
     constexpr int kNW = NW; // waves per workgroup
     __shared__ uint32_t tbl[PAIR ? 65536 / 4 : 256 * 32];
@@ -354,11 +351,6 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) vo
 
     if (!PAIR) { // stage the class table: entry b replicated into all 32 banks (dword q = copy q & 31 of entry q >> 5)
         for (uint32_t q = threadIdx.x; q < 256u * 32u; q += NW * 64) tbl[q] = a.prog->k2_table[q >> 5];
-    } else if (LT) { // dword q = copy (q & 63) of entry (q >> 6): class 0 in bit 0, class 1 in bit 16
-        for (uint32_t q = threadIdx.x; q < 256u * 64u; q += NW * 64) {
-            const uint32_t v = a.prog->k2_table[q >> 6];
-            tbl[q] = (v & 1u) | ((v >> 8 & 1u) << 16);
-        }
     } else { // build the pair table from the 256-entry one: index = first byte | second byte << 8
         const uint32_t *base = a.prog->k2_table;
         for (uint32_t q = threadIdx.x; q < 65536 / 4; q += NW * 64) { // one dword = 4 consecutive first bytes
@@ -408,20 +400,8 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) vo
 
             // class masks of one 16-byte piece: P01 = cls0 | cls1<<16, P23 = cls2 | cls3<<16
             uint32_t p01n, p23n = 0;
-            const uint32_t lane4 = lane << 2;
-            // (LT) address = [lane << 2, text byte, 0, 0]: selector byte 0 = lane4.b0, byte 1 = the text byte, 0x0c = constant zero
-#define GS_LT(w_, by_) (*reinterpret_cast<const uint32_t *>(tbl8 + __builtin_amdgcn_perm((w_), lane4, 0x0c0c0400u | ((uint32_t)(by_) << 8))))
             auto masks = [&](const u32x4 &d, uint32_t &p01, uint32_t &p23) {
-                if (PAIR && LT) {
-                    uint32_t acc = GS_LT(d.x, 0);
-                    acc = lshl_or<1>(GS_LT(d.x, 1), acc);  acc = lshl_or<2>(GS_LT(d.x, 2), acc);   acc = lshl_or<3>(GS_LT(d.x, 3), acc);
-                    acc = lshl_or<4>(GS_LT(d.y, 0), acc);  acc = lshl_or<5>(GS_LT(d.y, 1), acc);   acc = lshl_or<6>(GS_LT(d.y, 2), acc);
-                    acc = lshl_or<7>(GS_LT(d.y, 3), acc);  acc = lshl_or<8>(GS_LT(d.z, 0), acc);   acc = lshl_or<9>(GS_LT(d.z, 1), acc);
-                    acc = lshl_or<10>(GS_LT(d.z, 2), acc); acc = lshl_or<11>(GS_LT(d.z, 3), acc);  acc = lshl_or<12>(GS_LT(d.w, 0), acc);
-                    acc = lshl_or<13>(GS_LT(d.w, 1), acc); acc = lshl_or<14>(GS_LT(d.w, 2), acc);  acc = lshl_or<15>(GS_LT(d.w, 3), acc);
-                    p01 = acc;
-                    p23 = 0;
-                } else if (PAIR) {
+                if (PAIR) {
                     // 8 two-byte lookups; e_k has class 0 of its two positions in bits 0-1, class 1 in bits 4-5
                     const uint32_t e0 = tbl8[d.x & 0xffffu], e1 = tbl8[d.x >> 16], e2 = tbl8[d.y & 0xffffu], e3 = tbl8[d.y >> 16];
                     const uint32_t e4 = tbl8[d.z & 0xffffu], e5 = tbl8[d.z >> 16], e6 = tbl8[d.w & 0xffffu], e7 = tbl8[d.w >> 16];
@@ -453,31 +433,14 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) vo
             // The pair form keeps its look-ups one step further ahead: those of step k + 2 are issued before step k is computed
             // and merged after it, so a wave does not sit out its own LDS latency (random 16-bit indices: bank conflicts make
             // it long) between issuing eight look-ups and using them.
-            uint32_t ea[LT ? 16 : 8];
+            uint32_t ea[8];
 #pragma unroll
-            for (int i = 0; i < (LT ? 16 : 8); i++) ea[i] = 0;
+            for (int i = 0; i < 8; i++) ea[i] = 0;
             auto lookups = [&](const u32x4 &d) {
-                if (LT) {
-                    ea[0] = GS_LT(d.x, 0), ea[1] = GS_LT(d.x, 1), ea[2] = GS_LT(d.x, 2), ea[3] = GS_LT(d.x, 3);
-                    ea[4] = GS_LT(d.y, 0), ea[5] = GS_LT(d.y, 1), ea[6] = GS_LT(d.y, 2), ea[7] = GS_LT(d.y, 3);
-                    ea[8 % (LT ? 16 : 8)] = GS_LT(d.z, 0), ea[9 % (LT ? 16 : 8)] = GS_LT(d.z, 1), ea[10 % (LT ? 16 : 8)] = GS_LT(d.z, 2), ea[11 % (LT ? 16 : 8)] = GS_LT(d.z, 3);
-                    ea[12 % (LT ? 16 : 8)] = GS_LT(d.w, 0), ea[13 % (LT ? 16 : 8)] = GS_LT(d.w, 1), ea[14 % (LT ? 16 : 8)] = GS_LT(d.w, 2), ea[15 % (LT ? 16 : 8)] = GS_LT(d.w, 3);
-                    return;
-                }
                 ea[0] = tbl8[d.x & 0xffffu], ea[1] = tbl8[d.x >> 16], ea[2] = tbl8[d.y & 0xffffu], ea[3] = tbl8[d.y >> 16];
                 ea[4] = tbl8[d.z & 0xffffu], ea[5] = tbl8[d.z >> 16], ea[6] = tbl8[d.w & 0xffffu], ea[7] = tbl8[d.w >> 16];
             };
             auto merge = [&]() -> uint32_t { // (the same five operations as in masks())
-                if (LT) {
-                    constexpr int M = LT ? 16 : 8; // (index arithmetic keeps the 8-entry instantiation well formed)
-                    uint32_t acc = ea[0];
-                    acc = lshl_or<1>(ea[1], acc);        acc = lshl_or<2>(ea[2], acc);        acc = lshl_or<3>(ea[3], acc);
-                    acc = lshl_or<4>(ea[4], acc);        acc = lshl_or<5>(ea[5], acc);        acc = lshl_or<6>(ea[6], acc);
-                    acc = lshl_or<7>(ea[7], acc);        acc = lshl_or<8>(ea[8 % M], acc);    acc = lshl_or<9>(ea[9 % M], acc);
-                    acc = lshl_or<10>(ea[10 % M], acc);  acc = lshl_or<11>(ea[11 % M], acc);  acc = lshl_or<12>(ea[12 % M], acc);
-                    acc = lshl_or<13>(ea[13 % M], acc);  acc = lshl_or<14>(ea[14 % M], acc);  acc = lshl_or<15>(ea[15 % M], acc);
-                    return acc;
-                }
                 const uint32_t g = lshl_or<26>(ea[7], lshl_or<24>(ea[6], lshl_or<18>(ea[5], lshl_or<16>(ea[4], lshl_or<10>(ea[3], lshl_or<8>(ea[2], lshl_or<2>(ea[1], ea[0])))))));
                 const uint32_t sw = ((g >> 4) ^ g) & 0x00f000f0u;
                 const uint32_t h = g ^ sw ^ (sw << 4);
@@ -573,7 +536,6 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) vo
     }
 }
 #undef GS_LUT
-#undef GS_LT
 
 // ------------------------------------------------------------------------------------
 // K3: bucket filter over 4 window positions (alternations; class sequences with > 4 classes).
@@ -1301,9 +1263,6 @@ static void launch_k2(bool wide, bool pair, int wg, const ScanArgs &a, dim3 g, h
         else if (a.nruns == 2) hipLaunchKernelGGL((k2_classrun_scan<12, true, false, true, 2, 8, true>), g, dim3(512), 0, st, a, tiles);
         else if (a.nruns == 3) hipLaunchKernelGGL((k2_classrun_scan<12, true, false, true, 3, 8, true>), g, dim3(512), 0, st, a, tiles);
         else hipLaunchKernelGGL((k2_classrun_scan<12, true, false, true, 0, 8, true>), g, dim3(512), 0, st, a, tiles);
-    } else if (pair && a.k2_lane_table && ITER == 12 && NT && !wide && (a.nruns == 1 || a.nruns == 2)) { // the per-lane table form
-        if (a.nruns == 1) hipLaunchKernelGGL((k2_classrun_scan<12, true, false, true, 1, 8, false, true>), g, dim3(512), 0, st, a, tiles);
-        else hipLaunchKernelGGL((k2_classrun_scan<12, true, false, true, 2, 8, false, true>), g, dim3(512), 0, st, a, tiles);
     } else if (pair) {
         if (wide) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, true, true>), g, dim3(512), 0, st, a, tiles);
         else if (a.nruns == 1) hipLaunchKernelGGL((k2_classrun_scan<ITER, NT, false, true, 1>), g, dim3(512), 0, st, a, tiles);
@@ -1358,10 +1317,6 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
     a.nruns = pg.nruns;
     a.k3_off = pg.k3_off;
     a.vm_filter = pg.vm_filter;
-    // (experiment switch, read once: 16 GiB, '[0-9]{16}' 5.60 -> 5.94 TB/s, the identifier pattern with its 61 M records
-    // 5.18 -> 4.87: profiles/r02_k_kernel_sweep_lane_table.txt.  Not the default.)
-    static const uint32_t lane_table = getenv("GSCAN_K2_LANETBL") ? 1u : 0u;
-    a.k2_lane_table = lane_table;
     a.report_shift = pg.report_shift;
     // the filter IS the pattern when every alternative has its own bucket and lies inside the filtered positions
     a.k3_one_bucket = 1;
@@ -1374,7 +1329,7 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
         if (pg.alt_len[i] > 3u) a.k3_exact3 = 0;
     }
     // Three filter positions are enough when a hit of theirs is rare: expected hits per KiB step of a wave, pricing a
-    // class by its size over the ~64 byte values text is made of, below 2 %.  (GSCAN_K3_DEPTH overrides: measurements.)
+    // class by its size over the ~64 byte values text is made of, below 2 %.
     {
         double p3 = 0;
         for (uint32_t i = 0; i < pg.n_alts; i++) {
@@ -1390,7 +1345,6 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
             p3 += prod;
         }
         a.k3_depth = p3 * 1024.0 < 0.02 || a.k3_exact3 ? 3u : 4u; // (windows of <= 3 bytes: three positions are the whole pattern)
-        if (const char *e = getenv("GSCAN_K3_DEPTH")) a.k3_depth = (uint32_t)atoi(e);
     }
     for (int r = 0; r < kK2MaxRuns; r++) {
         a.run_desc[r] = (uint32_t)pg.run_cls[r] | ((uint32_t)pg.run_len[r] << 8) | ((uint32_t)pg.run_off[r] << 16);

@@ -48,7 +48,6 @@ struct ScanArgs {
     uint32_t k3_exact3;                                   // K3: ... and within THREE positions (the three-position filter is exact too)
     uint32_t k3_one_bucket;                               // K3: the filter table uses bucket 0 only (its bytes are 0 / 1)
     uint32_t vm_filter;                                   // K3: every filter hit is put to the VM (DevProgram::vm_filter)
-    uint32_t k2_lane_table;                               // K2, two classes: the per-lane single-byte table instead of the pair table (experiment switch)
     uint32_t report_shift;   // reported offset = device window start + this (1 when the windows carry a leading context position)
     uint32_t run_desc[kK2MaxRuns];                        // K2: cls | len<<8 | off<<16
     // K2, windows of <= 17 bytes: the run's shift program, decoded on the host -- cls @0, then the shift amounts of the
