@@ -154,7 +154,6 @@ struct IngestCfg {
     size_t second_after;  // bytes handed to a device before its second copy stream is made
     bool scan_stream;     // GSCAN_SCAN_STREAM=1 (measurements): the scans and read-backs on a stream of their own
     int ahead_threads;    // GSCAN_AHEAD_THREADS (measurements): helper threads of gscan_prefault_files
-    bool warm_copy;       // GSCAN_WARM_COPY=0 (measurements): no helper makes the process's first transfer
     bool numa;
     int nt_copy;          // GSCAN_NT_COPY
     long pool_cap;        // GSCAN_POOL_CAP (test hook): 0 = two blocks per reader
@@ -181,7 +180,6 @@ const IngestCfg &ingest_cfg()
         v.second_after = (size_t)env("GSCAN_SECOND_STREAM_MIB", 1024, 0, 1 << 20) << 20;
         v.scan_stream = env("GSCAN_SCAN_STREAM", 0, 0, 1) != 0;
         v.ahead_threads = (int)env("GSCAN_AHEAD_THREADS", 8, 1, 32);
-        v.warm_copy = env("GSCAN_WARM_COPY", 1, 0, 1) != 0;
         v.numa = env("GSCAN_NUMA", 1, 0, 1) != 0;
         v.nt_copy = (int)env("GSCAN_NT_COPY", 0, 0, 1);
         v.pool_cap = env("GSCAN_POOL_CAP", 0, 0, 4096);
@@ -461,28 +459,10 @@ private:
             readers_ = gscan_auto_readers(cpus, std::max(1, sharing), std::max(1, ndev > 0 ? ndev : device_count()));
         }
         cap_ = ingest_cfg().pool_cap > 0 ? (size_t)ingest_cfg().pool_cap : (size_t)readers_ * 2;
-        // The first host -> device transfer of a process costs the runtime 8 - 25 ms of set-up INSIDE the call that asks for it
-        // (profiles/r04_b_*, r05_c_cfg1_*: "submit_fd" -> "program on the device" 12.5 ms), whichever thread makes it.  A helper
-        // makes it -- 64 bytes -- while the opener creates the device's stream and sizes its arenas.
-        if (ingest_cfg().warm_copy) {
-            try {
-                warm_ = std::thread([this] {
-                    (void)hipSetDevice(hip_device_of(device_));
-                    void *d = nullptr;
-                    char h[64] = {0};
-                    if (hipMalloc(&d, 256) == hipSuccess) {
-                        (void)hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice);
-                        (void)hipFree(d);
-                    }
-                    (void)hipGetLastError();
-                    trace("ingest: first transfer made");
-                });
-            } catch (...) {
-            }
-        }
-        // (measured under the load it was written for, round 5: eight reader pools, 8 .. 64 readers, no DMA -- the non-temporal
-        // copy is SLOWER than plain pread at every reader count, 69 / 99 / 73 / 55 against 83 / 116 / 99 / 64 GB/s; off unless asked for)
-        nt_copy_ = ingest_cfg().nt_copy > 0;
+        // (The first host -> device transfer of a process costs the runtime 8 - 25 ms of set-up inside the call that asks for
+        // it.  A helper thread making it -- 64 bytes -- while the opener creates the device's stream was tried: SLOWER, one
+        // 256 MiB file 0.127 against 0.114 s, 16 GiB 0.631 against 0.609 s -- the two calls meet inside the runtime;
+        // profiles/r05_d_cfg1_*.)
     }
     ~Ingest()
     {
@@ -493,7 +473,6 @@ private:
         }
         for (std::thread &t : threads_) t.join();
         if (second_maker_.joinable()) second_maker_.join();
-        if (warm_.joinable()) warm_.join();
         (void)hipSetDevice(hip_device_of(device_));
         for (auto &l : lanes_)
             for (PinBlock *b : l->fifo) free_block(b, false); // (every context is closed: gscan_close has waited for the device)
@@ -811,7 +790,7 @@ private:
     std::atomic<size_t> handed_{0};             // bytes handed to this device so far (second_stream)
     std::atomic<hipStream_t> second_{nullptr};
     std::atomic<bool> second_started_{false};
-    std::thread second_maker_, warm_;
+    std::thread second_maker_;
     std::atomic<long> n_made_{0};           // staging blocks asked of the runtime so far (GSCAN_FAIL_ALLOC_AFTER)
     uint64_t n_waits_ev_ = 0, n_waits_cv_ = 0; // (under m_) how often the pool's slow paths ran: slept on a block's event / on the other readers
     bool started_ = false, stop_ = false;

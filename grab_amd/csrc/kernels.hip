@@ -963,7 +963,13 @@ __device__ __forceinline__ unsigned long long load8(const uint8_t *q) // any ali
 // carried from record to record.  Newlines are searched 8 bytes at a time.
 // (descriptors are per wave sub-tile: st = tile * nw + wave covers sub_bytes bytes; the descriptors of a segment are
 // consecutive, those of a segment's last tile beyond its end are empty)
-__global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t sub_bytes, uint32_t *__restrict__ ext,
+// (Round 5: FOUR waves per descriptor, wave w taking the batches of 64 records w, w + 4, ...  The pass is a chain of dependent
+// loads per lane -- record, line start 8 bytes at a time, the record in front, tail, line end, the gather's reservation -- some
+// 50 us per batch, and a sub-tile of the identifier scan holds ~110 records: two batches one after the other on ONE wave were
+// what a window's 119 us came to (profiles/r05_d_per_window_passes.txt) while the other 5 000 waves of the launch had long gone.
+// The batches only meet in the gather buffer's reservation, one atomic each, in any order.)
+constexpr int kLinesWaves = 4;
+__global__ __launch_bounds__(64 * kLinesWaves) void k_lines(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t sub_bytes, uint32_t *__restrict__ ext,
                                               uint8_t *__restrict__ gather, uint32_t gather_cap)
 {
     const uint32_t st = blockIdx.x;
@@ -988,10 +994,10 @@ __global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__rest
     const DevProgram *pg = a.prog;
     const uint32_t m = a.m, tail_extra = pg->tail_extra;
     const unsigned long long kNl = 0x0a0a0a0a0a0a0a0aull;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     // 64 records at a time: every lane settles one record (printed? its match end, line begin, line end) and copies its
     // printed line's text into the gather buffer -- one reservation per 64 records, the lines back to back in record order
-    for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
+    for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < cnt; i0 += 64u * kLinesWaves) {
         const uint32_t i = i0 + lane;
         uint32_t mylen = 0, mylb = 0; // the printed line [lb, le) of this lane's record (0: nothing to gather)
         uint32_t *e = ext + 4ull * (base + i);
@@ -1418,7 +1424,7 @@ hipError_t launch_ends(const ScanArgs &a, uint32_t nw, uint32_t sub_bytes, uint3
 hipError_t launch_lines(const ScanArgs &a, uint32_t nw, uint32_t sub_bytes, uint32_t *ext, uint8_t *gather, uint32_t gather_cap, hipStream_t st)
 {
     if (a.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_lines, dim3(a.n_tiles * nw), dim3(64), 0, st, a, a.tiles, nw, sub_bytes, ext, gather, gather_cap);
+    hipLaunchKernelGGL(k_lines, dim3(a.n_tiles * nw), dim3(64 * kLinesWaves), 0, st, a, a.tiles, nw, sub_bytes, ext, gather, gather_cap);
     return hipGetLastError();
 }
 

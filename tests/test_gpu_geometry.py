@@ -286,12 +286,21 @@ def test_queue_over_eight_device_indices(tmp_path, built, oracle_built):
             # link and the queue's back-pressure evens them out; what this box can show is that none is starved)
             mean = sum(per.values()) / 8
             assert all(0.3 * mean <= v <= 2.0 * mean for v in per.values()), per
-        argv = ["-n", str(min(16, len(os.sched_getaffinity(0)))), "-r", "-O", "-l", synth.IDENT_RE, os.path.join("big", "x00")]
+        # the identifier regex (dense output) over 48 files = 3 GiB: three of the directories under one root.  (Round 4 ran this
+        # over 16 files: with sixteen workers whose contexts open at different moments -- since round 5 the device indices no
+        # longer queue behind one process-wide lock to create their streams -- the first five to be ready take three windows
+        # each and the queue is empty before the rest have opened; 48 files outlast the bring-up.)
+        os.makedirs(os.path.join(d, "mid"))
+        for k in range(3):
+            os.makedirs(os.path.join(d, "mid", "x%02d" % k))
+            for i in range(16):
+                os.link(os.path.join(d, "big", "x00", "g%02d.txt" % i), os.path.join(d, "mid", "x%02d" % k, "g%02d.txt" % i))
+        argv = ["-n", str(min(16, len(os.sched_getaffinity(0)))), "-r", "-O", "-l", synth.IDENT_RE, "mid"]
         rc, out, err = _run(built.bin_path(), argv, d, env)
-        orc, oout, _ = _run(_oracles(oracle_built)[-1], ["-n", "8"] + argv[2:], d)
+        orc, oout, _ = _run(_oracles(oracle_built)[-1], ["-n", str(min(16, len(os.sched_getaffinity(0))))] + argv[2:], d)
         assert rc == orc == 0, err
         assert len(out) == len(oout) and hashlib.md5(b"\n".join(sorted(out.splitlines()))).digest() == hashlib.md5(b"\n".join(sorted(oout.splitlines()))).digest()
         per = {int(m.group(1)) for m in re.finditer(rb"\[grab bytes\] device (\d+): [1-9]", err)}
-        assert len(per) >= 4, per  # (16 files over 16 workers on 8 device indices)
+        assert len(per) >= 4, per  # (48 files over 16 workers on 8 device indices)
     finally:
         shutil.rmtree(d, ignore_errors=True)
