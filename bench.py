@@ -283,31 +283,51 @@ def check_launch(ctx, res, arena, pattern, files, file_bytes, plants, total, ove
     return "ok"
 
 
-def clocks_snapshot():
-    """The device's shader clock (MHz) and socket power (W) right now, from sysfs / rocm-smi's sources: the kernels' rates
-    follow the clock the power management grants (*Clock and power*), so every kernel block carries them."""
+def gpu_cards():
+    """sysfs directories of the amdgpu devices (the box may hold more GPUs than this process was given: the container sees
+    every card's sysfs)."""
+    import glob
+
+    return [c for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")) if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+
+
+def card_of_device(index=0):
+    """The sysfs directory of HIP device `index`, by its PCI address; None if that cannot be told.  (Round 4's records read
+    the FIRST card's clock and power -- on a box with eight GPUs of which the process is given one that was, seven times
+    out of eight, an idle neighbour: 111 MHz, 240 W.)"""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        for c in gpu_cards():
+            if os.path.basename(os.path.realpath(c)).lower().startswith(want):
+                return c
+    except Exception:
+        pass
+    return None
+
+
+def clocks_snapshot(card=None):
+    """One card's shader clock (MHz) and socket power (W) right now, from sysfs: the kernels' rates follow the clock the power
+    management grants (*Clock and power*).  card: its sysfs directory (default: the first one there is)."""
     import glob
 
     out = {}
     try:
-        for card in sorted(glob.glob("/sys/class/drm/card*/device")):
-            f = os.path.join(card, "pp_dpm_sclk")
-            if not os.path.exists(f):
-                continue
-            for ln in open(f).read().splitlines():
-                if ln.rstrip().endswith("*"):
-                    out["sclk_mhz"] = int(re.search(r"(\d+)\s*Mhz", ln, re.I).group(1))
-            for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
-                for name in ("power1_average", "power1_input"):
-                    pf = os.path.join(hw, name)
-                    if os.path.exists(pf):
-                        try:
-                            out["power_w"] = round(int(open(pf).read().strip()) / 1e6, 1)
-                        except (OSError, ValueError):
-                            pass
-                        break
-            if out:
-                break
+        card = card or (gpu_cards() or [None])[0]
+        if not card:
+            return None
+        for ln in open(os.path.join(card, "pp_dpm_sclk")).read().splitlines():
+            if ln.rstrip().endswith("*"):
+                out["sclk_mhz"] = int(re.search(r"(\d+)\s*Mhz", ln, re.I).group(1))
+        for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
+            for name in ("power1_average", "power1_input"):
+                pf = os.path.join(hw, name)
+                if os.path.exists(pf):
+                    try:
+                        out["power_w"] = round(int(open(pf).read().strip()) / 1e6, 1)
+                    except (OSError, ValueError):
+                        pass
+                    break
     except Exception:
         pass
     return out or None
@@ -322,15 +342,21 @@ class ClockSampler:
         import threading
 
         self.period = period_s
+        # the card of the device the kernels run on; if its PCI address cannot be matched, every card is sampled and the one
+        # that draws the most is reported (the busy one)
+        self.card = card_of_device(torch.cuda.current_device())
+        self.cards = [self.card] if self.card else gpu_cards()
+        self.series = {c: [] for c in self.cards}
         self.samples = []
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
         while not self._stop.is_set():
-            c = clocks_snapshot()
-            if c:
-                self.samples.append(c)
+            for card in self.cards:
+                c = clocks_snapshot(card)
+                if c:
+                    self.series[card].append(c)
             self._stop.wait(self.period)
 
     def start(self):
@@ -340,11 +366,14 @@ class ClockSampler:
     def stop(self):
         self._stop.set()
         self._thread.join()
+        best = max(self.series, key=lambda c: sum(x.get("power_w", 0) for x in self.series[c]) / max(1, len(self.series[c])), default=None)
+        self.samples = self.series.get(best, [])
         clk = sorted(c["sclk_mhz"] for c in self.samples if "sclk_mhz" in c)
         pw = sorted(c["power_w"] for c in self.samples if "power_w" in c)
         if not clk and not pw:
             return None
-        out = {"samples": len(self.samples), "sampled": "every %d ms while the timed launches ran" % round(self.period * 1e3)}
+        out = {"samples": len(self.samples), "sampled": "every %d ms while the timed launches ran" % round(self.period * 1e3),
+               "card": os.path.basename(os.path.realpath(best)) if best else None, "card_by": "PCI address of the HIP device" if self.card else "the card drawing the most power of %d" % len(self.cards)}
         if clk:
             out.update({"sclk_mhz": clk[len(clk) // 2], "sclk_mhz_min": clk[0], "sclk_mhz_max": clk[-1]})
         if pw:

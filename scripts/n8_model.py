@@ -3,8 +3,9 @@
 
   F -- the fixed cost with eight device indices' worth of reader pools, streams, slots and pinned blocks going through ONE
        HIP runtime: `grab -n 32 -r` under GSCAN_VIRTUAL_DEVICES=8 (+ a faked two-socket sysfs tree for the placement) against
-       `grab -n 8 -r` on the one index, same corpus, same link -- the difference of the wall clocks IS F(8 indices) - F(1);
-       the marks (runtime up, worker 0's context, workers joined, exit) and every index's first DMA beside it.
+       `grab -n 8 -r` on the one index, same corpus: F(8 indices) - F(1) = how much later the LAST index queues its first
+       DMA + how much longer the exit takes (the wall clocks also differ by what eight pools lose on ONE shared link, which
+       eight GPUs would not: reported beside it, not counted).
   D -- the host's page cache -> pinned ceiling with the DMA and the scan stubbed out (GSCAN_DIAG=1: the readers fill their
        blocks and hand them straight back), eight pools on both sockets, 1 / 2 / 4 / 8 readers per pool = 8 ... 64 readers,
        plain pread against pread + non-temporal copy (GSCAN_NT_COPY).
@@ -89,12 +90,21 @@ def measure(grab, d, nbytes, pattern="foobardoesnotexist", reps=2, host_copy=Tru
         eight = run([grab, "-n", w8, "-r", pattern, d], env8, reps)
         if not one or not eight:
             return {"error": "grab failed"}
+        o1, o8 = summary(one, nbytes), summary(eight, nbytes)
         out = {"bytes": nbytes,
-               "one_index": dict(summary(one, nbytes), command="grab -n %s -r" % w1),
-               "eight_indices": dict(summary(eight, nbytes), command="GSCAN_VIRTUAL_DEVICES=8 grab -n %s -r (eight reader pools, 16 streams, 96 slots through one runtime and one link)" % w8),
-               "F8_minus_F1_measured_s": round(eight[0] - one[0], 4),
-               "what": "same corpus, same GPU, same link: the wall clocks differ by what eight device indices' bring-up and teardown cost beyond one's"}
-        out["F1_measured_s"] = round(one[0] - nbytes / (out["one_index"].get("scan_phase_GBps", 50.0) * 1e9), 4) if out["one_index"].get("scan_phase_GBps") else None
+               "one_index": dict(o1, command="grab -n %s -r" % w1),
+               "eight_indices": dict(o8, command="GSCAN_VIRTUAL_DEVICES=8 grab -n %s -r (eight reader pools, their streams and 96 slots through one runtime -- and, here, one link)" % w8)}
+        # F(8 indices) - F(1), from the marks: how much later the LAST index's first DMA is queued than the one index's, plus
+        # how much longer the exit takes.  (The wall clocks' difference also holds what eight pools lose by sharing ONE link
+        # and ONE GPU's queues on this box -- scan_phase_GBps of the two runs says how much -- which eight GPUs would not.)
+        try:
+            ramp = o8["first_dma_s"]["last_index"] - o1["first_dma_s"]["last_index"]
+            out["F8_minus_F1_measured_s"] = round(ramp + (o8["exit_s"] - o1["exit_s"]), 4)
+            out["F8_minus_F1_parts_s"] = {"last_index_first_dma_later_by": round(ramp, 4), "exit_longer_by": round(o8["exit_s"] - o1["exit_s"], 4)}
+        except (KeyError, TypeError):
+            out["F8_minus_F1_measured_s"] = None
+        out["wall_delta_s"] = round(eight[0] - one[0], 4)
+        out["F1_measured_s"] = round(one[0] - nbytes / (o1["scan_phase_GBps"] * 1e9), 4) if o1.get("scan_phase_GBps") else None
         if host_copy:
             table = {}
             best = None
@@ -117,6 +127,20 @@ def measure(grab, d, nbytes, pattern="foobardoesnotexist", reps=2, host_copy=Tru
                 out["host_copy_best"] = {"GBps": best[0], "nt_copy": best[1], "readers": best[2]}
                 out["read_mode_best"] = "non-temporal copy" if best[1] else "pread"
             out["host_copy_what"] = "GSCAN_DIAG=1: page cache -> pinned blocks only (no DMA, no scan), eight reader pools bound to the two sockets' CPUs by a faked sysfs tree, corpus pages interleaved"
+        # T(N) = F(N) + bytes / min(N x P, D) with the measured terms: P = the one index's scan phase, D = the best
+        # host copy rate above (an UPPER bound of what the host can feed: with the DMA reading the same memory a reader moves
+        # half of what it moves alone), F(8) = F(1) + the measured difference
+        try:
+            P, D = o1["scan_phase_GBps"], out["host_copy_best"]["GBps"]
+            F1, F8 = out["F1_measured_s"], out["F1_measured_s"] + out["F8_minus_F1_measured_s"]
+            gb = nbytes / 1e9
+            T1, T8 = F1 + gb / P, F8 + gb / min(8 * P, D)
+            out["forecast_N8"] = {"P_GBps": P, "D_GBps": D, "F1_s": round(F1, 3), "F8_s": round(F8, 3), "T1_s": round(T1, 3), "T8_s": round(T8, 3),
+                                  "GBps": round(gb / T8, 1), "strong_scaling_efficiency": round(T1 / (8 * T8), 3),
+                                  "bound_by": "D (the host's page cache -> pinned copy)" if D < 8 * P else "the links",
+                                  "efficiency_if_F8_were_F1": round(T1 / (8 * (F1 + gb / min(8 * P, D))), 3)}
+        except (KeyError, TypeError, ZeroDivisionError):
+            pass
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
