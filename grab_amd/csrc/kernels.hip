@@ -963,13 +963,11 @@ __device__ __forceinline__ unsigned long long load8(const uint8_t *q) // any ali
 // carried from record to record.  Newlines are searched 8 bytes at a time.
 // (descriptors are per wave sub-tile: st = tile * nw + wave covers sub_bytes bytes; the descriptors of a segment are
 // consecutive, those of a segment's last tile beyond its end are empty)
-// (Round 5: FOUR waves per descriptor, wave w taking the batches of 64 records w, w + 4, ...  The pass is a chain of dependent
-// loads per lane -- record, line start 8 bytes at a time, the record in front, tail, line end, the gather's reservation -- some
-// 50 us per batch, and a sub-tile of the identifier scan holds ~110 records: two batches one after the other on ONE wave were
-// what a window's 119 us came to (profiles/r05_d_per_window_passes.txt) while the other 5 000 waves of the launch had long gone.
-// The batches only meet in the gather buffer's reservation, one atomic each, in any order.)
-constexpr int kLinesWaves = 4;
-__global__ __launch_bounds__(64 * kLinesWaves) void k_lines(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t sub_bytes, uint32_t *__restrict__ ext,
+// (Round 5, measured and not adopted: FOUR waves per descriptor, wave w taking the batches of 64 records w, w + 4, ... -- 125
+// against 119 us per 64 MiB window, profiles/r05_j_per_window_passes.txt: the pass is not paced by descriptors with two batches
+// but by its longest chains of dependent loads, the records in lines of several hundred bytes.  Those chains are what the
+// 32-byte steps below shorten.)
+__global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t sub_bytes, uint32_t *__restrict__ ext,
                                               uint8_t *__restrict__ gather, uint32_t gather_cap)
 {
     const uint32_t st = blockIdx.x;
@@ -994,10 +992,10 @@ __global__ __launch_bounds__(64 * kLinesWaves) void k_lines(ScanArgs a, const Ti
     const DevProgram *pg = a.prog;
     const uint32_t m = a.m, tail_extra = pg->tail_extra;
     const unsigned long long kNl = 0x0a0a0a0a0a0a0a0aull;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x;
     // 64 records at a time: every lane settles one record (printed? its match end, line begin, line end) and copies its
     // printed line's text into the gather buffer -- one reservation per 64 records, the lines back to back in record order
-    for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < cnt; i0 += 64u * kLinesWaves) {
+    for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
         const uint32_t i = i0 + lane;
         uint32_t mylen = 0, mylb = 0; // the printed line [lb, le) of this lane's record (0: nothing to gather)
         uint32_t *e = ext + 4ull * (base + i);
@@ -1006,6 +1004,20 @@ __global__ __launch_bounds__(64 * kLinesWaves) void k_lines(ScanArgs a, const Ti
             // start of p's line: the byte after the last newline before p
             uint32_t ls = p;
             bool found = false;
+            // (32 bytes per step while they are there -- four loads in flight instead of one: a line of several hundred bytes is a
+            // chain of that many dependent round trips otherwise, and the launch takes as long as its longest chain)
+            while (!found && ls >= 32 && p - ls < kLineBack) {
+                const unsigned long long z3 = zero_bytes(load8(seg + ls - 8) ^ kNl), z2 = zero_bytes(load8(seg + ls - 16) ^ kNl);
+                const unsigned long long z1 = zero_bytes(load8(seg + ls - 24) ^ kNl), z0 = zero_bytes(load8(seg + ls - 32) ^ kNl);
+                if (z3 | z2 | z1 | z0) { // the nearest newline: the highest zero byte of the highest piece that has one
+                    const unsigned long long z = z3 ? z3 : z2 ? z2 : z1 ? z1 : z0;
+                    const uint32_t at = z3 ? 8u : z2 ? 16u : z1 ? 24u : 32u;
+                    ls = ls - at + (uint32_t)((63 - __clzll((long long)z)) >> 3) + 1;
+                    found = true;
+                } else {
+                    ls -= 32;
+                }
+            }
             while (!found && ls >= 8 && p - ls < kLineBack) {
                 const unsigned long long z = zero_bytes(load8(seg + ls - 8) ^ kNl);
                 if (z) {
@@ -1058,6 +1070,17 @@ __global__ __launch_bounds__(64 * kLinesWaves) void k_lines(ScanArgs a, const Ti
                 // the rest of the line, at most 511 bytes of it (grab.cc:173,194-196)
                 le = m1;
                 found = false;
+                while (!found && le + 32 <= slen && le - m1 < 480u) { // (32 bytes per step: see the line start)
+                    const unsigned long long z0 = zero_bytes(load8(seg + le) ^ kNl), z1 = zero_bytes(load8(seg + le + 8) ^ kNl);
+                    const unsigned long long z2 = zero_bytes(load8(seg + le + 16) ^ kNl), z3 = zero_bytes(load8(seg + le + 24) ^ kNl);
+                    if (z0 | z1 | z2 | z3) { // the next newline: the lowest zero byte of the lowest piece that has one
+                        const unsigned long long z = z0 ? z0 : z1 ? z1 : z2 ? z2 : z3;
+                        le += (z0 ? 0u : z1 ? 8u : z2 ? 16u : 24u) + ((uint32_t)(__ffsll((long long)z) - 1) >> 3);
+                        found = true;
+                    } else {
+                        le += 32;
+                    }
+                }
                 while (!found && le + 8 <= slen && le - m1 < 504u) {
                     const unsigned long long z = zero_bytes(load8(seg + le) ^ kNl);
                     if (z) {
@@ -1095,6 +1118,13 @@ __global__ __launch_bounds__(64 * kLinesWaves) void k_lines(ScanArgs a, const Ti
             const uint8_t *src = seg + mylb;
             uint8_t *dst = gather + (gb + incl - mylen);
             uint32_t o = 0;
+            for (; o + 32 <= mylen; o += 32) { // (four loads, then four stores: the text and the gather buffer do not overlap)
+                const unsigned long long v0 = load8(src + o), v1 = load8(src + o + 8), v2 = load8(src + o + 16), v3 = load8(src + o + 24);
+                __builtin_memcpy(dst + o, &v0, 8);
+                __builtin_memcpy(dst + o + 8, &v1, 8);
+                __builtin_memcpy(dst + o + 16, &v2, 8);
+                __builtin_memcpy(dst + o + 24, &v3, 8);
+            }
             for (; o + 8 <= mylen; o += 8) {
                 const unsigned long long v = load8(src + o);
                 __builtin_memcpy(dst + o, &v, 8);
@@ -1424,7 +1454,7 @@ hipError_t launch_ends(const ScanArgs &a, uint32_t nw, uint32_t sub_bytes, uint3
 hipError_t launch_lines(const ScanArgs &a, uint32_t nw, uint32_t sub_bytes, uint32_t *ext, uint8_t *gather, uint32_t gather_cap, hipStream_t st)
 {
     if (a.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_lines, dim3(a.n_tiles * nw), dim3(64 * kLinesWaves), 0, st, a, a.tiles, nw, sub_bytes, ext, gather, gather_cap);
+    hipLaunchKernelGGL(k_lines, dim3(a.n_tiles * nw), dim3(64), 0, st, a, a.tiles, nw, sub_bytes, ext, gather, gather_cap);
     return hipGetLastError();
 }
 
