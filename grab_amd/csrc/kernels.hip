@@ -976,6 +976,9 @@ __global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__rest
     const unsigned long long d = a.desc[st];
     const uint32_t cnt = (uint32_t)d;
     if (cnt == 0 || a.counter[kShards * kCtrStride] != 0) return; // (overflow: the host rescans with a bigger buffer and this pass runs again)
+    __shared__ uint8_t s_tail[256]; // the tail class, one byte per byte value (one wave per workgroup: its own writes, then its reads)
+    for (uint32_t b = threadIdx.x; b < 256u; b += 64u) s_tail[b] = (uint8_t)((a.prog->tail_bits[b >> 5] >> (b & 31u)) & 1u);
+    __syncthreads();
     const uint32_t base = (uint32_t)(d >> 32);
     uint64_t seg_off;
     uint32_t slen, tile_off;
@@ -1055,11 +1058,21 @@ __global__ __launch_bounds__(64) void k_lines(ScanArgs a, const TileDesc *__rest
             }
             uint32_t m1 = p + m, le = 0;
             if (verdict == 1) {
-                // the match: window + greedy tail
+                // the match: window + greedy tail -- eight text bytes per load, the class test a 256-byte table in LDS (as k_ends
+                // does it; a byte load and a look-up in the program's bitmap in global memory per tail byte were two dependent
+                // round trips each)
                 uint32_t extra = 0;
-                while (m1 < slen && extra < tail_extra) {
-                    const uint32_t b = seg[m1];
-                    if (!((pg->tail_bits[b >> 5] >> (b & 31)) & 1u)) break;
+                bool open = true; // the tail has not been seen to stop yet
+                while (open && m1 + 8 <= slen && extra + 8 <= tail_extra && extra < kLineBack) {
+                    const unsigned long long v = load8(seg + m1);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (open && !s_tail[(uint32_t)(v >> (8 * k)) & 0xffu]) open = false;
+                        if (open) m1++, extra++;
+                    }
+                }
+                while (open && m1 < slen && extra < tail_extra) {
+                    if (!s_tail[seg[m1]]) break;
                     m1++;
                     extra++;
                     if (extra >= kLineBack && extra < tail_extra) {
