@@ -41,6 +41,12 @@ One JSON line on rank 0: the driver's contract fields, plus
                   only) run by this script over the native harness (grab_amd/bin/gscan_sweep, same kernels, same
                   arena size); falls back to the committed profile, labelled, if rocprofv3 cannot run
 `--mode e2e` prints only the e2e measurement as the line's value (metric "GB/s end to end").
+
+The default one-GPU run is two processes in a row (orchestrate()): the kernel blocks in a child (--phase kernels: the driver's
+timed region, the other kernels, the PMC passes), then -- that child and its GPU context gone -- the end-to-end blocks from the
+parent, which never touches the GPU itself; corpora are written by generator children.  A `grab` run beside a process that has
+used the GPU measures that process too (profiles/r05_m_*).  --in-process keeps everything in one process (rounds 1 - 4); runs
+under torch.distributed (N > 1) are in-process as before.
 """
 import argparse
 import json
@@ -459,6 +465,39 @@ def interleave_page_placement():
         return 0
 
 
+def gen_child(code):
+    """Corpus generation in a SHORT-LIVED process of its own: the synthetic text is made on the device (torch), and a process
+    that has used the GPU costs the `grab` runs that follow -- as its children -- up to a quarter of a second each for as long
+    as it is alive (profiles/r05_m_*: one 32 GiB file 0.82-0.87 s under a parent that holds no context, 1.09-1.19 s under one
+    that has launched a kernel; round 4's binary just the same, r05_h_*).  The generator is gone before anything is timed."""
+    pre = "import sys\nsys.path.insert(0, %r)\nsys.path.insert(0, %r)\n" % (ROOT, os.path.join(ROOT, "scripts"))
+    r = subprocess.run([sys.executable, "-c", pre + code], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("corpus generator failed: " + r.stderr[-300:])
+    return r.stdout
+
+
+def gen_corpus(d, nfiles, file_bytes, device=None):
+    """Files 0..nfiles-1 of the bench corpus (the same text and the same planted needles as build_corpus's arena) as
+    d/xx/fNNNN.txt, built piecewise in HBM, never 64 GiB at once."""
+    device = device or torch.device("cuda", 0)
+    nd = torch.frombuffer(bytearray(synth.NEEDLE), dtype=torch.uint8).to(device)
+    step = 64
+    for lo in range(0, nfiles, step):
+        n = min(step, nfiles - lo)
+        part = torch.empty(n * file_bytes, dtype=torch.uint8, device=device)
+        for i in range(n):
+            view = part[i * file_bytes:(i + 1) * file_bytes]
+            view.copy_(synth.torch_text(file_bytes, lo + i, device))
+            offs = plant_offsets(lo + i, file_bytes, NEEDLES_PER_FILE)
+            idx = (torch.from_numpy(offs).to(device)[:, None] + torch.arange(nd.numel(), device=device)[None, :]).reshape(-1)
+            view[idx] = nd.repeat(NEEDLES_PER_FILE)
+            sub = os.path.join(d, "%02d" % ((lo + i) % 16))
+            os.makedirs(sub, exist_ok=True)
+            view.cpu().numpy().tofile(os.path.join(sub, "f%04d.txt" % (lo + i)))
+        del part
+
+
 def write_corpus(arena, d, nfiles, file_bytes):
     """Files 0..nfiles-1 of the HBM arena as d/xx/fNNNN.txt (16 sub-directories: something for the walkers to share)."""
     t0 = time.perf_counter()
@@ -579,7 +618,7 @@ def e2e_measure(d, nfiles, file_bytes, pattern, flags, n_gpus, want_lines, reps=
     workers = max(1, min(workers, allowed))
     env = dict(os.environ, GRAB_TIMING="1")
     vis = os.environ.get("HIP_VISIBLE_DEVICES")
-    devs = [x for x in vis.split(",") if x] if vis else [str(i) for i in range(torch.cuda.device_count())]
+    devs = [x for x in vis.split(",") if x] if vis else [str(i) for i in range(n_gpus)]
     env["HIP_VISIBLE_DEVICES"] = ",".join(devs[:n_gpus])
     argv = [bin_path(), "-n", str(workers), "-r"] + flags + [pattern, d]
     got = run_timed(argv, env, reps, warm=warm, count_only=count_only)
@@ -746,9 +785,6 @@ def e2e_cfg4(base, gib, n_gpus, want_cpu):
     queue, small files queued by name and read by the device's reader pool, 64 to a launch -- line count == file count,
     sorted output md5 against the reference; the same command over the first quarter of the tree beside it (`at_16GiB`:
     hard links, the same 0.25 s of start-up and teardown under a quarter of the work)."""
-    sys.path.insert(0, os.path.join(ROOT, "scripts"))
-    import fullsize_parity
-
     d = os.path.join(base, "grab_bench_cfg4_%d" % os.getpid())
     while gib > 1 and shutil.disk_usage(base).free < (gib << 30) * 1.2:
         gib //= 2
@@ -757,7 +793,7 @@ def e2e_cfg4(base, gib, n_gpus, want_cpu):
     try:
         os.makedirs(d)
         t0 = time.perf_counter()
-        fullsize_parity.gen_files(d, files, fb, 1, tree=(64, 64, 32))
+        gen_child("import fullsize_parity\nfullsize_parity.gen_files(%r, %d, %d, 1, tree=(64, 64, 32))\n" % (d, files, fb))
         gen_s = time.perf_counter() - t0
         needle = synth.NEEDLE.decode()
         e = e2e_measure(d, files, fb, needle, ["-O", "-l"], n_gpus, files, reps=2, detached=False)
@@ -821,9 +857,6 @@ def e2e_cfg5(base, gib, want_cpu):
     4 KiB overlap window, across every chunk end, ending exactly at a chunk end, at every chunk start and in the last 18 bytes
     (scripts/fullsize_parity.py gen_big); `grab -O -l` (1 GiB windows, dealt over the node's GPUs, printed in order)
     byte-exact against the reference.  The same on an 8 GiB file beside it (`at_8GiB`)."""
-    sys.path.insert(0, os.path.join(ROOT, "scripts"))
-    import fullsize_parity
-
     needle = synth.NEEDLE.decode()
     while gib > 1 and shutil.disk_usage(base).free < (gib << 30) * 1.2:
         gib //= 2
@@ -832,7 +865,7 @@ def e2e_cfg5(base, gib, want_cpu):
         path = os.path.join(base, "grab_bench_cfg5_%d.bin" % os.getpid())
         try:
             t0 = time.perf_counter()
-            plants = fullsize_parity.gen_big(path, g << 30, 1 << 30, int(31250 * g))
+            plants = int(gen_child("import fullsize_parity\nprint(fullsize_parity.gen_big(%r, %d, 1 << 30, %d))\n" % (path, g << 30, int(31250 * g))).split()[-1])
             gen_s = time.perf_counter() - t0
             e = one_file_block(["-O", "-l", needle], path, g << 30, "one %d GiB file" % g, want_cpu and out is None, ref_reps=2 if out is None else 1)
             e.update({"plants": int(plants), "corpus_write_s": round(gen_s, 1)})
@@ -846,14 +879,14 @@ def e2e_cfg5(base, gib, want_cpu):
     return out
 
 
-def e2e_cfg1(base, device, want_cpu):
+def e2e_cfg1(base, want_cpu):
     """BASELINE configs[0]: ONE 256 MiB file of synthetic text (seed k = 0), the literal that is not in it -- the
     reference's own CPU-runnable case: `grab foobardoesnotexist <file>` against `grab_jit` on one core.  A run this short
     is start-up and teardown of the HIP runtime more than anything else: the number is here whatever it says."""
     path = os.path.join(base, "grab_bench_cfg1_%d.txt" % os.getpid())
     size = 256 << 20
     try:
-        synth.torch_text(size, 0, device).cpu().numpy().tofile(path)
+        gen_child("import torch\nfrom grab_amd import synth\nsynth.torch_text(%d, 0, torch.device('cuda', 0)).cpu().numpy().tofile(%r)\n" % (size, path))
         e = one_file_block([synth.NEEDLE.decode()], path, size, "one 256 MiB file", want_cpu, reps=5, ref_reps=5)
         s = one_file_block(["-S", synth.NEEDLE.decode()], path, size, "one 256 MiB file", False, reps=3)
         e["with_-S"] = {k: s.get(k) for k in ("value", "wall_s", "lines", "error") if k in s}
@@ -864,6 +897,104 @@ def e2e_cfg1(base, device, want_cpu):
     finally:
         if os.path.exists(path):
             os.unlink(path)
+
+
+def e2e_phase(a, line, world, arena=None):
+    """The end-to-end blocks, added to `line`.  arena: the kernel phase's corpus in HBM (the in-process path: the files are
+    written out of it); None: the orchestrating process of the one-GPU run, which holds no GPU context -- the corpus is made by a
+    generator child."""
+    pattern = CONFIGS[a.config][0]
+    file_bytes = a.file_mib << 20
+    e2e_files = max(1, min(a.files, (a.e2e_gib << 30) // file_bytes))
+    d, use = e2e_dir_for(e2e_files * file_bytes)
+    if not d:
+        line["e2e"] = {"error": "no room in /dev/shm or /tmp"}
+        return
+    nfiles = use // file_bytes
+    try:
+        numa_nodes = interleave_page_placement()
+        t0 = time.perf_counter()
+        if arena is not None:
+            write_corpus(arena, d, nfiles, file_bytes)
+            del arena
+            torch.cuda.empty_cache()
+        else:
+            gen_child("import bench\nbench.gen_corpus(%r, %d, %d)\n" % (d, nfiles, file_bytes))
+        wsec = time.perf_counter() - t0
+        flags = ["-O", "-l"] if a.config == "cfg3" else []
+        want = NEEDLES_PER_FILE * nfiles if a.config != "cfg3" else None
+        e = e2e_measure(d, nfiles, file_bytes, pattern, flags, world, want)
+        e["corpus_write_s"] = round(wsec, 1)
+        e["corpus_pages"] = "interleaved over %d NUMA nodes" % numa_nodes if numa_nodes else "first touch (one NUMA node, or set_mempolicy unavailable)"
+        line["e2e"] = e
+        want_cpu = world == 1 and not a.no_cpu_baseline
+        if want_cpu:
+            line["cpu_baseline"] = cpu_baseline(d, nfiles, file_bytes, pattern, flags, count_only=a.config == "cfg3")
+            if line["cpu_baseline"] and "value" in e:
+                e["vs_cpu_baseline"] = round(e["value"] / line["cpu_baseline"]["value"], 3)
+                e["reference_digest"] = line["cpu_baseline"].get("digest")
+                e["same_as_reference"] = e.get("digest") is not None and e.get("digest") == e["reference_digest"]
+        # the N = 8 model's terms that one GPU can measure (DESIGN.md 6): the fixed cost with eight device indices
+        # through one runtime, the host's copy ceiling with the DMA stubbed out
+        if world == 1 and not a.no_e2e_extra:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                import n8_model
+
+                line["n8_model"] = n8_model.measure(bin_path(), d, nfiles * file_bytes, pattern=synth.NEEDLE.decode(), reps=2)
+            except Exception as ex:
+                line["n8_model"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+        # the other end-to-end BASELINE configurations, each with its own parity check and CPU baseline.  cfg3 runs on
+        # the cfg2 corpus; that corpus is removed before cfg5 (32 GiB) and cfg4 (64 GiB) write theirs
+        if not a.no_e2e_extra:
+            base = os.path.dirname(d)
+            full = nfiles * file_bytes >= (64 << 30)
+
+            def drop_corpus():
+                shutil.rmtree(d, ignore_errors=True)
+
+            for key, fn in (("e2e_cfg3", lambda: e2e_cfg3(d, nfiles, file_bytes, world, want_cpu)),
+                            ("e2e_cfg1", lambda: (drop_corpus(), e2e_cfg1(base, want_cpu))[1]),
+                            ("e2e_cfg5", lambda: e2e_cfg5(base, 32 if full else min(8, max(2, use >> 33)), want_cpu)),
+                            ("e2e_cfg4", lambda: e2e_cfg4(base, 64 if full else min(16, max(2, use >> 32)), world, want_cpu))):
+                try:
+                    line[key] = fn()
+                except Exception as ex:
+                    line[key] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+    except Exception as ex:  # (the kernel line is the contract: whatever goes wrong out here must not lose it)
+        line.setdefault("e2e", {})["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+        shutil.rmtree(d + "_cfg3", ignore_errors=True)
+        shutil.rmtree(d + "_cfg3s", ignore_errors=True)
+        shutil.rmtree(d + "_cfg3c", ignore_errors=True)
+
+
+def orchestrate(a):
+    """The default one-GPU run as TWO processes in a row: the kernel blocks (the driver's timed region, the other two kernels,
+    the live PMC traffic) in a child -- this same script with --phase kernels -- and, when that child has gone and taken its
+    GPU context with it, the end-to-end blocks from here, a process that never touches the GPU itself (corpora come from
+    generator children).  One JSON line at the end, as ever.  Why: a `grab` run as the child of a process that has used the GPU
+    loses 0.1 - 0.25 s of a second (profiles/r05_m_*, r05_h_*: round 4's binary just the same) -- the bench's own context was
+    in the measurement.  --in-process runs everything in one process as rounds 1 - 4 did."""
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--phase", "kernels"]
+    r = subprocess.run(argv, stdout=subprocess.PIPE)
+    out = r.stdout.decode("utf-8", "replace").strip().splitlines()
+    line = None
+    for ln in reversed(out):
+        if ln.startswith("{"):
+            try:
+                line = json.loads(ln)
+                break
+            except ValueError:
+                pass
+    if r.returncode != 0 or line is None:
+        sys.stdout.write(r.stdout.decode("utf-8", "replace"))
+        raise SystemExit("bench.py: the kernel phase failed (rc %d)" % r.returncode)
+    line["e2e_context"] = "measured from a process that holds no GPU context: the kernel blocks above ran in a child process that had exited, corpora come from generator children"
+    time.sleep(1.0)  # (the kernel phase's process is being taken apart)
+    e2e_phase(a, line, 1, None)
+    print(json.dumps(line), flush=True)
 
 
 def main():
@@ -883,16 +1014,22 @@ def main():
     ap.add_argument("--no-e2e-extra", action="store_true", help="skip the e2e_cfg3 / e2e_cfg4 / e2e_cfg5 blocks")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of rocprofv3 passes in this run")
     ap.add_argument("--e2e-gib", type=int, default=64, help="corpus written to /dev/shm for the end-to-end block")
+    ap.add_argument("--phase", default=None, choices=["kernels"], help="(internal) the kernel blocks only, as the child of the one-GPU run's orchestrating process")
+    ap.add_argument("--in-process", action="store_true", help="one-GPU run: kernel blocks and end-to-end blocks in ONE process, as rounds 1-4 ran them (the e2e children then run beside this process's GPU context)")
     a = ap.parse_args()
+    one_gpu = int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.gpus == 1
+    if a.mode == "kernel" and one_gpu and not a.no_e2e and not a.in_process and a.phase is None:
+        return orchestrate(a)
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the scan engine has no CPU path")
     if a.mode == "e2e" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
-        rank, world, local = 0, 1, 0  # plain python: one process drives `grab` over the first --gpus devices
+        rank, world, local = 0, 1, 0  # plain python: one process drives `grab` over the first --gpus devices -- and holds no GPU context itself
+        device = None
     else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: the scan engine has no CPU path")
         rank, world, local = dist_setup(a.gpus)
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
 
     pattern, cap_per_gib = CONFIGS[a.config]
     file_bytes = a.file_mib << 20
@@ -909,21 +1046,8 @@ def main():
             nfiles = use // file_bytes
             try:
                 t0 = time.perf_counter()
-                step = 64
-                for lo in range(0, nfiles, step):
-                    n = min(step, nfiles - lo)
-                    part = torch.empty(n * file_bytes, dtype=torch.uint8, device=device)
-                    nd = torch.frombuffer(bytearray(synth.NEEDLE), dtype=torch.uint8).to(device)
-                    for i in range(n):
-                        view = part[i * file_bytes:(i + 1) * file_bytes]
-                        view.copy_(synth.torch_text(file_bytes, lo + i, device))
-                        offs = plant_offsets(lo + i, file_bytes, NEEDLES_PER_FILE)
-                        idx = (torch.from_numpy(offs).to(device)[:, None] + torch.arange(nd.numel(), device=device)[None, :]).reshape(-1)
-                        view[idx] = nd.repeat(NEEDLES_PER_FILE)
-                        sub = os.path.join(d, "%02d" % ((lo + i) % 16))
-                        os.makedirs(sub, exist_ok=True)
-                        view.cpu().numpy().tofile(os.path.join(sub, "f%04d.txt" % (lo + i)))
-                    del part
+                interleave_page_placement()
+                gen_child("import bench\nbench.gen_corpus(%r, %d, %d)\n" % (d, nfiles, file_bytes))
                 gen_s = time.perf_counter() - t0
                 flags = ["-O", "-l"] if a.config == "cfg3" else []
                 want = NEEDLES_PER_FILE * nfiles if a.config != "cfg3" else None
@@ -941,7 +1065,8 @@ def main():
                     line["cpu_baseline"] = cpu_baseline(d, nfiles, file_bytes, pattern, flags)
             finally:
                 shutil.rmtree(d, ignore_errors=True)
-        barrier(world, device)
+        if world > 1:
+            barrier(world, device)
         if rank == 0:
             print(json.dumps(line), flush=True)
         if world > 1:
@@ -1060,65 +1185,10 @@ def main():
 
     # end to end on the same corpus: rank 0 writes it out and drives `grab` over the first `world` devices while the other
     # ranks wait at the barrier (their arenas stay allocated; nothing of theirs runs)
-    if not a.no_e2e:
+    if not a.no_e2e and a.phase is None:
         if rank == 0:
-            d, use = e2e_dir_for(e2e_files * file_bytes)
-            if d:
-                nfiles = use // file_bytes
-                try:
-                    numa_nodes = interleave_page_placement()
-                    wsec = write_corpus(arena, d, nfiles, file_bytes)
-                    del arena
-                    torch.cuda.empty_cache()
-                    flags = ["-O", "-l"] if a.config == "cfg3" else []
-                    want = NEEDLES_PER_FILE * nfiles if a.config != "cfg3" else None
-                    e = e2e_measure(d, nfiles, file_bytes, pattern, flags, world, want)
-                    e["corpus_write_s"] = round(wsec, 1)
-                    e["corpus_pages"] = "interleaved over %d NUMA nodes" % numa_nodes if numa_nodes else "first touch (one NUMA node, or set_mempolicy unavailable)"
-                    line["e2e"] = e
-                    want_cpu = world == 1 and not a.no_cpu_baseline
-                    if want_cpu:
-                        line["cpu_baseline"] = cpu_baseline(d, nfiles, file_bytes, pattern, flags, count_only=a.config == "cfg3")
-                        if line["cpu_baseline"] and "value" in e:
-                            e["vs_cpu_baseline"] = round(e["value"] / line["cpu_baseline"]["value"], 3)
-                            e["reference_digest"] = line["cpu_baseline"].get("digest")
-                            e["same_as_reference"] = e.get("digest") is not None and e.get("digest") == e["reference_digest"]
-                    # the N = 8 model's terms that one GPU can measure: the fixed cost with eight device indices
-                    # through one runtime, the host's copy ceiling with the DMA stubbed out
-                    if world == 1 and not a.no_e2e_extra:
-                        try:
-                            sys.path.insert(0, os.path.join(ROOT, "scripts"))
-                            import n8_model
-
-                            line["n8_model"] = n8_model.measure(bin_path(), d, nfiles * file_bytes, pattern=synth.NEEDLE.decode(), reps=2)
-                        except Exception as ex:
-                            line["n8_model"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
-                    # the other end-to-end BASELINE configurations, each with its own parity check and CPU baseline.  cfg3 runs on
-                    # the cfg2 corpus; that corpus is removed before cfg5 (32 GiB) and cfg4 (64 GiB) write theirs
-                    if not a.no_e2e_extra:
-                        base = os.path.dirname(d)
-                        full = nfiles * file_bytes >= (64 << 30)
-
-                        def drop_corpus():
-                            shutil.rmtree(d, ignore_errors=True)
-
-                        for key, fn in (("e2e_cfg3", lambda: e2e_cfg3(d, nfiles, file_bytes, world, want_cpu)),
-                                        ("e2e_cfg1", lambda: (drop_corpus(), e2e_cfg1(base, device, want_cpu))[1]),
-                                        ("e2e_cfg5", lambda: e2e_cfg5(base, 32 if full else min(8, max(2, use >> 33)), want_cpu)),
-                                        ("e2e_cfg4", lambda: e2e_cfg4(base, 64 if full else min(16, max(2, use >> 32)), world, want_cpu))):
-                            try:
-                                line[key] = fn()
-                            except Exception as ex:
-                                line[key] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
-                except Exception as ex:  # (the kernel line above is the contract: whatever goes wrong out here must not lose it)
-                    line.setdefault("e2e", {})["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
-                finally:
-                    shutil.rmtree(d, ignore_errors=True)
-                    shutil.rmtree(d + "_cfg3", ignore_errors=True)
-                    shutil.rmtree(d + "_cfg3s", ignore_errors=True)
-                    shutil.rmtree(d + "_cfg3c", ignore_errors=True)
-            else:
-                line["e2e"] = {"error": "no room in /dev/shm or /tmp"}
+            e2e_phase(a, line, world, arena)
+            arena = None
         barrier(world, device)
     if rank == 0:
         print(json.dumps(line), flush=True)
