@@ -526,6 +526,8 @@ def line_digest(argv, env=None, stdin_bytes=None):
     digest is what one can afford to run on both sides at full size).  The checker's tool; nothing of it is timed as
     the product.  stdin_bytes: digest these bytes instead of running argv."""
     tool = os.path.join(ROOT, "oracle", "linesum")
+    if not os.path.exists(tool):  # (__graft_entry__.build() makes it; a tree that was never built gets it here: one C file, gcc)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "linesum"], capture_output=True)
     if not os.path.exists(tool):
         return None, None, None
     t0 = time.perf_counter()
