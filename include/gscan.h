@@ -218,14 +218,15 @@ long gscan_parse_cpulist(const char *list, int *cpus, size_t cap);
 
 /*
  * Host-chunk path (what FileGrep::find uses): three ways to hand over the bytes that the
- * reference mmap()s and gives to pcre_exec (src/grab.cc:161,178).  Each starts H2D (copy stream)
- * + scan (compute stream) of one chunk; up to GSCAN_SLOTS chunks may be in flight and
+ * reference mmap()s and gives to pcre_exec (src/grab.cc:161,178).  Each starts H2D + scan of one
+ * chunk (on the DEVICE's copy streams, shared by its contexts: the scan rides on the first, behind
+ * the chunk's copies); up to GSCAN_SLOTS chunks may be in flight and
  * gscan_wait[_segs] returns them in submission order.  A gscan_wait that fails (a read error, a
  * device error) has dropped that chunk and freed its slot: the context stays usable.
  *
  *   gscan_submit_fd    a range of an open file.  The device's reader threads (GSCAN_READERS)
  *                      pread(2) it in pieces of gscan_block_size() bytes into a small pool of pinned
- *                      blocks and DMA every piece as soon as it is read, spread over the context's
+ *                      blocks and DMA every piece as soon as it is read, spread over the device's
  *                      copy streams; the reader that finishes the last piece launches the scan.
  *                      ASYNCHRONOUS: returns once the pieces are queued -- fd must stay open until
  *                      gscan_wait has returned the chunk; read errors surface there (GSCAN_EIO).
@@ -340,8 +341,8 @@ int gscan_wait_segs(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, cons
 
 /*
  * Device-resident path (bench, batching): scan nseg segments of an arena that is
- * already in HBM, one launch, on `stream` (a hipStream_t, NULL = the context's
- * compute stream).  Asynchronous; results stay on the device.
+ * already in HBM, one launch, on `stream` (a hipStream_t, NULL = the stream the context's
+ * scans ride on).  Asynchronous; results stay on the device.
  */
 int gscan_scan_device(gscan_ctx *ctx, const gscan_db *db, const void *dev_base,
                       const gscan_seg *segs, size_t nseg, void *stream,
