@@ -3,6 +3,7 @@ the NUMA map (device -> local CPUs) the readers and workers are placed by, patte
 and the shape of the ingest configuration."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -231,3 +232,27 @@ def test_visible_devices_are_narrowed_before_the_runtime_starts(built, tmp_path)
     assert narrowed(["foo", "f.txt"], GRAB_DEVICES="2") is None
     assert narrowed(["foo", "f.txt"], GRAB_DEVICE="1") is None
     assert narrowed(["foo", "f.txt"], GRAB_ALL_DEVICES="1") is None
+
+
+def test_prefault_files_without_a_device(built, tmp_path):
+    """gscan_prefault_files makes no HIP call: it can be called first thing in a process, with files that exist, files that do
+    not, directories, no files at all, more blocks than the arena may hold -- and a second call is a no-op (once per process)."""
+    f = tmp_path / "a.bin"
+    f.write_bytes(b"x" * (3 << 20))
+    code = (
+        "import ctypes as C, sys, time\n"
+        "from grab_amd import engine\n"
+        "L = engine.lib()\n"
+        "paths = [sys.argv[1].encode(), b'/nonexistent/file', sys.argv[2].encode()]\n"
+        "arr = (C.c_char_p * len(paths))(*paths)\n"
+        "assert L.gscan_prefault_files(1000, arr, len(paths)) == 0\n"
+        "assert L.gscan_prefault_files(4, arr, len(paths)) == 0\n"   # once per process
+        "assert L.gscan_prefault(18) == 0\n"
+        "time.sleep(0.3)\n"                                           # (the helpers read and touch in the background)
+        "print('ok')\n"
+    )
+    for env in ({}, {"GSCAN_BLOCK_MIB": "1"}, {"GSCAN_PREFAULT": "0"}):
+        r = subprocess.run([sys.executable, "-c", code, str(f), str(tmp_path)], cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-500:]
+    r = subprocess.run([sys.executable, "-c", "from grab_amd import engine; L = engine.lib(); assert L.gscan_prefault_files(0, None, 0) == 0; print('ok')"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-500:]
