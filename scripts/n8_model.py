@@ -79,6 +79,19 @@ def summary(got, nbytes):
     return out
 
 
+def forecast(P, D, F1, dF, nbytes, n=8):
+    """T(N) = F(N) + bytes / min(N x P, D) with the measured terms: P = the one index's scan phase (GB/s), D = the
+    best host copy rate (an UPPER bound of what the host can feed: with the DMA reading the same memory a reader moves half of
+    what it moves alone), F(N) = F(1) + dF (the measured difference between eight indices and one)."""
+    gb = nbytes / 1e9
+    F8 = F1 + dF
+    T1, T8 = F1 + gb / P, F8 + gb / min(n * P, D)
+    return {"P_GBps": P, "D_GBps": D, "F1_s": round(F1, 3), "F8_s": round(F8, 3), "T1_s": round(T1, 3), "T8_s": round(T8, 3),
+            "GBps": round(gb / T8, 1), "strong_scaling_efficiency": round(T1 / (n * T8), 3),
+            "bound_by": "D (the host's page cache -> pinned copy)" if D < n * P else "the links",
+            "efficiency_if_F8_were_F1": round(T1 / (n * (F1 + gb / min(n * P, D))), 3)}
+
+
 def measure(grab, d, nbytes, pattern="foobardoesnotexist", reps=2, host_copy=True):
     tmp = tempfile.mkdtemp(prefix="grab_n8_", dir="/tmp")
     try:
@@ -127,18 +140,8 @@ def measure(grab, d, nbytes, pattern="foobardoesnotexist", reps=2, host_copy=Tru
                 out["host_copy_best"] = {"GBps": best[0], "nt_copy": best[1], "readers": best[2]}
                 out["read_mode_best"] = "non-temporal copy" if best[1] else "pread"
             out["host_copy_what"] = "GSCAN_DIAG=1: page cache -> pinned blocks only (no DMA, no scan), eight reader pools bound to the two sockets' CPUs by a faked sysfs tree, corpus pages interleaved"
-        # T(N) = F(N) + bytes / min(N x P, D) with the measured terms: P = the one index's scan phase, D = the best
-        # host copy rate above (an UPPER bound of what the host can feed: with the DMA reading the same memory a reader moves
-        # half of what it moves alone), F(8) = F(1) + the measured difference
         try:
-            P, D = o1["scan_phase_GBps"], out["host_copy_best"]["GBps"]
-            F1, F8 = out["F1_measured_s"], out["F1_measured_s"] + out["F8_minus_F1_measured_s"]
-            gb = nbytes / 1e9
-            T1, T8 = F1 + gb / P, F8 + gb / min(8 * P, D)
-            out["forecast_N8"] = {"P_GBps": P, "D_GBps": D, "F1_s": round(F1, 3), "F8_s": round(F8, 3), "T1_s": round(T1, 3), "T8_s": round(T8, 3),
-                                  "GBps": round(gb / T8, 1), "strong_scaling_efficiency": round(T1 / (8 * T8), 3),
-                                  "bound_by": "D (the host's page cache -> pinned copy)" if D < 8 * P else "the links",
-                                  "efficiency_if_F8_were_F1": round(T1 / (8 * (F1 + gb / min(8 * P, D))), 3)}
+            out["forecast_N8"] = forecast(o1["scan_phase_GBps"], out["host_copy_best"]["GBps"], out["F1_measured_s"], out["F8_minus_F1_measured_s"], nbytes)
         except (KeyError, TypeError, ZeroDivisionError):
             pass
         return out

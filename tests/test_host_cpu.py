@@ -256,3 +256,19 @@ def test_prefault_files_without_a_device(built, tmp_path):
         assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-500:]
     r = subprocess.run([sys.executable, "-c", "from grab_amd import engine; L = engine.lib(); assert L.gscan_prefault_files(0, None, 0) == 0; print('ok')"], cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-500:]
+
+
+def test_n8_model_forecast_arithmetic():
+    """scripts/n8_model.py: T(N) = F(N) + bytes / min(N x P, D) from measured terms (DESIGN.md 6's table, run L's terms)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import n8_model
+
+    f = n8_model.forecast(50.98, 150.0, 0.1833, 0.3038, 64 << 30)
+    assert f["bound_by"].startswith("D") and abs(f["T1_s"] - 1.531) < 0.002 and abs(f["T8_s"] - 0.945) < 0.002
+    assert abs(f["strong_scaling_efficiency"] - 0.202) < 0.002 and abs(f["efficiency_if_F8_were_F1"] - 0.298) < 0.002
+    g = n8_model.forecast(50.0, 1000.0, 0.2, 0.0, 64 << 30)   # a host that can feed eight links: the links bound it
+    assert g["bound_by"] == "the links" and abs(g["T8_s"] - (0.2 + 68.719476736 / 400.0)) < 0.002
+    tree = n8_model.fake_pci_tree(os.path.join("/tmp", "grab_fake_pci_%d" % os.getpid()))
+    assert len([d for d in os.listdir(tree) if d.startswith("0000:")]) == 8
+    import shutil
+    shutil.rmtree(tree)
