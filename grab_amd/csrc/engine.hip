@@ -856,6 +856,7 @@ struct Slot {
     uint32_t *h_ext_spec = nullptr; // pinned, kShards rows of kSpecPer * 3
     std::vector<uint32_t> sorted_ext;
     bool has_ext = false;
+    bool resolved = false;      // the chunk went through k_resolve: the records are match starts, the extras their ends, the dropped ones are counted as struck
     uint32_t ext_words = 0;     // 4: {m1, lb, le, goff} per record ("line_extents"), 1: the match end ("match_ends"), 0: none
     // the text of the printed lines, gathered by k_lines ("line_extents"): device buffer, pinned copy of the used part
     uint8_t *d_gather = nullptr;
@@ -940,6 +941,8 @@ struct gscan_ctx {
     size_t dev_cap_req = 0;
     uint32_t *dv_recs = nullptr;
     size_t dv_rec_cap = 0;
+    uint32_t *dv_ends = nullptr; // the resolve pass's extras, parallel to dv_recs (databases with `resolve` only)
+    size_t dv_ends_cap = 0;
     unsigned long long *dv_desc = nullptr;
     gscan::TileDesc *dv_tiles = nullptr;
     size_t dv_tiles_cap = 0;
@@ -1175,7 +1178,9 @@ int slot_launch(gscan_ctx *c, Slot &s)
     gscan::fill_program(a, db.prog);
     if (s.n_tiles) HIPCHK(c, gscan::launch_scan(db.tier, c->variant, a, grid_for(c, db, s.n_tiles), c->compute));
     if (s.n_tiles && gscan::scan_needs_settle(db.tier, db.prog)) HIPCHK(c, gscan::launch_settle(a, nw, c->compute));
-    s.ext_words = !s.n_tiles ? 0u : (c->line_extents && db.prog.lines_ok) ? 4u : (c->match_ends && db.prog.ends_ok) ? 1u : 0u;
+    // (a database the device resolves always comes with its matches' ends: the list means nothing else)
+    s.resolved = s.n_tiles && db.prog.resolve;
+    s.ext_words = !s.n_tiles ? 0u : s.resolved ? 1u : (c->line_extents && db.prog.lines_ok) ? 4u : (c->match_ends && db.prog.ends_ok) ? 1u : 0u;
     s.has_ext = s.ext_words != 0;
     if (s.has_ext) {
         const size_t eb = 4 * (size_t)s.ext_words; // bytes per record
@@ -1199,6 +1204,8 @@ int slot_launch(gscan_ctx *c, Slot &s)
                 s.gather_cap = want;
             }
             HIPCHK(c, gscan::launch_lines(a, nw, tile_bytes / nw, s.d_ext, s.d_gather, (uint32_t)s.gather_cap, c->compute));
+        } else if (s.resolved) {
+            HIPCHK(c, gscan::launch_resolve(a, nw, s.d_ext, c->compute));
         } else {
             HIPCHK(c, gscan::launch_ends(a, nw, tile_bytes / nw, s.d_ext, c->compute));
         }
@@ -1398,6 +1405,9 @@ int gscan_db_info(const gscan_db *db, gscan_info *info)
     info->textfree = d.solitary && !d.alts.empty() && !d.alts[0].has_tail ? 1 : 0;
     info->exact = d.exact ? 1 : 0;
     info->vm = d.prog.vm_filter ? 1 : 0;
+    info->resolve = d.resolve ? 1 : 0;
+    info->reach = (int)d.reach;
+    info->n_windows = (int)d.dev_windows.size();
     return GSCAN_OK;
 }
 
@@ -1520,6 +1530,7 @@ void gscan_close(gscan_ctx *c)
     if (c->h_dense) hipHostFree(c->h_dense);
     if (c->h_gather) hipHostFree(c->h_gather);
     if (c->dv_recs) hipFree(c->dv_recs);
+    if (c->dv_ends) hipFree(c->dv_ends);
     if (c->dv_desc) hipFree(c->dv_desc);
     if (c->dv_tiles) hipFree(c->dv_tiles);
     for (auto &e : c->ev_pool) {
@@ -2076,7 +2087,13 @@ int gscan_wait_segs(gscan_ctx *c, uint64_t *tag, const uint32_t **starts, const 
         }
         return 0;
     };
-    const bool ordered = s->ordered && struck == 0;
+    // (a resolved chunk: the records k_resolve dropped are gone from the descriptors' runs and from the ordered copy -- what is
+    // left is the list)
+    if (s->resolved) {
+        if (struck > total) return fail(c, GSCAN_EHIP, "the resolve pass dropped %zu of %zu records", struck, total);
+        total -= struck;
+    }
+    const bool ordered = s->ordered && (struck == 0 || s->resolved);
     if (ordered && s->h_counter[K * kCS + 3] != total) return fail(c, GSCAN_EHIP, "ordered copy holds %u records, the shard counters %zu", s->h_counter[K * kCS + 3], total);
     if (ordered) {
         {
@@ -2345,6 +2362,14 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
         HIPCHK(c, hipMalloc((void **)&c->dv_recs, want * 4));
         c->dv_rec_cap = want;
     }
+    if (db->db.prog.resolve && c->dv_ends_cap < c->dv_rec_cap) {
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (c->dv_ends) hipFree(c->dv_ends);
+        c->dv_ends = nullptr;
+        c->dv_ends_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->dv_ends, c->dv_rec_cap * 4));
+        c->dv_ends_cap = c->dv_rec_cap;
+    }
 
     HIPCHK(c, hipMemsetAsync(c->dv_counter, 0, kCounterWords * 4, st));
     ScanArgs a;
@@ -2368,6 +2393,7 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
     if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used].a, st));
     if (n_tiles) HIPCHK(c, gscan::launch_scan(db->db.tier, c->variant, a, grid_for(c, db->db, n_tiles), st));
     if (n_tiles && gscan::scan_needs_settle(db->db.tier, db->db.prog)) HIPCHK(c, gscan::launch_settle(a, nw, st)); // inside the timed region
+    if (n_tiles && db->db.prog.resolve) HIPCHK(c, gscan::launch_resolve(a, nw, c->dv_ends, st));                   // likewise
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used].b, st));
         c->ev_used++;
@@ -2378,6 +2404,7 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
     res->tile_bytes = tile_bytes / nw;
     res->total = 0;
     res->overflow = 0;
+    res->ends = db->db.prog.resolve ? c->dv_ends : nullptr;
     return GSCAN_OK;
 }
 

@@ -128,68 +128,92 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
     // -O -l with every match's end from the device and nothing else asked for: the walk is two array reads per match and the
     // output one fixed-format line -- written through a local buffer, digits two at a time, without a call per match (a worker
     // formats BASELINE configs[2]'s 21 M lines per 8 GiB in this loop; at N GPUs that is N x 123 M lines per second)
-    if (ends && (flags & GRAB_NOLINE) && (flags & GRAB_OFFSETS) && !(flags & GRAB_SINGLE)) {
-        gscan_info info;
-        if (gscan_db_info(db, &info) == GSCAN_OK && info.ends_ok) {
-            static const char kPairs[] = "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
-                                         "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
-            constexpr size_t kBuf = 64u << 10;
-            char buf[kBuf];
-            const size_t need = plen + 1 + (sizeof kHead - 1) + 20 + 1; // one line at most
-            size_t w = 0, i = 0;
-            bool fell_back = false;
-            if (need < kBuf / 2) {
-                while (s + (size_t)minlen < clen) {
-                    while (i < nstarts && starts[i] < s) i++;
+    gscan_info info;
+    if (gscan_db_info(db, &info) != GSCAN_OK) return;
+    const bool resolve = info.resolve != 0; // the list is the device's list of MATCHES, each with its end (k_resolve)
+    if (ends && (flags & GRAB_NOLINE) && (flags & GRAB_OFFSETS) && !(flags & GRAB_SINGLE) && (info.ends_ok || resolve)) {
+        static const char kPairs[] = "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+                                     "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+        constexpr size_t kBuf = 64u << 10;
+        char buf[kBuf];
+        const size_t need = plen + 1 + (sizeof kHead - 1) + 20 + 1; // one line at most
+        size_t w = 0, i = 0;
+        bool fell_back = false;
+        // a resolved list is good from `reach` bytes behind the restart position on; what could begin a match closer than that
+        // is put to the host's matcher (gscan_next_resolved) -- after a match that is the byte or two behind its end, and
+        // almost never one a match can begin with: one look at the table of first bytes
+        uint8_t first[256];
+        const size_t reach = resolve ? (size_t)info.reach : 0;
+        const bool first_ok = reach && gscan_db_first(db, first) == 1;
+        if (need < kBuf / 2) {
+            while (s + (size_t)minlen < clen) {
+                size_t m0, m1;
+                bool ask = false;
+                const size_t near_end = std::min(clen, s + reach);
+                for (size_t q = s; q < near_end && !ask; q++) ask = !first_ok || first[(unsigned char)content[q]];
+                if (!ask) {
+                    while (i < nstarts && starts[i] < near_end) i++;
                     if (i >= nstarts) break;
-                    if (ends[i] == 0) { // this match's end is the host's to find (a tail longer than the device follows): the loop below takes over from s
-                        fell_back = true;
-                        break;
-                    }
-                    if (w + need > kBuf) {
-                        out.append(buf, w);
-                        w = 0;
-                    }
-                    if (flags & GRAB_PREFIX) {
-                        memcpy(buf + w, path, plen);
-                        w += plen;
-                        buf[w++] = ':';
-                    }
-                    memcpy(buf + w, kHead, sizeof kHead - 1);
-                    w += sizeof kHead - 1;
-                    char dig[24];
-                    char *q = dig + sizeof dig;
-                    unsigned long long v = (unsigned long long)(off + (long long)starts[i]);
-                    while (v >= 100) {
-                        const unsigned r = (unsigned)(v % 100);
-                        v /= 100;
-                        q -= 2;
-                        memcpy(q, kPairs + 2 * r, 2);
-                    }
-                    if (v >= 10) {
-                        q -= 2;
-                        memcpy(q, kPairs + 2 * (unsigned)v, 2);
+                    if (resolve && ends[i] == GSCAN_END_CAPTURES) break; // a match that sets a capturing group: rc == 0, the chunk ends (grab.cc:179)
+                    if (ends[i] == 0) { // this match is the host's to find (a tail longer than the device follows; the VM gave up)
+                        if (!resolve) {
+                            fell_back = true; // the loop below takes over from s
+                            break;
+                        }
+                        ask = true;
                     } else {
-                        *--q = (char)('0' + v);
+                        m0 = starts[i];
+                        m1 = ends[i];
+                        i++;
                     }
-                    const size_t nd = (size_t)(dig + sizeof dig - q);
-                    memcpy(buf + w, q, nd);
-                    w += nd;
-                    buf[w++] = '\n';
-                    n_loop++;
-                    s = ends[i]; // grab.cc:209 with a == 0
-                    i++;
                 }
-                if (w) out.append(buf, w);
-                if (!fell_back) return;
+                if (ask) {
+                    uint32_t b0 = 0, b1 = 0;
+                    if (gscan_next_resolved(db, content, clen, starts, ends, nstarts, &cur, (uint32_t)s, &b0, &b1) != 1) break;
+                    m0 = b0, m1 = b1;
+                }
+                if (w + need > kBuf) {
+                    out.append(buf, w);
+                    w = 0;
+                }
+                if (flags & GRAB_PREFIX) {
+                    memcpy(buf + w, path, plen);
+                    w += plen;
+                    buf[w++] = ':';
+                }
+                memcpy(buf + w, kHead, sizeof kHead - 1);
+                w += sizeof kHead - 1;
+                char dig[24];
+                char *q = dig + sizeof dig;
+                unsigned long long v = (unsigned long long)(off + (long long)m0);
+                while (v >= 100) {
+                    const unsigned r = (unsigned)(v % 100);
+                    v /= 100;
+                    q -= 2;
+                    memcpy(q, kPairs + 2 * r, 2);
+                }
+                if (v >= 10) {
+                    q -= 2;
+                    memcpy(q, kPairs + 2 * (unsigned)v, 2);
+                } else {
+                    *--q = (char)('0' + v);
+                }
+                const size_t nd = (size_t)(dig + sizeof dig - q);
+                memcpy(buf + w, q, nd);
+                w += nd;
+                buf[w++] = '\n';
+                n_loop++;
+                s = m1; // grab.cc:209 with a == 0
             }
+            if (w) out.append(buf, w);
+            if (!fell_back) return;
         }
     }
     size_t di = 0;                                         // next record of the device's pass
     bool device = ext && !(flags & GRAB_NOLINE);           // its verdicts apply at s
     // -O -l with the match ends from the device (k_ends): s is always 0 or a match end, the next match is the next listed
     // start and its end is in the list -- `content` is not looked at (a window that was never read stays unmapped pages)
-    const bool listed = ends && (flags & GRAB_NOLINE) && (flags & GRAB_OFFSETS);
+    const bool listed = !resolve && ends && (flags & GRAB_NOLINE) && (flags & GRAB_OFFSETS);
     while (s + (size_t)minlen < clen) {
         if (device) {
             while (di < nstarts && (starts[di] < s || ext[4 * di] == 0)) di++; // behind s, or not printed (an earlier candidate in its line)
@@ -221,7 +245,9 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
         }
         // rc = pcre_exec(d_pcreh, d_extra, start, end - start, 0, 0, ovector, 3)            (grab.cc:178)
         uint32_t b0 = 0, b1 = 0;
-        int rc = listed ? gscan_next_listed(db, clen, starts, ends, nstarts, &cur, (uint32_t)s, &b0, &b1) : -1;
+        int rc = resolve ? gscan_next_resolved(db, content, clen, starts, ends, nstarts, &cur, (uint32_t)s, &b0, &b1)
+                 : listed ? gscan_next_listed(db, clen, starts, ends, nstarts, &cur, (uint32_t)s, &b0, &b1)
+                          : -1;
         if (rc < 0) rc = gscan_next_match(db, content, clen, starts, nstarts, &cur, (uint32_t)s, &b0, &b1);
         if (rc != 1) break; // no match -- or one that sets a capturing group: 0 with ovector[3], same exit (grab.cc:179)
         const size_t m0 = b0, m1 = b1;
@@ -382,7 +408,11 @@ int FileGrep::prepare(const std::string &regex)
         gscan_db_info(db_, &info);
         anchored_ = info.tier == GSCAN_TIER_ANCHORED;
         never_ = anchored_ && info.n_alts == 0; // assertions that can never hold (a\Ab): nothing matches anywhere
-        context_ = info.has_context != 0;
+        // (a database the device resolves: the list is complete from the first offset that HAS a byte in front of it -- offset 0
+        // of a chunk is the host's to test when the windows carry a leading context position, whatever the list says)
+        resolve_ = info.resolve != 0;
+        reach_ = (size_t)info.reach;
+        context_ = resolve_ ? (info.has_context & 1) != 0 : info.has_context != 0;
         lines_ = info.lines_ok != 0;
         ends_ = info.ends_ok != 0;
         textfree_ = info.textfree != 0;
@@ -734,6 +764,12 @@ bool FileGrep::report_needs_text(unsigned rflags, size_t n, const uint32_t *ext,
 {
     if (context_) return true; // (matches at the restart position / chunk end are the host's to find, list or no list)
     if (n == 0) return false;
+    if (resolve_) { // the list holds the matches and their ends: the text is needed for printed lines, for what lies within `reach` of a restart position, and for the records the device left to the host
+        if (!(rflags & GRAB_NOLINE) || reach_ || !ends) return true;
+        for (size_t i = 0; i < n; i++)
+            if (ends[i] == GSCAN_END_ASK) return true;
+        return false;
+    }
     if (textfree_ && (rflags & GRAB_NOLINE)) return false; // a fixed-length pattern all of whose candidates are listed: gscan_next_match walks the list alone
     if (ends && (rflags & GRAB_NOLINE) && (rflags & GRAB_OFFSETS)) {
         for (size_t i = 0; i < n; i++)

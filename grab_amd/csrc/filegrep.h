@@ -100,6 +100,8 @@ private:
     bool anchored_ = false; // the pattern can only match at a restart position / chunk end: nothing goes to the GPU
     bool never_ = false;    // ... and not even there: the pattern's assertions contradict each other
     bool context_ = false;  // the pattern looks at the byte before / after its match
+    bool resolve_ = false;  // the device settles the matches and their ends (gscan_info.resolve); reach_: how far in front of a match the pattern looks
+    size_t reach_ = 0;
     bool lines_ = false;    // the device's line-extent pass applies to the pattern
     bool textfree_ = false; // fixed length, every candidate listed: without line printing the walk never reads the chunk (gscan_info.textfree)
     bool ends_ = false;     // the device's match-end pass applies to the pattern (-O -l is then walked without the text)

@@ -215,11 +215,12 @@ __device__ __forceinline__ void lane_count(const ScanArgs &a, uint32_t d, int su
     // keep the START of every group of consecutive candidates: drop a candidate whose predecessor is one (the
     // predecessor of the sub-tile's first position is unknown: kept -- reporting more of a group is allowed)
     const uint32_t prev = up1(x[NWORD - 1], 0u);
-    o.y[0] = x[0] & ~((x[0] << 1) | (prev >> 31));
+    const uint32_t sup = ~a.keep_all; // (ScanArgs::keep_all: every candidate is a record of its own -- the resolve pass's patterns)
+    o.y[0] = x[0] & ~(((x[0] << 1) | (prev >> 31)) & sup);
     uint32_t c = (uint32_t)__popc(o.y[0]);
 #pragma unroll
     for (int i = 1; i < NWORD; i++) {
-        o.y[i] = x[i] & ~__builtin_amdgcn_alignbit(x[i], x[i - 1], 31); // (x[i] << 1) | (x[i - 1] >> 31)
+        o.y[i] = x[i] & ~(__builtin_amdgcn_alignbit(x[i], x[i - 1], 31) & sup); // (x[i] << 1) | (x[i - 1] >> 31)
         c += (uint32_t)__popc(o.y[i]);
     }
     const uint32_t inc = wave_scan(c);

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kWG) void k1_anchor_scan(ScanArgs a, const TileDesc
                         }
                         bits = keep;
                     }
-                    bits &= ~(bits << 1); // keep group starts (within the lane; a superset of them is fine)
+                    bits &= ~((bits << 1) & ~a.keep_all); // keep group starts (within the lane; a superset of them is fine)
                 }
                 // outside the branch: one shift-or per step instead of moving the whole hit array through the join
                 hits[k >> 1] |= bits << (16 * (k & 1));
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 || (!PAIR && NW == 8) ? 6 : 1) vo
                 // of the previous lane (previous step's lane 63 for lane 0)
                 const uint32_t prev = up1(bits, last63);
                 last63 = __builtin_amdgcn_readlane(bits, 63);
-                bits &= ~((bits << 1) | (prev >> 15));
+                bits &= ~(((bits << 1) | (prev >> 15)) & ~a.keep_all);
                 hits[k >> 1] |= bits << (16 * (k & 1));
                 cnt += (uint32_t)__popc(bits);
             }
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : VM ? GSCAN_VM_WAVES : 1) vo
                     }
                     // keep group starts (within the lane; a superset of them is fine) -- unless hits may still be struck
                     // out by k3_settle, or have been by the VM: a real hit must not be dropped for following a false one
-                    if (!VM && exact && (direct || confirm_exact)) bits &= ~(bits << 1);
+                    if (!VM && exact && (direct || confirm_exact)) bits &= ~((bits << 1) & ~a.keep_all);
                     hits[k >> 1] |= bits << (16 * (k & 1));
                     cnt += (uint32_t)__popc(bits);
                 }
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : VM ? GSCAN_VM_WAVES : 1) vo
                     if (!confirm_hit(p)) keep &= ~(1u << b);
                 }
                 // keep group starts (within a lane's sixteen positions of one step) where the tables have the last word
-                if (confirm_exact) keep &= ~((keep << 1) & 0xfffefffeu);
+                if (confirm_exact) keep &= ~((keep << 1) & 0xfffefffeu & ~a.keep_all);
                 hits[w] = keep;
                 cnt += (uint32_t)__popc(keep);
             }
@@ -1191,6 +1191,75 @@ __global__ __launch_bounds__(64) void k_ends(ScanArgs a, const TileDesc *__restr
 }
 
 // ------------------------------------------------------------------------------------
+// The resolve pass (round 6; DevProgram::resolve): the pattern itself, run AT every record.
+// What it replaces: the reference's pcre_exec (/root/reference/src/grab.cc:178) as far as "is this offset a match start, and
+// where does that match end" goes -- rounds 1-5 left that question, for every pattern that is not one plain window, to the
+// host's backtracking matcher inside the report loop, candidate by candidate (35-320 ns each).  Here the scan
+// kernels have listed every offset where one of the pattern's START windows fits (ScanArgs::keep_all: no group-start
+// compression); this pass runs the pattern's VM program (vm.h -- TreeMatch's order of exploration construct by construct,
+// i.e. PCRE's) at each of them with the segment's real bytes in front (s0 = 0), and
+//   * drops the records at which no match starts: the survivors are moved to the front of the descriptor's run, the
+//     descriptor's count shrinks, counter[kShards * kCtrStride + 1] counts the dropped ones;
+//   * writes, parallel to the surviving records, ends[i] = the match's end -- or GSCAN_END_CAPTURES when its path closed a
+//     capturing group (the reference's one-pair ovector: pcre_exec returns 0 and the chunk loop ends, grab.cc:171,179), or
+//     GSCAN_END_ASK when the VM gave up (step / stack limit) or the answer looks odd: the host's matcher decides that one.
+// One wave per descriptor, one lane per record, 64 at a time.  A verdict reached this way is pcre_exec's for every restart
+// position s <= p - reach (Database::reach): the host asks its own matcher about the offsets closer to s than that
+// (gscan_next_resolved).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_resolve(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t *__restrict__ ends)
+{
+    const uint32_t st = blockIdx.x;
+    const unsigned long long d = a.desc[st];
+    const uint32_t cnt = (uint32_t)d;
+    if (cnt == 0 || a.counter[kShards * kCtrStride] != 0) return; // (overflow: the host rescans with a bigger buffer and this pass runs again)
+    __shared__ __attribute__((aligned(16))) uint32_t s_vm[sizeof(VmProg) / 4];
+    {
+        const uint32_t *vsrc = reinterpret_cast<const uint32_t *>(&a.prog->vm);
+        for (uint32_t q = threadIdx.x; q < (uint32_t)(sizeof(VmProg) / 4); q += 64u) s_vm[q] = vsrc[q];
+    }
+    __syncthreads();
+    const VmProg *vm = reinterpret_cast<const VmProg *>(s_vm);
+    const uint32_t base = (uint32_t)(d >> 32);
+    const uint32_t t = st / nw;
+    const uint8_t *seg = a.base + (tiles ? tiles[t].seg_off : a.seg0_off);
+    const uint32_t slen = tiles ? tiles[t].seg_len : a.seg0_len;
+    const uint32_t lane = threadIdx.x;
+    uint32_t out = 0; // survivors so far (wave-uniform)
+    for (uint32_t i0 = 0; i0 < cnt; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        uint32_t p = 0, code = 0;
+        bool keep = false;
+        if (i < cnt) {
+            p = a.recs[base + i];
+            if (p != kStruck && p < slen) {
+                VmOut o{0u, 0u};
+                const int v = vm_run(vm, seg, slen, p, 0u, o);
+                if (v == 1) {
+                    keep = true;
+                    code = o.end <= p ? 0u /* GSCAN_END_ASK */ : o.cap ? 0xfffffffeu /* GSCAN_END_CAPTURES */ : o.end;
+                } else if (v != 0) {
+                    keep = true; // gave up: the host's matcher decides
+                }
+            }
+        }
+        // (every lane has its record -- the loads above were waited for before the VM ran -- before any lane overwrites one:
+        // survivor k of this batch goes to index out + k <= i0 + its own lane)
+        const unsigned long long m = __ballot(keep);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (keep) {
+            a.recs[base + out + rank] = p;
+            ends[base + out + rank] = code;
+        }
+        out += (uint32_t)__popcll(m);
+    }
+    if (lane == 0 && out != cnt) {
+        a.desc[st] = (d & 0xffffffff00000000ull) | out;
+        atomicAdd(a.counter + kShards * kCtrStride + 1, cnt - out);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Ordered compaction of a chunk's result.  The scan kernels leave the records in 64 shard regions, every wave's run where
 // its reservation fell; the descriptors say where, in text order.  Fetching that took the host one strided 64-row copy per
 // array (2.7 ms per window for 2 MB: the rows go one by one) and a merge over ~5 000 runs.  These two kernels write the
@@ -1367,6 +1436,7 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
     a.k3_off = pg.k3_off;
     a.vm_filter = pg.vm_filter;
     a.report_shift = pg.report_shift;
+    a.keep_all = pg.resolve ? 0xffffffffu : 0u;
     // the filter IS the pattern when every alternative has its own bucket and lies inside the filtered positions
     a.k3_one_bucket = 1;
     for (int b = 0; b < 256; b++)
@@ -1437,7 +1507,7 @@ void fill_program(ScanArgs &a, const DevProgram &pg)
 // does the pattern need the second pass?  (the same condition the scan kernel reads as !k3_confirm_exact)
 bool scan_needs_settle(int tier, const DevProgram &pg)
 {
-    return tier == GSCAN_TIER_BUCKET && !pg.k3_confirm_exact && !pg.vm_filter; // (the VM has already decided every hit)
+    return tier == GSCAN_TIER_BUCKET && !pg.k3_confirm_exact && !pg.vm_filter && !pg.resolve; // (the VM has already decided every hit / k_resolve will)
 }
 
 hipError_t launch_settle(const ScanArgs &a, uint32_t nw, hipStream_t st)
@@ -1453,6 +1523,13 @@ hipError_t launch_order(const ScanArgs &a, uint32_t nw, const uint32_t *ext, uin
     if (n_desc == 0) return hipSuccess;
     hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(1024), 0, st, a.desc, n_desc, dpos, a.counter);
     hipLaunchKernelGGL(k_order_copy, dim3((n_desc + 3u) / 4u), dim3(256), 0, st, a.recs, ext, ew, a.desc, dpos, n_desc, out, out_ext, a.counter);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const ScanArgs &a, uint32_t nw, uint32_t *ends, hipStream_t st)
+{
+    if (a.n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_resolve, dim3(a.n_tiles * nw), dim3(64), 0, st, a, a.tiles, nw, ends);
     return hipGetLastError();
 }
 

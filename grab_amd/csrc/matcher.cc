@@ -827,6 +827,7 @@ int gscan_next_match(const gscan_db *db, const void *content_, size_t clen, cons
     const Database &d = db->db;
     const uint8_t *content = (const uint8_t *)content_;
     if (d.minlen <= 0 || !cur || (size_t)s >= clen) return 0;
+    if (d.resolve) return gscan_next_resolved(db, content_, clen, starts, nullptr, n, cur, s, m0, m1); // (a list nobody has resolved: every record is the matcher's)
     if (!cur->ready) { // first call for this chunk
         cur->li = 0;
         cur->ntails = (uint32_t)std::min(tail_positions(d, clen, cur->tails, GSCAN_MAX_TAILS), (size_t)GSCAN_MAX_TAILS);
@@ -905,10 +906,95 @@ int gscan_next_listed(const gscan_db *db, size_t clen, const uint32_t *starts, c
     return 1;
 }
 
+// The reference's loop step for a database whose matches the device settles (Database::resolve).  starts: every offset at which
+// a start window fits (ends == NULL: nobody has looked at them yet), or what k_resolve left of them with ends[i] = ovector[1],
+// GSCAN_END_ASK (ask the host matcher at starts[i]) or GSCAN_END_CAPTURES (a match that sets a capturing group).
+int gscan_next_resolved(const gscan_db *db, const void *content_, size_t clen, const uint32_t *starts, const uint32_t *ends, size_t n, gscan_cursor *cur,
+                        uint32_t s, uint32_t *m0, uint32_t *m1)
+{
+    const Database &d = db->db;
+    const uint8_t *content = (const uint8_t *)content_;
+    if (d.minlen <= 0 || !cur || (size_t)s >= clen) return 0;
+    if (!d.resolve) return -1;
+    if (!cur->ready) {
+        cur->li = 0;
+        cur->ntails = 0;
+        memset(cur->next_known, 0, sizeof cur->next_known);
+        cur->ready = 1;
+    }
+    // (1) the offsets the pattern can look back over the restart position from: the device's verdicts there were reached with
+    // bytes in front that pcre_exec, handed the subject FROM s (src/grab.cc:178), does not see -- the host's matcher decides
+    const size_t near_end = std::min(clen, (size_t)s + d.reach);
+    for (size_t q = s; q < near_end; q++) {
+        if (d.first_ok && !d.first.test(content[q])) continue;
+        MatchAt m;
+        if (match_at(d, content, clen, q, (size_t)s, m)) {
+            *m0 = (uint32_t)q; // (no \K in a database of this kind)
+            *m1 = m.end;
+            return m.captures ? 2 : 1;
+        }
+        if (m.gave_up) return 0; // rc <= 0 ends the chunk: src/grab.cc:179
+    }
+    // (2) from there on the list is the truth: the first record is the leftmost match
+    while (cur->li < n && (size_t)starts[cur->li] < near_end) cur->li++;
+    for (size_t i = cur->li; i < n; i++) {
+        const uint32_t e = ends ? ends[i] : GSCAN_END_ASK;
+        if (e == GSCAN_END_CAPTURES) return 2;
+        if (e != GSCAN_END_ASK) {
+            *m0 = starts[i];
+            *m1 = e;
+            return 1;
+        }
+        MatchAt m;
+        if (match_at(d, content, clen, starts[i], (size_t)s, m)) {
+            *m0 = starts[i];
+            *m1 = m.end;
+            return m.captures ? 2 : 1;
+        }
+        if (m.gave_up) return 0;
+    }
+    return 0;
+}
+
+int gscan_db_first(const gscan_db *db, uint8_t table[256])
+{
+    if (!db || !table) return GSCAN_EINVAL;
+    for (int b = 0; b < 256; b++) table[b] = db->db.first_ok ? db->db.first.test((unsigned)b) : 1;
+    return db->db.first_ok ? 1 : 0;
+}
+
 int gscan_vm_verdict(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p)
 {
     if (!db || !db->db.vm_ok || p < subject_start || (size_t)p > clen || clen > 0xfffffff0u) return -1;
     return gscan::vm_run(&db->db.prog.vm, (const uint8_t *)content, (uint32_t)clen, p, subject_start);
+}
+
+int gscan_vm_match(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p, uint32_t *end, int *captures)
+{
+    if (!db || !db->db.vm_ok || p < subject_start || (size_t)p > clen || clen > 0xfffffff0u) return -1;
+    gscan::VmOut o{0, 0};
+    const int v = gscan::vm_run(&db->db.prog.vm, (const uint8_t *)content, (uint32_t)clen, p, subject_start, o);
+    if (v == 1) {
+        if (end) *end = o.end;
+        if (captures) *captures = (int)o.cap;
+    }
+    return v;
+}
+
+long gscan_vm_resolve(const gscan_db *db, const void *content, size_t clen, const uint32_t *hits, size_t n, uint32_t *starts, uint32_t *ends)
+{
+    if (!db || !db->db.vm_ok || (!hits && n) || !starts || !ends || clen > 0xfffffff0u) return -1;
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) { // (what k_resolve does with one record, same source)
+        if ((size_t)hits[i] >= clen) continue;
+        gscan::VmOut o{0, 0};
+        const int v = gscan::vm_run(&db->db.prog.vm, (const uint8_t *)content, (uint32_t)clen, hits[i], 0, o);
+        if (v == 0) continue;
+        starts[k] = hits[i];
+        ends[k] = v != 1 || o.end <= hits[i] ? GSCAN_END_ASK : o.cap ? GSCAN_END_CAPTURES : o.end;
+        k++;
+    }
+    return (long)k;
 }
 
 int gscan_vm_pair(const gscan_db *db, unsigned b0, unsigned b1)

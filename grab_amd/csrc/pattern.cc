@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cctype>
 #include <cstring>
+#include <functional>
 
 #include "../../include/gscan.h"
 
@@ -2516,6 +2517,98 @@ uint64_t node_true_minlen(const Node &n)
 
 } // namespace
 
+
+// How far in front of a match start p the pattern can look: the device's verdict AT p, reached with the chunk's real bytes in
+// front of p, is what pcre_exec finds with the subject starting at s (src/grab.cc:178) for every s <= p - reach.
+// \b \B (?m)^ look at one byte; ^ \A \G hold at s itself only (reach 1: the host owns p == s); a look-behind steps back by its
+// length and may look further back from there.
+static uint32_t look_reach(const Node &n)
+{
+    uint32_t r = 0;
+    if (n.kind == Node::ASSERT && (n.acode == A_BOS || n.acode == A_MBOL || n.acode == A_WB || n.acode == A_NWB)) r = 1;
+    for (const Node &k : n.kids) r = std::max(r, look_reach(k));
+    if (n.kind == Node::LOOK && n.behind) {
+        uint32_t len = 0;
+        std::function<long(const Node &)> flen = [&](const Node &x) -> long { // the longest fixed length among its top-level alternatives
+            switch (x.kind) {
+            case Node::SET: return 1;
+            case Node::ASSERT:
+            case Node::LOOK: return 0;
+            case Node::ATOMIC: return flen(x.kids[0]);
+            case Node::CAT: {
+                long t = 0;
+                for (const Node &k : x.kids) t += std::max(0l, flen(k));
+                return t;
+            }
+            case Node::ALT: {
+                long t = 0;
+                for (const Node &k : x.kids) t = std::max(t, flen(k));
+                return t;
+            }
+            case Node::REP: return std::max(0l, flen(x.kids[0])) * (long)std::min<uint32_t>(x.max, 4096u);
+            default: return 4096;
+            }
+        };
+        len = (uint32_t)std::min<long>(flen(n.kids[0]), 1l << 20);
+        r += len;
+    }
+    return r;
+}
+
+static bool has_keep(const Node &n)
+{
+    if (n.kind == Node::ASSERT && n.acode == A_KEEP) return true;
+    for (const Node &k : n.kids)
+        if (has_keep(k)) return true;
+    return false;
+}
+
+// the bytes a match can begin with (nullable: it may begin without consuming one -- then nothing is known)
+struct vm_first_t {
+    ByteSet set;
+    bool nullable = false;
+};
+static vm_first_t vm_first_bytes(const Node &n)
+{
+    vm_first_t f;
+    switch (n.kind) {
+    case Node::SET: f.set = n.set; break;
+    case Node::CAT:
+        f.nullable = true;
+        for (const Node &k : n.kids) {
+            const vm_first_t g = vm_first_bytes(k);
+            f.set.merge(g.set);
+            if (!g.nullable) {
+                f.nullable = false;
+                break;
+            }
+        }
+        break;
+    case Node::ALT:
+        if (n.kids.empty()) f.nullable = true;
+        for (const Node &k : n.kids) {
+            const vm_first_t g = vm_first_bytes(k);
+            f.set.merge(g.set);
+            f.nullable = f.nullable || g.nullable;
+        }
+        break;
+    case Node::REP:
+        if (n.max == 0) {
+            f.nullable = true;
+            break;
+        }
+        f = vm_first_bytes(n.kids[0]);
+        if (n.min == 0) f.nullable = true;
+        break;
+    case Node::ATOMIC: f = vm_first_bytes(n.kids[0]); break;
+    default: // assertions consume nothing; what a reference repeats, a condition picks or a call matches is not known here
+        f.set.negate();
+        f.nullable = true;
+        break;
+    }
+    return f;
+}
+
 // DevProgram::vm_pair: the host matcher's verdict on every two-byte prefix a match could begin with (first the 256 one-byte
 // prefixes: a first byte no match can begin with spares its 256 pairs).  ~20 000 short matcher runs, a few milliseconds.
 static void fill_vm_pairs(Database &db)
@@ -2815,10 +2908,6 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
 
     // Device windows: the alternative's window, plus one context position in front (behind) when ANY alternative
     // looks at the byte before (after) its match -- its own condition there, "any byte" for the others.
-    for (const AltSeq &a : db.alts) {
-        db.dev_pre = db.dev_pre || (a.has_pre() && !a.gapped); // a gapped path's start is not where its device window is
-        db.dev_post = db.dev_post || a.has_post();
-    }
     auto class_id = [&](const ByteSet &b) -> int {
         for (size_t c = 0; c < db.classes.size(); c++)
             if (db.classes[c] == b) return (int)c;
@@ -2826,47 +2915,93 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         db.classes.push_back(b);
         return (int)db.classes.size() - 1;
     };
-    size_t min_dev = SIZE_MAX, total_dev = 0;
-    bool can_hit = false; // some alternative can match away from the subject start and the chunk end
-    for (const AltSeq &a : db.alts) {
-        std::vector<uint8_t> w;
-        if (db.dev_pre) {
-            const int id = class_id(a.gapped ? set_all() : a.pre);
-            if (id < 0) {
-                why = "too many distinct classes";
-                return 1;
+    // Two ways to put the alternatives in front of the kernels:
+    //  * HIT windows (rounds 1-5): a plain alternative's window with its context bytes; a gapped alternative  P . C{1,} . R  by
+    //    one repeat byte + the rest, C . R -- the kernels list where the part BEHIND the repeat begins and the host walks the run
+    //    back to the match start (matcher.cc, next_gapped);
+    //  * START windows (round 6, Database::resolve): every alternative by what a match must BEGIN with -- the leading context
+    //    byte, then the window, or for a gapped alternative P and one repeat byte, P . C -- so that every listed offset is a
+    //    possible match START and nothing else; the device's resolve pass (k_resolve) runs the pattern's VM program there with
+    //    the chunk's real bytes in front of it and leaves the list of MATCHES with their ends.  No trailing context byte: a
+    //    window that ends with the chunk is listed like any other, the VM knows where the chunk ends.
+    struct Windows {
+        std::vector<std::vector<uint8_t>> w;
+        bool pre = false, post = false, can_hit = false;
+        size_t min_dev = SIZE_MAX, total = 0;
+        double density = 0; // expected hits per text byte, pricing a class by its size over the ~64 byte values text is made of
+    };
+    auto make_windows = [&](bool starts, Windows &out) -> int { // 0 ok, 1 refused (why is set)
+        for (const AltSeq &a : db.alts) {
+            out.pre = out.pre || (a.has_pre() && (starts || !a.gapped)); // (hit windows: a gapped path's start is not where its device window is)
+            out.post = out.post || (!starts && a.has_post());
+        }
+        for (const AltSeq &a : db.alts) {
+            if (starts && a.pre.count() == 0) continue; // (can only sit at the subject start: the host's own test there finds it)
+            std::vector<uint8_t> w;
+            if (out.pre) {
+                const int id = class_id(!starts && a.gapped ? set_all() : a.pre);
+                if (id < 0) return 1;
+                w.push_back((uint8_t)id);
             }
-            w.push_back((uint8_t)id);
-        }
-        if (a.gapped) { // the kernels look for one repeat byte + the rest
-            const int id = class_id(a.gap);
-            if (id < 0) {
-                why = "too many distinct classes";
-                return 1;
+            if (starts && a.gapped) w.insert(w.end(), a.pwindow.begin(), a.pwindow.end());
+            if (a.gapped) { // one repeat byte: behind P (start windows), in front of the rest (hit windows)
+                const int id = class_id(a.gap);
+                if (id < 0) return 1;
+                w.push_back((uint8_t)id);
             }
-            w.push_back((uint8_t)id);
-        }
-        w.insert(w.end(), a.window.begin(), a.window.end());
-        if (db.dev_post) {
-            const int id = class_id(a.post);
-            if (id < 0) {
-                why = "too many distinct classes";
-                return 1;
+            if (!(starts && a.gapped)) w.insert(w.end(), a.window.begin(), a.window.end());
+            if (out.post) {
+                const int id = class_id(a.post);
+                if (id < 0) return 1;
+                w.push_back((uint8_t)id);
             }
-            w.push_back((uint8_t)id);
+            if (w.size() > (size_t)kMaxWindow) {
+                if (!starts) return 2;
+                w.resize((size_t)kMaxWindow); // (a start window is a necessary condition: any prefix of it is one too)
+            }
+            out.can_hit = out.can_hit || ((a.gapped || a.pre.count() > 0) && a.post.count() > 0);
+            out.min_dev = std::min(out.min_dev, w.size());
+            out.total += w.size();
+            double prod = 1;
+            for (uint8_t c : w) prod *= std::min(1.0, db.classes[c].count() / 64.0);
+            out.density += prod;
+            out.w.push_back(std::move(w));
         }
-        if (w.size() > (size_t)kMaxWindow) {
-            why = "window longer than the engine supports";
-            return 1;
-        }
-        can_hit = can_hit || ((a.gapped || a.pre.count() > 0) && a.post.count() > 0);
-        min_dev = std::min(min_dev, w.size());
-        total_dev += w.size();
-        db.dev_windows.push_back(std::move(w));
+        return 0;
+    };
+    Windows hitw, startw;
+    if (int rc = make_windows(false, hitw)) {
+        why = rc == 2 ? "window longer than the engine supports" : "too many distinct classes";
+        return 1;
     }
-    if (total_dev > (size_t)kAltWindowBytes) {
+    if (hitw.total > (size_t)kAltWindowBytes) {
         why = "pattern unfolds into too many alternatives";
         return 1;
+    }
+    // The resolve pass: for every pattern the VM can run whole (no subroutine calls, within its program limits; no \K: where
+    // a match is REPORTED to start is not something the VM tracks) -- unless it is the one-window kind the kernels and the
+    // per-record passes of rounds 1-3 already settle on their own (literals, the identifier regex: k_ends, k_lines, the host's
+    // two-array-read walk), or its start windows would list a large part of the text where its hit windows list next to
+    // nothing (.*needle: every byte of a line can begin a match, but only the needle is worth looking for).
+    db.reach = look_reach(*db.tree);
+    {
+        const bool simple = db.exact && db.alts.size() == 1 && !db.alts[0].gapped && !hitw.pre && !hitw.post;
+        bool want = hitw.can_hit && db.vm_ok && !simple && !has_keep(*db.tree) && db.reach <= 255u && !getenv("GSCAN_NO_RESOLVE");
+        if (want && make_windows(true, startw) != 0) want = false;
+        if (want && (startw.w.empty() || startw.total > (size_t)kAltWindowBytes)) want = false;
+        if (want && !(startw.density <= 0.35 || startw.density <= 4.0 * hitw.density)) want = false;
+        db.resolve = want;
+    }
+    const Windows &win = db.resolve ? startw : hitw;
+    db.dev_pre = win.pre;
+    db.dev_post = win.post;
+    db.dev_windows = win.w;
+    const size_t min_dev = win.min_dev;
+    const bool can_hit = hitw.can_hit; // some alternative can match away from the subject start and the chunk end
+    {
+        const vm_first_t f = vm_first_bytes(*db.tree);
+        db.first = f.set;
+        db.first_ok = !f.nullable;
     }
 
     if (db.exact && db.alts.size() == 1 && !db.alts[0].gapped && !db.dev_pre && !db.dev_post && db.dev_windows[0] == db.alts[0].window) {
@@ -2885,22 +3020,28 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     pg.report_shift = db.dev_pre ? 1u : 0u;
     pg.n_classes = (uint32_t)db.classes.size();
     for (size_t c = 0; c < db.classes.size(); c++) memcpy(pg.cls_bits[c], db.classes[c].w, 32);
-    pg.n_alts = (uint32_t)db.alts.size();
+    pg.n_alts = (uint32_t)db.dev_windows.size(); // (start windows: the alternatives that can only sit at the subject start have none)
     {
         size_t at = 0;
-        for (size_t i = 0; i < db.alts.size(); i++) {
+        for (size_t i = 0; i < db.dev_windows.size(); i++) {
             const std::vector<uint8_t> &w = db.dev_windows[i];
             pg.alt_off[i] = (uint16_t)at;
             pg.alt_len[i] = (uint16_t)w.size();
             pg.alt_bucket[i] = (uint8_t)(i % kK3Buckets);
             memcpy(pg.alt_window + at, w.data(), w.size());
             at += w.size();
-            // (a gapped alternative's device window begins with its repeat byte, behind a context position if there is one)
-            const AltSeq &alt = db.alts[i];
-            pg.alt_gap_cls[i] = alt.gapped && !db.dev_pre && !w.empty() ? w[0] : (uint8_t)0xff;
-            pg.alt_plen[i] = (uint16_t)alt.pwindow.size();
+            // (a gapped alternative's HIT window begins with its repeat byte, behind a context position if there is one; a start
+            // window stands for a match AT the hit, whatever the alternative)
+            pg.alt_gap_cls[i] = (uint8_t)0xff;
+            pg.alt_plen[i] = 0;
+            if (!db.resolve) {
+                const AltSeq &alt = db.alts[i];
+                pg.alt_gap_cls[i] = alt.gapped && !db.dev_pre && !w.empty() ? w[0] : (uint8_t)0xff;
+                pg.alt_plen[i] = (uint16_t)alt.pwindow.size();
+            }
         }
     }
+    pg.resolve = db.resolve ? 1u : 0u;
     if (!can_hit) { // ^foo, foo$ and the like: a match can only sit at the subject start / chunk end, which is the host's job
         db.tier = GSCAN_TIER_ANCHORED;
         return 0;
@@ -2930,7 +3071,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         pg.k3_off = (uint32_t)best_off;
         for (int b = 0; b < 256; b++) {
             uint32_t e = 0;
-            for (size_t i = 0; i < db.alts.size(); i++) {
+            for (size_t i = 0; i < db.dev_windows.size(); i++) {
                 const std::vector<uint8_t> &w = db.dev_windows[i];
                 for (int k = 0; k < kK3Depth; k++) {
                     const size_t pos = best_off + k;
@@ -2944,14 +3085,14 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         for (int k = 0; k < kK3Confirm; k++)
             for (int b = 0; b < 256; b++) {
                 uint32_t e = 0;
-                for (size_t i = 0; i < db.alts.size(); i++) {
+                for (size_t i = 0; i < db.dev_windows.size(); i++) {
                     const std::vector<uint8_t> &w = db.dev_windows[i];
                     if ((size_t)k >= w.size() || db.classes[w[(size_t)k]].test((unsigned)b)) e |= 1u << pg.alt_bucket[i];
                 }
                 pg.k3_pos[k][b] = (uint8_t)e;
             }
-        pg.k3_confirm_exact = db.alts.size() <= (size_t)kK3Buckets;
-        for (size_t i = 0; i < db.alts.size(); i++) {
+        pg.k3_confirm_exact = db.dev_windows.size() <= (size_t)kK3Buckets;
+        for (size_t i = 0; i < db.dev_windows.size(); i++) {
             if (db.dev_windows[i].size() > (size_t)kK3Confirm) pg.k3_confirm_exact = 0;
             if (i < (size_t)kK3Buckets) pg.k3_blen[i] = (uint8_t)std::min<size_t>(db.dev_windows[i].size(), 255);
         }
@@ -2978,14 +3119,14 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
 
     // Inexact patterns: the device confirms its own candidates with the VM (vm.h) where one verdict per offset serves every
     // restart position, i.e. the pattern never looks behind the match start.  That is K3's cold path.
-    const bool vm_dev = !db.exact && db.vm_ok && !db.dev_pre && vm_independent_of_subject_start(*db.tree) && !getenv("GSCAN_NO_VM");
+    const bool vm_dev = !db.resolve && !db.exact && db.vm_ok && !db.dev_pre && vm_independent_of_subject_start(*db.tree) && !getenv("GSCAN_NO_VM");
 
     // several alternatives: the bucket filter is the one kernel that takes them -- unless they all look the same to the device
     // ([0-9]+\.[0-9]+ unfolds into two alternatives over the one window [0-9]\.[0-9]; what tells them apart is the host's
     // business): one window is K1's or K2's
     bool one_window = true;
     for (const std::vector<uint8_t> &w : db.dev_windows) one_window = one_window && w == db.dev_windows[0];
-    if (getenv("GSCAN_SAME_WINDOW_K3")) one_window = db.alts.size() == 1; // (A/B switch: the round-2 choice)
+    if (getenv("GSCAN_SAME_WINDOW_K3")) one_window = db.dev_windows.size() == 1; // (A/B switch: the round-2 choice)
     if (!one_window) {
         db.tier = GSCAN_TIER_BUCKET;
         pg.vm_filter = vm_dev;

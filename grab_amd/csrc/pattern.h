@@ -155,6 +155,7 @@ struct DevProgram {
     // Candidates confirmed on the device (vm.h): K3 runs the pattern's VM program at every filter hit and drops the hits at
     // which no match can start.  For a gapped alternative the hit is the LAST byte of its unbounded repeat (device window =
     // repeat byte + the rest): the possible starts are walked back along the run of repeat bytes.
+    uint32_t resolve;                    // 1: the windows are START windows and every record goes through k_resolve (Database::resolve)
     uint32_t vm_filter;                  // 1: on
     // bit b0 << 8 | b1: a match may begin with the bytes b0 b1 (matcher.cc, tree_prefix_viable: the host matcher run on
     // every two-byte prefix at compile time).  The hits the filter passes are put to this table first: most die here,
@@ -226,6 +227,15 @@ struct Database {
     // the first listed start >= s -- the host's walk never has to look at the text (matcher.cc, gscan_next_match).
     bool solitary = false;
     std::vector<const Node *> group_nodes; // [g] = the capturing group g inside `tree` (what (?g) calls), [0] = the tree
+    // The device settles the matches itself (k_resolve, kernels.hip): dev_windows are START windows -- what a match must begin
+    // with, one set per alternative that can sit away from the subject start -- the kernels list every offset where one of
+    // them fits (no group-start compression), and a per-record pass runs the pattern's VM program there with the chunk's real
+    // bytes in front: what comes back is the list of MATCH starts with their ends.  That verdict is pcre_exec's for every
+    // restart position s <= p - reach; the host (gscan_next_resolved) asks its own matcher about the `reach` offsets from s on.
+    bool resolve = false;
+    uint32_t reach = 0;     // how far in front of a match start the pattern can look (0: not at all)
+    ByteSet first;          // the bytes a match can begin with ...
+    bool first_ok = false;  // ... if that is known (the pattern cannot begin without consuming a byte)
     bool vm_ok = false; // prog.vm holds the tree as a VM program (vm.h): gscan_vm_verdict works; prog.vm_filter says whether the device uses it
 };
 

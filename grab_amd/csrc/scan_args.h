@@ -49,6 +49,8 @@ struct ScanArgs {
     uint32_t k3_one_bucket;                               // K3: the filter table uses bucket 0 only (its bytes are 0 / 1)
     uint32_t vm_filter;                                   // K3: every filter hit is put to the VM (DevProgram::vm_filter)
     uint32_t report_shift;   // reported offset = device window start + this (1 when the windows carry a leading context position)
+    uint32_t keep_all;       // 0xffffffff: list EVERY candidate, not only the start of every group of consecutive ones (DevProgram::resolve:
+                             // each record is a match start of its own for k_resolve); 0: group starts (a mask: x & ~(prev & ~keep_all))
     uint32_t run_desc[kK2MaxRuns];                        // K2: cls | len<<8 | off<<16
     // K2, windows of <= 17 bytes: the run's shift program, decoded on the host -- cls @0, then the shift amounts of the
     // doubling steps (0 = step not taken) 1 @1, 2 @2 (2 bits), 4 @4 (3 bits), 8 @7 (4 bits), the remainder @11 (5 bits),
@@ -89,6 +91,10 @@ constexpr uint32_t kLineAskHost = 0xffffffffu;
 // the chunk's records (and their ew extra words each) once more, in text order and back to back: out[0 .. total), out_ext[0 ..
 // total * ew); counter[kShards * kCtrStride + 3] = total (kernels.hip, k_order_prefix / k_order_copy); dpos: n_tiles * waves words
 hipError_t launch_order(const ScanArgs &a, uint32_t waves, const uint32_t *ext, uint32_t ew, uint32_t *dpos, uint32_t *out, uint32_t *out_ext, hipStream_t st);
+// the resolve pass (DevProgram::resolve): the pattern's VM program run at every record; records at which no match starts are
+// dropped (the descriptors' counts shrink, counter[kShards * kCtrStride + 1] counts them), ends[record index] = the match's end,
+// GSCAN_END_ASK or GSCAN_END_CAPTURES for the others (kernels.hip, k_resolve)
+hipError_t launch_resolve(const ScanArgs &a, uint32_t waves, uint32_t *ends, hipStream_t st);
 // match ends for -O -l: ends[record index] = end of the match that starts at the record (0: ask the host) (kernels.hip, k_ends)
 hipError_t launch_ends(const ScanArgs &a, uint32_t waves, uint32_t sub_bytes, uint32_t *ends, hipStream_t st);
 

@@ -67,6 +67,9 @@ struct VmIns {
 
 struct VmProg {
     uint32_t n_ins, n_slots, n_cls, ok; // ok: the pattern compiled into a program within the limits
+    uint32_t n_groups;                  // capturing groups whose spans the program records (slots [2g, 2g + 1], g = 1 ..): vm_run reports
+                                        // whether the match set one (the reference's one-pair ovector, src/grab.cc:171,179); 0: none recorded
+    uint32_t pad_[3];
     VmIns ins[kVmMaxIns];
     uint32_t cls[kVmMaxCls][8];
 };
@@ -141,9 +144,14 @@ struct VmSlots {
     }
 };
 
+// What vm_run found when it answers 1: the match's end (ovector[1]) and whether its path closed a capturing group.
+struct VmOut {
+    uint32_t end, cap;
+};
+
 // 0: no match starts at p;  1: a match starts at p;  2: gave up.  c[0..clen) is the chunk (segment), s0 its subject start.
 template <int NREG>
-GSCAN_HD inline int vm_run_t(const VmProg *pg, const uint8_t *c, uint32_t clen, uint32_t p, uint32_t s0)
+GSCAN_HD inline int vm_run_t(const VmProg *pg, const uint8_t *c, uint32_t clen, uint32_t p, uint32_t s0, VmOut &out)
 {
     VmSlots<NREG> slots;
     uint32_t stk[2 * kVmStack];
@@ -360,8 +368,13 @@ GSCAN_HD inline int vm_run_t(const VmProg *pg, const uint8_t *c, uint32_t clen, 
             if (pos >= s0 + in.a) pos -= in.a, pc++;
             else fail = true;
             break;
-        case V_MATCH:
-            return 1; // (an empty match AT p is "no match" for tree_match_at; such a candidate is simply kept)
+        case V_MATCH: { // (an empty match AT p is "no match" for tree_match_at: the callers that use `end` ask the host about it)
+            out.end = pos;
+            uint32_t cap = 0;
+            for (uint32_t g = 1; g <= pg->n_groups; g++) cap |= slots.get(2 * g + 1) != kVmUnset ? 1u : 0u;
+            out.cap = cap;
+            return 1;
+        }
         default: // V_FAIL and anything unknown
             fail = true;
             break;
@@ -418,9 +431,14 @@ GSCAN_HD inline int vm_run_t(const VmProg *pg, const uint8_t *c, uint32_t clen, 
 #undef VM_TEST
 }
 
+GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, uint32_t p, uint32_t s0, VmOut &out)
+{
+    return pg->n_slots <= 8u ? vm_run_t<8>(pg, c, clen, p, s0, out) : vm_run_t<0>(pg, c, clen, p, s0, out);
+}
 GSCAN_HD inline int vm_run(const VmProg *pg, const uint8_t *c, uint32_t clen, uint32_t p, uint32_t s0)
 {
-    return pg->n_slots <= 8u ? vm_run_t<8>(pg, c, clen, p, s0) : vm_run_t<0>(pg, c, clen, p, s0);
+    VmOut out;
+    return vm_run(pg, c, clen, p, s0, out);
 }
 
 } // namespace gscan

@@ -335,10 +335,14 @@ bool looks_behind(const Node &n)
 // The tree as a VM program; false if it does not fit the VM's limits (the pattern then stays with the host matcher).
 bool vm_compile(const Node &root, int n_groups, bool has_backref, VmProg &out)
 {
-    Builder b(out, n_groups, has_backref);
+    // (the groups' spans are recorded whenever there are groups, not only for back references and conditions: "did the match
+    // set a capturing group" is part of the verdict -- the reference's ovector holds one pair, src/grab.cc:171,179)
+    (void)has_backref;
+    Builder b(out, n_groups, n_groups > 0);
     b.gen(root);
     b.emit(V_MATCH);
     out.n_slots = b.next_slot;
+    out.n_groups = n_groups > 0 ? (uint32_t)n_groups : 0u;
     out.ok = b.ok ? 1u : 0u;
     return b.ok;
 }

@@ -21,18 +21,18 @@ SLOTS = 3  # GSCAN_SLOTS (include/gscan.h): chunks one context keeps in flight
 SYMBOLS = [
     "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_match_info", "gscan_next_match", "gscan_tail_positions", "gscan_db_dev_window",
     "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
-    "gscan_acquire", "gscan_block_size", "gscan_prefault", "gscan_prefault_files", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_submit_files", "gscan_last_file_errors", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_gather", "gscan_last_ends", "gscan_next_listed",
+    "gscan_acquire", "gscan_block_size", "gscan_prefault", "gscan_prefault_files", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_submit_files", "gscan_last_file_errors", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_gather", "gscan_last_ends", "gscan_next_listed", "gscan_next_resolved", "gscan_db_first",
     "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
     "gscan_set_option", "gscan_kernel_time", "gscan_resource_errors",
     "gscan_ingest_info", "gscan_pool_stats", "gscan_auto_readers", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
-    "gscan_vm_verdict", "gscan_vm_filter", "gscan_vm_pair", "gscan_prefix_viable",
+    "gscan_vm_verdict", "gscan_vm_match", "gscan_vm_resolve", "gscan_vm_filter", "gscan_vm_pair", "gscan_prefix_viable",
 ]
 
 
 class Info(C.Structure):
     _fields_ = [("tier", C.c_int), ("minlen", C.c_int), ("n_classes", C.c_int), ("has_tail", C.c_int),
                 ("tail_extra", C.c_uint32), ("anchor_off", C.c_int), ("anchor_len", C.c_int),
-                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int), ("lines_ok", C.c_int), ("exact", C.c_int), ("vm", C.c_int), ("gapped", C.c_int), ("textfree", C.c_int), ("ends_ok", C.c_int)]
+                ("is_literal", C.c_int), ("n_alts", C.c_int), ("has_context", C.c_int), ("lines_ok", C.c_int), ("exact", C.c_int), ("vm", C.c_int), ("gapped", C.c_int), ("textfree", C.c_int), ("ends_ok", C.c_int), ("resolve", C.c_int), ("reach", C.c_int), ("n_windows", C.c_int)]
 
 
 class Cursor(C.Structure):
@@ -53,7 +53,7 @@ class File(C.Structure):
 class DevResult(C.Structure):
     _fields_ = [("recs", C.c_void_p), ("desc", C.c_void_p),
                 ("n_tiles", C.c_uint64), ("tile_bytes", C.c_uint32), ("total", C.c_uint64),
-                ("overflow", C.c_int)]
+                ("overflow", C.c_int), ("ends", C.c_void_p)]
 
 
 _lib = None
@@ -136,7 +136,10 @@ def lib():
         L.gscan_parse_cpulist.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_size_t]
         L.gscan_parse_cpulist.restype = C.c_long
         L.gscan_vm_verdict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]
+        L.gscan_vm_match.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
         L.gscan_vm_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gscan_vm_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.gscan_vm_resolve.restype = C.c_long
         L.gscan_vm_filter.restype = C.c_long
         L.gscan_vm_pair.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
         L.gscan_prefix_viable.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -217,6 +220,24 @@ class Database:
         """The device VM's answer AT p, run on the host: 0 no match starts at p, 1 one does, 2 gave up, -1 no VM program."""
         buf = np.frombuffer(content, np.uint8)
         return int(lib().gscan_vm_verdict(self._h, buf.ctypes.data, buf.size, subject_start, p))
+
+    def vm_match(self, content, p, subject_start=0):
+        """The VM's full answer AT p: (verdict, end, captures) -- end / captures are meaningful for verdict 1 only."""
+        buf = np.frombuffer(content, np.uint8)
+        end, cap = C.c_uint32(0), C.c_int(0)
+        v = int(lib().gscan_vm_match(self._h, buf.ctypes.data, buf.size, subject_start, p, C.byref(end), C.byref(cap)))
+        return v, int(end.value), int(cap.value)
+
+    def vm_resolve(self, content, hits):
+        """k_resolve on the host: (starts, ends) of the hits at which the VM finds a match or gives up."""
+        buf = np.ascontiguousarray(np.frombuffer(content, np.uint8))
+        h = np.ascontiguousarray(np.asarray(hits, np.uint32))
+        st, en = np.zeros(h.size, np.uint32), np.zeros(h.size, np.uint32)
+        k = lib().gscan_vm_resolve(self._h, buf.ctypes.data if buf.size else None, buf.size, h.ctypes.data if h.size else None, h.size,
+                                   st.ctypes.data if h.size else C.c_void_p(8), en.ctypes.data if h.size else C.c_void_p(8))
+        if k < 0:
+            raise EngineError("gscan_vm_resolve: no VM program")
+        return st[:k].copy(), en[:k].copy()
 
     def vm_pair(self, b0, b1):
         """The device's two-byte table: 1 a match may begin with b0 b1, 0 none can, -1 no table."""

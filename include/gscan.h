@@ -95,6 +95,14 @@ typedef struct gscan_info {
                             listed and ends where its window ends, so gscan_next_match never looks at `content` (it may be NULL) */
     int ends_ok;         /* 1 if the match-end pass applies (gscan_set_option "match_ends"): one plain alternative without context that
                             ends in an unbounded greedy repeat whose class contains the window's first class (gscan_next_listed) */
+    int resolve;         /* 1: the DEVICE settles the matches (round 6).  The kernels scan for what a match must BEGIN with -- START windows, one
+                            per alternative -- and list every offset where one fits; a per-record pass (k_resolve) runs the pattern's VM
+                            program there with the chunk's real bytes in front of the offset and keeps the offsets at which a match
+                            starts, each with its end: gscan_wait's list is the list of MATCH starts, gscan_last_ends their ends, and
+                            gscan_next_resolved walks it without asking the host matcher (but for the `reach` offsets behind s) */
+    int reach;           /* resolve: how far in front of a match start the pattern looks (\b ^: 1, a look-behind: its length, else 0).  The
+                            device's verdict at p is pcre_exec's for every restart position s <= p - reach */
+    int n_windows;       /* device windows the kernels scan for (gscan_db_dev_window: 0 .. n_windows - 1); == n_alts unless resolve is set */
 } gscan_info;
 
 /* one scan unit inside a device-resident arena (gscan_scan_device) */
@@ -124,6 +132,7 @@ typedef struct gscan_dev_result {
     uint32_t tile_bytes;
     uint64_t total;        /* number of records the scan produced (valid after gscan_dev_sync) */
     int overflow;          /* 1 if the record buffer was too small: total says how many are needed */
+    const uint32_t *ends;  /* device, parallel to recs: the resolve pass's ends (databases with gscan_info.resolve: recs are match starts); else NULL */
 } gscan_dev_result;
 
 /* ---- pattern database (host only; no device needed) ---- */
@@ -190,6 +199,12 @@ size_t gscan_tail_positions(const gscan_db *db, size_t clen, uint32_t *out, size
  *                     begin at offset 0 of some subject that starts with these n bytes?  (0 only if the host matcher fails
  *                     without looking at or beyond byte n.) */
 int gscan_vm_verdict(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p);
+/* the VM's full answer: as gscan_vm_verdict, and for 1 the match's end (ovector[1]) and whether its path closed a capturing group
+ * -- what the device's resolve pass (gscan_info.resolve) writes next to every record */
+int gscan_vm_match(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p, uint32_t *end, int *captures);
+/* k_resolve on the host (tests): of hits[0..n) -- offsets where a start window fits -- the ones at which the VM finds a match
+ * or gives up, into starts, and what the device writes next to them into ends; returns how many, -1 if there is no program */
+long gscan_vm_resolve(const gscan_db *db, const void *content, size_t clen, const uint32_t *hits, size_t n, uint32_t *starts, uint32_t *ends);
 int gscan_vm_pair(const gscan_db *db, unsigned b0, unsigned b1);
 int gscan_prefix_viable(const gscan_db *db, const void *bytes, size_t n);
 long gscan_vm_filter(const gscan_db *db, const void *content, size_t clen, const uint32_t *hits, size_t n, uint32_t *kept);
@@ -333,6 +348,26 @@ const uint32_t *gscan_last_ends(const gscan_ctx *ctx);
  */
 int gscan_next_listed(const gscan_db *db, size_t clen, const uint32_t *starts, const uint32_t *ends, size_t n,
                       gscan_cursor *cur, uint32_t s, uint32_t *m0, uint32_t *m1);
+/*
+ * The loop step for a database with gscan_info.resolve set:  rc = pcre_exec(h, extra, start, end - start, 0, 0, ovector, 3)
+ * (src/grab.cc:178) answered from the device's list.  starts / ends as gscan_wait / gscan_last_ends returned them (ends may be
+ * NULL: every record is then put to the host matcher, which is what the list means before k_resolve has seen it):
+ *   ends[i] == GSCAN_END_ASK       the device's VM gave up at starts[i] (step / stack limit): the host matcher decides;
+ *   ends[i] == GSCAN_END_CAPTURES  a match starts there whose path closes a capturing group: pcre_exec returns 0 with the
+ *                                  reference's int ovector[3] (src/grab.cc:171) and the chunk loop ends (src/grab.cc:179);
+ *   else                           a match [starts[i], ends[i]).
+ * The verdicts were reached with the chunk's real bytes in front of starts[i]; pcre_exec sees nothing in front of the restart
+ * position s, so the `reach` offsets from s on are the host matcher's (content is read there, and only there
+ * and at GSCAN_END_ASK records: with reach == 0 and no such record it may be NULL).  Returns as gscan_next_match; -1 if the
+ * database is not of this kind.
+ */
+#define GSCAN_END_ASK 0u
+#define GSCAN_END_CAPTURES 0xfffffffeu
+int gscan_next_resolved(const gscan_db *db, const void *content, size_t clen, const uint32_t *starts, const uint32_t *ends, size_t n,
+                        gscan_cursor *cur, uint32_t s, uint32_t *m0, uint32_t *m1);
+/* the bytes a match can begin with: table[b] = 1 if b can; returns 1 if that is known (0: the pattern may begin without
+ * consuming a byte -- an assertion, an optional item -- and every table entry is 1) */
+int gscan_db_first(const gscan_db *db, uint8_t table[256]);
 /* the same for a chunk of several segments: the records of segment i are
  * starts[seg_first[i] .. seg_first[i+1]), segment-relative; seg_first has *nseg + 1 entries
  * (a single-segment chunk reports *nseg = 1). */

@@ -79,7 +79,7 @@ def db_candidates(db, data):
     import scan_oracle as so
 
     out = [np.zeros(0, np.int64)]
-    for a in range(db.info.n_alts):
+    for a in range(db.info.n_windows):
         tables, shift = db.dev_window(a)
         out.append(so.window_starts(data, tables) + shift)
     return np.unique(np.concatenate(out))
@@ -93,6 +93,20 @@ def engine_list(db, data):
     import scan_oracle as so
 
     cands = db_candidates(db, data)
+    if db.info.resolve:  # start windows, every offset where one fits (no group-start compression): what k_resolve is handed
+        return cands.astype(np.uint32)
     if db.info.vm:
         return db.vm_filter(np.ascontiguousarray(data), cands.astype(np.uint32)).astype(np.uint32)
     return so.group_starts(cands).astype(np.uint32)
+
+
+END_ASK, END_CAPTURES = 0, 0xfffffffe  # GSCAN_END_* (include/gscan.h)
+
+
+def resolved_list(db, data):
+    """What the device's resolve pass (k_resolve) makes of engine_list() for a database with info.resolve: the offsets at which the
+    pattern's VM program -- run on the host here, same source -- finds a match with the chunk's real bytes in front of them, and
+    per offset the match's end, END_CAPTURES (the match sets a capturing group) or END_ASK (the VM gave up: the host decides)."""
+    import numpy as np
+
+    return db.vm_resolve(np.ascontiguousarray(data), engine_list(db, data))

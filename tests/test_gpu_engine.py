@@ -10,7 +10,7 @@ import pytest
 
 from conftest import ROOT
 from grab_amd import engine, synth
-from inputs import db_candidates, engine_list
+from inputs import resolved_list, db_candidates, engine_list
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import scan_oracle as so  # noqa: E402
@@ -72,6 +72,8 @@ def as_specified(db, got, data):
     """What ctx.scan() has to return for `data`: the contract above against the candidate set -- or, for a database whose
     candidates the device confirms itself (info.vm), EXACTLY the device hits its VM filter keeps, no more, no fewer
     (tests/inputs.py engine_list runs the kernel's cold path, same source, on the host)."""
+    if db.info.resolve:  # the device settles the matches: EXACTLY the offsets at which the pattern's VM program finds one (or gives up), run on the host here
+        return np.array_equal(np.asarray(got, np.uint32), resolved_list(db, np.ascontiguousarray(data))[0])
     if db.info.vm:
         return np.array_equal(np.asarray(got, np.uint32), engine_list(db, np.ascontiguousarray(data)))
     return same(got, table_candidates(db, data))
@@ -581,8 +583,16 @@ def test_shared_buckets_second_pass(ctx):
 
     words = ["alpha", "betaa", "gamma", "delta", "epsil", "zetaa", "etaaa", "theta", "iotaa", "kappa", "lambd", "muuuu"]
     pattern = "|".join(words)
-    db = engine.Database(pattern)
-    assert db.info.tier == engine.TIER_BUCKET and db.info.n_alts == 12
+    # (since round 6 such a pattern goes through the resolve pass, which settles every record with the pattern's VM program;
+    # k3_settle remains for databases without one -- GSCAN_NO_RESOLVE=1 at compile time is that path's switch)
+    assert engine.Database(pattern).info.resolve
+    os.environ["GSCAN_NO_RESOLVE"] = "1"
+    try:
+        db = engine.Database(pattern)
+        db2 = engine.Database("|".join("abcdefghijkl") + "|zz")
+    finally:
+        del os.environ["GSCAN_NO_RESOLVE"]
+    assert db.info.tier == engine.TIER_BUCKET and db.info.n_alts == 12 and not db.info.resolve
     data = sample(2_000_003, 31)
     rng = np.random.default_rng(31)
     crosses = [b"alpaa", b"iotha", b"iopha", b"alota", b"betpa", b"kapaa", b"kaaaa", b"betaa", b"iotaa", b"alpha", b"muuuu", b"lambd"]
@@ -594,9 +604,7 @@ def test_shared_buckets_second_pass(ctx):
     got = ctx.scan(db, data)
     assert same(got, want) and len(got) > 500
     # dense: every byte is a hit of some single-letter alternative -> overflow -> regrow -> settle on the rescan
-    dense = "|".join("abcdefghijkl") + "|zz"
-    db2 = engine.Database(dense)
-    assert db2.info.n_alts == 13
+    assert db2.info.n_alts == 13 and not db2.info.resolve
     got = ctx.scan(db2, data[:700_001])
     assert same(got, table_candidates(db2, data[:700_001]))
     # device-resident: total counts the survivors only, fetch skips the struck records
@@ -721,6 +729,9 @@ def test_match_ends_on_device(ctx):
             db = engine.Database(pattern)
             assert not db.info.ends_ok
             starts = ctx.scan(db, data)
+            if db.info.resolve:  # (the resolve pass's ends come with every chunk, option or no option: tests/test_gpu_resolve.py)
+                assert np.array_equal(ctx.last_ends(len(starts)), resolved_list(db, data)[1]), pattern
+                continue
             assert ctx.last_ends(len(starts)) is None, pattern
     finally:
         ctx.set_option("match_ends", 0)

@@ -11,7 +11,7 @@ import pytest
 
 from conftest import GOLDEN, ROOT, golden_ids, split_args
 from grab_amd import engine, filegrep
-from inputs import build, db_candidates, engine_list
+from inputs import build, db_candidates, engine_list, resolved_list
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import scan_oracle as so  # noqa: E402
@@ -39,11 +39,14 @@ def host_find(db, data, flags, chunk, path=b"", minimal=True):
     for off, clen in so.chunks(len(data), chunk):
         part = data[off:off + clen]
         starts = db_candidates(db, part)
-        if db.info.vm:
+        ends = None
+        if db.info.resolve:  # the device settles the matches: the list of match starts and their ends (minimal) / every offset a start window fits, for the host matcher (not minimal)
+            starts, ends = resolved_list(db, part) if minimal else (engine_list(db, part), None)
+        elif db.info.vm:
             starts = engine_list(db, part)  # the device confirms the candidates itself: every hit it keeps, nothing else
         elif minimal:
             starts = so.group_starts(starts)
-        text = filegrep.report_chunk(db, flags, path, part, off, starts.astype(np.uint32))
+        text = filegrep.report_chunk(db, flags, path, part, off, starts.astype(np.uint32), ends=ends)
         if text:
             out.append(text)
             if flags & filegrep.SINGLE:
