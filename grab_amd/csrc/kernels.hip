@@ -1203,20 +1203,24 @@ __global__ __launch_bounds__(64) void k_ends(ScanArgs a, const TileDesc *__restr
 //   * writes, parallel to the surviving records, ends[i] = the match's end -- or GSCAN_END_CAPTURES when its path closed a
 //     capturing group (the reference's one-pair ovector: pcre_exec returns 0 and the chunk loop ends, grab.cc:171,179), or
 //     GSCAN_END_ASK when the VM gave up (step / stack limit) or the answer looks odd: the host's matcher decides that one.
-// One wave per descriptor, one lane per record, 64 at a time.  A verdict reached this way is pcre_exec's for every restart
+// One workgroup of four waves per descriptor, one lane per record: first every record's verdict, side by side, then the
+// survivors are moved to the front of the run.  A verdict reached this way is pcre_exec's for every restart
 // position s <= p - reach (Database::reach): the host asks its own matcher about the offsets closer to s than that
 // (gscan_next_resolved).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_resolve(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t *__restrict__ ends)
+constexpr uint32_t kResolveWG = 256;   // threads per descriptor: four waves run the VM side by side, then compact the run together
+constexpr uint32_t kResolveDrop = 0xffffffffu; // (in ends[], between the two phases: no match starts at this record)
+__global__ __launch_bounds__(kResolveWG) void k_resolve(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t *__restrict__ ends)
 {
     const uint32_t st = blockIdx.x;
     const unsigned long long d = a.desc[st];
     const uint32_t cnt = (uint32_t)d;
     if (cnt == 0 || a.counter[kShards * kCtrStride] != 0) return; // (overflow: the host rescans with a bigger buffer and this pass runs again)
     __shared__ __attribute__((aligned(16))) uint32_t s_vm[sizeof(VmProg) / 4];
+    __shared__ uint32_t s_cnt[kResolveWG / 64];
     {
         const uint32_t *vsrc = reinterpret_cast<const uint32_t *>(&a.prog->vm);
-        for (uint32_t q = threadIdx.x; q < (uint32_t)(sizeof(VmProg) / 4); q += 64u) s_vm[q] = vsrc[q];
+        for (uint32_t q = threadIdx.x; q < (uint32_t)(sizeof(VmProg) / 4); q += kResolveWG) s_vm[q] = vsrc[q];
     }
     __syncthreads();
     const VmProg *vm = reinterpret_cast<const VmProg *>(s_vm);
@@ -1224,36 +1228,51 @@ __global__ __launch_bounds__(64) void k_resolve(ScanArgs a, const TileDesc *__re
     const uint32_t t = st / nw;
     const uint8_t *seg = a.base + (tiles ? tiles[t].seg_off : a.seg0_off);
     const uint32_t slen = tiles ? tiles[t].seg_len : a.seg0_len;
-    const uint32_t lane = threadIdx.x;
-    uint32_t out = 0; // survivors so far (wave-uniform)
-    for (uint32_t i0 = 0; i0 < cnt; i0 += 64u) {
-        const uint32_t i = i0 + lane;
-        uint32_t p = 0, code = 0;
-        bool keep = false;
+    // phase 1: every record's verdict, in place (ends[i]); the records stay where they are
+    for (uint32_t i = threadIdx.x; i < cnt; i += kResolveWG) {
+        const uint32_t p = a.recs[base + i];
+        uint32_t code = kResolveDrop;
+        if (p != kStruck && p < slen) {
+            VmOut o{0u, 0u};
+            const int v = vm_run(vm, seg, slen, p, 0u, o);
+            if (v == 1) code = o.end <= p ? 0u /* GSCAN_END_ASK */ : o.cap ? 0xfffffffeu /* GSCAN_END_CAPTURES */ : o.end;
+            else if (v != 0) code = 0u; // gave up: the host's matcher decides
+        }
+        ends[base + i] = code;
+    }
+    __syncthreads();
+    // phase 2: the survivors to the front of the run, kResolveWG records per round.  (Survivor k of a round goes to index
+    // out + k <= the index its own thread read from: a round's loads are all done before its first store, and later rounds read
+    // further on.)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t out = 0; // survivors so far (uniform)
+    for (uint32_t i0 = 0; i0 < cnt; i0 += kResolveWG) {
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t p = 0, code = kResolveDrop;
         if (i < cnt) {
             p = a.recs[base + i];
-            if (p != kStruck && p < slen) {
-                VmOut o{0u, 0u};
-                const int v = vm_run(vm, seg, slen, p, 0u, o);
-                if (v == 1) {
-                    keep = true;
-                    code = o.end <= p ? 0u /* GSCAN_END_ASK */ : o.cap ? 0xfffffffeu /* GSCAN_END_CAPTURES */ : o.end;
-                } else if (v != 0) {
-                    keep = true; // gave up: the host's matcher decides
-                }
-            }
+            code = ends[base + i];
         }
-        // (every lane has its record -- the loads above were waited for before the VM ran -- before any lane overwrites one:
-        // survivor k of this batch goes to index out + k <= i0 + its own lane)
+        const bool keep = code != kResolveDrop;
         const unsigned long long m = __ballot(keep);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kResolveWG / 64; w++) {
+            const uint32_t c = s_cnt[w];
+            before += w < wave ? c : 0u;
+            total += c;
+        }
+        const uint32_t rank = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (keep) {
             a.recs[base + out + rank] = p;
             ends[base + out + rank] = code;
         }
-        out += (uint32_t)__popcll(m);
+        out += total;
+        __syncthreads();
     }
-    if (lane == 0 && out != cnt) {
+    if (threadIdx.x == 0 && out != cnt) {
         a.desc[st] = (d & 0xffffffff00000000ull) | out;
         atomicAdd(a.counter + kShards * kCtrStride + 1, cnt - out);
     }
@@ -1529,7 +1548,7 @@ hipError_t launch_order(const ScanArgs &a, uint32_t nw, const uint32_t *ext, uin
 hipError_t launch_resolve(const ScanArgs &a, uint32_t nw, uint32_t *ends, hipStream_t st)
 {
     if (a.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_resolve, dim3(a.n_tiles * nw), dim3(64), 0, st, a, a.tiles, nw, ends);
+    hipLaunchKernelGGL(k_resolve, dim3(a.n_tiles * nw), dim3(kResolveWG), 0, st, a, a.tiles, nw, ends);
     return hipGetLastError();
 }
 

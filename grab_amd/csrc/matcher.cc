@@ -924,7 +924,9 @@ int gscan_next_resolved(const gscan_db *db, const void *content_, size_t clen, c
     }
     // (1) the offsets the pattern can look back over the restart position from: the device's verdicts there were reached with
     // bytes in front that pcre_exec, handed the subject FROM s (src/grab.cc:178), does not see -- the host's matcher decides
-    const size_t near_end = std::min(clen, (size_t)s + d.reach);
+    // (... unless the byte in front of s is, to this pattern, what the subject start is: a non-word byte for \b, a newline for (?m)^)
+    const bool same = d.reach == 1 && s > 0 && d.start_like.test(content[s - 1]);
+    const size_t near_end = same ? (size_t)s : std::min(clen, (size_t)s + d.reach);
     for (size_t q = s; q < near_end; q++) {
         if (d.first_ok && !d.first.test(content[q])) continue;
         MatchAt m;
@@ -959,7 +961,7 @@ int gscan_next_resolved(const gscan_db *db, const void *content_, size_t clen, c
 int gscan_db_first(const gscan_db *db, uint8_t table[256])
 {
     if (!db || !table) return GSCAN_EINVAL;
-    for (int b = 0; b < 256; b++) table[b] = db->db.first_ok ? db->db.first.test((unsigned)b) : 1;
+    for (int b = 0; b < 256; b++) table[b] = (uint8_t)((db->db.first_ok ? db->db.first.test((unsigned)b) : 1) | (db->db.start_like.test((unsigned)b) ? 2 : 0));
     return db->db.first_ok ? 1 : 0;
 }
 

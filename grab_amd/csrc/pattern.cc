@@ -2555,6 +2555,34 @@ static uint32_t look_reach(const Node &n)
     return r;
 }
 
+// reach == 1: the bytes b for which "b stands in front of p" and "nothing stands in front of p" are the same thing to every
+// assertion of the pattern that looks there -- a non-word byte for \b and \B, a newline for (?m)^, a byte outside its class
+// for a one-byte look-behind (positive: fails either way; negative: holds either way); none for ^ \A \G.  When the byte in
+// front of a restart position is one of them, the device's verdict AT the restart position is pcre_exec's too.
+static void start_like_bytes(const Node &n, ByteSet &e)
+{
+    if (n.kind == Node::ASSERT) {
+        ByteSet keep;
+        bool narrows = true;
+        switch (n.acode) {
+        case A_WB:
+        case A_NWB: keep = set_not(set_word()); break;
+        case A_MBOL: keep.set('\n'); break;
+        case A_BOS: break; // (nothing is like the subject start)
+        default: narrows = false; break;
+        }
+        if (narrows) e = set_and(e, keep);
+    }
+    if (n.kind == Node::LOOK && n.behind) {
+        const Node *b = &n.kids[0];
+        while ((b->kind == Node::CAT || b->kind == Node::ALT) && b->kids.size() == 1 && !b->cap) b = &b->kids[0];
+        if (b->kind == Node::SET) e = set_and(e, set_not(b->set));
+        else e = ByteSet();
+        return; // (what stands inside the look-behind looks further back: such a pattern's reach is > 1 anyway)
+    }
+    for (const Node &k : n.kids) start_like_bytes(k, e);
+}
+
 static bool has_keep(const Node &n)
 {
     if (n.kind == Node::ASSERT && n.acode == A_KEEP) return true;
@@ -3002,6 +3030,11 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         const vm_first_t f = vm_first_bytes(*db.tree);
         db.first = f.set;
         db.first_ok = !f.nullable;
+        db.start_like = ByteSet();
+        if (db.reach == 1) {
+            db.start_like = set_all();
+            start_like_bytes(*db.tree, db.start_like);
+        }
     }
 
     if (db.exact && db.alts.size() == 1 && !db.alts[0].gapped && !db.dev_pre && !db.dev_post && db.dev_windows[0] == db.alts[0].window) {

@@ -236,6 +236,7 @@ struct Database {
     uint32_t reach = 0;     // how far in front of a match start the pattern can look (0: not at all)
     ByteSet first;          // the bytes a match can begin with ...
     bool first_ok = false;  // ... if that is known (the pattern cannot begin without consuming a byte)
+    ByteSet start_like;     // reach == 1: a byte of this set in front of p is to the pattern what the subject start is (pattern.cc, start_like_bytes)
     bool vm_ok = false; // prog.vm holds the tree as a VM program (vm.h): gscan_vm_verdict works; prog.vm_filter says whether the device uses it
 };
 

@@ -88,18 +88,46 @@ enum : uint32_t {
 GSCAN_HD inline bool vm_is_word(uint32_t b) { return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_'; }
 GSCAN_HD inline uint32_t vm_lower(uint32_t b) { return b >= 'A' && b <= 'Z' ? b + 32 : b; }
 
+// The text as the VM reads it: eight bytes per load, kept in a register pair.  On the device a byte of text is a round trip
+// to the L2 (the VM comes to it long after the scan streamed it through), and a class repeat or a literal walks the text
+// byte by byte: a dependent chain of such round trips per byte was most of what a VM run cost (k_resolve: 2.2 ms per 64 MiB
+// window of a pattern with a candidate every five bytes).  The window follows the position: a miss refills it FROM the byte
+// asked for, so a forward walk loads once per eight bytes and a look back costs one load.
+struct VmText {
+    const uint8_t *c;
+    uint32_t clen;
+    uint32_t base;          // the window holds the bytes [base, base + 8) of the text (beyond clen: zeros)
+    unsigned long long v;
+    GSCAN_HD inline VmText(const uint8_t *c_, uint32_t clen_) : c(c_), clen(clen_), base(0xfffffff0u), v(0) {}
+    GSCAN_HD inline uint32_t at(uint32_t pos) // pos < clen
+    {
+        uint32_t d = pos - base;
+        if (d >= 8u) {
+            base = pos;
+            d = 0;
+            if (pos + 8u <= clen) {
+                __builtin_memcpy(&v, c + pos, 8);
+            } else {
+                v = 0;
+                for (uint32_t k = 0; pos + k < clen; k++) v |= (unsigned long long)c[pos + k] << (8u * k);
+            }
+        }
+        return (uint32_t)(v >> (8u * d)) & 0xffu;
+    }
+};
+
 // Assertion codes: pattern.h (A_BOS = 1 ... A_KEEP = 8).  s0: the subject start -- nothing lies before it.
-GSCAN_HD inline bool vm_holds(uint32_t code, const uint8_t *c, uint32_t clen, uint32_t s0, uint32_t pos)
+GSCAN_HD inline bool vm_holds(uint32_t code, VmText &c, uint32_t clen, uint32_t s0, uint32_t pos)
 {
     switch (code) {
     case 1: return pos == s0;                                                        // A_BOS
-    case 2: return pos == s0 || (pos > s0 && c[pos - 1] == '\n' && pos < clen);      // A_MBOL
-    case 3: return pos == clen || (c[pos] == '\n' && pos + 1 == clen);               // A_EOL
-    case 4: return pos == clen || c[pos] == '\n';                                    // A_MEOL
+    case 2: return pos == s0 || (pos > s0 && pos < clen && c.at(pos - 1) == '\n');   // A_MBOL
+    case 3: return pos == clen || (pos + 1 == clen && c.at(pos) == '\n');            // A_EOL
+    case 4: return pos == clen || c.at(pos) == '\n';                                 // A_MEOL
     case 5: return pos == clen;                                                      // A_EOS
     case 6:
     case 7: {                                                                        // A_WB, A_NWB
-        const bool l = pos > s0 && vm_is_word(c[pos - 1]), r = pos < clen && vm_is_word(c[pos]);
+        const bool l = pos > s0 && vm_is_word(c.at(pos - 1)), r = pos < clen && vm_is_word(c.at(pos));
         return (l != r) == (code == 6);
     }
     case 8: return true;                                                             // A_KEEP: where the match is REPORTED to start is the host's business
@@ -144,6 +172,8 @@ struct VmSlots {
     }
 };
 
+GSCAN_HD inline uint32_t vm_in_class(const VmProg *pg, uint32_t cls, uint32_t b) { return (pg->cls[cls][b >> 5] >> (b & 31u)) & 1u; }
+
 // What vm_run found when it answers 1: the match's end (ovector[1]) and whether its path closed a capturing group.
 struct VmOut {
     uint32_t end, cap;
@@ -151,8 +181,9 @@ struct VmOut {
 
 // 0: no match starts at p;  1: a match starts at p;  2: gave up.  c[0..clen) is the chunk (segment), s0 its subject start.
 template <int NREG>
-GSCAN_HD inline int vm_run_t(const VmProg *pg, const uint8_t *c, uint32_t clen, uint32_t p, uint32_t s0, VmOut &out)
+GSCAN_HD inline int vm_run_t(const VmProg *pg, const uint8_t *text, uint32_t clen, uint32_t p, uint32_t s0, VmOut &out)
 {
+    VmText c(text, clen);
     VmSlots<NREG> slots;
     uint32_t stk[2 * kVmStack];
     slots.init(pg->n_slots);
@@ -167,7 +198,7 @@ GSCAN_HD inline int vm_run_t(const VmProg *pg, const uint8_t *c, uint32_t clen, 
         stk[2 * sp + 1] = (w1_);               \
         sp++;                                  \
     } while (0)
-#define VM_TEST(cls_, b_) ((pg->cls[(cls_)][(b_) >> 5] >> ((b_) & 31)) & 1u)
+#define VM_TEST(cls_, b_) vm_in_class(pg, (cls_), (b_))
 
     for (;;) {
         bool fail = false;
@@ -175,13 +206,13 @@ GSCAN_HD inline int vm_run_t(const VmProg *pg, const uint8_t *c, uint32_t clen, 
         const VmIns in = pg->ins[pc];
         switch (in.op & 0xffu) {
         case V_SET:
-            if (pos < clen && VM_TEST(in.a, (uint32_t)c[pos])) pos++, pc++;
+            if (pos < clen && VM_TEST(in.a, c.at(pos))) pos++, pc++;
             else fail = true;
             break;
         case V_REPSET: {
             const uint32_t mode = (in.op >> 8) & 3u;
             uint32_t k = 0;
-            while (k < in.c && pos + k < clen && VM_TEST(in.a, (uint32_t)c[pos + k])) k++;
+            while (k < in.c && pos + k < clen && VM_TEST(in.a, c.at(pos + k))) k++;
             steps += k >> 3;
             if (k < in.b) {
                 fail = true;
@@ -210,8 +241,9 @@ GSCAN_HD inline int vm_run_t(const VmProg *pg, const uint8_t *c, uint32_t clen, 
         case V_JMP: pc = in.a; break;
         case V_SPLIT: {
             const uint32_t ca = in.c & 0xffffu, cb = in.c >> 16;
-            const bool oka = ca == 0xffffu || (pos < clen && VM_TEST(ca, (uint32_t)c[pos]));
-            const bool okb = cb == 0xffffu || (pos < clen && VM_TEST(cb, (uint32_t)c[pos]));
+            const uint32_t nb = pos < clen && (ca != 0xffffu || cb != 0xffffu) ? c.at(pos) : 0u; // the next byte, if anyone asks
+            const bool oka = ca == 0xffffu || (pos < clen && VM_TEST(ca, nb));
+            const bool okb = cb == 0xffffu || (pos < clen && VM_TEST(cb, nb));
             if (oka && okb) {
                 VM_PUSH(VK_CHOICE | (in.b << 4), pos);
                 live++;
@@ -307,7 +339,7 @@ GSCAN_HD inline int vm_run_t(const VmProg *pg, const uint8_t *c, uint32_t clen, 
             steps += len >> 2;
             const bool icase = (in.op >> 8) & 1u;
             for (uint32_t q = 0; q < len; q++) {
-                const uint32_t x = c[lo + q], y = c[pos + q];
+                const uint32_t x = text[lo + q], y = text[pos + q];
                 if (icase ? vm_lower(x) != vm_lower(y) : x != y) {
                     fail = true;
                     break;

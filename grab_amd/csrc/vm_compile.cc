@@ -13,6 +13,7 @@
 //                  cut; a look-behind steps back by the fixed length of each of its top-level alternatives
 //   BACKREF        compares with what the group captured (fails while the group is unset)
 //   \K             nothing: where the match is reported to start is the host's business
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -98,29 +99,6 @@ struct Builder {
         return -1;
     }
 
-    void group_repeat(const Node &n, int mode)
-    {
-        const uint32_t cnt = new_slot(), mark = new_slot();
-        emit(V_REP_ENTER, cnt);
-        const uint32_t top = emit(V_REP_TOP | ((uint32_t)mode << 8), cnt, n.min, n.max);
-        emit(V_SAVE, mark);
-        gen(n.kids[0]);
-        emit(V_REP_END | ((n.max == kVmInf ? 1u : 0u) << 8) | (top << 16), cnt, mark, n.min);
-        if (here() > 0xffffu) ok = false;
-        if (ok) pg.ins[top].op |= here() << 16; // the exit
-    }
-
-    void behind_alt(const Node &alt)
-    {
-        const long len = look_len(alt);
-        if (len < 0) {
-            emit(V_FAIL);
-            return;
-        }
-        if (len > 0) emit(V_BACK, (uint32_t)len);
-        gen(alt);
-    }
-
     // What a match of the node can begin with: the set of first bytes, and whether it can match without consuming one (then
     // what follows decides and nothing can be predicted).
     struct First {
@@ -174,6 +152,64 @@ struct Builder {
         }
         return f;
     }
+    // "nothing is known about what comes next" (the end of the pattern, of a look-around's or an atomic group's body)
+    static First unknown()
+    {
+        First f;
+        f.set.negate();
+        f.nullable = true;
+        return f;
+    }
+    // what can follow item i of a sequence: the first bytes of the items behind it, and of `follow` if they can all match ""
+    static First behind(const std::vector<Node> &kids, size_t i, const First &follow)
+    {
+        First f;
+        f.nullable = true;
+        for (size_t j = i + 1; j < kids.size() && f.nullable; j++) {
+            const First g = first_of(kids[j]);
+            f.set.merge(g.set);
+            f.nullable = g.nullable;
+        }
+        if (f.nullable) {
+            f.set.merge(follow.set);
+            f.nullable = follow.nullable;
+        }
+        return f;
+    }
+    static bool disjoint(const ByteSet &a, const ByteSet &b)
+    {
+        for (int k = 0; k < 8; k++)
+            if (a.w[k] & b.w[k]) return false;
+        return true;
+    }
+
+    void group_repeat(const Node &n, int mode, const First &follow)
+    {
+        const uint32_t cnt = new_slot(), mark = new_slot();
+        emit(V_REP_ENTER, cnt);
+        const uint32_t top = emit(V_REP_TOP | ((uint32_t)mode << 8), cnt, n.min, n.max);
+        emit(V_SAVE, mark);
+        // behind an iteration comes another one, or what follows the repeat
+        First f = first_of(n.kids[0]);
+        f.set.merge(follow.set);
+        f.nullable = f.nullable || follow.nullable;
+        gen(n.kids[0], f);
+        emit(V_REP_END | ((n.max == kVmInf ? 1u : 0u) << 8) | (top << 16), cnt, mark, n.min);
+        if (here() > 0xffffu) ok = false;
+        if (ok) pg.ins[top].op |= here() << 16; // the exit
+    }
+
+    void behind_alt(const Node &alt)
+    {
+        const long len = look_len(alt);
+        if (len < 0) {
+            emit(V_FAIL);
+            return;
+        }
+        if (len > 0) emit(V_BACK, (uint32_t)len);
+        gen(alt, unknown());
+    }
+
     // class id of what the alternatives kids[from..] can begin with, 0xffff if one of them may match ""
     uint32_t first_class(const std::vector<const Node *> &kids, size_t from, size_t to)
     {
@@ -187,7 +223,7 @@ struct Builder {
         return ok ? id : 0xffffu;
     }
 
-    void alternatives(const std::vector<const Node *> &kids, bool behind)
+    void alternatives(const std::vector<const Node *> &kids, bool behind, const First &follow)
     {
         std::vector<uint32_t> jumps;
         for (size_t i = 0; i < kids.size(); i++) {
@@ -199,7 +235,7 @@ struct Builder {
                 split = emit(V_SPLIT, here() + 1, 0, ca | (cb << 16));
             }
             if (behind) behind_alt(*kids[i]);
-            else gen(*kids[i]);
+            else gen(*kids[i], follow);
             if (!last) {
                 jumps.push_back(emit(V_JMP, 0));
                 if (ok) pg.ins[split].b = here();
@@ -209,7 +245,13 @@ struct Builder {
             if (ok) pg.ins[j].a = here();
     }
 
-    void gen(const Node &n)
+    // follow: what can come right behind the node -- the bytes the rest of the pattern can begin with, nullable if the match may
+    // end there (or nothing is known).  It serves one decision: a greedy repeat of a class that what follows can neither begin
+    // with nor do without (\w* in front of \s*\( , [^()]* in front of \) , \d+ in front of \.) is compiled as a POSSESSIVE one --
+    // giving a byte back puts a byte of the class in front of something that cannot begin with it, so no such path ever
+    // matches, and a failing candidate costs a handful of steps instead of three per byte of its run (pcre_compile does the same:
+    // auto-possessification).  k_resolve runs the program at every candidate: that is most of what the pass costs.
+    void gen(const Node &n, const First &follow)
     {
         if (!ok) return;
         switch (n.kind) {
@@ -217,7 +259,7 @@ struct Builder {
         case Node::CAT: {
             const bool cap = use_caps && n.cap && n.group > 0 && n.group <= n_groups;
             if (cap) emit(V_SAVE, tmp_slot(n.group));
-            for (const Node &k : n.kids) gen(k);
+            for (size_t i = 0; i < n.kids.size(); i++) gen(n.kids[i], behind(n.kids, i, follow));
             if (cap) emit(V_CLOSE, cap_slot(n.group), tmp_slot(n.group));
             break;
         }
@@ -225,24 +267,26 @@ struct Builder {
             std::vector<const Node *> kids;
             for (const Node &k : n.kids) kids.push_back(&k);
             if (kids.empty()) break;
-            alternatives(kids, false);
+            alternatives(kids, false, follow);
             break;
         }
         case Node::REP: {
             if (n.max == 0) break;
             const Node &kid = n.kids[0];
             if (kid.kind == Node::SET) {
-                emit(V_REPSET | ((uint32_t)n.mode << 8), cls_id(kid.set), n.min, n.max);
+                int mode = n.mode;
+                if (mode == 0 && n.max > n.min && !follow.nullable && disjoint(follow.set, kid.set) && !getenv("GSCAN_VM_NO_POSSESSIFY")) mode = 2;
+                emit(V_REPSET | ((uint32_t)mode << 8), cls_id(kid.set), n.min, n.max);
                 break;
             }
             if (n.mode == 2) { // possessive: the greedy repeat matched on its own, never re-entered
                 const uint32_t b = emit(V_BAR_BEGIN | (0u << 8));
-                group_repeat(n, 0);
+                group_repeat(n, 0, unknown());
                 emit(V_BAR_END | (0u << 8));
                 if (ok) pg.ins[b].op |= here() << 16;
                 break;
             }
-            group_repeat(n, n.mode);
+            group_repeat(n, n.mode, follow);
             break;
         }
         case Node::ASSERT:
@@ -253,11 +297,11 @@ struct Builder {
             const uint32_t b = emit(V_BAR_BEGIN | (kind << 8));
             const Node &body = n.kids[0];
             if (!n.behind) {
-                gen(body);
+                gen(body, unknown());
             } else if (body.kind == Node::ALT) {
                 std::vector<const Node *> kids;
                 for (const Node &k : body.kids) kids.push_back(&k);
-                alternatives(kids, true);
+                alternatives(kids, true, unknown());
             } else {
                 behind_alt(body);
             }
@@ -268,7 +312,7 @@ struct Builder {
         }
         case Node::ATOMIC: {
             const uint32_t b = emit(V_BAR_BEGIN | (0u << 8));
-            gen(n.kids[0]);
+            gen(n.kids[0], unknown());
             emit(V_BAR_END | (0u << 8));
             if (ok) pg.ins[b].op |= here() << 16;
             break;
@@ -284,7 +328,7 @@ struct Builder {
             const Node *no = n.kids.size() > base + 1 ? &n.kids[base + 1] : nullptr;
             if (n.cond == Node::C_DEFINE) break;
             if (n.cond == Node::C_IN_RECURSION || n.cond == Node::C_IN_RECURSION_OF) {
-                if (no) gen(*no);
+                if (no) gen(*no, follow);
                 break;
             }
             if (n.cond == Node::C_GROUP && (!use_caps || n.group <= 0 || n.group > n_groups)) {
@@ -297,16 +341,16 @@ struct Builder {
                 } else {
                     Node look = n.kids[0];
                     if (!holds) look.neg = !look.neg;
-                    gen(look);
+                    gen(look, unknown());
                 }
             };
             const uint32_t split = emit(V_SPLIT, here() + 1, 0, 0xffffu | (0xffffu << 16));
             guard(true);
-            gen(*yes);
+            gen(*yes, follow);
             const uint32_t jump = emit(V_JMP, 0);
             if (ok) pg.ins[split].b = here();
             guard(false);
-            if (no) gen(*no);
+            if (no) gen(*no, follow);
             if (ok) pg.ins[jump].a = here();
             break;
         }
@@ -339,7 +383,7 @@ bool vm_compile(const Node &root, int n_groups, bool has_backref, VmProg &out)
     // set a capturing group" is part of the verdict -- the reference's ovector holds one pair, src/grab.cc:171,179)
     (void)has_backref;
     Builder b(out, n_groups, n_groups > 0);
-    b.gen(root);
+    b.gen(root, Builder::unknown());
     b.emit(V_MATCH);
     out.n_slots = b.next_slot;
     out.n_groups = n_groups > 0 ? (uint32_t)n_groups : 0u;

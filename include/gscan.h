@@ -365,8 +365,11 @@ int gscan_next_listed(const gscan_db *db, size_t clen, const uint32_t *starts, c
 #define GSCAN_END_CAPTURES 0xfffffffeu
 int gscan_next_resolved(const gscan_db *db, const void *content, size_t clen, const uint32_t *starts, const uint32_t *ends, size_t n,
                         gscan_cursor *cur, uint32_t s, uint32_t *m0, uint32_t *m1);
-/* the bytes a match can begin with: table[b] = 1 if b can; returns 1 if that is known (0: the pattern may begin without
- * consuming a byte -- an assertion, an optional item -- and every table entry is 1) */
+/* the bytes a match can begin with: table[b] & 1 if b can; returns 1 if that is known (0: the pattern may begin without
+ * consuming a byte -- an assertion, an optional item -- and bit 0 of every entry is set).  table[b] & 2 (reach == 1 only): b in
+ * front of an offset is to the pattern what the subject start is -- a non-word byte for \b \B, a newline for (?m)^, a byte
+ * outside a one-byte look-behind's class -- so with such a byte in front of the restart position the device's verdict AT the
+ * restart position is pcre_exec's too and gscan_next_resolved asks nobody. */
 int gscan_db_first(const gscan_db *db, uint8_t table[256]);
 /* the same for a chunk of several segments: the records of segment i are
  * starts[seg_first[i] .. seg_first[i+1]), segment-relative; seg_first has *nseg + 1 entries
