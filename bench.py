@@ -203,7 +203,7 @@ def live_traffic(patterns, gib, timeout_s=90):
                 return None
             per = {}
             for row in csv.DictReader(open(files[0])):
-                if "scan" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                if "_scan" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
                     per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
             # the sweep runs the patterns in order, each kernel twice (warm-up + 1): kernels appear in pattern order
             names = list(per)
@@ -215,6 +215,51 @@ def live_traffic(patterns, gib, timeout_s=90):
             out[p]["traffic_bytes"] = int(2 * out[p]["FETCH_SIZE_KiB"] * 1024 + out[p]["WRITE_SIZE_KiB"] * 1024)
         return out
     except Exception:  # (timeouts, a profiler that cannot attach: the committed profile is the fall-back)
+        return None
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
+def live_sq(patterns, gib=4, timeout_s=90):
+    """The SQ counters of the scan kernels, measured NOW: ONE rocprofv3 pass (--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
+    SQ_WAVE_CYCLES, counters only) over grab_amd/bin/gscan_sweep on a `gib` GiB arena of the same text, one launch per pattern
+    after a warm-up.  {pattern: {"valu_insts_per_byte", "valu_issue_frac", "kernel"}} -- wave-level VALU instructions per input
+    byte, and the fraction of the SIMDs' VALU issue slots taken: SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 4 waves per SIMD), both
+    in quad-cycles -- or None."""
+    import csv
+    import glob
+    import tempfile
+
+    sweep = os.path.join(os.path.dirname(bin_path()), "gscan_sweep")
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not (os.path.exists(sweep) and os.path.exists(rocprof)):
+        return None
+    ctrs = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES")
+    base = tempfile.mkdtemp(prefix="grab_sq_", dir="/tmp")
+    try:
+        argv = [rocprof, "--pmc"] + list(ctrs) + ["--output-format", "csv", "-d", base, "--", sweep, "--gib", str(gib), "--iters", "1", "--variants", "-1", "--bpc", "0"]
+        for p in patterns:
+            argv += ["--pattern", p]
+        r = subprocess.run(argv, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=timeout_s)
+        files = glob.glob(os.path.join(base, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None
+        per = {}
+        for row in csv.DictReader(open(files[0])):
+            if "_scan" in row["Kernel_Name"] and row["Counter_Name"] in ctrs:
+                per.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        names = list(per)
+        if len(names) != len(patterns):
+            return None
+        out = {}
+        for p, k in zip(patterns, names):
+            v = {c: sum(per[k].get(c, [0])) / max(1, len(per[k].get(c, [0]))) for c in ctrs}
+            if not v["SQ_WAVE_CYCLES"]:
+                return None
+            out[p] = {"kernel": k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-70:],
+                      "valu_insts_per_byte": v["SQ_INSTS_VALU"] / float(gib << 30), "valu_issue_frac": round(v["SQ_ACTIVE_INST_VALU"] / (v["SQ_WAVE_CYCLES"] / 4.0), 4)}
+        return out
+    except Exception:
         return None
     finally:
         shutil.rmtree(base, ignore_errors=True)
@@ -387,19 +432,15 @@ class ClockSampler:
         return out
 
 
-# The SQ counters of the three bench kernels (profiles/r04_w_sq_counters.txt: rocprofv3 --pmc passes over gscan_sweep, 4 GiB,
-# the kernels' code unchanged since): wave-level VALU instructions per input byte and the fraction of the SIMDs' VALU issue
-# slots taken (SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 4 waves per SIMD)).  With them a kernel time says what shader clock
-# the launch effectively ran at -- instructions / (time x 1024 SIMDs x issue fraction / 4 cycles per wave64 instruction) --
-# and how far that is from the part's 2.4 GHz: the table kernels draw the power cap, and their rate moves with the clock
-# the cap leaves them.
-SQ_PASS = {"cfg2": {"valu_insts_per_byte": 203661888 / (4 << 30), "valu_issue_frac": 0.669},
-           "cfg3": {"valu_insts_per_byte": 242272778 / (4 << 30), "valu_issue_frac": 0.722},
-           "alt": {"valu_insts_per_byte": 278997568 / (4 << 30), "valu_issue_frac": 0.895}}
+# With the SQ counters of a kernel -- wave-level VALU instructions per input byte, and the fraction of the SIMDs' VALU issue
+# slots taken (SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 4 waves per SIMD)) -- a kernel time says what shader clock the launch
+# effectively ran at: instructions / (time x 1024 SIMDs x issue fraction / 4 cycles per wave64 instruction).  The table kernels
+# draw the power cap, and their rate moves with the clock the cap leaves them.  The counters are taken in this run
+# (live_sq); without a profiler there are none, and no figure derived from them.
 SIMDS, MAX_SCLK_GHZ = 256 * 4, 2.4
 
 
-def roofline_block(config, nbytes, total, kern_ms, launches, live=None):
+def roofline_block(config, nbytes, total, kern_ms, launches, live=None, sq=None):
     alg_bytes = nbytes + REC_BYTES * total  # per launch: every input byte once + one u32 per candidate
     kern_avg_ms = kern_ms / max(launches, 1)
     achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
@@ -409,15 +450,16 @@ def roofline_block(config, nbytes, total, kern_ms, launches, live=None):
         source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this script over grab_amd/bin/gscan_sweep (same kernel %s, %d GiB arena, 2 x FETCH_SIZE + WRITE_SIZE)" % (rec["kernel"], nbytes >> 30)
     else:
         traffic, source = measured_traffic(config, nbytes)
-    sq = SQ_PASS.get(config)
     extra = {}
-    if sq:
-        clk = sq["valu_insts_per_byte"] * nbytes / (kern_avg_ms * 1e-3 * SIMDS * sq["valu_issue_frac"] / 4.0) / 1e9
-        extra = {"valu_issue_frac": sq["valu_issue_frac"], "valu_issue_source": "profiles/r04_w_sq_counters.txt (SQ_ACTIVE_INST_VALU over SQ_WAVE_CYCLES / 4)",
-                 "implied_sclk_ghz": round(clk, 3), "frac_of_clock_scaled_ceiling": round(min(1.0, clk / MAX_SCLK_GHZ), 4),
-                 "frac_at_max_sclk": round(achieved / HBM_PEAK_GBPS * MAX_SCLK_GHZ / clk, 4) if config != "cfg2" else None}
+    rec = sq.get(CONFIGS[config][0]) if sq else None
+    if rec:
+        clk = rec["valu_insts_per_byte"] * nbytes / (kern_avg_ms * 1e-3 * SIMDS * rec["valu_issue_frac"] / 4.0) / 1e9
+        extra = {"valu_issue_frac": rec["valu_issue_frac"], "valu_lane_ops_per_byte": round(rec["valu_insts_per_byte"] * 64, 2),
+                 "valu_issue_source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES pass run by this script over grab_amd/bin/gscan_sweep (same kernel %s, 4 GiB arena): SQ_ACTIVE_INST_VALU over SQ_WAVE_CYCLES / 4" % rec["kernel"],
+                 "implied_sclk_ghz": round(clk, 3)}
     return dict({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": source,
+                 "traffic_over_algorithmic": traffic and round(traffic / alg_bytes, 4),
                  "kernel_ms": round(kern_avg_ms, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(alg_bytes)}, **extra)
 
 
@@ -781,6 +823,81 @@ def e2e_cfg3(d, nfiles, file_bytes, n_gpus, want_cpu):
         shutil.rmtree(d1, ignore_errors=True)
 
 
+# VERDICT r5's table: ordinary patterns for which rounds 1-5 left "is this offset a match, and where does it end" to the host's
+# backtracking matcher, candidate by candidate (17 MB/s per worker for the first of them).  Since round 6 the device's resolve
+# pass settles them (k_resolve) and the host's loop is two array reads per printed match.
+DENSE_PATTERNS = [r"\b[A-Za-z_]\w*\s*\(", r"(?<=\$)\d+", r"\s\w{8,}\s", r"\b[A-Z][a-z]+\b", r"\([^()]*\)", r"\b[a-z]{3,}\b"]
+
+
+def e2e_dense(d, nfiles, file_bytes, n_gpus, want_cpu):
+    """`grab -n W -r -O -l PATTERN` over the first 16 GiB of the cfg2 corpus for each of DENSE_PATTERNS: wall clock (output to
+    /dev/null), every output line against the reference's by count + order-independent digest at the same
+    16 GiB, and the reference timed on all host cores over a 4 GiB sample of the same files."""
+    n16 = min(nfiles, (16 << 30) // file_bytes)
+    n4 = min(n16, max(1, (4 << 30) // file_bytes))
+    d16, d4 = d + "_dense", d + "_densec"
+    ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
+    out = {"bytes": n16 * file_bytes, "flags": "-O -l", "patterns": {}}
+    try:
+        link_subset(d, d16, n16)
+        link_subset(d, d4, n4)
+        worst_rate = worst_ratio = None
+        for k, pat in enumerate(DENSE_PATTERNS):
+            e = e2e_measure(d16, n16, file_bytes, pat, ["-O", "-l"], n_gpus, None, reps=2, detached=False, count_only=True, warm=True, back_to_back=False)
+            row = {kk: e.get(kk) for kk in ("value", "wall_s", "scan_phase_GBps", "lines", "digest", "matches_per_s", "workers", "error") if kk in e}
+            if os.path.exists(ref) and "value" in e:
+                n_ref, dg_ref, ref_s = line_digest([ref, "-n", str(min(64, usable_cores())), "-r", "-O", "-l", pat, d16])
+                row.update({"reference_lines": n_ref, "same_as_reference": dg_ref is not None and e.get("digest") == dg_ref and e.get("lines") == n_ref,
+                            "reference_through_the_digest_s": ref_s and round(ref_s, 1)})
+            if want_cpu and "value" in e:
+                cb = cpu_baseline(d4, n4, file_bytes, pat, ["-O", "-l"], threads=[usable_cores()], reps=1, warm=k == 0, count_only=True)
+                if cb:
+                    row["cpu_baseline"] = {kk: cb.get(kk) for kk in ("value", "unit", "cores", "kind", "sample", "wall_s")}
+                    row["vs_cpu_baseline"] = round(e["value"] / cb["value"], 2)
+                    worst_ratio = row["vs_cpu_baseline"] if worst_ratio is None else min(worst_ratio, row["vs_cpu_baseline"])
+            if "value" in e:
+                worst_rate = e["value"] if worst_rate is None else min(worst_rate, e["value"])
+            out["patterns"][pat] = row
+        out["worst_GBps"] = worst_rate
+        out["worst_vs_cpu_baseline"] = worst_ratio
+        out["all_same_as_reference"] = all(r.get("same_as_reference") for r in out["patterns"].values()) if os.path.exists(ref) else None
+        return out
+    finally:
+        shutil.rmtree(d16, ignore_errors=True)
+        shutil.rmtree(d4, ignore_errors=True)
+
+
+def e2e_cfg3_lines(d, nfiles, file_bytes, n_gpus, want_cpu):
+    """The line-printing modes of BASELINE configs[2]'s pattern (SURVEY.md A.4's third known answer, at scale): `grab -n W -r -O
+    IDENT` (offset + line) and `grab -n W -r IDENT` (lines) over the first 16 GiB: wall clock to /dev/null, every output line
+    against the reference's (count + digest)."""
+    ident = synth.IDENT_RE
+    n16 = min(nfiles, (16 << 30) // file_bytes)
+    n4 = min(n16, max(1, (4 << 30) // file_bytes))
+    d16, d4 = d + "_lines", d + "_linesc"
+    ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
+    out = {"bytes": n16 * file_bytes}
+    try:
+        link_subset(d, d16, n16)
+        link_subset(d, d4, n4)
+        for k, (name, flags) in enumerate((("-O", ["-O"]), ("lines only", []))):
+            e = e2e_measure(d16, n16, file_bytes, ident, flags, n_gpus, None, reps=2, detached=False, count_only=True, warm=True, back_to_back=False)
+            row = {kk: e.get(kk) for kk in ("value", "wall_s", "scan_phase_GBps", "lines", "digest", "workers", "error") if kk in e}
+            if os.path.exists(ref) and "value" in e:
+                n_ref, dg_ref, ref_s = line_digest([ref, "-n", str(min(64, usable_cores())), "-r"] + flags + [ident, d16])
+                row.update({"reference_lines": n_ref, "same_as_reference": dg_ref is not None and e.get("digest") == dg_ref and e.get("lines") == n_ref})
+            if want_cpu and "value" in e:
+                cb = cpu_baseline(d4, n4, file_bytes, ident, flags, threads=[usable_cores()], reps=1, warm=k == 0, count_only=True)
+                if cb:
+                    row["cpu_baseline"] = {kk: cb.get(kk) for kk in ("value", "unit", "cores", "kind", "sample", "wall_s")}
+                    row["vs_cpu_baseline"] = round(e["value"] / cb["value"], 2)
+            out[name] = row
+        return out
+    finally:
+        shutil.rmtree(d16, ignore_errors=True)
+        shutil.rmtree(d4, ignore_errors=True)
+
+
 def e2e_cfg4(base, gib, n_gpus, want_cpu):
     """BASELINE configs[3] at `gib` GiB (64: the size it is quoted on -- 131 072 files of 512 KiB in a 64 x 64 x 32 tree, one
     needle per file; scripts/fullsize_parity.py gen_files is the generator): `grab -n W -r -O -l` -- the parallel walk, the
@@ -938,7 +1055,7 @@ def e2e_phase(a, line, world, arena=None):
                 e["same_as_reference"] = e.get("digest") is not None and e.get("digest") == e["reference_digest"]
         # the N = 8 model's terms that one GPU can measure: the fixed cost with eight device indices
         # through one runtime, the host's copy ceiling with the DMA stubbed out
-        if world == 1 and not a.no_e2e_extra:
+        if world == 1 and not a.no_e2e_extra and a.n8_model:
             try:
                 sys.path.insert(0, os.path.join(ROOT, "scripts"))
                 import n8_model
@@ -956,6 +1073,8 @@ def e2e_phase(a, line, world, arena=None):
                 shutil.rmtree(d, ignore_errors=True)
 
             for key, fn in (("e2e_cfg3", lambda: e2e_cfg3(d, nfiles, file_bytes, world, want_cpu)),
+                            ("e2e_cfg3_lines", lambda: e2e_cfg3_lines(d, nfiles, file_bytes, world, want_cpu)),
+                            ("e2e_dense", lambda: e2e_dense(d, nfiles, file_bytes, world, want_cpu)),
                             ("e2e_cfg1", lambda: (drop_corpus(), e2e_cfg1(base, want_cpu))[1]),
                             ("e2e_cfg5", lambda: e2e_cfg5(base, 32 if full else min(8, max(2, use >> 33)), want_cpu)),
                             ("e2e_cfg4", lambda: e2e_cfg4(base, 64 if full else min(16, max(2, use >> 32)), world, want_cpu))):
@@ -966,6 +1085,21 @@ def e2e_phase(a, line, world, arena=None):
     except Exception as ex:  # (the kernel line is the contract: whatever goes wrong out here must not lose it)
         line.setdefault("e2e", {})["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
     finally:
+        # the end-to-end figures side by side INSIDE `roofline` as well (the driver's record keeps that object whole)
+        try:
+            def gbps(key, sub=None):
+                blk = line.get(key) or {}
+                blk = blk.get(sub, {}) if sub else blk
+                return blk.get("value") if isinstance(blk, dict) else None
+            dense = line.get("e2e_dense") or {}
+            line.setdefault("roofline", {})["e2e_summary"] = {
+                "unit": "GB/s, wall clock of one `grab` process, page cache warm; cfg3 / lines / dense: output to /dev/null (SURVEY.md 8d)",
+                "cfg2": gbps("e2e"), "cfg3": gbps("e2e_cfg3"), "cfg1_s": (line.get("e2e_cfg1") or {}).get("wall_s"), "cfg4": gbps("e2e_cfg4"), "cfg5": gbps("e2e_cfg5"),
+                "cfg3_with_lines_-O": gbps("e2e_cfg3_lines", "-O"), "cfg3_lines_only": gbps("e2e_cfg3_lines", "lines only"),
+                "dense_worst_GBps": dense.get("worst_GBps"), "dense_worst_vs_cpu_baseline": dense.get("worst_vs_cpu_baseline"),
+                "dense_all_same_as_reference": dense.get("all_same_as_reference")}
+        except Exception:
+            pass
         shutil.rmtree(d, ignore_errors=True)
         shutil.rmtree(d + "_cfg3", ignore_errors=True)
         shutil.rmtree(d + "_cfg3s", ignore_errors=True)
@@ -1015,6 +1149,7 @@ def main():
     ap.add_argument("--no-kernels", action="store_true", help="skip the other two kernels' roofline blocks")
     ap.add_argument("--no-e2e-extra", action="store_true", help="skip the e2e_cfg3 / e2e_cfg4 / e2e_cfg5 blocks")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of rocprofv3 passes in this run")
+    ap.add_argument("--n8-model", action="store_true", help="also measure the terms of the N = 8 forecast (DESIGN.md 6; scripts/n8_model.py): rounds 4-5 ran it by default, nothing more can be learned from it on one GPU")
     ap.add_argument("--e2e-gib", type=int, default=64, help="corpus written to /dev/shm for the end-to-end block")
     ap.add_argument("--phase", default=None, choices=["kernels"], help="(internal) the kernel blocks only, as the child of the one-GPU run's orchestrating process")
     ap.add_argument("--in-process", action="store_true", help="one-GPU run: kernel blocks and end-to-end blocks in ONE process, as rounds 1-4 ran them (the e2e children then run beside this process's GPU context)")
@@ -1119,9 +1254,10 @@ def main():
 
     # HBM traffic per launch, measured in this run (rank 0 of a one-GPU run; the PMC passes run the native harness next to
     # this process: same kernels, an arena of the same size)
-    live = None
+    live = sq = None
     if rank == 0 and world == 1 and not a.no_live_traffic:
         live = live_traffic([CONFIGS[k][0] for k in sorted(CONFIGS)], max(1, nbytes >> 30))
+        sq = live_sq([CONFIGS[k][0] for k in sorted(CONFIGS)])
 
     line = None
     if rank == 0:
@@ -1141,7 +1277,7 @@ def main():
             "matches_per_step": int(matches_all),
             "matches_per_s": round(matches_all / (elapsed / a.steps), 1),
             "check": check,
-            "roofline": roofline_block(a.config, nbytes, total, kern_ms, launches, live),
+            "roofline": roofline_block(a.config, nbytes, total, kern_ms, launches, live, sq),
             "clocks": clk_run,
         }
 
@@ -1162,7 +1298,7 @@ def main():
             for name in names:
                 pat2, cap2 = CONFIGS[name]
                 wall, tot2, ovf2, kms2, nl2, res2, clk2 = time_kernel(ctx, dbs[name], arena, segs, stream, nbytes, cap2, steps2, 1, device)
-                blk = roofline_block(name, nbytes, tot2, kms2, nl2, live)
+                blk = roofline_block(name, nbytes, tot2, kms2, nl2, live, sq)
                 blk.update({"records_per_launch": int(tot2), "overflow": bool(ovf2), "value": round(nbytes / (wall / steps2) / 1e9, 2), "clocks": clk2})
                 passes[name].append(blk)
                 if k == 0:
@@ -1183,6 +1319,17 @@ def main():
             others[name] = blk
         if rank == 0:
             line["kernels"] = others
+            # ... and the three kernels side by side INSIDE `roofline` (the driver's record keeps that object whole): each one's
+            # median fraction of the HBM roofline, what the counters say it read and wrote over what the algorithm needs, the
+            # share of VALU issue slots taken, and whether its timed launch's records passed the check -- all of THIS run
+            def brief(blk):
+                return {"frac": blk["frac"], "kernel_ms": blk["kernel_ms"], "traffic_over_algorithmic": blk.get("traffic_over_algorithmic"),
+                        "valu_issue_frac": blk.get("valu_issue_frac"), "frac_min": blk.get("frac_min"), "frac_max": blk.get("frac_max")}
+            ks = {a.config: brief(line["roofline"])}
+            for name in names:
+                ks[name] = brief(others[name])
+            ks["check"] = "ok" if line["check"] == "ok" and all(others[n]["check"] == "ok" for n in names) else "FAILED"
+            line["roofline"]["kernels"] = ks
     ctx.close()
 
     # end to end on the same corpus: rank 0 writes it out and drives `grab` over the first `world` devices while the other

@@ -1209,21 +1209,41 @@ __global__ __launch_bounds__(64) void k_ends(ScanArgs a, const TileDesc *__restr
 // (gscan_next_resolved).
 // ------------------------------------------------------------------------------------
 constexpr uint32_t kResolveWG = 256;   // threads per descriptor: four waves run the VM side by side, then compact the run together
+constexpr uint32_t kResolveChunkMax = 1024;  // descriptors one workgroup looks after, at most
 constexpr uint32_t kResolveDrop = 0xffffffffu; // (in ends[], between the two phases: no match starts at this record)
-__global__ __launch_bounds__(kResolveWG) void k_resolve(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t *__restrict__ ends)
+// chunk: descriptors per workgroup (<= kResolveChunkMax).  1 for a window of the host-chunk path (a few thousand descriptors, many of them
+// with hundreds of records: one workgroup each); more for an arena of millions of descriptors nearly all of which are empty
+// (the device-resident path over 64 GiB: 5.6 M) -- the workgroup fetches its descriptors' counts with one coalesced load and
+// leaves at once if none has a record, instead of a workgroup launch per empty descriptor.
+__global__ __launch_bounds__(kResolveWG) void k_resolve(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t *__restrict__ ends, uint32_t chunk)
 {
-    const uint32_t st = blockIdx.x;
-    const unsigned long long d = a.desc[st];
-    const uint32_t cnt = (uint32_t)d;
-    if (cnt == 0 || a.counter[kShards * kCtrStride] != 0) return; // (overflow: the host rescans with a bigger buffer and this pass runs again)
     __shared__ __attribute__((aligned(16))) uint32_t s_vm[sizeof(VmProg) / 4];
     __shared__ uint32_t s_cnt[kResolveWG / 64];
+    __shared__ unsigned long long s_busy[kResolveChunkMax / 64]; // bit k of word j: descriptor st0 + 64 j + k has records
+    const uint32_t n_desc = a.n_tiles * nw, st0 = blockIdx.x * chunk;
+    const bool overflow = a.counter[kShards * kCtrStride] != 0; // (the host rescans with a bigger buffer and this pass runs again)
+    for (uint32_t j = threadIdx.x >> 6; j < kResolveChunkMax / 64; j += kResolveWG / 64) {
+        const uint32_t k = 64u * j + (threadIdx.x & 63u), stq = st0 + k;
+        const bool any = !overflow && k < chunk && stq < n_desc && (uint32_t)a.desc[stq] != 0u;
+        const unsigned long long m = __ballot(any);
+        if ((threadIdx.x & 63u) == 0) s_busy[j] = m;
+    }
+    __syncthreads();
+    bool some = false;
+#pragma unroll
+    for (uint32_t j = 0; j < kResolveChunkMax / 64; j++) some = some || s_busy[j] != 0ull;
+    if (!some) return;
     {
         const uint32_t *vsrc = reinterpret_cast<const uint32_t *>(&a.prog->vm);
         for (uint32_t q = threadIdx.x; q < (uint32_t)(sizeof(VmProg) / 4); q += kResolveWG) s_vm[q] = vsrc[q];
     }
     __syncthreads();
     const VmProg *vm = reinterpret_cast<const VmProg *>(s_vm);
+    for (uint32_t j = 0; j < kResolveChunkMax / 64; j++)
+    for (unsigned long long busy = s_busy[j]; busy; busy &= busy - 1ull) {
+    const uint32_t st = st0 + 64u * j + (uint32_t)(__ffsll((long long)busy) - 1);
+    const unsigned long long d = a.desc[st];
+    const uint32_t cnt = (uint32_t)d;
     const uint32_t base = (uint32_t)(d >> 32);
     const uint32_t t = st / nw;
     const uint8_t *seg = a.base + (tiles ? tiles[t].seg_off : a.seg0_off);
@@ -1276,6 +1296,8 @@ __global__ __launch_bounds__(kResolveWG) void k_resolve(ScanArgs a, const TileDe
         a.desc[st] = (d & 0xffffffff00000000ull) | out;
         atomicAdd(a.counter + kShards * kCtrStride + 1, cnt - out);
     }
+    __syncthreads();
+    } // (the next descriptor of this workgroup's chunk)
 }
 
 // ------------------------------------------------------------------------------------
@@ -1548,7 +1570,9 @@ hipError_t launch_order(const ScanArgs &a, uint32_t nw, const uint32_t *ext, uin
 hipError_t launch_resolve(const ScanArgs &a, uint32_t nw, uint32_t *ends, hipStream_t st)
 {
     if (a.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_resolve, dim3(a.n_tiles * nw), dim3(kResolveWG), 0, st, a, a.tiles, nw, ends);
+    const uint32_t n_desc = a.n_tiles * nw;
+    const uint32_t chunk = std::max(1u, std::min(kResolveChunkMax, n_desc / 8192u));
+    hipLaunchKernelGGL(k_resolve, dim3((n_desc + chunk - 1) / chunk), dim3(kResolveWG), 0, st, a, a.tiles, nw, ends, chunk);
     return hipGetLastError();
 }
 

@@ -2629,7 +2629,11 @@ static vm_first_t vm_first_bytes(const Node &n)
         if (n.min == 0) f.nullable = true;
         break;
     case Node::ATOMIC: f = vm_first_bytes(n.kids[0]); break;
-    default: // assertions consume nothing; what a reference repeats, a condition picks or a call matches is not known here
+    case Node::ASSERT:
+    case Node::LOOK: // consume nothing: what stands behind them decides
+        f.nullable = true;
+        break;
+    default: // what a reference repeats, a condition picks or a call matches is not known here
         f.set.negate();
         f.nullable = true;
         break;
@@ -3017,7 +3021,18 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         bool want = hitw.can_hit && db.vm_ok && !simple && !has_keep(*db.tree) && db.reach <= 255u && !getenv("GSCAN_NO_RESOLVE");
         if (want && make_windows(true, startw) != 0) want = false;
         if (want && (startw.w.empty() || startw.total > (size_t)kAltWindowBytes)) want = false;
-        if (want && !(startw.density <= 0.35 || startw.density <= 4.0 * hitw.density)) want = false;
+        const double dmax = getenv("GSCAN_RESOLVE_MAX_DENSITY") ? atof(getenv("GSCAN_RESOLVE_MAX_DENSITY")) : 0.35;
+        if (want && !(startw.density <= dmax || startw.density <= 4.0 * hitw.density)) want = false;
+        // Start windows that list a large part of the text, of a pattern without a gapped alternative that K3 can confirm in its
+        // own cold path (the two-byte table in front of the VM drops most hits before they become records: (\w)\1{3,}x|foobardoes(?=not),
+        // three offsets in four are hits, 125 matches per 8 GiB): that path stays -- 0.58 s against 0.90 s for 8 GiB,
+        // profiles/r06_e_density_ab.txt.  (With a gapped alternative the same path walks every run back from every hit and the
+        // host matcher follows: \w+(?=\() took 15.6 s there against 1.8 s through the resolve pass.)
+        if (want && startw.density > dmax && !db.exact && !hitw.pre && vm_independent_of_subject_start(*db.tree)) {
+            bool gapped = false;
+            for (const AltSeq &a : db.alts) gapped = gapped || a.gapped;
+            if (!gapped) want = false;
+        }
         db.resolve = want;
     }
     const Windows &win = db.resolve ? startw : hitw;

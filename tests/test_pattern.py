@@ -62,7 +62,7 @@ SUPPORTED = [
     (r"\Afoo", engine.TIER_ANCHORED, 3),
     (r"foo\z", engine.TIER_ANCHORED, 3),
     (r"foo\Z", engine.TIER_ANCHORED, 3),
-    ("^foo|bar", engine.TIER_BUCKET, 3),
+    ("^foo|bar", engine.TIER_LITERAL, 3),     # (start windows: ^foo can only sit at a restart position -- the host's test there finds it; the kernels look for bar)
     (r"\b\w+\b", engine.TIER_CLASSRUN, 1),
     (r"\b[a-z.]o", engine.TIER_BUCKET, 2),   # mixed first class: split into its word / non-word parts
     (r"\bfoo\w*\b", engine.TIER_LITERAL, 3),
@@ -70,10 +70,11 @@ SUPPORTED = [
     (r"a\b b", engine.TIER_LITERAL, 3),       # decided on the spot: always true
     # one unbounded repeat in the middle ("gapped"): the kernels look for one repeat byte + the rest.  Two alternatives (with
     # the repeat in front of the window and without) -- over ONE device window where the repeat leads: K1's or K2's then
-    ("a+b", engine.TIER_LITERAL, 2),
-    (r"\d+\.\d+", engine.TIER_CLASSRUN, 3),
+    # (round 6: such patterns go through the resolve pass and are scanned for by their START windows -- aa | ab, \d\d | \d\.\d)
+    ("a+b", engine.TIER_BUCKET, 2),
+    (r"\d+\.\d+", engine.TIER_BUCKET, 3),
     ("foo.*bar", engine.TIER_BUCKET, 6),
-    (r"[a-z]+\b", engine.TIER_CLASSRUN, 1),
+    (r"[a-z]+\b", engine.TIER_BUCKET, 1),
     ("a*b", engine.TIER_BUCKET, 1),
     ("a{2,}b", engine.TIER_BUCKET, 3),
     ("fo.*$", engine.TIER_ANCHORED, 2),

@@ -6,6 +6,7 @@ the offset itself (look-behind, \\b and ^ see the difference); how often the VM 
 that keeps everything would be sound and useless.  Then the whole host side of the new contract: the list "every device
 hit the VM keeps" fed to the reference's loop prints what libpcre prints."""
 import ctypes as C
+import os
 import random
 
 import numpy as np
@@ -88,10 +89,15 @@ def test_prefix_probe_is_one_sided(seed, built):
     checked = said_no = tables = 0
     pats = TARGETS if seed == 61 else [gen(rng, BIN_ATOMS if seed == 63 else ATOMS) for _ in range(400)]
     for pat in pats:
+        # (the table belongs to K3's VM form, which since round 6 only the patterns outside the resolve pass use: compiled with that
+        # pass switched off, every inexact pattern that never looks behind gets one, as in rounds 2-5)
+        os.environ["GSCAN_NO_RESOLVE"] = "1"
         try:
             db = engine.Database(pat)
         except ValueError:
             continue
+        finally:
+            del os.environ["GSCAN_NO_RESOLVE"]
         if db.minlen < 0:
             continue
         # (the probe reads nothing in front of the prefix: only patterns the device may judge by offset alone get a table)
