@@ -49,6 +49,7 @@
 #include <vector>
 
 #include "scan_args.h"
+#include "../../include/gscan_test.h"
 
 
 namespace gscan {
@@ -326,7 +327,10 @@ public:
                 i->refs_++;
                 return i;
             }
-        all().push_back(new Ingest(device));
+        all().push_back(new Ingest(device, (int)all().size() + 1));
+        // the host's page cache feeds every pool of the process: with one more device being driven, the pools that are there
+        // already may have to make do with fewer active readers (gscan_auto_readers: 24 in all)
+        for (Ingest *i : all()) i->relimit((int)all().size());
         return all().back();
     }
     static void release(Ingest *g)
@@ -335,6 +339,7 @@ public:
             std::lock_guard<std::mutex> lk(gm());
             if (--g->refs_ > 0) return;
             all().erase(std::find(all().begin(), all().end(), g));
+            for (Ingest *i : all()) i->relimit((int)all().size());
         }
         delete g;
     }
@@ -362,7 +367,7 @@ public:
         std::lock_guard<std::mutex> lk(m_);
         if (!started_) {
             started_ = true;
-            for (int i = 0; i < readers_; i++) threads_.emplace_back([this] { reader_main(); });
+            for (int i = 0; i < readers_; i++) threads_.emplace_back([this, i] { reader_main(i); });
         }
         tasks_.insert(tasks_.end(), t, t + n);
         if (n == 1) cv_tasks_.notify_one();
@@ -419,7 +424,9 @@ private:
         return v;
     }
 
-    explicit Ingest(int device) : device_(device)
+    // driven: devices this process drives by now, this one included -- NOT the devices that are visible: a serial `grab -r`, or a
+    // Python caller with one context, on an eight-GPU node drives one and gets the one-device reader count
+    Ingest(int device, int driven) : device_(device)
     {
         readers_ = ingest_cfg().readers;
         // Where the readers run: on the CPUs of the device's NUMA node (the pinned blocks are first touched by them, and the
@@ -456,8 +463,11 @@ private:
             }
             int cpus = numa_cpus_;
             if (cpus <= 0) cpus = have_mask_ ? CPU_COUNT(&mask_) : (int)std::thread::hardware_concurrency();
-            readers_ = gscan_auto_readers(cpus, std::max(1, sharing), std::max(1, ndev > 0 ? ndev : device_count()));
+            auto_cpus_ = cpus;
+            auto_sharing_ = std::max(1, sharing);
+            readers_ = gscan_auto_readers(cpus, auto_sharing_, std::max(1, driven));
         }
+        limit_.store(readers_, std::memory_order_relaxed);
         cap_ = ingest_cfg().pool_cap > 0 ? (size_t)ingest_cfg().pool_cap : (size_t)readers_ * 2;
         // (The first host -> device transfer of a process costs the runtime 8 - 25 ms of set-up inside the call that asks for
         // it.  A helper thread making it -- 64 bytes -- while the opener creates the device's stream was tried: SLOWER, one
@@ -480,6 +490,16 @@ private:
         for (PinBlock *b : slot_free_) free_block(b, false);
         for (hipStream_t st : shared_)
             if (st) (void)hipStreamDestroy(st);
+    }
+    // (under gm()) the process drives `driven` devices now: reader i of this pool takes tasks while i < limit_
+    void relimit(int driven)
+    {
+        if (auto_cpus_ <= 0) return; // (GSCAN_READERS: the caller's count stands)
+        const int want = std::min(readers_, gscan_auto_readers(auto_cpus_, auto_sharing_, std::max(1, driven)));
+        if (limit_.exchange(want, std::memory_order_relaxed) != want) {
+            std::lock_guard<std::mutex> lk(m_);
+            cv_tasks_.notify_all();
+        }
     }
     void free_block(PinBlock *b, bool wait)
     {
@@ -650,7 +670,7 @@ private:
         cv_blocks_.notify_one();
     }
 
-    void reader_main()
+    void reader_main(int index)
     {
         if (have_mask_) (void)pthread_setaffinity_np(pthread_self(), sizeof mask_, &mask_);
         (void)hipSetDevice(hip_device_of(device_));
@@ -660,8 +680,8 @@ private:
             double t0 = g_timing ? now() : 0;
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_tasks_.wait(lk, [&] { return !tasks_.empty() || stop_; });
-                if (tasks_.empty()) return; // stop_: every context on the device is closed, nothing can be queued any more
+                cv_tasks_.wait(lk, [&] { return (!tasks_.empty() && index < limit_.load(std::memory_order_relaxed)) || stop_; });
+                if (stop_ && (tasks_.empty() || index >= limit_.load(std::memory_order_relaxed))) return; // every context on the device is closed, nothing can be queued any more
                 t = tasks_.front();
                 tasks_.pop_front();
             }
@@ -781,6 +801,8 @@ private:
     int device_;
     int refs_ = 1;
     int readers_ = 8;
+    std::atomic<int> limit_{8}; // readers that take tasks: readers_, fewer once the process drives more devices (relimit)
+    int auto_cpus_ = 0, auto_sharing_ = 1; // what the automatic count was worked out from (0: the count was given)
     int numa_cpus_ = 0; // CPUs of the device's NUMA node the readers are bound to (0: not bound by NUMA)
     cpu_set_t mask_;
     bool have_mask_ = false;
@@ -861,7 +883,6 @@ struct Slot {
     // the text of the printed lines, gathered by k_lines ("line_extents"): device buffer, pinned copy of the used part
     uint8_t *d_gather = nullptr;
     size_t gather_cap = 0;
-    bool gather_in_text = false; // d_gather is the second half of the d_text allocation (contexts that had "line_extents" on when the slot was sized)
     size_t gather_bytes = 0;
     bool gather_ok = false;
     const void *ext = nullptr;  // caller's buffer this chunk was copied from (gscan_wait hands it back as *content)
@@ -1039,26 +1060,18 @@ int slot_reserve_pinned(gscan_ctx *c, Slot &s, size_t len)
 
 int slot_reserve_device(gscan_ctx *c, Slot &s, size_t len)
 {
-    if (len > s.d_text_cap || (c->line_extents && !s.gather_in_text)) {
-        const size_t had = s.d_text_cap; // (a slot that is only re-made for the gather half keeps the size it had)
+    if (len > s.d_text_cap) {
         if (s.d_text) hipFree(s.d_text);
-        if (s.d_gather && !s.gather_in_text) hipFree(s.d_gather);
         s.d_text = nullptr;
-        s.d_gather = nullptr;
-        s.d_text_cap = s.gather_cap = 0;
-        s.gather_in_text = false;
-        size_t cap = std::max<size_t>((std::max(len, had) + kPad + 0xfffff) & ~(size_t)0xfffff, 1u << 20);
-        // with the line pass on, the window's gather buffer (the printed lines never overlap: their text fits the window) comes
-        // out of the same allocation: hipMalloc is not cheap and every slot of every context would make a second one
-        trace("slot: text buffer, %zu MiB ...", (c->line_extents ? 2 * cap : cap) >> 20);
-        HIPCHK(c, hipMalloc((void **)&s.d_text, c->line_extents ? 2 * cap : cap));
+        s.d_text_cap = 0;
+        size_t cap = std::max<size_t>((len + kPad + 0xfffff) & ~(size_t)0xfffff, 1u << 20);
+        // (the line pass's gather buffer -- as big again: the printed lines never overlap, their text fits the window -- is NOT
+        // made here: round 3 took both out of one allocation, and a file that prints nothing paid for 514 MiB where it needed
+        // 257, 15 ms of BASELINE configs[0]'s 100.  slot_launch makes it once this context's windows have had records.)
+        trace("slot: text buffer, %zu MiB ...", cap >> 20);
+        HIPCHK(c, hipMalloc((void **)&s.d_text, cap));
         trace("slot: ... allocated");
         s.d_text_cap = cap - kPad;
-        if (c->line_extents) {
-            s.d_gather = s.d_text + cap;
-            s.gather_cap = std::min<size_t>(cap, 0xfffffff0u);
-            s.gather_in_text = true;
-        }
     }
     // descriptors: one per wave sub-tile, at the smallest sub-tile any variant uses (+ the padding of a last, partial tile)
     size_t tiles = len / gscan::kMinSubTileBytes + 2 * gscan::kMaxWavesPerTile;
@@ -1194,16 +1207,19 @@ int slot_launch(gscan_ctx *c, Slot &s)
         if (!s.h_ext_spec) HIPCHK(c, hipHostMalloc((void **)&s.h_ext_spec, kSpecRecs * 16, hipHostMallocDefault));
         if (s.ext_words == 4) {
             // the printed lines never overlap (the loop restarts at the end of the line it printed): their text fits the window
+            // ... once this context's windows have had records to print (hint_total: what its last chunks produced): until then
+            // the pass runs without a gather buffer -- every printed line is marked "take the text from the chunk" -- which is what a
+            // window without records costs nothing and the first windows of a dense output a few page faults
             const size_t want = std::min<size_t>(std::max<size_t>(s.len, 1u << 20), 0xfffffff0u);
-            if (s.gather_cap < want) { // (a slot sized before the option was switched on)
-                if (s.d_gather && !s.gather_in_text) hipFree(s.d_gather);
-                s.gather_in_text = false;
+            if (s.gather_cap < want && c->hint_total.load(std::memory_order_relaxed) > 0) {
+                if (s.d_gather) hipFree(s.d_gather);
                 s.d_gather = nullptr;
                 s.gather_cap = 0;
-                HIPCHK(c, hipMalloc((void **)&s.d_gather, want));
-                s.gather_cap = want;
+                HIPCHK(c, hipMalloc((void **)&s.d_gather, want + want / 4));
+                s.gather_cap = std::min<size_t>(want + want / 4, 0xfffffff0u);
             }
-            HIPCHK(c, gscan::launch_lines(a, nw, tile_bytes / nw, s.d_ext, s.d_gather, (uint32_t)s.gather_cap, c->compute));
+            const bool have_gather = s.gather_cap >= want;
+            HIPCHK(c, gscan::launch_lines(a, nw, tile_bytes / nw, s.d_ext, have_gather ? s.d_gather : nullptr, have_gather ? (uint32_t)s.gather_cap : 0u, c->compute));
         } else if (s.resolved) {
             HIPCHK(c, gscan::launch_resolve(a, nw, s.d_ext, c->compute));
         } else {
@@ -1257,7 +1273,7 @@ int slot_launch(gscan_ctx *c, Slot &s)
             HIPCHK(c, hipMemcpyAsync(s.h_spec, s.d_sorted, s.spec_n * 4, hipMemcpyDeviceToHost, c->compute));
             if (s.has_ext) HIPCHK(c, hipMemcpyAsync(s.h_ext_spec, s.d_sorted + s.rec_cap, s.spec_n * 4 * s.ext_words, hipMemcpyDeviceToHost, c->compute));
         }
-        if (s.ext_words == 4 && hint_g) { // ... and of the gathered line text
+        if (s.ext_words == 4 && hint_g && s.gather_cap) { // ... and of the gathered line text
             const size_t gw = std::min<size_t>(std::min<size_t>(s.gather_cap, kGatherPinnedMax), hint_g + hint_g / 4);
             if (gw > s.gspec_cap) {
                 if (s.h_gspec) hipHostFree(s.h_gspec);
@@ -1293,7 +1309,7 @@ void free_slot(gscan_ctx *c, Slot &s)
     if (s.d_dpos) hipFree(s.d_dpos);
     if (s.h_big) hipHostFree(s.h_big);
     if (s.h_gspec) hipHostFree(s.h_gspec);
-    if (s.d_gather && !s.gather_in_text) hipFree(s.d_gather);
+    if (s.d_gather) hipFree(s.d_gather);
     if (s.pinned) hipHostFree(s.pinned);
     if (s.d_text) hipFree(s.d_text);
     if (s.d_recs) hipFree(s.d_recs);
@@ -1545,7 +1561,7 @@ const char *gscan_strerror(const gscan_ctx *c) { return c ? c->err.c_str() : "no
 
 namespace {
 // the slot's pinned buffer for `len` bytes: a block of the process-wide pool when it fits, else the slot's own allocation
-int slot_pinned_for(gscan_ctx *c, Slot &s, size_t len, void **out)
+static int slot_pinned_for(gscan_ctx *c, Slot &s, size_t len, void **out)
 {
     if (len <= block_bytes()) {
         if (!s.blk) s.blk = c->ingest->take_slot_block();
@@ -1558,7 +1574,7 @@ int slot_pinned_for(gscan_ctx *c, Slot &s, size_t len, void **out)
     *out = s.pinned;
     return 0;
 }
-bool slot_owns(const Slot &s, const void *p) { return p && (p == s.pinned || (s.blk && p == s.blk->p)); }
+static bool slot_owns(const Slot &s, const void *p) { return p && (p == s.pinned || (s.blk && p == s.blk->p)); }
 } // namespace
 
 int gscan_acquire(gscan_ctx *c, size_t len, void **pinned)
@@ -1587,7 +1603,7 @@ struct AheadSrc {
     off_t off;
     size_t n;
 };
-int prefault_start(size_t plain, const std::vector<AheadSrc> &ahead_src)
+static int prefault_start(size_t plain, const std::vector<AheadSrc> &ahead_src)
 {
     if (g_prefault.base || plain + ahead_src.size() == 0) return GSCAN_OK; // once per process
     if (!ingest_cfg().prefault) return GSCAN_OK;
@@ -1863,11 +1879,35 @@ int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off
     Slot *s = free_slot_for_submit(c);
     if (!s) return fail(c, GSCAN_EBUSY, "no free slot (all in flight, or one is acquired)");
     trace("submit_fd: %zu bytes", len);
-    int rc = ensure_prog(c, db, c->compute);
-    if (rc) return rc;
-    trace("submit_fd: program on the device");
-    rc = slot_reserve_device(c, *s, len);
-    if (rc) return rc;
+    int rc = 0;
+    if (c->prog_id == 0 && len > s->d_text_cap) {
+        // The first range of a context: the program's upload -- the process's first host-to-device transfer, 8 - 25 ms of
+        // set-up inside the runtime (profiles/r04_b_*) -- and the slot's device buffers (hipMalloc: 15 ms per half GiB) are both
+        // on the way to the first DMA, and neither needs the other: the buffers are made by a helper thread meanwhile.
+        // BASELINE configs[0] is one such range and little else.
+        std::string helper_err;
+        int helper_rc = 0;
+        std::thread helper([&] {
+            t_err_sink = &helper_err;
+            if (hipSetDevice(c->hip_dev) != hipSuccess) helper_rc = fail(c, GSCAN_EHIP, "hipSetDevice failed in the slot's helper thread");
+            else helper_rc = slot_reserve_device(c, *s, len);
+            t_err_sink = nullptr;
+        });
+        rc = ensure_prog(c, db, c->compute);
+        trace("submit_fd: program on its way");
+        helper.join();
+        if (!rc && helper_rc) {
+            c->err = helper_err;
+            rc = helper_rc;
+        }
+        if (rc) return rc;
+    } else {
+        rc = ensure_prog(c, db, c->compute);
+        if (rc) return rc;
+        trace("submit_fd: program on the device");
+        rc = slot_reserve_device(c, *s, len);
+        if (rc) return rc;
+    }
     trace("submit_fd: slot sized");
     // fan the range out to the device's reader threads: every piece is DMA'd on one of this context's copy streams the
     // moment it is read, and whoever finishes the last piece launches the scan (fd_finish).  This thread goes on.

@@ -1211,45 +1211,64 @@ __global__ __launch_bounds__(64) void k_ends(ScanArgs a, const TileDesc *__restr
 constexpr uint32_t kResolveWG = 256;   // threads per descriptor: four waves run the VM side by side, then compact the run together
 constexpr uint32_t kResolveChunkMax = 1024;  // descriptors one workgroup looks after, at most
 constexpr uint32_t kResolveDrop = 0xffffffffu; // (in ends[], between the two phases: no match starts at this record)
-// chunk: descriptors per workgroup (<= kResolveChunkMax).  1 for a window of the host-chunk path (a few thousand descriptors, many of them
-// with hundreds of records: one workgroup each); more for an arena of millions of descriptors nearly all of which are empty
-// (the device-resident path over 64 GiB: 5.6 M) -- the workgroup fetches its descriptors' counts with one coalesced load and
-// leaves at once if none has a record, instead of a workgroup launch per empty descriptor.
+// chunk: descriptors per workgroup (<= kResolveChunkMax).  1 for a window of the host-chunk path (a few thousand descriptors,
+// many of them with hundreds of records: one workgroup each); hundreds for an arena of millions of descriptors nearly all of
+// which are empty (the device-resident path over 64 GiB: 5.6 M).  The workgroup fetches its descriptors' counts with coalesced
+// loads and leaves at once if there is no record; otherwise the records of ALL its descriptors form one work list (a prefix sum
+// over the counts; a record finds its descriptor by bisection) that the four waves work off side by side -- a launch with
+// 65 536 records scattered over 5.6 M descriptors costs what its records cost, not a pass per descriptor.
 __global__ __launch_bounds__(kResolveWG) void k_resolve(ScanArgs a, const TileDesc *__restrict__ tiles, uint32_t nw, uint32_t *__restrict__ ends, uint32_t chunk)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_vm[sizeof(VmProg) / 4];
-    __shared__ uint32_t s_cnt[kResolveWG / 64];
-    __shared__ unsigned long long s_busy[kResolveChunkMax / 64]; // bit k of word j: descriptor st0 + 64 j + k has records
+    __shared__ uint32_t s_off[kResolveChunkMax + 1]; // first the descriptors' record counts, then their exclusive prefix sums; [kResolveChunkMax] = the total
+    __shared__ uint32_t s_wave[kResolveWG / 64];
     const uint32_t n_desc = a.n_tiles * nw, st0 = blockIdx.x * chunk;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool overflow = a.counter[kShards * kCtrStride] != 0; // (the host rescans with a bigger buffer and this pass runs again)
-    for (uint32_t j = threadIdx.x >> 6; j < kResolveChunkMax / 64; j += kResolveWG / 64) {
-        const uint32_t k = 64u * j + (threadIdx.x & 63u), stq = st0 + k;
-        const bool any = !overflow && k < chunk && stq < n_desc && (uint32_t)a.desc[stq] != 0u;
-        const unsigned long long m = __ballot(any);
-        if ((threadIdx.x & 63u) == 0) s_busy[j] = m;
+    for (uint32_t k = threadIdx.x; k < kResolveChunkMax; k += kResolveWG) {
+        const uint32_t stq = st0 + k;
+        s_off[k] = !overflow && k < chunk && stq < n_desc ? (uint32_t)a.desc[stq] : 0u;
     }
     __syncthreads();
-    bool some = false;
+    constexpr uint32_t kPer = kResolveChunkMax / kResolveWG; // consecutive entries per thread
+    uint32_t c[kPer], sum = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < kResolveChunkMax / 64; j++) some = some || s_busy[j] != 0ull;
-    if (!some) return;
+    for (uint32_t q = 0; q < kPer; q++) sum += c[q] = s_off[kPer * threadIdx.x + q];
+    const uint32_t incl = wave_scan(sum);
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kResolveWG / 64; w++) {
+        const uint32_t v = s_wave[w];
+        before += w < wave ? v : 0u;
+        total += v;
+    }
+    if (total == 0u) return;
     {
+        uint32_t at = before + incl - sum;
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; q++) {
+            s_off[kPer * threadIdx.x + q] = at;
+            at += c[q];
+        }
+        if (threadIdx.x == 0) s_off[kResolveChunkMax] = total;
         const uint32_t *vsrc = reinterpret_cast<const uint32_t *>(&a.prog->vm);
         for (uint32_t q = threadIdx.x; q < (uint32_t)(sizeof(VmProg) / 4); q += kResolveWG) s_vm[q] = vsrc[q];
     }
     __syncthreads();
     const VmProg *vm = reinterpret_cast<const VmProg *>(s_vm);
-    for (uint32_t j = 0; j < kResolveChunkMax / 64; j++)
-    for (unsigned long long busy = s_busy[j]; busy; busy &= busy - 1ull) {
-    const uint32_t st = st0 + 64u * j + (uint32_t)(__ffsll((long long)busy) - 1);
-    const unsigned long long d = a.desc[st];
-    const uint32_t cnt = (uint32_t)d;
-    const uint32_t base = (uint32_t)(d >> 32);
-    const uint32_t t = st / nw;
-    const uint8_t *seg = a.base + (tiles ? tiles[t].seg_off : a.seg0_off);
-    const uint32_t slen = tiles ? tiles[t].seg_len : a.seg0_len;
     // phase 1: every record's verdict, in place (ends[i]); the records stay where they are
-    for (uint32_t i = threadIdx.x; i < cnt; i += kResolveWG) {
+    for (uint32_t r = threadIdx.x; r < total; r += kResolveWG) {
+        uint32_t j = 0; // the descriptor record r belongs to: the last one whose prefix sum is <= r
+#pragma unroll
+        for (uint32_t step = kResolveChunkMax / 2; step; step >>= 1)
+            if (s_off[j + step] <= r) j += step;
+        const uint32_t st = st0 + j, i = r - s_off[j];
+        const uint32_t base = (uint32_t)(a.desc[st] >> 32);
+        const uint32_t t = st / nw;
+        const uint8_t *seg = a.base + (tiles ? tiles[t].seg_off : a.seg0_off);
+        const uint32_t slen = tiles ? tiles[t].seg_len : a.seg0_len;
         const uint32_t p = a.recs[base + i];
         uint32_t code = kResolveDrop;
         if (p != kStruck && p < slen) {
@@ -1261,43 +1280,37 @@ __global__ __launch_bounds__(kResolveWG) void k_resolve(ScanArgs a, const TileDe
         ends[base + i] = code;
     }
     __syncthreads();
-    // phase 2: the survivors to the front of the run, kResolveWG records per round.  (Survivor k of a round goes to index
-    // out + k <= the index its own thread read from: a round's loads are all done before its first store, and later rounds read
-    // further on.)
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t out = 0; // survivors so far (uniform)
-    for (uint32_t i0 = 0; i0 < cnt; i0 += kResolveWG) {
-        const uint32_t i = i0 + threadIdx.x;
-        uint32_t p = 0, code = kResolveDrop;
-        if (i < cnt) {
-            p = a.recs[base + i];
-            code = ends[base + i];
+    // phase 2: the survivors to the front of every descriptor's run, a wave per descriptor, 64 records per round.  (Survivor k of a
+    // round goes to index out + k <= the index its own lane read from: a round's loads are done before its first store, and
+    // later rounds read further on.)
+    for (uint32_t j = wave; j < chunk; j += kResolveWG / 64) {
+        const uint32_t cnt = s_off[j + 1] - s_off[j];
+        if (cnt == 0u) continue; // (wave-uniform)
+        const uint32_t st = st0 + j;
+        const unsigned long long d = a.desc[st];
+        const uint32_t base = (uint32_t)(d >> 32);
+        uint32_t out = 0;
+        for (uint32_t i0 = 0; i0 < cnt; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            uint32_t p = 0, code = kResolveDrop;
+            if (i < cnt) {
+                p = a.recs[base + i];
+                code = ends[base + i];
+            }
+            const bool keep = code != kResolveDrop;
+            const unsigned long long m = __ballot(keep);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (keep && out + rank != i) {
+                a.recs[base + out + rank] = p;
+                ends[base + out + rank] = code;
+            }
+            out += (uint32_t)__popcll(m);
         }
-        const bool keep = code != kResolveDrop;
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < kResolveWG / 64; w++) {
-            const uint32_t c = s_cnt[w];
-            before += w < wave ? c : 0u;
-            total += c;
+        if (lane == 0 && out != cnt) {
+            a.desc[st] = (d & 0xffffffff00000000ull) | out;
+            atomicAdd(a.counter + kShards * kCtrStride + 1, cnt - out);
         }
-        const uint32_t rank = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (keep) {
-            a.recs[base + out + rank] = p;
-            ends[base + out + rank] = code;
-        }
-        out += total;
-        __syncthreads();
     }
-    if (threadIdx.x == 0 && out != cnt) {
-        a.desc[st] = (d & 0xffffffff00000000ull) | out;
-        atomicAdd(a.counter + kShards * kCtrStride + 1, cnt - out);
-    }
-    __syncthreads();
-    } // (the next descriptor of this workgroup's chunk)
 }
 
 // ------------------------------------------------------------------------------------

@@ -18,6 +18,7 @@
 #include <ucontext.h>
 
 #include "../../include/gscan.h"
+#include "../../include/gscan_test.h"
 #include "db.h"
 
 using gscan::AltSeq;

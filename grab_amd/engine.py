@@ -17,15 +17,19 @@ LITERAL = 1
 TIER_NULL, TIER_LITERAL, TIER_CLASSRUN, TIER_BUCKET, TIER_ANCHORED = 0, 1, 2, 3, 4
 SLOTS = 3  # GSCAN_SLOTS (include/gscan.h): chunks one context keeps in flight
 
-# every symbol include/gscan.h declares
+# every symbol include/gscan.h declares (what a binding of the engine needs) ...
 SYMBOLS = [
-    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_match_info", "gscan_next_match", "gscan_tail_positions", "gscan_db_dev_window",
-    "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count",
-    "gscan_acquire", "gscan_block_size", "gscan_prefault", "gscan_prefault_files", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_submit_files", "gscan_last_file_errors", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_gather", "gscan_last_ends", "gscan_next_listed", "gscan_next_resolved", "gscan_db_first",
-    "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity",
-    "gscan_set_option", "gscan_kernel_time", "gscan_resource_errors",
-    "gscan_ingest_info", "gscan_pool_stats", "gscan_auto_readers", "gscan_device_cpulist", "gscan_pci_cpulist", "gscan_parse_cpulist",
+    "gscan_compile", "gscan_free", "gscan_db_info", "gscan_match_info", "gscan_next_match", "gscan_next_listed", "gscan_next_resolved", "gscan_db_first", "gscan_resource_errors",
+    "gscan_open", "gscan_close", "gscan_strerror", "gscan_device_count", "gscan_device_cpulist", "gscan_parse_cpulist",
+    "gscan_acquire", "gscan_block_size", "gscan_prefault", "gscan_prefault_files", "gscan_ingest_info", "gscan_submit", "gscan_submit_segs", "gscan_submit_fd", "gscan_submit_files",
+    "gscan_last_file_errors", "gscan_wait", "gscan_wait_segs", "gscan_last_ext", "gscan_last_gather", "gscan_last_ends",
+    "gscan_scan_device", "gscan_dev_sync", "gscan_dev_fetch", "gscan_set_capacity", "gscan_set_option", "gscan_kernel_time",
+]
+# ... and include/gscan_test.h (test and diagnostic hooks: the compiler's tables, the matcher's and the VM's verdict at one offset, the pool's counters)
+TEST_SYMBOLS = [
+    "gscan_db_class", "gscan_db_alt_class", "gscan_match_at", "gscan_match_end", "gscan_tail_positions", "gscan_db_dev_window",
     "gscan_vm_verdict", "gscan_vm_match", "gscan_vm_resolve", "gscan_vm_filter", "gscan_vm_pair", "gscan_prefix_viable",
+    "gscan_pool_stats", "gscan_auto_readers", "gscan_pci_cpulist",
 ]
 
 

@@ -42,7 +42,13 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 1
+#define GSCAN_ABI_VERSION 2
+
+/* libgscan.so is built with -fvisibility=hidden: it exports the functions declared here (and the test / diagnostic hooks of
+ * include/gscan_test.h) and nothing else -- tests/test_abi.py compares the library's dynamic symbol table with the two headers */
+#ifndef GSCAN_API
+#define GSCAN_API __attribute__((visibility("default")))
+#endif
 
 /* return codes */
 #define GSCAN_OK 0
@@ -136,23 +142,15 @@ typedef struct gscan_dev_result {
 } gscan_dev_result;
 
 /* ---- pattern database (host only; no device needed) ---- */
-int gscan_compile(const char *pat, size_t len, unsigned flags, gscan_db **out, int *minlen,
+GSCAN_API int gscan_compile(const char *pat, size_t len, unsigned flags, gscan_db **out, int *minlen,
                   char *err, size_t errcap);
-void gscan_free(gscan_db *db);
-int gscan_db_info(const gscan_db *db, gscan_info *info);
-/* 256-entry membership table (1 byte each) of window position `pos`; pos == -1: the tail class (alternative 0) */
-int gscan_db_class(const gscan_db *db, int pos, uint8_t table[256]);
-/* the same for alternative `alt`; *len (optional) receives that alternative's window length */
-int gscan_db_alt_class(const gscan_db *db, int alt, int pos, uint8_t table[256], int *len);
-/* 1 if the pattern matches AT offset p of content[0..clen) with the subject starting at p, else 0 */
-int gscan_match_at(const gscan_db *db, const void *content, size_t clen, uint32_t p);
-/* ovector[1] for a match starting at `start` of content[0..clen), subject starting there: src/grab.cc:178 semantics */
-uint32_t gscan_match_end(const gscan_db *db, const void *content, size_t clen, uint32_t start);
+GSCAN_API void gscan_free(gscan_db *db);
+GSCAN_API int gscan_db_info(const gscan_db *db, gscan_info *info);
 /* pcre_exec's verdict on a match attempt AT p when the subject starts at subject_start <= p (the position the
  * reference restarted at: src/grab.cc:178 passes subject = start, so ^ \b \B see nothing before it):
  * 0 no match starts at p;  1 match, *end = ovector[1];  2 match whose path closes a capturing group -- with the
  * reference's int ovector[3] (src/grab.cc:171) pcre_exec returns 0 for it and the chunk loop ends (src/grab.cc:179). */
-int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p,
+GSCAN_API int gscan_match_info(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p,
                      uint32_t *end);
 /*
  * The reference's inner loop, one step:  rc = pcre_exec(h, extra, start, end - start, 0, 0, ovector, 3)
@@ -176,7 +174,7 @@ typedef struct gscan_cursor {
     uint32_t next_at[GSCAN_MAX_ALTS + 1];
     uint8_t next_known[GSCAN_MAX_ALTS + 1];
 } gscan_cursor;
-int gscan_next_match(const gscan_db *db, const void *content, size_t clen, const uint32_t *starts, size_t n,
+GSCAN_API int gscan_next_match(const gscan_db *db, const void *content, size_t clen, const uint32_t *starts, size_t n,
                      gscan_cursor *cur, uint32_t s, uint32_t *m0, uint32_t *m1);
 /* Match attempts this process abandoned at the matcher's resource limits (its counterpart of PCRE_ERROR_MATCHLIMIT /
  * PCRE_ERROR_JIT_STACKLIMIT): gscan_next_match then answers 0, which ends the chunk exactly as every pcre_exec error
@@ -184,39 +182,13 @@ int gscan_next_match(const gscan_db *db, const void *content, size_t clen, const
  * interpreter, its JIT and this matcher all differ -- so differential tests skip inputs on which either side did.
  * Limit: 2^28 matcher steps per attempt (GSCAN_MATCH_LIMIT in the environment overrides it), 12000 nested group iterations (an attempt that outgrows 192 KiB of the caller's stack is repeated on a
  * 16 MiB stack of the matcher's own). */
-uint64_t gscan_resource_errors(void);
-/* the offsets gscan_next_match tests itself because a window there would end with the chunk (patterns with
- * look-ahead context only: foo\b, foo$ ...); exported for tests.  Returns how many there are; fills at most cap. */
-size_t gscan_tail_positions(const gscan_db *db, size_t clen, uint32_t *out, size_t cap);
-/* The device's VM (grab_amd/csrc/vm.h), run on the host -- for tests and diagnostics.
- *   gscan_vm_verdict  at offset p with the subject starting at subject_start: 0 no match starts at p, 1 a match starts at p,
- *                     2 the VM gave up (step / stack limit), -1 the pattern has no VM program.  Never 0 where
- *                     gscan_match_info finds a match.
- *   gscan_vm_filter   what the K3 kernel does with its filter hits when gscan_info.vm is set: of hits[0..n) (offsets of device
- *                     windows) the ones it keeps, in order, into kept (may be NULL); returns how many, -1 if vm is not set.
- *   gscan_vm_pair     the device's two-byte table (DevProgram::vm_pair): 1 a match may begin with the bytes b0 b1, 0 none can,
- *                     -1 the pattern has no table.  gscan_prefix_viable: the probe the table is built from -- may a match
- *                     begin at offset 0 of some subject that starts with these n bytes?  (0 only if the host matcher fails
- *                     without looking at or beyond byte n.) */
-int gscan_vm_verdict(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p);
-/* the VM's full answer: as gscan_vm_verdict, and for 1 the match's end (ovector[1]) and whether its path closed a capturing group
- * -- what the device's resolve pass (gscan_info.resolve) writes next to every record */
-int gscan_vm_match(const gscan_db *db, const void *content, size_t clen, uint32_t subject_start, uint32_t p, uint32_t *end, int *captures);
-/* k_resolve on the host (tests): of hits[0..n) -- offsets where a start window fits -- the ones at which the VM finds a match
- * or gives up, into starts, and what the device writes next to them into ends; returns how many, -1 if there is no program */
-long gscan_vm_resolve(const gscan_db *db, const void *content, size_t clen, const uint32_t *hits, size_t n, uint32_t *starts, uint32_t *ends);
-int gscan_vm_pair(const gscan_db *db, unsigned b0, unsigned b1);
-int gscan_prefix_viable(const gscan_db *db, const void *bytes, size_t n);
-long gscan_vm_filter(const gscan_db *db, const void *content, size_t clen, const uint32_t *hits, size_t n, uint32_t *kept);
-/* What the kernels scan for alternative `alt`: the membership table of DEVICE window position `pos` (the window plus
- * its context positions), the device window length, and the shift from a device hit to the reported match start. */
-int gscan_db_dev_window(const gscan_db *db, int alt, int pos, uint8_t table[256], int *len, int *shift);
+GSCAN_API uint64_t gscan_resource_errors(void);
 
 /* ---- device context: one per worker thread ---- */
-int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out);
-void gscan_close(gscan_ctx *ctx);
-const char *gscan_strerror(const gscan_ctx *ctx);
-int gscan_device_count(void);
+GSCAN_API int gscan_open(int hip_device, size_t max_chunk, gscan_ctx **out);
+GSCAN_API void gscan_close(gscan_ctx *ctx);
+GSCAN_API const char *gscan_strerror(const gscan_ctx *ctx);
+GSCAN_API int gscan_device_count(void);
 /*
  * Where a device's host-side work belongs.  The reader threads of a device (gscan_submit_fd) run on the CPUs of the
  * device's NUMA node -- sysfs <pci root>/<bus id>/local_cpulist, e.g. "0-31,64-95" -- so that the pinned staging blocks
@@ -224,12 +196,11 @@ int gscan_device_count(void);
  * of device (i mod #devices) the same way (the reference pins thread i to CPU i, src/main.cc:200-215).
  *   gscan_device_cpulist  the list for a HIP device (bus id from the runtime; root /sys/bus/pci/devices, or
  *                         $GSCAN_SYSFS_PCI); returns its length, <0 if unknown
- *   gscan_pci_cpulist     the same for an explicit sysfs root + bus id (no device needed: tests)
+ *   (gscan_pci_cpulist, include/gscan_test.h: the same for an explicit sysfs root + bus id -- no device needed)
  *   gscan_parse_cpulist   "0-3,8,10-11" -> CPU numbers; returns how many there are, fills at most cap
  */
-int gscan_device_cpulist(int hip_device, char *buf, size_t cap);
-int gscan_pci_cpulist(const char *sysfs_pci_root, const char *busid, char *buf, size_t cap);
-long gscan_parse_cpulist(const char *list, int *cpus, size_t cap);
+GSCAN_API int gscan_device_cpulist(int hip_device, char *buf, size_t cap);
+GSCAN_API long gscan_parse_cpulist(const char *list, int *cpus, size_t cap);
 
 /*
  * Host-chunk path (what FileGrep::find uses): three ways to hand over the bytes that the
@@ -266,41 +237,33 @@ long gscan_parse_cpulist(const char *list, int *cpus, size_t cap);
  *                      stay valid and unchanged until gscan_wait has returned the chunk.
  */
 #define GSCAN_SLOTS 3
-int gscan_acquire(gscan_ctx *ctx, size_t len, void **pinned);
-size_t gscan_block_size(void);
+GSCAN_API int gscan_acquire(gscan_ctx *ctx, size_t len, void **pinned);
+GSCAN_API size_t gscan_block_size(void);
 /* Optional, before the first other call of a process that is about to scan (the command line calls it first thing in main):
  * helper threads map and touch `blocks` staging blocks' worth of memory WHILE the HIP runtime starts; the reader pool then
  * only registers them with the runtime instead of allocating pinned memory block by block while the pipe fills (1.5 - 2 ms
  * each, one at a time).  No HIP call is made here.  GSCAN_PREFAULT=0 in the environment turns it into a no-op. */
-int gscan_prefault(size_t blocks);
+GSCAN_API int gscan_prefault(size_t blocks);
 /* The same, and the helper threads FILL the first blocks with the first bytes of the files named (in the order given, piece by
  * piece of gscan_block_size() bytes, `blocks` pieces at most): what the reader threads would pread once the runtime is up is
  * read while it starts (hipInit takes 50 ms; 256 MiB are read in 10).  A gscan_submit_fd whose range holds such a piece --
  * same file (device + inode), same offset, same length -- takes the block as it is: registered, DMA'd, nothing is read twice.
  * For callers that know their input before the first HIP call (the command line with explicit paths: BASELINE configs[0]). */
-int gscan_prefault_files(size_t blocks, const char *const *paths, size_t npaths);
+GSCAN_API int gscan_prefault_files(size_t blocks, const char *const *paths, size_t npaths);
 /* the ingest configuration in force (environment: GSCAN_BLOCK_MIB, GSCAN_READERS, GSCAN_COPY_STREAMS = the copy streams of a
  * DEVICE, shared by its contexts); any pointer may be NULL */
-void gscan_ingest_info(size_t *block_bytes, int *readers, int *copy_streams);
-/* the staging-block pool of the context's device, for tests and diagnostics: out[0] blocks allocated, out[1] the pool's cap,
- * out[2] how often a reader had to sleep on a block's DMA event because every block was in flight, out[3] how often it had
- * to sleep until another reader brought a block back.  (tests/test_gpu_pool.py forces these slow paths and checks they ran.) */
-int gscan_pool_stats(const gscan_ctx *ctx, uint64_t out[4]);
-/* reader threads a device gets when GSCAN_READERS is unset (*readers == 0 above): 8, fewer when the device's share of its
- * NUMA node's CPUs (local_cpus / devices_sharing that node) is small or when the node drives so many devices (devices_total)
- * that 8 readers each would outrun what the host's page cache can feed (24 in all); exported for tests */
-int gscan_auto_readers(int local_cpus, int devices_sharing, int devices_total);
-int gscan_submit(gscan_ctx *ctx, const gscan_db *db, const void *host_bytes, size_t len,
+GSCAN_API void gscan_ingest_info(size_t *block_bytes, int *readers, int *copy_streams);
+GSCAN_API int gscan_submit(gscan_ctx *ctx, const gscan_db *db, const void *host_bytes, size_t len,
                  uint64_t tag);
-int gscan_submit_segs(gscan_ctx *ctx, const gscan_db *db, const void *pinned, const gscan_seg *segs,
+GSCAN_API int gscan_submit_segs(gscan_ctx *ctx, const gscan_db *db, const void *pinned, const gscan_seg *segs,
                       size_t nseg, uint64_t tag);
-int gscan_submit_fd(gscan_ctx *ctx, const gscan_db *db, int fd, long long file_off, size_t len,
+GSCAN_API int gscan_submit_fd(gscan_ctx *ctx, const gscan_db *db, int fd, long long file_off, size_t len,
                     uint64_t tag);
-int gscan_submit_files(gscan_ctx *ctx, const gscan_db *db, const gscan_file *files, size_t n, uint64_t tag);
+GSCAN_API int gscan_submit_files(gscan_ctx *ctx, const gscan_db *db, const gscan_file *files, size_t n, uint64_t tag);
 /* per-segment status of the gscan_submit_files batch the last gscan_wait_segs handed out: 0 the file was read in full, an
  * errno from open(2) / pread(2), -1 the file was shorter than `len`.  *n = number of segments; NULL (and *n = 0) if that
  * chunk was not such a batch.  Same lifetime as its starts. */
-const int *gscan_last_file_errors(const gscan_ctx *ctx, size_t *n);
+GSCAN_API const int *gscan_last_file_errors(const gscan_ctx *ctx, size_t *n);
 /* starts[0..n), ascending: the START of every group of consecutive candidate offsets of the
  * chunk (offsets p at which the pattern matches), possibly with further candidates of the
  * same groups in between.  That is all pcre_exec's "leftmost match at or after s" needs:
@@ -313,7 +276,7 @@ const int *gscan_last_file_errors(const gscan_ctx *ctx, size_t *n);
  * transfer, no merge on the host), and a new chunk may take that slot (it does so only when no other slot is free).
  * Consume a chunk's result before handing over the next one -- FileGrep does.  A pinned *content stays until the second
  * gscan_acquire / gscan_submit* after this call reuses the slot. */
-int gscan_wait(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, size_t *n,
+GSCAN_API int gscan_wait(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, size_t *n,
                const void **content);
 /*
  * Line extents, orbit selection and line gather on the device, for the reference's line-printing modes (src/grab.cc:188-209:
@@ -330,8 +293,8 @@ int gscan_wait(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, size_t *n
  * starts, same lifetime), or NULL if that chunk has none; gscan_last_gather the gathered text (NULL: none was fetched --
  * treat every goff as 0xffffffff), valid until the next gscan_wait / gscan_wait_segs on this context.
  */
-const uint32_t *gscan_last_ext(const gscan_ctx *ctx);
-const uint8_t *gscan_last_gather(const gscan_ctx *ctx, size_t *bytes);
+GSCAN_API const uint32_t *gscan_last_ext(const gscan_ctx *ctx);
+GSCAN_API const uint8_t *gscan_last_gather(const gscan_ctx *ctx, size_t *bytes);
 /*
  * Match ends on the device, for -O -l (src/grab.cc:175-213 with d_print_line off: print the offset, restart at the match
  * end).  With gscan_set_option(ctx, "match_ends", 1) and a pattern whose gscan_info.ends_ok is set, every chunk also
@@ -339,14 +302,14 @@ const uint8_t *gscan_last_gather(const gscan_ctx *ctx, size_t *bytes);
  * where the device left it to the host (a tail that runs on for more than 4 KiB).  gscan_last_ends returns the array for
  * the chunk the last gscan_wait / gscan_wait_segs handed out (parallel to its starts, same lifetime), or NULL.
  */
-const uint32_t *gscan_last_ends(const gscan_ctx *ctx);
+GSCAN_API const uint32_t *gscan_last_ends(const gscan_ctx *ctx);
 /*
  * gscan_next_match for such a chunk, WITHOUT the text: valid when s is 0 or the end of the previous match of this walk
  * (the byte that stopped its tail cannot begin a match, so the leftmost match from s is the first listed start >= s).
  * Returns 0 no match, 1 match with [*m0, *m1), -1: this match's end is the host's to find -- make this step with
  * gscan_next_match (same cursor).  `cur` as for gscan_next_match.
  */
-int gscan_next_listed(const gscan_db *db, size_t clen, const uint32_t *starts, const uint32_t *ends, size_t n,
+GSCAN_API int gscan_next_listed(const gscan_db *db, size_t clen, const uint32_t *starts, const uint32_t *ends, size_t n,
                       gscan_cursor *cur, uint32_t s, uint32_t *m0, uint32_t *m1);
 /*
  * The loop step for a database with gscan_info.resolve set:  rc = pcre_exec(h, extra, start, end - start, 0, 0, ovector, 3)
@@ -363,18 +326,18 @@ int gscan_next_listed(const gscan_db *db, size_t clen, const uint32_t *starts, c
  */
 #define GSCAN_END_ASK 0u
 #define GSCAN_END_CAPTURES 0xfffffffeu
-int gscan_next_resolved(const gscan_db *db, const void *content, size_t clen, const uint32_t *starts, const uint32_t *ends, size_t n,
+GSCAN_API int gscan_next_resolved(const gscan_db *db, const void *content, size_t clen, const uint32_t *starts, const uint32_t *ends, size_t n,
                         gscan_cursor *cur, uint32_t s, uint32_t *m0, uint32_t *m1);
 /* the bytes a match can begin with: table[b] & 1 if b can; returns 1 if that is known (0: the pattern may begin without
  * consuming a byte -- an assertion, an optional item -- and bit 0 of every entry is set).  table[b] & 2 (reach == 1 only): b in
  * front of an offset is to the pattern what the subject start is -- a non-word byte for \b \B, a newline for (?m)^, a byte
  * outside a one-byte look-behind's class -- so with such a byte in front of the restart position the device's verdict AT the
  * restart position is pcre_exec's too and gscan_next_resolved asks nobody. */
-int gscan_db_first(const gscan_db *db, uint8_t table[256]);
+GSCAN_API int gscan_db_first(const gscan_db *db, uint8_t table[256]);
 /* the same for a chunk of several segments: the records of segment i are
  * starts[seg_first[i] .. seg_first[i+1]), segment-relative; seg_first has *nseg + 1 entries
  * (a single-segment chunk reports *nseg = 1). */
-int gscan_wait_segs(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, const size_t **seg_first,
+GSCAN_API int gscan_wait_segs(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, const size_t **seg_first,
                     size_t *nseg, const void **content);
 
 /*
@@ -382,22 +345,22 @@ int gscan_wait_segs(gscan_ctx *ctx, uint64_t *tag, const uint32_t **starts, cons
  * already in HBM, one launch, on `stream` (a hipStream_t, NULL = the stream the context's
  * scans ride on).  Asynchronous; results stay on the device.
  */
-int gscan_scan_device(gscan_ctx *ctx, const gscan_db *db, const void *dev_base,
+GSCAN_API int gscan_scan_device(gscan_ctx *ctx, const gscan_db *db, const void *dev_base,
                       const gscan_seg *segs, size_t nseg, void *stream,
                       gscan_dev_result *res);
 /* wait for the scan, fill res->total / res->overflow */
-int gscan_dev_sync(gscan_ctx *ctx, gscan_dev_result *res);
+GSCAN_API int gscan_dev_sync(gscan_ctx *ctx, gscan_dev_result *res);
 /* copy the records of segment `seg` to the host, ascending; returns count or <0 */
-long gscan_dev_fetch(gscan_ctx *ctx, const gscan_dev_result *res, size_t seg, uint32_t *out,
+GSCAN_API long gscan_dev_fetch(gscan_ctx *ctx, const gscan_dev_result *res, size_t seg, uint32_t *out,
                      size_t cap);
 /* record-buffer capacity (records, split into 8 equal shard regions) for device scans;
  * default = arena bytes / 16 */
-int gscan_set_capacity(gscan_ctx *ctx, size_t n_records);
+GSCAN_API int gscan_set_capacity(gscan_ctx *ctx, size_t n_records);
 /* tuning knobs for A/B runs: name in {"variant","blocks_per_cu","register_min","line_extents","match_ends"}; see DESIGN.md */
-int gscan_set_option(gscan_ctx *ctx, const char *name, long value);
+GSCAN_API int gscan_set_option(gscan_ctx *ctx, const char *name, long value);
 /* scan-kernel time of the gscan_scan_device launches since the last reset: HIP events recorded
  * around each launch on the launch's own stream.  Waits for the launches to finish. */
-int gscan_kernel_time(gscan_ctx *ctx, double *sum_ms, uint64_t *launches, int reset);
+GSCAN_API int gscan_kernel_time(gscan_ctx *ctx, double *sum_ms, uint64_t *launches, int reset);
 
 #ifdef __cplusplus
 }

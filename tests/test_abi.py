@@ -16,14 +16,26 @@ def _declared(header):
     return sorted(set(re.findall(r"\b(g(?:scan|rab)_[a-z_0-9]+)\s*\(", text)))
 
 
+def _exported(lib):
+    """The library's dynamic symbol table: every defined global function / object a client could bind."""
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    return sorted(ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TtDdBbRrWwVv")
+
+
 def test_gscan_exports(built):
+    """libgscan.so exports EXACTLY what its two headers declare -- gscan.h, the engine's C ABI, and gscan_test.h, the test and
+    diagnostic hooks -- and nothing else: no C++ internals, no unprefixed helpers (built with -fvisibility=hidden, GSCAN_API)."""
     from grab_amd import engine
 
-    names = _declared("gscan.h")
+    names, hooks = _declared("gscan.h"), _declared("gscan_test.h")
     assert sorted(engine.SYMBOLS) == names, "engine.py binds exactly what gscan.h declares"
+    assert sorted(engine.TEST_SYMBOLS) == hooks, "... and gscan_test.h"
+    assert not set(names) & set(hooks)
     L = C.CDLL(built.lib_path("libgscan.so"))
-    for n in names:
+    for n in names + hooks:
         assert hasattr(L, n), n
+    extra = [x for x in _exported(built.lib_path("libgscan.so")) if x not in names + hooks and not x.startswith("__hip_") and x not in ("_init", "_fini")]
+    assert extra == [], "libgscan.so exports symbols no header declares: %s" % extra[:10]
 
 
 def test_grab_host_exports(built):
