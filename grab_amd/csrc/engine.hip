@@ -135,6 +135,8 @@ struct Prefault {
         std::string path;
         dev_t dev = 0;
         ino_t ino = 0;
+        off_t size = 0;               // what the file looked like when the helper read the piece: a file rewritten in place in
+        struct timespec mtim{}, ctim{}; // between (same inode, same size) must not be scanned from stale staging bytes
         off_t off = 0;
         size_t n = 0;
         std::atomic<bool> claimed{false};
@@ -189,6 +191,12 @@ const IngestCfg &ingest_cfg()
         v.virtual_devices = (int)env("GSCAN_VIRTUAL_DEVICES", 0, 0, 64);
         v.virtual_fail_open = (int)env("GSCAN_VIRTUAL_FAIL_OPEN", -1, -1, 64);
         v.prefault = env("GSCAN_PREFAULT", 1, 0, 1) != 0;
+        // (GSCAN_DIAG makes the readers skip the read or the DMA: a measurement of the ingest pipe whose "results" are whatever
+        // the staging blocks held.  It takes a second switch to get it, so that no stray variable turns a scan into that.)
+        if (v.diag && !getenv("GSCAN_TEST_HOOKS")) {
+            fprintf(stderr, "gscan: GSCAN_DIAG=%d ignored (it needs GSCAN_TEST_HOOKS=1 as well: a measurement of the ingest pipe, not a scan)\n", v.diag);
+            v.diag = 0;
+        }
         if (v.diag) fprintf(stderr, "gscan: GSCAN_DIAG=%d -- a measurement of the ingest pipe, NOT a scan: whatever is reported is meaningless\n", v.diag);
         return v;
     }();
@@ -1669,6 +1677,9 @@ static int prefault_start(size_t plain, const std::vector<AheadSrc> &ahead_src)
                 if (ok) {
                     pc.dev = st.st_dev;
                     pc.ino = st.st_ino;
+                    pc.size = st.st_size;
+                    pc.mtim = st.st_mtim;
+                    pc.ctim = st.st_ctim;
                     for (size_t o = (pc.n + 4095) & ~size_t(4095); o < used; o += 4096) at[o] = 0; // (the slack behind the piece is staging memory too)
                 }
                 state[k].store(ok ? 2 : 3, std::memory_order_release);
@@ -1951,9 +1962,14 @@ int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off
             for (size_t a = 0; a < g_prefault.ahead; a++) {
                 Prefault::Piece &pc = g_prefault.piece[a];
                 if (pc.off != t.off || pc.n != t.n || pc.claimed.load(std::memory_order_relaxed)) continue;
-                // (dev / ino are the helper's to write: wait for it -- it has had the whole start of the runtime)
-                while (!g_prefault.state[a].load(std::memory_order_acquire)) std::this_thread::yield();
+                // (dev / ino are the helper's to write: wait for it -- it has had the whole start of the runtime; but not for ever:
+                // a helper stuck on slow storage leaves the piece to the ordinary read)
+                for (int spins = 0; !g_prefault.state[a].load(std::memory_order_acquire) && spins < 20000; spins++) std::this_thread::yield();
                 if (g_prefault.state[a].load(std::memory_order_acquire) != 2 || pc.dev != fst.st_dev || pc.ino != fst.st_ino) continue;
+                // the same file AS IT WAS READ: size and both time stamps unchanged since the helper's fstat
+                if (pc.size != fst.st_size || pc.mtim.tv_sec != fst.st_mtim.tv_sec || pc.mtim.tv_nsec != fst.st_mtim.tv_nsec ||
+                    pc.ctim.tv_sec != fst.st_ctim.tv_sec || pc.ctim.tv_nsec != fst.st_ctim.tv_nsec)
+                    continue;
                 if (pc.claimed.exchange(true)) continue;
                 g_prefault.unclaimed.fetch_sub(1, std::memory_order_relaxed);
                 t.ahead = (int)a;

@@ -944,6 +944,7 @@ __global__ __launch_bounds__(256) void k3_settle(ScanArgs a, const TileDesc *__r
 // ------------------------------------------------------------------------------------
 constexpr uint32_t kLineAsk = 0xffffffffu;
 constexpr uint32_t kLineBack = 4096; // how far a line start / a tail end is searched before the host is asked
+static_assert(kLineBack % 32 == 0, "k_lines looks back / ahead 32 bytes per step: the ask-the-host bound is tested once per step");
 
 // exact "which bytes of x are zero" (bit 7 of every zero byte), no borrow across bytes
 __device__ __forceinline__ unsigned long long zero_bytes(unsigned long long x)

@@ -123,7 +123,7 @@ def measure(grab, d, nbytes, pattern="foobardoesnotexist", reps=2, host_copy=Tru
             best = None
             for nt in (0, 1):
                 for per in (1, 2, 4, 8):
-                    e = dict(env8, GSCAN_DIAG="1", GSCAN_READERS=str(per), GSCAN_NT_COPY=str(nt))
+                    e = dict(env8, GSCAN_DIAG="1", GSCAN_TEST_HOOKS="1", GSCAN_READERS=str(per), GSCAN_NT_COPY=str(nt))
                     got = run([grab, "-n", w8, "-r", pattern, d], e, 1, pause=0.2)
                     if not got:
                         continue

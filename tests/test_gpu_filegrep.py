@@ -252,6 +252,31 @@ def test_line_pass_equals_host_walk(built, oracle_built, tmp_path):
             assert out == oout, (pattern, flags)
 
 
+def test_line_pass_at_its_look_back_bound(built, oracle_built, tmp_path):
+    """k_lines follows a match's tail and looks for a line's start 4096 bytes (kLineBack) at most before it asks the host: tails
+    of exactly 4095 / 4096 / 4097 bytes of the tail class, a line that starts exactly 4096 bytes in front of its first record
+    (and one byte more, one less), the same again right behind a 32-byte step of the searches -- with the pass and without it the
+    output is the oracle's (the boundary had no test)."""
+    parts = []
+    for tail in (4095, 4096, 4097, 4064, 4128):
+        parts.append(b"xx\n" + b"Q" + b"a" * tail + b" rest of the line\nnext Qab\n")
+    for back in (4095, 4096, 4097, 4064, 4128, 33):
+        parts.append(b"\n" + b"." * back + b"Qabc and more\nQz\n")
+    for back in (4096, 4097):  # ... and a second record in such a line: not printed (the first one of the line is)
+        parts.append(b"\n" + b"Qfirst" + b"." * back + b"Qsecond\n")
+    data = b"".join(parts) * 3
+    (tmp_path / "f").write_bytes(data)
+    for pattern in ["Q[a-z]*", "Q[a-z]{2,}"]:
+        for flags in (["-O"], [], ["-O", "-l"]):
+            argv = flags + [pattern, "f"]
+            rc, out, err = _run(built.bin_path(), argv, str(tmp_path))
+            r = subprocess.run([built.bin_path()] + argv, cwd=str(tmp_path), capture_output=True, env=dict(os.environ, GRAB_LINE_PASS="0", GRAB_NO_ENDS="1"))
+            orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), argv, str(tmp_path))
+            assert rc == r.returncode == orc == 0, err
+            assert out == oout, (pattern, flags)
+            assert r.stdout == oout, (pattern, flags)
+
+
 def test_offsets_without_the_text_equals_host_walk(built, oracle_built, tmp_path):
     """-O -l with the match ends from the device (k_ends, the default: the walk never looks at the window) and with the host
     walk over the mapped text (GRAB_NO_ENDS=1) print the same bytes, and both equal the oracle: identifiers longer than the
