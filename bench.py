@@ -751,7 +751,8 @@ def cpu_baseline(d, nfiles, file_bytes, pattern, flags, threads=None, reps=2, wa
                 os.path.dirname(d), nbytes / (1 << 30), " ".join(os.path.basename(a) if a == binary else a for a in argv[:-1]), reps),
             "lines": out.count(b"\n") if out is not None else None, "matches_per_s": round(out.count(b"\n") / dt, 1) if out is not None else None, "wall_s": round(dt, 4),
             "digest": getattr(out, "digest", None) if count_only else (line_digest(None, stdin_bytes=out)[1] if out is not None else None),
-            "engine": "libpcre 8.39 JIT (pcre_exec); the -H hyperscan path does not exist in the mounted reference"}
+            "engine": "libpcre 8.39 JIT (pcre_exec); the -H hyperscan path does not exist in the mounted reference",
+            "lines_note": None if out is not None else "the timed runs of this sample write to /dev/null (SURVEY.md 8d): no line count or digest here -- the reference's full output is counted and digested in the block's reference_lines / reference_digest / same_as_reference"}
 
 
 def sorted_md5(argv, env=None):

@@ -84,7 +84,7 @@ def main():
             if b"gave up" in oerr or b"abandoned" in err:
                 skipped += 1
                 continue
-            key = "tier%d%s" % (db.info.tier, "+vm" if db.info.vm else "")
+            key = "tier%d%s" % (db.info.tier, "+resolve" if db.info.resolve else "+vm" if db.info.vm else "")
             tiers[key] = tiers.get(key, 0) + 1
             if threaded and "-O" in flags and "-l" not in flags:
                 # offset line + text belong together, and the text may hold newlines of its own (a match of [^a] or \s):

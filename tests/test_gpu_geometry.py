@@ -286,6 +286,20 @@ def test_queue_over_eight_device_indices(tmp_path, built, oracle_built):
             # link and the queue's back-pressure evens them out; what this box can show is that none is starved)
             mean = sum(per.values()) / 8
             assert all(0.3 * mean <= v <= 2.0 * mean for v in per.values()), per
+        # ... and on a node that HAS several devices (not gpurun's box): the same command over the real ones, every device with its
+        # own link -- the queue's back-pressure has to even them out: within +-25 % of the mean
+        import torch
+
+        real = torch.cuda.device_count()
+        if real >= 2:
+            env_real = {k: v for k, v in env.items() if not k.startswith("GSCAN_VIRTUAL") and k != "GSCAN_SYSFS_PCI"}
+            rc, out, err = _run(built.bin_path(), ["-n", str(4 * real)] + argv[2:], d, env_real)
+            assert rc == 0 and sorted(out.splitlines()) == sorted(oout.splitlines()), err
+            per = {}
+            for m in re.finditer(rb"\[grab bytes\] device (\d+): (\d+)", err):
+                per[int(m.group(1))] = per.get(int(m.group(1)), 0) + int(m.group(2))
+            mean = sum(per.values()) / real
+            assert sorted(per) == list(range(real)) and all(0.75 * mean <= v <= 1.25 * mean for v in per.values()), per
         # the identifier regex (dense output) over 48 files = 3 GiB: three of the directories under one root.  (Round 4 ran this
         # over 16 files: with sixteen workers whose contexts open at different moments -- since round 5 the device indices no
         # longer queue behind one process-wide lock to create their streams -- the first five to be ready take three windows
