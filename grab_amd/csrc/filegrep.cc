@@ -152,14 +152,19 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
         memset(first, 1, sizeof first);
         const bool first_ok = reach && gscan_db_first(db, first) == 1;
         if (need < kBuf / 2) {
+            // Does the restart at s have to LOOK at the text?  At the chunk's start only when offset 0 cannot be listed (windows with a
+            // leading context byte); behind a match of the list the device has said so in bit 31 of its end (GSCAN_END_LOOK: it
+            // looked at the two bytes around the end itself); behind a match the host's matcher found: yes.  Without a look the
+            // walk reads two arrays and nothing of the chunk.
+            bool look = reach && (info.has_context & 1);
             while (s + (size_t)minlen < clen) {
                 size_t m0, m1;
                 bool ask = false;
-                // (with a reach the walk looks at the byte or two around every restart position, i.e. around the ends of the next
-                // records: a cache miss each, a hundred bytes apart -- the list says where they will be)
-                if (reach && i + 8 < nstarts && ends[i + 8] - 1 < clen) __builtin_prefetch(content + ends[i + 8] - 1);
-                const size_t near_end = reach == 1 && s > 0 && (first[(unsigned char)content[s - 1]] & 2) ? s : std::min(clen, s + reach);
-                for (size_t q = s; q < near_end && !ask; q++) ask = !first_ok || (first[(unsigned char)content[q]] & 1);
+                size_t near_end = s;
+                if (look) {
+                    near_end = reach == 1 && s > 0 && (first[(unsigned char)content[s - 1]] & 2) ? s : std::min(clen, s + reach);
+                    for (size_t q = s; q < near_end && !ask; q++) ask = !first_ok || (first[(unsigned char)content[q]] & 1);
+                }
                 if (!ask) {
                     while (i < nstarts && starts[i] < near_end) i++;
                     if (i >= nstarts) break;
@@ -172,7 +177,10 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
                         ask = true;
                     } else {
                         m0 = starts[i];
-                        m1 = ends[i];
+                        m1 = ends[i] & ~GSCAN_END_LOOK;
+                        look = resolve && (ends[i] & GSCAN_END_LOOK);
+                        // (a look touches the byte or two around the restart position: a cache miss, the list says where the next ones are)
+                        if (look && i + 8 < nstarts) __builtin_prefetch(content + (ends[i + 8] & ~GSCAN_END_LOOK) - 1);
                         i++;
                     }
                 }
@@ -180,6 +188,7 @@ void grab_report_chunk(const gscan_db *db, int minlen, unsigned flags, const cha
                     uint32_t b0 = 0, b1 = 0;
                     if (gscan_next_resolved(db, content, clen, starts, ends, nstarts, &cur, (uint32_t)s, &b0, &b1) != 1) break;
                     m0 = b0, m1 = b1;
+                    look = reach != 0;
                 }
                 if (w + need > kBuf) {
                     out.append(buf, w);
@@ -774,9 +783,9 @@ bool FileGrep::report_needs_text(unsigned rflags, size_t n, const uint32_t *ext,
     if (context_) return true; // (matches at the restart position / chunk end are the host's to find, list or no list)
     if (n == 0) return false;
     if (resolve_) { // the list holds the matches and their ends: the text is needed for printed lines, for what lies within `reach` of a restart position, and for the records the device left to the host
-        if (!(rflags & GRAB_NOLINE) || reach_ || !ends) return true;
-        for (size_t i = 0; i < n; i++)
-            if (ends[i] == GSCAN_END_ASK) return true;
+        if (!(rflags & GRAB_NOLINE) || !ends) return true;
+        for (size_t i = 0; i < n; i++) // (a record the host has to decide, or a match behind whose end it has to look: GSCAN_END_LOOK)
+            if (ends[i] == GSCAN_END_ASK || (ends[i] != GSCAN_END_CAPTURES && (ends[i] & GSCAN_END_LOOK))) return true;
         return false;
     }
     if (textfree_ && (rflags & GRAB_NOLINE)) return false; // a fixed-length pattern all of whose candidates are listed: gscan_next_match walks the list alone

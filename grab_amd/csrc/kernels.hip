@@ -1275,8 +1275,7 @@ __global__ __launch_bounds__(kResolveWG) void k_resolve(ScanArgs a, const TileDe
         if (p != kStruck && p < slen) {
             VmOut o{0u, 0u};
             const int v = vm_run(vm, seg, slen, p, 0u, o);
-            if (v == 1) code = o.end <= p ? 0u /* GSCAN_END_ASK */ : o.cap ? 0xfffffffeu /* GSCAN_END_CAPTURES */ : o.end;
-            else if (v != 0) code = 0u; // gave up: the host's matcher decides
+            if (v != 0) code = resolve_code(a.prog, seg, slen, p, v, o); // (2 = gave up: GSCAN_END_ASK, the host's matcher decides)
         }
         ends[base + i] = code;
     }

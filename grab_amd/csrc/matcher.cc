@@ -945,7 +945,7 @@ int gscan_next_resolved(const gscan_db *db, const void *content_, size_t clen, c
         if (e == GSCAN_END_CAPTURES) return 2;
         if (e != GSCAN_END_ASK) {
             *m0 = starts[i];
-            *m1 = e;
+            *m1 = e & ~GSCAN_END_LOOK;
             return 1;
         }
         MatchAt m;
@@ -994,7 +994,7 @@ long gscan_vm_resolve(const gscan_db *db, const void *content, size_t clen, cons
         const int v = gscan::vm_run(&db->db.prog.vm, (const uint8_t *)content, (uint32_t)clen, hits[i], 0, o);
         if (v == 0) continue;
         starts[k] = hits[i];
-        ends[k] = v != 1 || o.end <= hits[i] ? GSCAN_END_ASK : o.cap ? GSCAN_END_CAPTURES : o.end;
+        ends[k] = gscan::resolve_code(&db->db.prog, (const uint8_t *)content, (uint32_t)clen, hits[i], v, o);
         k++;
     }
     return (long)k;

@@ -3090,6 +3090,10 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         }
     }
     pg.resolve = db.resolve ? 1u : 0u;
+    pg.reach = db.reach;
+    pg.first_ok = db.first_ok ? 1u : 0u;
+    memcpy(pg.first_bits, db.first.w, 32);
+    memcpy(pg.start_like_bits, db.start_like.w, 32);
     if (!can_hit) { // ^foo, foo$ and the like: a match can only sit at the subject start / chunk end, which is the host's job
         db.tier = GSCAN_TIER_ANCHORED;
         return 0;

@@ -156,6 +156,10 @@ struct DevProgram {
     // which no match can start.  For a gapped alternative the hit is the LAST byte of its unbounded repeat (device window =
     // repeat byte + the rest): the possible starts are walked back along the run of repeat bytes.
     uint32_t resolve;                    // 1: the windows are START windows and every record goes through k_resolve (Database::resolve)
+    // resolve: what the host would look at behind a match's end before it trusts the list again (gscan_next_resolved) -- the device
+    // looks for it (resolve_code below): Database::reach, ::first / ::first_ok, ::start_like as bitmaps
+    uint32_t reach, first_ok;
+    uint32_t first_bits[8], start_like_bits[8];
     uint32_t vm_filter;                  // 1: on
     // bit b0 << 8 | b1: a match may begin with the bytes b0 b1 (matcher.cc, tree_prefix_viable: the host matcher run on
     // every two-byte prefix at compile time).  The hits the filter passes are put to this table first: most die here,
@@ -288,6 +292,31 @@ GSCAN_HD inline bool vm_keep_hit(const DevProgram *pg, const VmProg *vm, const u
         }
     }
     return false;
+}
+
+// What k_resolve writes next to a record at which the VM (verdict v: 1 match, 2 gave up; out: its end / captured) did not say
+// "no match": the match's end, GSCAN_END_CAPTURES, or GSCAN_END_ASK -- and, in bit 31 of an end (GSCAN_END_LOOK), whether the
+// host has to LOOK at the text when it restarts behind this match: pcre_exec sees nothing in front of the restart position
+// (src/grab.cc:178), so with a pattern that looks back (reach > 0) the list is good only from `reach` bytes further on and
+// the offsets in between are the host matcher's -- unless no match can begin there anyway (the byte at the end cannot begin
+// one) or the byte in front of the end is to the pattern what the subject start is (start_like).  Both are a look at two bytes
+// the device has at hand; the host's -O -l walk then touches the text for a few matches in a thousand instead of for each.
+// Shared by the kernel and its host mirror (gscan_vm_resolve).
+GSCAN_HD inline uint32_t resolve_code(const DevProgram *pg, const uint8_t *seg, uint32_t slen, uint32_t p, int v, const VmOut &o)
+{
+    if (v != 1 || o.end <= p) return 0u;              // GSCAN_END_ASK
+    if (o.cap) return 0xfffffffeu;                    // GSCAN_END_CAPTURES
+    uint32_t look = 0;
+    const uint32_t e = o.end;
+    if (pg->reach > 1u) {
+        look = 1;
+    } else if (pg->reach == 1u && e < slen) {
+        const uint32_t before = seg[e - 1], at = seg[e];
+        const bool same = (pg->start_like_bits[before >> 5] >> (before & 31u)) & 1u;
+        const bool can_begin = !pg->first_ok || ((pg->first_bits[at >> 5] >> (at & 31u)) & 1u);
+        look = !same && can_begin;
+    }
+    return e | (look << 31);
 }
 
 // rc: 0 ok, 1 unsupported, -1 malformed.  `why` gets a short reason.

@@ -318,7 +318,7 @@ GSCAN_API int gscan_next_listed(const gscan_db *db, size_t clen, const uint32_t 
  *   ends[i] == GSCAN_END_ASK       the device's VM gave up at starts[i] (step / stack limit): the host matcher decides;
  *   ends[i] == GSCAN_END_CAPTURES  a match starts there whose path closes a capturing group: pcre_exec returns 0 with the
  *                                  reference's int ovector[3] (src/grab.cc:171) and the chunk loop ends (src/grab.cc:179);
- *   else                           a match [starts[i], ends[i]).
+ *   else                           a match [starts[i], ends[i] & ~GSCAN_END_LOOK).
  * The verdicts were reached with the chunk's real bytes in front of starts[i]; pcre_exec sees nothing in front of the restart
  * position s, so the `reach` offsets from s on are the host matcher's (content is read there, and only there
  * and at GSCAN_END_ASK records: with reach == 0 and no such record it may be NULL).  Returns as gscan_next_match; -1 if the
@@ -326,6 +326,12 @@ GSCAN_API int gscan_next_listed(const gscan_db *db, size_t clen, const uint32_t 
  */
 #define GSCAN_END_ASK 0u
 #define GSCAN_END_CAPTURES 0xfffffffeu
+/* bit 31 of a match end (ends are chunk offsets, <= 2^30 + 4096): behind THIS match's end the host has to look at the text before
+ * it trusts the list again -- the pattern looks back (reach > 0), a match could begin within `reach` bytes of the end, and the
+ * byte in front of the end is not one the pattern takes for the subject start.  Clear: a walk that restarts at this end
+ * (-O -l: src/grab.cc:209 with a == 0) goes straight to the next record, without reading a byte of the chunk.  Set by the device
+ * (k_resolve looks at the two bytes around the end); gscan_next_resolved does not need it (it looks itself) and masks it. */
+#define GSCAN_END_LOOK 0x80000000u
 GSCAN_API int gscan_next_resolved(const gscan_db *db, const void *content, size_t clen, const uint32_t *starts, const uint32_t *ends, size_t n,
                         gscan_cursor *cur, uint32_t s, uint32_t *m0, uint32_t *m1);
 /* the bytes a match can begin with: table[b] & 1 if b can; returns 1 if that is known (0: the pattern may begin without

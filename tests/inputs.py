@@ -100,7 +100,7 @@ def engine_list(db, data):
     return so.group_starts(cands).astype(np.uint32)
 
 
-END_ASK, END_CAPTURES = 0, 0xfffffffe  # GSCAN_END_* (include/gscan.h)
+END_ASK, END_CAPTURES, END_LOOK = 0, 0xfffffffe, 0x80000000  # GSCAN_END_* (include/gscan.h)
 
 
 def resolved_list(db, data):
