@@ -941,6 +941,7 @@ struct gscan_ctx {
     DevProgram *d_prog = nullptr;
     DevProgram *h_prog = nullptr; // pinned staging
     uint64_t prog_id = 0;
+    uint32_t rec_permille = 0; // of the database uploaded last: DevProgram::est_permille if every hit of its windows becomes a record (resolve without K3's own VM in front), else 0
     hipEvent_t prog_ev = nullptr;      // behind the last upload of the program ...
     hipStream_t prog_stream = nullptr; // ... on this stream
     bool prog_pending = false;
@@ -1011,6 +1012,9 @@ int fail(gscan_ctx *c, int code, const char *fmt, ...)
     } while (0)
 
 void slot_drain_reads(Slot &s);
+
+// (before a slot is sized for a chunk of this database: slot_reserve_device)
+void note_db(gscan_ctx *c, const gscan_db *db) { c->rec_permille = db->db.prog.resolve && !db->db.prog.vm_filter ? db->db.prog.est_permille : 0u; }
 
 int ensure_prog(gscan_ctx *c, const gscan_db *db, hipStream_t st)
 {
@@ -1096,7 +1100,12 @@ int slot_reserve_device(gscan_ctx *c, Slot &s, size_t len)
         trace("slot: descriptors pinned (%zu KiB)", cap * 8 >> 10);
         s.tiles_cap = cap;
     }
-    size_t want = std::max<size_t>((len / 64 + gscan::kShards - 1) / gscan::kShards * gscan::kShards, kSpecRecs);
+    // records: one per 64 bytes of text to begin with (a shard that overflows makes the host regrow and rescan) -- more from the
+    // start for a database whose every window hit is a record (the resolve pass's: no group-start compression) when its windows
+    // are expected to hit often: twice the compiler's estimate, so that the first window of every slot is not scanned twice
+    size_t per = len / 64;
+    if (c->rec_permille > 16) per = std::max(per, (size_t)((double)len * std::min(1000u, 2 * c->rec_permille) / 1000.0));
+    size_t want = std::max<size_t>((per + gscan::kShards - 1) / gscan::kShards * gscan::kShards, kSpecRecs);
     if (want > s.rec_cap) {
         if (s.d_recs) hipFree(s.d_recs);
         s.d_recs = nullptr;
@@ -1779,6 +1788,7 @@ int gscan_submit(gscan_ctx *c, const gscan_db *db, const void *host_bytes, size_
     } else if (own && len > (host_bytes == s->pinned ? s->pinned_cap : block_bytes())) {
         return fail(c, GSCAN_EINVAL, "submitted %zu bytes into a smaller acquired buffer", len);
     }
+    note_db(c, db);
     int rc = ensure_prog(c, db, c->compute);
     if (rc) return rc;
     rc = slot_reserve_device(c, *s, len);
@@ -1850,6 +1860,7 @@ int gscan_submit_segs(gscan_ctx *c, const gscan_db *db, const void *pinned, cons
         if (segs[i].offset + segs[i].len > cap) return fail(c, GSCAN_EINVAL, "segment %zu lies outside the acquired buffer", i);
         used = std::max<size_t>(used, segs[i].offset + segs[i].len);
     }
+    note_db(c, db);
     int rc = ensure_prog(c, db, c->compute);
     if (rc) return rc;
     rc = slot_reserve_device(c, *s, used);
@@ -1889,6 +1900,7 @@ int gscan_submit_fd(gscan_ctx *c, const gscan_db *db, int fd, long long file_off
     HIPCHK(c, hipSetDevice(c->hip_dev));
     Slot *s = free_slot_for_submit(c);
     if (!s) return fail(c, GSCAN_EBUSY, "no free slot (all in flight, or one is acquired)");
+    note_db(c, db);
     trace("submit_fd: %zu bytes", len);
     int rc = 0;
     if (c->prog_id == 0 && len > s->d_text_cap) {
@@ -1996,6 +2008,7 @@ int gscan_submit_files(gscan_ctx *c, const gscan_db *db, const gscan_file *files
     HIPCHK(c, hipSetDevice(c->hip_dev));
     Slot *s = free_slot_for_submit(c);
     if (!s) return fail(c, GSCAN_EBUSY, "no free slot (all in flight, or one is acquired)");
+    note_db(c, db);
     int rc = ensure_prog(c, db, c->compute);
     if (rc) return rc;
     rc = slot_reserve_device(c, *s, used);

@@ -2011,6 +2011,29 @@ int byte_rank(unsigned b)
     return 20;
 }
 
+// How often a byte value turns up in text, roughly (source code, logs, prose): what a class costs as a filter position is
+// the sum over its members -- \W has 193 members and takes one byte in four, [a-z] has 26 and takes six in ten.  (Pricing a
+// class by its SIZE, as the K3 depth choice does, is fine for telling literals from classes and useless for telling \w from \W.)
+double byte_prob(unsigned b)
+{
+    if (b >= 'a' && b <= 'z') return 0.58 / 26;
+    if (b == ' ') return 0.14;
+    if (b >= 'A' && b <= 'Z') return 0.05 / 26;
+    if (b >= '0' && b <= '9') return 0.06 / 10;
+    if (b == '\n') return 0.025;
+    if (b == '_') return 0.01;
+    if (b == '\t') return 0.01;
+    if (b >= 33 && b < 127) return 0.115 / 31; // punctuation
+    return 0.01 / 160;                        // control characters, high bytes
+}
+double class_prob(const ByteSet &c)
+{
+    double p = 0;
+    for (unsigned b = 0; b < 256; b++)
+        if (c.test(b)) p += byte_prob(b);
+    return std::min(1.0, p);
+}
+
 std::atomic<uint64_t> g_next_id{1};
 
 uint64_t node_minlen(const Node &n);
@@ -2583,6 +2606,28 @@ static void start_like_bytes(const Node &n, ByteSet &e)
     for (const Node &k : n.kids) start_like_bytes(k, e);
 }
 
+// One-byte look-behinds at the very head of the pattern -- (?<=\$)\d+ , (?<![A-Za-z0-9_])[A-Z]{2,} , (?<=\()[^()\n]+(?=\)) -- say
+// which bytes may stand in front of a match that has a byte in front of it at all: a condition for the START windows' leading
+// context position (the unfolder leaves look-arounds to the matcher: without this such a pattern's windows begin with its first
+// consuming item, and [^()\n]+ lists nineteen bytes in twenty).  The set of allowed preceding bytes; all of them if there is none.
+static ByteSet leading_behind(const Node &root)
+{
+    ByteSet allow = set_all();
+    const Node *seq = &root;
+    while ((seq->kind == Node::CAT && seq->kids.size() == 1 && !seq->cap) || (seq->kind == Node::ALT && seq->kids.size() == 1)) seq = &seq->kids[0];
+    if (seq->kind != Node::CAT) return allow;
+    for (const Node &k : seq->kids) {
+        if (k.kind == Node::ASSERT) continue; // zero-width: what follows still stands at the match start
+        if (k.kind != Node::LOOK) break;
+        if (!k.behind) continue;              // a look-ahead: zero-width too
+        const Node *b = &k.kids[0];
+        while ((b->kind == Node::CAT || b->kind == Node::ALT) && b->kids.size() == 1 && !b->cap) b = &b->kids[0];
+        if (b->kind != Node::SET) continue;   // (longer or branching bodies: no condition taken from them)
+        allow = set_and(allow, k.neg ? set_not(b->set) : b->set);
+    }
+    return allow;
+}
+
 static bool has_keep(const Node &n)
 {
     if (n.kind == Node::ASSERT && n.acode == A_KEEP) return true;
@@ -2960,18 +3005,21 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         std::vector<std::vector<uint8_t>> w;
         bool pre = false, post = false, can_hit = false;
         size_t min_dev = SIZE_MAX, total = 0;
-        double density = 0; // expected hits per text byte, pricing a class by its size over the ~64 byte values text is made of
+        double density = 0; // expected hits per text byte: every window's classes priced by how often their members turn up in text (class_prob)
     };
+    const ByteSet lead = leading_behind(*db.tree);
     auto make_windows = [&](bool starts, Windows &out) -> int { // 0 ok, 1 refused (why is set)
         for (const AltSeq &a : db.alts) {
             out.pre = out.pre || (a.has_pre() && (starts || !a.gapped)); // (hit windows: a gapped path's start is not where its device window is)
             out.post = out.post || (!starts && a.has_post());
         }
+        if (starts && lead.count() != 256) out.pre = true;
         for (const AltSeq &a : db.alts) {
-            if (starts && a.pre.count() == 0) continue; // (can only sit at the subject start: the host's own test there finds it)
+            const ByteSet pre = starts ? set_and(a.pre, lead) : a.pre;
+            if (starts && pre.count() == 0) continue; // (can only sit at the subject start: the host's own test there finds it)
             std::vector<uint8_t> w;
             if (out.pre) {
-                const int id = class_id(!starts && a.gapped ? set_all() : a.pre);
+                const int id = class_id(!starts && a.gapped ? set_all() : pre);
                 if (id < 0) return 1;
                 w.push_back((uint8_t)id);
             }
@@ -2995,13 +3043,14 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             out.min_dev = std::min(out.min_dev, w.size());
             out.total += w.size();
             double prod = 1;
-            for (uint8_t c : w) prod *= std::min(1.0, db.classes[c].count() / 64.0);
+            for (uint8_t c : w) prod *= class_prob(db.classes[c]);
             out.density += prod;
             out.w.push_back(std::move(w));
         }
         return 0;
     };
     Windows hitw, startw;
+    bool dense_starts = false;
     if (int rc = make_windows(false, hitw)) {
         why = rc == 2 ? "window longer than the engine supports" : "too many distinct classes";
         return 1;
@@ -3034,6 +3083,12 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             if (!gapped) want = false;
         }
         db.resolve = want;
+        // Start windows that list a large part of the text (\w+(?=\() : three bytes in four): K3 puts every filter hit to the VM in
+        // its own cold path first (DevProgram::vm_filter, the wave-wide survivor queue of round 5) and only the offsets at which a
+        // match does start become records -- one in twenty -- for k_resolve to measure.  Without it the scan wrote 48 M records
+        // per 64 MiB window, every slot's record buffers grew to gigabytes and the run was allocation and teardown:
+        // 1.0 s for 4 GiB (profiles/r06_v_dense_candidates.txt).
+        dense_starts = want && startw.density > dmax;
     }
     const Windows &win = db.resolve ? startw : hitw;
     db.dev_pre = win.pre;
@@ -3091,6 +3146,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     }
     pg.resolve = db.resolve ? 1u : 0u;
     pg.reach = db.reach;
+    pg.est_permille = (uint32_t)std::min(1000.0, std::ceil(1000.0 * (db.resolve ? startw.density : hitw.density)));
     pg.first_ok = db.first_ok ? 1u : 0u;
     memcpy(pg.first_bits, db.first.w, 32);
     memcpy(pg.start_like_bits, db.start_like.w, 32);
@@ -3181,7 +3237,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     if (getenv("GSCAN_SAME_WINDOW_K3")) one_window = db.dev_windows.size() == 1; // (A/B switch: the round-2 choice)
     if (!one_window) {
         db.tier = GSCAN_TIER_BUCKET;
-        pg.vm_filter = vm_dev;
+        pg.vm_filter = vm_dev || dense_starts;
         if (vm_dev) fill_vm_pairs(db);
         return 0;
     }
@@ -3261,6 +3317,10 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         pg.vm_filter = 1;
         db.tier = GSCAN_TIER_BUCKET;
         fill_vm_pairs(db);
+    }
+    if (dense_starts) { // (one dense start window: K3 for its VM cold path, whatever K2 would make of the window)
+        pg.vm_filter = 1;
+        db.tier = GSCAN_TIER_BUCKET;
     }
     return 0;
 }

@@ -159,6 +159,7 @@ struct DevProgram {
     // resolve: what the host would look at behind a match's end before it trusts the list again (gscan_next_resolved) -- the device
     // looks for it (resolve_code below): Database::reach, ::first / ::first_ok, ::start_like as bitmaps
     uint32_t reach, first_ok;
+    uint32_t est_permille;               // the windows' expected hits per 1000 bytes of text (pattern.cc, class_prob): sizes the record buffers of a database whose every hit is a record
     uint32_t first_bits[8], start_like_bits[8];
     uint32_t vm_filter;                  // 1: on
     // bit b0 << 8 | b1: a match may begin with the bytes b0 b1 (matcher.cc, tree_prefix_viable: the host matcher run on
@@ -262,6 +263,8 @@ GSCAN_HD inline bool vm_start_viable(const DevProgram *pg, const uint8_t *seg, u
 }
 GSCAN_HD inline bool vm_keep_hit(const DevProgram *pg, const VmProg *vm, const uint8_t *seg, uint32_t slen, uint32_t q)
 {
+    if (pg->resolve) // start windows: the hit stands for a match AT the hit (behind the context position, if the windows carry one) and nothing else
+        return q + pg->report_shift < slen && vm_run(vm, seg, slen, q + pg->report_shift, 0) != 0;
     if (vm_start_viable(pg, seg, slen, q) && vm_run(vm, seg, slen, q, 0) != 0) return true;
     const uint32_t n = pg->n_alts;
     for (uint32_t i = 0; i < n; i++) {

@@ -140,7 +140,19 @@ struct Builder {
         }
         case Node::ATOMIC: f = first_of(n.kids[0]); break;
         case Node::ASSERT:
+            f.nullable = true;
+            break;
         case Node::LOOK:
+            // a positive look-ahead consumes nothing but says what the NEXT byte has to be: for what these sets are used for -- a
+            // split's first-byte prediction, "can giving back a byte of the repeat in front ever help" -- that is an answer
+            // (\w+(?=\() : the repeat is compiled possessive).  Negative ones and look-behinds say nothing about the next byte.
+            if (!n.behind && !n.neg) {
+                const First g = first_of(n.kids[0]);
+                if (!g.nullable) {
+                    f.set = g.set;
+                    break;
+                }
+            }
             f.nullable = true;
             break;
         case Node::COND:
