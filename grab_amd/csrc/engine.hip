@@ -1104,7 +1104,7 @@ int slot_reserve_device(gscan_ctx *c, Slot &s, size_t len)
     // start for a database whose every window hit is a record (the resolve pass's: no group-start compression) when its windows
     // are expected to hit often: twice the compiler's estimate, so that the first window of every slot is not scanned twice
     size_t per = len / 64;
-    if (c->rec_permille > 16) per = std::max(per, (size_t)((double)len * std::min(1000u, 2 * c->rec_permille) / 1000.0));
+    if (c->rec_permille > 16) per = std::max(per, (size_t)((double)len * std::min(250u, 2 * c->rec_permille) / 1000.0)); // (at most a record per four bytes up front: denser still, and the regrow path sizes it)
     size_t want = std::max<size_t>((per + gscan::kShards - 1) / gscan::kShards * gscan::kShards, kSpecRecs);
     if (want > s.rec_cap) {
         if (s.d_recs) hipFree(s.d_recs);

@@ -3050,7 +3050,6 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         return 0;
     };
     Windows hitw, startw;
-    bool dense_starts = false;
     if (int rc = make_windows(false, hitw)) {
         why = rc == 2 ? "window longer than the engine supports" : "too many distinct classes";
         return 1;
@@ -3083,12 +3082,10 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
             if (!gapped) want = false;
         }
         db.resolve = want;
-        // Start windows that list a large part of the text (\w+(?=\() : three bytes in four): K3 puts every filter hit to the VM in
-        // its own cold path first (DevProgram::vm_filter, the wave-wide survivor queue of round 5) and only the offsets at which a
-        // match does start become records -- one in twenty -- for k_resolve to measure.  Without it the scan wrote 48 M records
-        // per 64 MiB window, every slot's record buffers grew to gigabytes and the run was allocation and teardown:
-        // 1.0 s for 4 GiB (profiles/r06_v_dense_candidates.txt).
-        dense_starts = want && startw.density > dmax;
+        // (Round 6, measured and taken out again: start windows that list a large part of the text -- \w+(?=\() , three bytes in
+        // four -- put to the VM in K3's own cold path first, so that only match starts become records.  The survivor queue runs the
+        // VM worse than k_resolve's work list does: 341 ms of kernels for 4 GiB against 125 ms, the same wall clock --
+        // profiles/r06_v_dense_candidates.txt.)
     }
     const Windows &win = db.resolve ? startw : hitw;
     db.dev_pre = win.pre;
@@ -3237,7 +3234,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
     if (getenv("GSCAN_SAME_WINDOW_K3")) one_window = db.dev_windows.size() == 1; // (A/B switch: the round-2 choice)
     if (!one_window) {
         db.tier = GSCAN_TIER_BUCKET;
-        pg.vm_filter = vm_dev || dense_starts;
+        pg.vm_filter = vm_dev;
         if (vm_dev) fill_vm_pairs(db);
         return 0;
     }
@@ -3317,10 +3314,6 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         pg.vm_filter = 1;
         db.tier = GSCAN_TIER_BUCKET;
         fill_vm_pairs(db);
-    }
-    if (dense_starts) { // (one dense start window: K3 for its VM cold path, whatever K2 would make of the window)
-        pg.vm_filter = 1;
-        db.tier = GSCAN_TIER_BUCKET;
     }
     return 0;
 }

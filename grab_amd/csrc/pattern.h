@@ -263,8 +263,6 @@ GSCAN_HD inline bool vm_start_viable(const DevProgram *pg, const uint8_t *seg, u
 }
 GSCAN_HD inline bool vm_keep_hit(const DevProgram *pg, const VmProg *vm, const uint8_t *seg, uint32_t slen, uint32_t q)
 {
-    if (pg->resolve) // start windows: the hit stands for a match AT the hit (behind the context position, if the windows carry one) and nothing else
-        return q + pg->report_shift < slen && vm_run(vm, seg, slen, q + pg->report_shift, 0) != 0;
     if (vm_start_viable(pg, seg, slen, q) && vm_run(vm, seg, slen, q, 0) != 0) return true;
     const uint32_t n = pg->n_alts;
     for (uint32_t i = 0; i < n; i++) {

@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 DENSE = [r"\b[A-Za-z_]\w*\s*\(", r"(?<=\$)\d+", r"\s\w{8,}\s", r"\b[A-Z][a-z]+\b", r"\([^()]*\)", r"\b[a-z]{3,}\b"]
 MORE = [r"foo|bar|[0-9]{5}", r"\d+\.\d+", r"\bfoobardoesnotexist\b", r"(?<=ab)c+|(?<!a)b\w", r"(?m)^\w+ \w+$", r"(a)b|cd+e", r"(?i)\bxyzzy\b|\bplugh\b",
         r"[a-z]+_[0-9]+\.[a-z]+", r"\Bab\B", r"x(?=(a))ab|ab\d",
-        # start windows that list most of the text: K3 puts the hits to the VM in its own cold path first (info.vm), k_resolve measures the survivors
+        # start windows that list most of the text (the record buffers regrow), a leading look-behind as the windows' context byte
         r"\w+(?=\()", r"\w+\s*=\s*\w+\s*\(", r"(?<=\()[^()\n]+(?=\))", r"(?:foo|bar)+does.*exist|[0-9]+\.[0-9]+\.[0-9]+|\b(?:[a-z]+_)+[a-z]+\b"]
 
 
