@@ -378,7 +378,9 @@ public:
             for (int i = 0; i < readers_; i++) threads_.emplace_back([this, i] { reader_main(i); });
         }
         tasks_.insert(tasks_.end(), t, t + n);
-        if (n == 1) cv_tasks_.notify_one();
+        // (one task, one reader woken -- unless some readers sit out (relimit): notify_one might pick one of those, which goes back
+        // to sleep without the task, and nobody else would hear of it)
+        if (n == 1 && limit_.load(std::memory_order_relaxed) >= readers_) cv_tasks_.notify_one();
         else cv_tasks_.notify_all();
     }
     int readers() const { return readers_; }
@@ -948,6 +950,7 @@ struct gscan_ctx {
     // options
     // defaults from the sweeps under profiles/: 12 KiB per wave (110 VGPRs -> 4 waves/SIMD) with
     // nontemporal loads, one workgroup per tile
+    int k3_depth = 0; // option "k3_depth"
     int variant = 38; // 12 KiB per wave, nontemporal loads, K2's lane-table form for windows of <= 17 bytes
     int blocks_per_cu = 0;
     size_t register_min = 1u << 20; // caller buffers of at least this many bytes are registered and DMA'd in place
@@ -1206,6 +1209,7 @@ int slot_launch(gscan_ctx *c, Slot &s)
     a.counter = s.d_counter;
     a.prog = c->d_prog;
     gscan::fill_program(a, db.prog);
+    if (c->k3_depth) a.k3_depth = (uint32_t)c->k3_depth;
     if (s.n_tiles) HIPCHK(c, gscan::launch_scan(db.tier, c->variant, a, grid_for(c, db, s.n_tiles), c->compute));
     if (s.n_tiles && gscan::scan_needs_settle(db.tier, db.prog)) HIPCHK(c, gscan::launch_settle(a, nw, c->compute));
     // (a database the device resolves always comes with its matches' ends: the list means nothing else)
@@ -2360,6 +2364,11 @@ int gscan_set_option(gscan_ctx *c, const char *name, long value)
         c->match_ends = value != 0;
         return GSCAN_OK;
     }
+    if (!strcmp(name, "k3_depth")) { // K3's filter positions: 0 = the compiler's choice (3 or 4), else 2, 3 or 4 (A/B runs, tests: every depth lists the same records)
+        if (value != 0 && (value < 2 || value > 4)) return GSCAN_EINVAL;
+        c->k3_depth = (int)value;
+        return GSCAN_OK;
+    }
     if (!strcmp(name, "blocks_per_cu")) {
         if (value < 0 || value > 64) return GSCAN_EINVAL;
         c->blocks_per_cu = (int)value;
@@ -2452,6 +2461,7 @@ int gscan_scan_device(gscan_ctx *c, const gscan_db *db, const void *dev_base, co
     a.counter = c->dv_counter;
     a.prog = c->d_prog;
     gscan::fill_program(a, db->db.prog);
+    if (c->k3_depth) a.k3_depth = (uint32_t)c->k3_depth;
     if (c->ev_used == c->ev_pool.size() && c->ev_pool.size() < 4096) {
         EvPair e;
         HIPCHK(c, hipEventCreate(&e.a));

@@ -1,6 +1,6 @@
 // gscan_sweep.hip -- native A/B harness for the scan kernels (no Python, no torch).
 //
-//   gscan_sweep [--gib G] [--seg-mib M] [--pattern P]... [--iters N] [--variants 0,1,2,4,5,6,38] [--bpc 0,4,8,16]
+//   gscan_sweep [--gib G] [--seg-mib M] [--pattern P]... [--iters N] [--variants 0,1,2,4,5,6,38] [--bpc 0,4,8,16] [--k3-depth 0,2,3,4]
 //   (--pattern may be given several times: the patterns run one after the other on the same arena; variant -1 = the engine's default)
 //
 // Fills a G GiB arena in HBM with synthetic text (57-symbol alphabet, SURVEY.md 8d
@@ -83,7 +83,7 @@ int main(int argc, char **argv)
     double gib = 8;
     int seg_mib = 64, iters = 10;
     std::vector<std::string> patterns;
-    std::vector<long> variants = {0, 1, 2, 4, 5, 6}, bpcs = {0, 8};
+    std::vector<long> variants = {0, 1, 2, 4, 5, 6}, bpcs = {0, 8}, depths = {0}; // depth: K3's filter positions (0 = the compiler's choice)
     int plant_every_mib = 1;
     bool ceiling = false;
     for (int i = 1; i < argc; i++) {
@@ -94,6 +94,7 @@ int main(int argc, char **argv)
         else if (is("--iters")) iters = atoi(argv[++i]);
         else if (is("--variants")) variants = parse_list(argv[++i]);
         else if (is("--bpc")) bpcs = parse_list(argv[++i]);
+        else if (is("--k3-depth")) depths = parse_list(argv[++i]);
         else if (is("--plant-mib")) plant_every_mib = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--ceiling")) ceiling = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
@@ -155,14 +156,15 @@ int main(int argc, char **argv)
         gscan_info info;
         gscan_db_info(db, &info);
 
-        struct Cell { long variant, bpc; double sum = 0, best = 1e30; int n = 0; uint64_t matches = 0; };
+        struct Cell { long variant, bpc, depth; double sum = 0, best = 1e30; int n = 0; uint64_t matches = 0; };
         std::vector<Cell> cells;
-        for (long v : variants) for (long b : bpcs) { Cell c; c.variant = v; c.bpc = b; cells.push_back(c); }
+        for (long v : variants) for (long b : bpcs) for (long d : depths) { Cell c; c.variant = v; c.bpc = b; c.depth = d; cells.push_back(c); }
         printf("# arena %.2f GiB in %zu x %d MiB segments, pattern '%s' (tier %d, minlen %d), %d iters\n", total / 1073741824.0, nseg, seg_mib, pattern.c_str(), info.tier, minlen, iters);
         for (int it = -1; it < iters; it++) { // it == -1: warm-up round
             for (Cell &c : cells) {
                 if (c.variant >= 0) gscan_set_option(ctx, "variant", c.variant);
                 gscan_set_option(ctx, "blocks_per_cu", c.bpc);
+                gscan_set_option(ctx, "k3_depth", c.depth);
                 gscan_dev_result res;
                 int rc = gscan_scan_device(ctx, db, arena, segs.data(), nseg, nullptr, &res);
                 if (rc != GSCAN_OK) { fprintf(stderr, "scan failed: %s\n", gscan_strerror(ctx)); return 1; }
@@ -176,6 +178,7 @@ int main(int argc, char **argv)
         }
         for (const Cell &c : cells) {
             const double bytes = (double)total + 4.0 * c.matches;
+            if (depths.size() > 1 || depths[0] != 0) printf("k3_depth %ld ", c.depth);
             printf("variant %ld bpc %2ld : mean %8.3f ms  min %8.3f ms  -> %8.1f GB/s mean, %8.1f GB/s best   matches %llu\n", c.variant, c.bpc,
                    c.sum / c.n, c.best, bytes / (c.sum / c.n) / 1e6, bytes / c.best / 1e6, (unsigned long long)c.matches);
         }
