@@ -2364,8 +2364,8 @@ int gscan_set_option(gscan_ctx *c, const char *name, long value)
         c->match_ends = value != 0;
         return GSCAN_OK;
     }
-    if (!strcmp(name, "k3_depth")) { // K3's filter positions: 0 = the compiler's choice (3 or 4), else 2, 3 or 4 (A/B runs, tests: every depth lists the same records)
-        if (value != 0 && (value < 2 || value > 4)) return GSCAN_EINVAL;
+    if (!strcmp(name, "k3_depth")) { // K3's filter positions: 0 = the compiler's choice, else 3 or 4 (A/B runs, tests: both depths list the same records)
+        if (value != 0 && value != 3 && value != 4) return GSCAN_EINVAL;
         c->k3_depth = (int)value;
         return GSCAN_OK;
     }

@@ -1,6 +1,6 @@
 // gscan_sweep.hip -- native A/B harness for the scan kernels (no Python, no torch).
 //
-//   gscan_sweep [--gib G] [--seg-mib M] [--pattern P]... [--iters N] [--variants 0,1,2,4,5,6,38] [--bpc 0,4,8,16] [--k3-depth 0,2,3,4]
+//   gscan_sweep [--gib G] [--seg-mib M] [--pattern P]... [--iters N] [--variants 0,1,2,4,5,6,38] [--bpc 0,4,8,16] [--k3-depth 0,3,4]
 //   (--pattern may be given several times: the patterns run one after the other on the same arena; variant -1 = the engine's default)
 //
 // Fills a G GiB arena in HBM with synthetic text (57-symbol alphabet, SURVEY.md 8d

@@ -571,15 +571,6 @@ __device__ __forceinline__ void and_b0_b1_into(uint32_t &dst, uint32_t x, uint32
     else if constexpr (BYTE == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1" : "+v"(dst) : "v"(x), "v"(y));
     else asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1" : "+v"(dst) : "v"(x), "v"(y));
 }
-// two filter positions: byte BYTE of dst = byte 0 of x (P_0) & byte 2 of y (P_1 in the LDS layout [P_0, P_2, P_1, P_3])
-template <int BYTE>
-__device__ __forceinline__ void and_b0_b2_into(uint32_t &dst, uint32_t x, uint32_t y)
-{
-    if constexpr (BYTE == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2" : "=v"(dst) : "v"(x), "v"(y));
-    else if constexpr (BYTE == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_2" : "+v"(dst) : "v"(x), "v"(y));
-    else if constexpr (BYTE == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_2" : "+v"(dst) : "v"(x), "v"(y));
-    else asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_2" : "+v"(dst) : "v"(x), "v"(y));
-}
 // 16-bit mask of the NONZERO bytes of H[0..3] (byte k of H[q] = position 4 q + k).  one: every byte is 0 or 1 already (a
 // single bucket).  Bytes -> 0 / 1 by the exact SWAR test, then one v_dot4_u32_u8 per register with the weights 1 2 4 8 /
 // 16 32 64 128 adds the four bits of a register into place.
@@ -597,7 +588,10 @@ __device__ __forceinline__ uint32_t nonzero_bytes16(const uint32_t (&H)[4], bool
 }
 // DEPTH: window positions the filter looks at.  4 by default; 3 when the compiler expects three positions to be selective
 // enough (ScanArgs::k3_depth: literal-like alternatives) -- two SDWA operations per byte instead of three and one look-up
-// less per step, paid for with more trips into the confirm path.
+// less per step, paid for with more trips into the confirm path.  (TWO positions -- one operation per byte, 16 instead of 32 per
+// step, 94 VGPRs -- was built and measured in round 6: 15 - 45 % SLOWER for every pattern tried, the three-literal alternation
+// included: with two positions a wave-step has a hit more often than not and the cold path runs every step.
+// profiles/r06_aa_k3_depth_sweep.txt; the change itself: profiles/r06_aa_k3_two_position_filter.patch.)
 // NW: waves per workgroup.  8 (512 threads, ITER 12: 4 waves per SIMD) or 12 (768 threads, ITER 8, two workgroups per CU
 // = 6 waves per SIMD within 80 VGPRs: the same 96 KiB tile, fewer bytes in flight per wave, more waves to hide the LDS
 // and HBM latency behind).
@@ -635,7 +629,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : VM ? GSCAN_VM_WAVES : 1) vo
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t lane4 = lane << 2;
     const uint32_t koff = a.k3_off, m = a.m;
-    const bool exact = DEPTH == 2 ? false : (DEPTH == 4 ? a.k3_exact : a.k3_exact3) != 0; // the filtered positions ARE the pattern (three positions: windows of <= 3 bytes; two: never -- every hit is confirmed)
+    const bool exact = (DEPTH == 4 ? a.k3_exact : a.k3_exact3) != 0; // the filtered positions ARE the pattern (three positions: windows of <= 3 bytes)
     const bool confirm_exact = a.prog->k3_confirm_exact != 0; // wave-uniform (scalar load)
     const bool vm_quick = VM && a.prog->vm_pair_ok == 2;      // (DevProgram::vm_pair may drop a hit on its own)
     const bool one_bucket = a.k3_one_bucket != 0;             // every table byte is 0 or 1
@@ -732,8 +726,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : VM ? GSCAN_VM_WAVES : 1) vo
                 GS_E(4, d.y, 0);  GS_E(5, d.y, 1);  GS_E(6, d.y, 2);  GS_E(7, d.y, 3);
                 GS_E(8, d.z, 0);  GS_E(9, d.z, 1);  GS_E(10, d.z, 2); GS_E(11, d.z, 3);
                 GS_E(12, d.w, 0); GS_E(13, d.w, 1); GS_E(14, d.w, 2); GS_E(15, d.w, 3);
-                GS_E(16, nd, 0);
-                if (DEPTH >= 3) GS_E(17, nd, 1);
+                GS_E(16, nd, 0);  GS_E(17, nd, 1);
                 if (DEPTH == 4) GS_E(18, nd, 2);
 #undef GS_E
                 if (PF) { // this step's text is look-up addresses now: its registers take the next tile's
@@ -745,20 +738,10 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : VM ? GSCAN_VM_WAVES : 1) vo
                 // (plain shift + and in place of the selects: twice that -- profiles/r01_o_sweep_k3_sdwa.txt)
                 uint32_t H[4]; // byte k of H[q] = h_{4q+k}: the buckets that accept the four filter positions from position 4 q + k on
                 uint32_t Y[18];
-                if constexpr (DEPTH == 2) {
-                    // two positions: h_j = P_0(t_j) & P_1(t_{j+1}), ONE operation per byte, packed by the destination select
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        and_b0_b2_into<0>(H[q], e[4 * q], e[4 * q + 1]);
-                        and_b0_b2_into<1>(H[q], e[4 * q + 1], e[4 * q + 2]);
-                        and_b0_b2_into<2>(H[q], e[4 * q + 2], e[4 * q + 3]);
-                        and_b0_b2_into<3>(H[q], e[4 * q + 3], e[4 * q + 4]);
-                    }
-                }
+                for (int j = 0; j < (DEPTH == 3 ? 16 : 18); j++) Y[j] = and_w0_w1(e[j], e[j + 1]);
 #pragma unroll
-                for (int j = 0; j < (DEPTH == 2 ? 0 : DEPTH == 3 ? 16 : 18); j++) Y[j] = and_w0_w1(e[j], e[j + 1]);
-#pragma unroll
-                for (int q = 0; q < (DEPTH == 2 ? 0 : 4); q++) {
+                for (int q = 0; q < 4; q++) {
                     and_b0_b1_into<0>(H[q], Y[4 * q], DEPTH == 3 ? e[4 * q + 2] : Y[4 * q + 2]);
                     and_b0_b1_into<1>(H[q], Y[4 * q + 1], DEPTH == 3 ? e[4 * q + 3] : Y[4 * q + 3]);
                     and_b0_b1_into<2>(H[q], Y[4 * q + 2], DEPTH == 3 ? e[4 * q + 4] : Y[4 * q + 4]);
@@ -1484,8 +1467,7 @@ static hipError_t launch_iter(int tier, bool nt, bool wide, int wg, const ScanAr
         } else if (wg == -1 && ITER == 12 && nt) { // the prefetching form
             if (a.k3_depth == 3) hipLaunchKernelGGL((k3_bucket_scan<12, true, 3, 8, false, true>), g, dim3(kK3WG), 0, st, a, tiles);
             else hipLaunchKernelGGL((k3_bucket_scan<12, true, 4, 8, false, true>), g, dim3(kK3WG), 0, st, a, tiles);
-        } else if (a.k3_depth == 2 && ITER == 12 && nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true, ITER == 12 ? 2 : 4>), g, dim3(kK3WG), 0, st, a, tiles);
-        else if (a.k3_depth == 3 && ITER == 12 && nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true, ITER == 12 ? 3 : 4>), g, dim3(kK3WG), 0, st, a, tiles);
+        } else if (a.k3_depth == 3 && ITER == 12 && nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true, ITER == 12 ? 3 : 4>), g, dim3(kK3WG), 0, st, a, tiles);
         else if (nt) hipLaunchKernelGGL((k3_bucket_scan<ITER, true>), g, dim3(kK3WG), 0, st, a, tiles);
         else hipLaunchKernelGGL((k3_bucket_scan<ITER, false>), g, dim3(kK3WG), 0, st, a, tiles);
     } else if (tier == GSCAN_TIER_LITERAL) {

@@ -162,11 +162,12 @@ def test_parity_patterns(ctx, liboracle, variant):
     ctx.set_option("variant", DEFAULT_VARIANT)
 
 
-@pytest.mark.parametrize("depth", [2, 3, 4])
+@pytest.mark.parametrize("depth", [3, 4])
 def test_k3_filter_depths(ctx, liboracle, depth):
-    """K3 with two, three or four filter positions (option "k3_depth"; the compiler picks 3 or 4, 2 is the form VERDICT r5 task 4
-    asked to be built and measured): the filter only decides what reaches the confirm tables, so every depth lists the same
-    records -- against libpcre for the exact forms, against the compiler's tables for all, ragged sizes included."""
+    """K3 with three or four filter positions whatever the compiler would pick (option "k3_depth"): the filter only decides what
+    reaches the confirm tables, so both depths list the same records -- against libpcre for the exact forms, against the
+    compiler's tables for all, ragged sizes included.  (Two positions: built, green under this test and slower -- session AA,
+    profiles/r06_aa_*.)"""
     ctx.set_option("k3_depth", depth)
     try:
         for name, pattern, tier in KERNEL_FORMS:
@@ -185,7 +186,7 @@ def test_k3_filter_depths(ctx, liboracle, depth):
     finally:
         ctx.set_option("k3_depth", 0)
     with pytest.raises(engine.EngineError):
-        ctx.set_option("k3_depth", 5)
+        ctx.set_option("k3_depth", 2)
 
 
 def runs_text(n, seed):
