@@ -19,6 +19,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a HIP device (run on the MI355X box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """No test may run for ever: a child process that never ends (round 6, session Z: a lost wake-up in the reader pools) took a
+    whole GPU session with it.  With pytest-timeout loaded every test without a limit of its own gets 15 minutes (the slowest
+    takes about one); a --timeout on the command line stands."""
+    if not config.pluginmanager.hasplugin("timeout") or config.getoption("timeout", None):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900))
+
+
 @pytest.fixture(scope="session")
 def built():
     """Product libraries + CLI (hipcc cross-compiles without a GPU)."""
