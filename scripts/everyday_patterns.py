@@ -27,15 +27,18 @@ PATTERNS = [
 
 
 def main():
+    # everyday_patterns.py [GiB] [output flags, default "-O -l"; "" = lines printed, "-O" = lines + offsets] [indices into PATTERNS: 0,7,12]
     gib = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    oflags = (sys.argv[2] if len(sys.argv) > 2 else "-O -l").split()
+    pats = [PATTERNS[int(i)] for i in sys.argv[3].split(",")] if len(sys.argv) > 3 else PATTERNS
     d = "/dev/shm/grab_everyday_%d" % os.getpid()
     nfiles, fb = gib * 16, 64 << 20
     ref = os.path.join(ROOT, "oracle", "_ref", "grab_jit")
     try:
         bench.gen_child("import bench\nbench.gen_corpus(%r, %d, %d)\n" % (d, nfiles, fb))
         cores = bench.usable_cores()
-        for pat in PATTERNS:
-            rec = {"pattern": pat, "bytes": nfiles * fb}
+        for pat in pats:
+            rec = {"pattern": pat, "bytes": nfiles * fb, "flags": " ".join(oflags)}
             try:
                 info = engine.Database(pat).info
                 rec.update({"tier": info.tier, "resolve": info.resolve, "reach": info.reach, "exact": info.exact, "vm": info.vm, "windows": info.n_windows})
@@ -43,7 +46,7 @@ def main():
                 rec["refused"] = str(ex)[:200]
                 print(json.dumps(rec), flush=True)
                 continue
-            argv = [bin_path(), "-n", "8", "-r", "-O", "-l", pat, d]
+            argv = [bin_path(), "-n", "8", "-r"] + oflags + [pat, d]
             n, dg, _ = bench.line_digest(argv)
             best = None
             for _ in range(2):
@@ -55,9 +58,9 @@ def main():
                     best = dt if best is None else min(best, dt)
             rec.update({"lines": n, "wall_s": best and round(best, 3), "GBps": best and round(nfiles * fb / best / 1e9, 2)})
             if os.path.exists(ref):
-                rn, rdg, _ = bench.line_digest([ref, "-n", str(min(64, cores)), "-r", "-O", "-l", pat, d])
+                rn, rdg, _ = bench.line_digest([ref, "-n", str(min(64, cores)), "-r"] + oflags + [pat, d])
                 t0 = time.perf_counter()
-                subprocess.run([ref, "-n", str(cores), "-r", "-O", "-l", pat, d], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                subprocess.run([ref, "-n", str(cores), "-r"] + oflags + [pat, d], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 rt = time.perf_counter() - t0
                 rec.update({"reference_lines": rn, "same_as_reference": dg is not None and dg == rdg and n == rn, "reference_cores": cores,
                             "reference_s": round(rt, 3), "reference_GBps": round(nfiles * fb / rt / 1e9, 2), "vs_reference": best and round(rt / best, 2)})
