@@ -362,7 +362,8 @@ GSCAN_API long gscan_dev_fetch(gscan_ctx *ctx, const gscan_dev_result *res, size
 /* record-buffer capacity (records, split into 8 equal shard regions) for device scans;
  * default = arena bytes / 16 */
 GSCAN_API int gscan_set_capacity(gscan_ctx *ctx, size_t n_records);
-/* tuning knobs for A/B runs: name in {"variant","blocks_per_cu","register_min","line_extents","match_ends"}; see DESIGN.md */
+/* tuning knobs for A/B runs: name in {"variant","blocks_per_cu","register_min","line_extents","match_ends","k3_depth"}; see DESIGN.md
+ * ("k3_depth": 0 = the compiler's choice, 3 / 4 = K3's filter looks at that many window positions -- the records are the same) */
 GSCAN_API int gscan_set_option(gscan_ctx *ctx, const char *name, long value);
 /* scan-kernel time of the gscan_scan_device launches since the last reset: HIP events recorded
  * around each launch on the launch's own stream.  Waits for the launches to finish. */
