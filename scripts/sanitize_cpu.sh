@@ -38,12 +38,11 @@ echo "end of sanitizer reports"
 # lost wake-up of round 6 was found there.)
 unset LD_PRELOAD
 cd "$W/repo/grab_amd/csrc" || exit 1
+cp "$ROOT/grab_amd/lib/libgscan.so" ../lib/libgscan.so   # (the product's own build: the ASan one cannot be loaded beside TSan's runtime; the walk never enters it)
 $CLANG -O1 -g -std=c++17 -fPIC -pthread -fsanitize=thread -DGRAB_PCRE_VALIDATE -idirafter /opt/conda/include -shared filegrep.cc capi_host.cc walk.cc placement.cc \
     -o ../lib/libgrabhost.so -L../lib -lgscan /usr/lib/x86_64-linux-gnu/libpcre.so.3 -Wl,-rpath,'$ORIGIN' >> "$W/logs/build.txt" 2>&1 || { tail "$W/logs/build.txt"; exit 1; }
 sleep 1; touch ../bin/grab ../bin/gscan_sweep
 cd "$W/repo" || exit 1
-# (libgscan.so stays the ASan build: preload both runtimes' worth of symbols is not possible -- TSan's alone; ASan's calls in
-# libgscan.so resolve lazily and the walk never enters it)
 LD_PRELOAD=$($CLANG -print-file-name=libclang_rt.tsan-x86_64.so) TSAN_OPTIONS="log_path=$W/logs/tsan:report_signal_unsafe=0" \
     python -m pytest tests/test_host_cpu.py -q -p no:cacheprovider -k "walk or place" 2>&1 | tail -2
 echo "thread sanitizer reports:"; cat "$W"/logs/tsan.* 2>/dev/null | head -60; echo "end of thread sanitizer reports"
