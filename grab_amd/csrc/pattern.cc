@@ -348,8 +348,12 @@ struct Parser {
             break;
         }
         case '1': case '2': case '3': case '4': case '5': case '6': case '7': case '8': case '9':
-            if (!in_class) return fail(1, "back reference / octal escape");
-            if (c >= '8') return fail(1, "\\8 / \\9 in class");
+            // (outside a class this is reached for \NN with NN >= 10 and fewer than NN groups in the pattern -- parse_backref has
+            // passed -- and pcre_compile then reads an octal escape of up to three digits, as inside a class)
+            if (c >= '8') { // \8 \9 that are no back references: the digit itself
+                s.set((unsigned)c);
+                break;
+            }
             {
                 unsigned v = (unsigned)(c - '0');
                 int k = 1;
@@ -358,7 +362,7 @@ struct Parser {
                     i++;
                     k++;
                 }
-                if (v > 255) return fail(-1, "octal value too large");
+                if (v > 255) return fail(-1, "octal value is greater than \\377 in 8-bit non-UTF-8 mode");
                 s.set(v);
             }
             break;
@@ -582,7 +586,7 @@ struct Parser {
             size_t j = i;
             long v = 0;
             while (j < n && isdigit(p[j]) && v < 100000) v = v * 10 + (p[j++] - '0');
-            if (v >= 10 && v > ngroups) return 0; // an octal escape (or \8 \9): escape() deals with it
+            if (v >= 8 && v > ngroups) return 0; // (pcre_compile: a back reference if the number is < 8 or there are that many groups) an octal escape, or a literal 8 / 9: escape() deals with it
             num = (int)v;
             i = j;
         } else if (c == 'g') {

@@ -520,3 +520,43 @@ def test_deep_group_repeats_and_small_stacks(built, liboracle):
     text = b"ab" * 4000 + b"x"
     assert liboracle.oracle_all_starts(b"(?:ab)+x", text, len(text), s.ctypes.data, e.ctypes.data, 4) >= 1 and (s[0], e[0]) == (0, 8001)
 
+
+
+OCTAL = [  # (pattern, accepted by pcre_compile)
+    (r"\101", True), (r"\377", True), (r"\400", False), (r"\777", False), (r"\12", True), (r"\1011", True), (r"x\1231", True), (r"[\101]x", True), (r"\18", True),
+    (r"\7", False), (r"\8", True), (r"\9", True), (r"\81", True), (r"\80", True), (r"[\8]", True), (r"\08", True), (r"(a)\8", True), (r"(a)\11", True),
+    (r"(a)(b)(c)(d)(e)(f)(g)(h)\8", True), (r"(a)(b)(c)(d)(e)(f)(g)(h)(i)(j)\10", True), (r"(a)(b)(c)(d)(e)(f)(g)(h)(i)(j)\11", True), (r"\11(a)(b)(c)(d)(e)(f)(g)(h)(i)(j)(k)", True),
+]
+
+
+@pytest.mark.parametrize("pattern,ok", OCTAL)
+def test_octal_escapes_and_digits_that_are_no_back_references(pattern, ok, built, liboracle):
+    r"""pcre_compile's rule for \N outside a class: a back reference if N < 8 or the pattern has N groups (anywhere), else \8 \9
+    are the digits themselves and anything else is an octal escape of up to three digits (> \377: an error in 8-bit mode).
+    Until round 6 every such escape was refused ("back reference / octal escape").  minlen and the chunk's output against
+    libpcre under the reference's loop."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import inputs
+    from grab_amd import filegrep
+
+    pb = pattern.encode()
+    ml = C.c_int(-9)
+    rc = liboracle.oracle_minlen(pb, C.byref(ml))
+    assert (rc == 0) == ok
+    if not ok:
+        with pytest.raises(ValueError):
+            engine.Database(pattern)
+        return
+    db = engine.Database(pattern)
+    assert db.minlen == ml.value
+    text = np.frombuffer(b"xxAxx A1 \n yy\t81 9 S \xff z aa\t a\n1 AB 8 80 a8 xS1 \x018 abcdefghijb abcdefghijH abcdefghij\t abcdefgh8 \tabcdefghijk\n".ljust(320, b"."), np.uint8).copy()
+    starts, ends = inputs.resolved_list(db, text) if db.info.resolve else (inputs.engine_list(db, text), None)
+    for flags in (3, 1, 0):
+        out, n = C.c_void_p(), C.c_size_t()
+        assert liboracle.oracle_scan_chunk(pb, b"", text.ctypes.data, text.size, 0, flags, C.byref(out), C.byref(n)) == 0
+        want = C.string_at(out, n.value)
+        liboracle.oracle_free(out)
+        assert filegrep.report_chunk(db, flags, b"", text, 0, starts, ends=ends) == want, (pattern, flags)
