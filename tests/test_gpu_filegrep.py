@@ -136,6 +136,19 @@ def test_literal_flag_S(built, tmp_path):
     assert rc == 0 and out == b"Match at offset 14\n"
 
 
+def test_octal_escapes_through_the_cli(built, oracle_built, tmp_path):
+    r"""\NN outside a class that is no back reference (round 6: pcre_compile's rule, tests/test_pattern.py) end to end: K1 / K2 / K3
+    databases made from such patterns print what the oracle prints."""
+    p = tmp_path / "f"
+    p.write_bytes((b"xxAxx A1 \n yy\t81 9 S \xff z aa\t a\n1 AB 8 80 a8 xS1 \x018 ABBA \tx\n" * 400).ljust(40000, b"."))
+    for pattern in (r"\101", r"\1011", r"x\1231", r"\81", r"\8|\101B", r"\11x|\12\61", r"[\101-\103]{2,}", r"\b\1011\b"):
+        for flags in (["-O", "-l"], []):
+            rc, out, err = _run(built.bin_path(), flags + [pattern, "f"], str(tmp_path))
+            orc, oout, _ = _run(os.path.join(oracle_built, "grab_oracle"), flags + [pattern, "f"], str(tmp_path))
+            assert rc == orc == 0, err
+            assert out == oout and len(out) > 0, (pattern, flags)
+
+
 def test_random_patterns_cli_vs_oracle(built, oracle_built, tmp_path):
     """End to end on the GPU with random patterns of the supported grammar (tests/test_fuzz.py's generator): whatever tier
     the compiler picks, `grab` prints what the oracle (libpcre under the reference's loop) prints for the same file."""
