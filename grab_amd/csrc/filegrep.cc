@@ -387,7 +387,7 @@ int FileGrep::validate(const std::string &regex, bool literal, std::string &why,
     gscan_db *db = nullptr;
     char reason[160] = {0};
     int got = 1;
-    const int rc = gscan_compile(regex.data(), regex.size(), literal ? GSCAN_LITERAL : 0u, &db, &got, reason, sizeof reason);
+    const int rc = gscan_compile(regex.data(), regex.size(), (literal ? GSCAN_LITERAL : 0u) | (cross_check ? GSCAN_PCRE_CHECKED : 0u), &db, &got, reason, sizeof reason);
     if (rc == GSCAN_UNSUPPORTED) {
         why = std::string("FileGrep::prepare: pattern is outside the GPU engine's subset (") + reason + ")";
         return -2;

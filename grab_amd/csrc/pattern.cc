@@ -7,6 +7,7 @@
 #include <cctype>
 #include <cstring>
 #include <functional>
+#include <map>
 
 #include "../../include/gscan.h"
 
@@ -146,6 +147,7 @@ struct Parser {
     bool ungreedy = false; // (?U): quantifiers are lazy unless followed by ?
     bool dupnames = false; // (?J): two groups may share a name -- taken as long as none do
     bool has_accept = false; // (*ACCEPT) somewhere: pcre_study gives no minimum length
+    bool pcre_checked = false; // GSCAN_PCRE_CHECKED
 
     // (?x): white space and #-comments between the items of a pattern mean nothing (not inside [...] or \Q..\E)
     void skip_extended()
@@ -271,6 +273,11 @@ struct Parser {
             return true;
         case 'N':
             if (in_class) return fail(-1, "\\N in class");
+            if (!eof() && p[i] == '{') { // \N{3} is three non-newlines; \N{name} / \N{U+41} is Perl's named character: pcre_compile's error 37
+                uint32_t mn, mx;
+                size_t end;
+                if (!counted(mn, mx, end)) return fail(-1, "PCRE does not support \\L, \\l, \\N{name}, \\U, or \\u");
+            }
             out = set_dot();
             is_set_escape = true;
             return true;
@@ -308,7 +315,7 @@ struct Parser {
                     s.set(v);
                     break;
                 }
-                v = 0; // not a valid \x{..}: falls back to \x with 0 digits
+                return fail(-1, "non-hex character in \\x{} (closing brace missing?)"); // (libpcre >= 8.34: error 79; before that \x with no digits and a literal '{')
             }
             int k = 0;
             while (k < 2 && !eof() && hexval(p[i]) >= 0) {
@@ -374,10 +381,25 @@ struct Parser {
         return true;
     }
 
+    // pcre_compile's check_posix_syntax: from a '[' followed by ':' '.' or '=' (j points at that character), is there the same
+    // character followed by ']' before a ']' or another "[:"?
+    bool posix_syntax(size_t j) const
+    {
+        const int term = p[j];
+        for (j++; j < n; j++) {
+            if (p[j] == '\\' && j + 1 < n && p[j + 1] == ']') j++;
+            else if ((p[j] == '[' && j + 1 < n && p[j + 1] == term) || p[j] == ']') return false;
+            else if (p[j] == term && j + 1 < n && p[j + 1] == ']') return true;
+        }
+        return false;
+    }
+
     bool bracket(ByteSet &out) // i points just past '['
     {
         ByteSet s;
         bool neg = false;
+        // "[:alpha:]" on its own: pcre_compile's error 12
+        if (!eof() && (p[i] == ':' || p[i] == '.' || p[i] == '=') && posix_syntax(i)) return fail(-1, "POSIX named classes are supported only within a class");
         if (!eof() && p[i] == '^') {
             neg = true;
             i++;
@@ -454,7 +476,6 @@ struct Parser {
             }
         range_check:
             if (!lo_is_set && i + 1 < n && p[i] == '-' && p[i + 1] != ']') {
-                size_t save = i;
                 i++;
                 ByteSet hi;
                 bool hi_is_set = false;
@@ -463,23 +484,13 @@ struct Parser {
                 } else if (p[i] == '\\') {
                     i++;
                     if (!escape(hi, true, hi_is_set)) return false;
-                } else if (p[i] == '[' && i + 1 < n && p[i + 1] == ':') {
-                    hi_is_set = true; // "a-[:digit:]": '-' is literal, class handled next round
-                    i = save;
-                    s.merge(lo);
-                    s.set('-');
-                    i++;
-                    continue;
+                } else if (p[i] == '[' && i + 1 < n && (p[i + 1] == ':' || p[i + 1] == '.' || p[i + 1] == '=') && posix_syntax(i + 1)) {
+                    return fail(-1, "invalid range in character class"); // "a-[:digit:]" (libpcre >= 8.34: error 83)
                 } else {
                     hi.set(p[i]);
                     i++;
                 }
-                if (hi_is_set) { // e.g. [a-\d]: '-' literal
-                    s.merge(lo);
-                    s.set('-');
-                    s.merge(hi);
-                    continue;
-                }
+                if (hi_is_set) return fail(-1, "invalid range in character class"); // [a-\d] (libpcre >= 8.34: error 83; before that the '-' was a literal)
                 int l = lo.single(), h = hi.single();
                 if (h < l) return fail(-1, "range out of order in character class");
                 s.set_range((unsigned)l, (unsigned)h);
@@ -1168,7 +1179,11 @@ struct Parser {
                             none.kind = Node::CAT;
                             a.kids.push_back(std::move(none));
                             i = j + 1;
-                            if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?')) return fail(-1, "nothing to repeat");
+                            {
+                                uint32_t mn, mx;
+                                size_t end;
+                                if (!eof() && (p[i] == '*' || p[i] == '+' || p[i] == '?' || (p[i] == '{' && counted(mn, mx, end)))) return fail(-1, "nothing to repeat");
+                            }
                             break;
                         }
                         return fail(1, "backtracking control verb / start-of-pattern setting");
@@ -1300,8 +1315,9 @@ struct Parser {
             // quantifier (a quoted \Q..\E char may be quantified once the quote ended; PCRE
             // applies a quantifier after \E to the last quoted char -- same thing here)
             skip_extended();
-            while (!quoting && i + 1 < n && p[i] == '\\' && p[i + 1] == 'E') { // (a stray \E means nothing: a quantifier behind it is this item's)
-                i += 2;
+            while (!quoting && i + 1 < n && p[i] == '\\' && (p[i + 1] == 'E' || (p[i + 1] == 'Q' && i + 3 < n && p[i + 2] == '\\' && p[i + 3] == 'E'))) {
+                // (a stray \E means nothing, and neither does an empty \Q\E: a quantifier behind them is this item's)
+                i += p[i + 1] == 'E' ? 2 : 4;
                 skip_extended();
             }
             if (!quoting && !eof()) {
@@ -1367,12 +1383,120 @@ struct Parser {
         return true;
     }
 
+    // pcre_compile's error 40, "recursive call could loop indefinitely": a call of group g (0: the pattern) from inside g that can
+    // be reached from g's start without a byte being consumed -- (?R), ((?1)), (a|(?R)), ^(?R), (?=(?R))a, (x)(\\1(?2)).  Returns "the
+    // node may match nothing" the way could_be_empty_branch sees it: assertions are empty, a back reference always may be, a call
+    // may if the group it calls may, a condition if one of its branches (or the else it does not have) may.  `open`: everything in
+    // front of the node, back to g's start, may.
+    // A call of a group that is not complete where the call stands -- a forward reference, or a group the call sits in -- ends
+    // could_be_empty_branch's scan of its branch with "may be empty", whatever follows: ((?2)b(?1))(a) is an error, (b(?2)(?1))(a)
+    // is not.  Hence the nodes' positions (preorder numbers; a group's span is [its own, its last descendant's]).
+    std::vector<const Node *> group_nodes; // [g]: the capturing wrapper of group g
+    std::map<const Node *, std::pair<int, int>> span_;
+    int collect_groups(const Node &nd, int at)
+    {
+        const int mine = at++;
+        if (nd.kind == Node::CAT && nd.cap && nd.group > 0) {
+            if ((size_t)nd.group >= group_nodes.size()) group_nodes.resize((size_t)nd.group + 1, nullptr);
+            if (!group_nodes[(size_t)nd.group]) group_nodes[(size_t)nd.group] = &nd;
+        }
+        for (const Node &k : nd.kids) at = collect_groups(k, at);
+        if (nd.kind == Node::RECURSE || (nd.kind == Node::CAT && nd.cap && nd.group > 0)) span_[&nd] = {mine, at - 1};
+        return at;
+    }
+    bool incomplete_call(const Node &call) const // RECURSE: the called group is not complete at the call
+    {
+        if (call.group == 0) return true;
+        if (call.group < 0 || (size_t)call.group >= group_nodes.size() || !group_nodes[(size_t)call.group]) return false;
+        const auto c = span_.find(&call), g = span_.find(group_nodes[(size_t)call.group]);
+        if (c == span_.end() || g == span_.end()) return false;
+        return g->second.first > c->second.first || g->second.second >= c->second.first; // opens behind the call, or has not closed in front of it
+    }
+    bool scan_left(const Node &nd, int g, bool open, bool &loops, int depth = 0) const
+    {
+        switch (nd.kind) {
+        case Node::SET: return false;
+        case Node::BACKREF: return true;
+        case Node::RECURSE: {
+            if (open && nd.group == g) loops = true;
+            if (incomplete_call(nd)) return true; // (the CAT it stands in makes that the whole branch's answer)
+            if (nd.group == g || nd.group <= 0 || depth > 8 || (size_t)nd.group >= group_nodes.size() || !group_nodes[(size_t)nd.group]) return false;
+            bool ignore = false; // (what the called group calls in its turn is its own business)
+            return scan_left(*group_nodes[(size_t)nd.group], -1, false, ignore, depth + 1);
+        }
+        case Node::CAT: {
+            bool e = true, wild = false;
+            for (const Node &k : nd.kids) {
+                const bool ke = scan_left(k, g, open && e, loops, depth);
+                if (wild) continue; // (the scan of this branch has ended with "may be empty")
+                e = e && ke;
+                if (e && k.kind == Node::RECURSE && incomplete_call(k)) wild = true; // (a quantified call sits in a bracket of its own: ((?2)?b(?1))(a) is fine)
+            }
+            return e;
+        }
+        case Node::ALT: {
+            bool any = nd.kids.empty();
+            for (const Node &k : nd.kids) any = scan_left(k, g, open, loops, depth) || any;
+            return any;
+        }
+        case Node::REP: {
+            if (nd.max == 0 || nd.kids.empty()) return true;
+            const bool ke = scan_left(nd.kids[0], g, open, loops, depth);
+            return ke || nd.min == 0;
+        }
+        case Node::ATOMIC: return nd.kids.empty() ? true : scan_left(nd.kids[0], g, open, loops, depth);
+        case Node::LOOK:
+            // (observed with libpcre 8.39 and 8.45: a call in the SECOND or a later alternative of an assertion is not diagnosed --
+            // (?!(?R))a is an error, (?!a|(?R))b is not; could_be_empty_branch skips an assertion alternative by alternative and an
+            // assertion that is still open has no end to skip to)
+            for (const Node &k : nd.kids) {
+                if (k.kind == Node::ALT) {
+                    for (size_t a = 0; a < k.kids.size(); a++) (void)scan_left(k.kids[a], g, open && a == 0, loops, depth);
+                } else {
+                    (void)scan_left(k, g, open, loops, depth);
+                }
+            }
+            return true;
+        case Node::ASSERT: return true;
+        case Node::COND: {
+            const size_t first = nd.cond == Node::C_ASSERT ? 1 : 0;
+            bool any = nd.kids.size() - first < 2; // no else branch: it is empty
+            // (pcre_compile does not make the check for a call inside a conditional group, whose condition may be there to stop the
+            // recursion -- (?(R)a+|(?R)b) --: cond_depth)
+            for (size_t k = 0; k < nd.kids.size(); k++) {
+                const bool ke = scan_left(nd.kids[k], g, false, loops, depth);
+                if (k >= first) any = any || ke;
+            }
+            return any;
+        }
+        default: return false;
+        }
+    }
+    bool left_recursion(const Node &nd) const
+    {
+        if (nd.kind == Node::COND) return false; // (nothing inside a conditional group is checked: scan_left)
+        // ((?|..) and (?J): a call by number goes to the FIRST group of that number -- only that one can be open around its own call)
+        if (nd.kind == Node::CAT && nd.cap && nd.group > 0 && !nd.kids.empty() && (size_t)nd.group < group_nodes.size() && group_nodes[(size_t)nd.group] == &nd) {
+            bool loops = false;
+            (void)scan_left(nd.kids[0], nd.group, true, loops); // (the wrapper holds the body as its one kid)
+            if (loops) return true;
+        }
+        for (const Node &k : nd.kids)
+            if (left_recursion(k)) return true;
+        return false;
+    }
+
     bool parse(Node &root)
     {
         if (!parse_alt(root)) return false;
         if (!eof()) return fail(-1, "unmatched parentheses"); // a ')' at depth 0
         if (saw_bare_S && saw_bare_hv) return fail(1, "\\S next to \\h or \\v (libpcre's auto-possessification treats them as disjoint; 0xa0 and 0x85 are in both)");
-        return resolve_refs(root);
+        if (!resolve_refs(root)) return false;
+        bool loops = false;
+        (void)collect_groups(root, 0);
+        (void)scan_left(root, 0, true, loops);
+        if (!pcre_checked && (loops || left_recursion(root))) return fail(-1, "recursive call could loop indefinitely");
+        return true;
     }
 };
 
@@ -2746,6 +2870,7 @@ int compile_pattern(const char *pat, size_t len, unsigned flags, Database &db, s
         }
     } else {
         Parser ps{(const unsigned char *)pat, len};
+        ps.pcre_checked = (flags & GSCAN_PCRE_CHECKED) != 0;
         if (!ps.parse(root)) {
             why = ps.why;
             return ps.rc;

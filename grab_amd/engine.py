@@ -14,6 +14,7 @@ from .build import lib_path
 OK, UNSUPPORTED = 0, 1
 EINVAL, ENOMEM, EHIP, EBUSY, EEMPTY, ETOOBIG, EIO = -1, -2, -3, -4, -5, -6, -7
 LITERAL = 1
+PCRE_CHECKED = 2  # GSCAN_PCRE_CHECKED: pcre_compile has accepted the text (what FileGrep::prepare passes)
 TIER_NULL, TIER_LITERAL, TIER_CLASSRUN, TIER_BUCKET, TIER_ANCHORED = 0, 1, 2, 3, 4
 SLOTS = 3  # GSCAN_SLOTS (include/gscan.h): chunks one context keeps in flight
 
@@ -162,14 +163,14 @@ class EngineError(RuntimeError):
 class Database:
     """A compiled pattern (gscan_db). Host only; needs no device."""
 
-    def __init__(self, pattern, literal=False):
+    def __init__(self, pattern, literal=False, pcre_checked=False):
         if isinstance(pattern, str):
             pattern = pattern.encode("latin-1")
         self.pattern = pattern
         self._h = C.c_void_p()
         ml = C.c_int(0)
         err = C.create_string_buffer(200)
-        rc = lib().gscan_compile(pattern, len(pattern), LITERAL if literal else 0, C.byref(self._h), C.byref(ml), err, 200)
+        rc = lib().gscan_compile(pattern, len(pattern), (LITERAL if literal else 0) | (PCRE_CHECKED if pcre_checked else 0), C.byref(self._h), C.byref(ml), err, 200)
         if rc == UNSUPPORTED:
             raise Unsupported(err.value.decode())
         if rc != OK:

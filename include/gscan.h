@@ -63,6 +63,9 @@ extern "C" {
 
 /* gscan_compile flags */
 #define GSCAN_LITERAL 1u /* treat the pattern as a literal byte string (grab's documented -S) */
+#define GSCAN_PCRE_CHECKED 2u /* pcre_compile has accepted this text (FileGrep::prepare asks it first): the one diagnostic the compiler
+                                 mirrors by analysis rather than by syntax -- error 40, "recursive call could loop indefinitely" -- is
+                                 not made, so that no corner of libpcre's rule can turn a pattern it accepts into a refusal */
 
 /* engine tiers (gscan_info.tier) */
 #define GSCAN_TIER_NULL 0    /* pattern can match the empty string: PCRE minlen -1, grab skips every file (Q2) */

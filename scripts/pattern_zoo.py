@@ -48,6 +48,32 @@ ZOO = [
     # PCRE extras
     r"\p{Lu}\p{Ll}+", r"[[:upper:]][[:lower:]]+", r"[[:digit:]]+[[:space:]][[:alpha:]]+", r"\d++\.", r"(?>\w+)\(", r"a*+b", r"(?i:foo)bar", r"foo(?!bar)", r"(?<!foo)bar", r"\Afoo", r"bar\z", r"\bfoo\b|\bbar\b", r"\Bfoo", r"(?s)a.b", r"(?x) f o o  # comment",
     r"(?U)a+", r"a+?b", r"\x41\x42", r"\101", r"[\x00-\x1f]", r"[^\x20-\x7e\n]", r"\R", r"\h+", r"\N+", r"(?|(a)|(b))c", r"(?P<w>\w+) (?P=w)", r"(?:(?:a|b)(?:c|d)){2,}", r"(foo|bar|baz)+qux", r"\Qa.b\E", r"(*UTF8)a", r"(*ANYCRLF)a$", r"a(*SKIP)b", r"(?R)?x", r"\Kfoo", r"(\d+)(?(1)a|b)",
+    # feature variety: empty alternatives, counted / lazy / possessive repeats, anchors and (?m), case folding, high bytes, look-around,
+    # atomic groups, nested repeats, back references by number / name / relative, conditions, class syntax corners, escapes, settings
+    r"a|", r"|a", r"(?:a|)b", r"(?:|a)+b", r"a{0}b", r"a{0,}b", r"a{,3}", r"a{2}{3}", r"x{1,2}?y", r"(?:ab){2,3}?c", r"[a-c]{2,4}+d", r"\d{3,}?\.", r"\w*?\(", r".*?;", r".+?=", r"[^;]*+;", r"(?s).{3}\n", r"(?s)\{.*?\}", r"(?s)/\*.*?\*/",
+    r"(?m)^$", r"(?m)^.{0,3}$", r"(?m)^.*error.*$", r"(?m)^(?!#).+", r"(?m)^(?=.*foo)(?=.*bar).*$", r"(?m)^\s*#.*$", r"(?m)^[^#\n]*=", r"(?m)\S$", r"(?m)^\t+", r"(?m)^ {4}\S", r"(?m)^.{80,}$", r"(?m)^[A-Z].*\.$", r"\A\d+", r"\d+\Z", r"\n\n", r"\r?\n", r"[\r\n]+",
+    r"(?i)ERROR", r"(?i)[a-f]{4}", r"(?i)\bcon(?:nection|fig)\b", r"(?i:a)B", r"(?i)a(?-i)B", r"((?i)a)B", r"(?i)[^a-z]{2}[a-z]", r"(?i)\x41b", r"(?i)straße|strasse", r"(?i)\bé\w+", r"[à-ÿ]+", r"[\x80-\xff]{2,}", r"[^\x00-\x7f]",
+    r"\bfoo\B", r"\B\w\B", r"\b\d+\b(?!\.)", r"(?<=\s)\w+(?=\s)", r"(?<=^|,)\w+", r"(?<=ab|cd)e", r"(?<=a{2})b", r"(?<!\\)\"", r"(?<![a-z])[a-z]{2}(?![a-z])", r"(?<=\d)(?=(?:\d{3})+\b)", r"(?=\d{4})\d{2}", r"(?!0)\d+", r"\w+(?<!ing)\b", r"\b\w+(?<=ed)\b",
+    r"(?>a+)b", r"(?>\d+)\.(?>\d+)", r"(?>[a-z]+|[0-9]+)x", r"a++b", r"[a-z]*+\d", r"(?:a+)+b", r"(?:a*)*b", r"(?:a|aa)+b", r"(a+)+$", r"(\w+\s?)+$", r"(?:\w+\s)*\w+\.", r"(?:[a-z]+,)*[a-z]+;",
+    r"(\w+)=\1", r"(['\"]).*?\1", r"(a)(b)?\2", r"(?:(a)|b)\1", r"(\d)\d\1", r"\b(\w)(\w)\2\1\b", r"(?<n>\d+)-\k<n>", r"(?'q'['\"])\w+\k'q'", r"\g{1}(x)", r"(a)\g{-1}", r"(?i)(foo)\s\1",
+    r"(?(?=\d)\d{2}|[a-z]{2})", r"(a)?(?(1)b|c)", r"(?<q>\")?\w+(?(q)\")", r"(?(?<=a)b|c)",
+    r"[]]", r"[^]]", r"[]a]+", r"[a\]]+", r"[\[\]]", r"[a-]", r"[-a]", r"[a\-z]", r"[\w-]+", r"[\d.]+", r"[\s\S]", r"[^\W\d]+", r"[[:alnum:]_]+", r"[^[:space:]]+", r"[[:^digit:]]{3}", r"[[:punct:]]{2,}", r"[[:xdigit:]]{8}", r"[a-z&&[^aeiou]]",
+    r"\.", r"\\", r"\/", r"\-", r"a\ b", r"\e", r"\a", r"\f", r"\cA", r"\x{41}", r"\o{101}", r"\N{U+41}", r"\p{L}+", r"\P{L}+", r"\pL\pN", r"\p{Lu}", r"\X", r"\C", r"\v+", r"\H+", r"\V+", r"\D{3}", r"\S+@\S+", r"\W{2,}",
+    r"foo.*bar", r"foo.+bar", r"foo.{1,10}bar", r"foo[^\n]*bar", r"foo(?:.|\n)*?bar", r"^foo", r"foo$", r"^foo$", r"(?m)^foo$", r"foo\n", r"foo(?=\n)", r"\bfoo\b.*\bbar\b", r".*foo", r".*", r".+", r".", r"\w", r"a", r"ab", r"abc", r"abcd", r"abcde",
+    r"(?#comment)foo", r"(?x)\d+ \s* # digits\n [a-z]+", r"(?xx)[a b]c", r"(?J)(?<n>a)|(?<n>b)", r"(?-m)^a", r"(?s-i:a.)b", r"(?:(?i)a)b", r"(?^)a",
+    # syntax corners: what pcre_compile rejects the product's compiler has to reject too (and the other way round)
+    r"\cA", r"\c", r"\c[", r"\x", r"\xg", r"\x4", r"\x{", r"\x{41", r"\x{100}", r"\x{}", r"\0", r"\00", r"\012", r"\0123", r"\o{}", r"\o{400}",
+    r"[a-\d]", r"[\d-z]", r"[z-a]", r"[a-a]", r"[\x41-\x43]", r"[[:foo:]]", r"[[.a.]]", r"[[=a=]]", r"[:alpha:]", r"[[:alpha:][:digit:]]", r"[[:alpha:]-z]", r"[a-[:digit:]]", r"[", r"[]", r"[^]", r"[a", r"[\]", r"a]", r"[\b]", r"[\B]", r"[\R]", r"[\X]", r"[\N]", r"[\Qa-c\E]", r"[\E]", r"[a\Q]\E]",
+    r"(?<=a+)b", r"(?<=a|bc)d", r"(?<=(?:a|bc))d", r"(?<=a*)b", r"(?<=a{2,3})b", r"(?<=\Ka)b", r"(?<=\b)a", r"(?<!^)a", r"(?<=a(?=b))b", r"(?<=(a))b", r"(?<=\1)(a)", r"(?<=a\C)b", r"(?<=\R)a", r"(?<=\X)a",
+    r"a**", r"a+*", r"a?*", r"a*?+", r"a{2}*", r"a{2,1}", r"a{65536}", r"a{65535}", r"x{1001}y", r"*a", r"+a", r"?a", r"{1}a", r"a{1", r"a{1,", r"a{,}", r"a|*", r"(*)", r"(+)", r"()", r"(?:)", r"(|)", r"()*", r"(a)*?", r"^*", r"$+", r"\b+", r"(?=a)*", r"(?=a)+b", r"(?!a){2}b", r"\A*a",
+    r"(?P=n)", r"(?P<n>a)(?P=n)", r"(?P<n>a)(?P>n)", r"(?<n>a)\k{n}", r"(?<n>a)\g{n}", r"\g", r"\g1", r"\g{", r"\g{0}", r"\g{-1}", r"\g-1(a)", r"(a)\g+1(b)", r"\k", r"\k<n>", r"(?<1a>x)", r"(?<n>a)(?<n>b)", r"(?<>a)", r"(?P<n", r"(?&n)(?<n>a)", r"(?1)(a)", r"(a)(?1)", r"(?R)", r"(?0)", r"(?+1)(a)", r"(?-1)",
+    r"(?", r"(?<", r"(?a)", r"(?i", r"(?i-", r"(?-)", r"(?i-i)a", r"(?im-sx)a", r"(?i:)", r"(?i:a", r"(?#", r"(?#)a", r"(a", r"a)", r"(?:a", r"(?>a", r"(?|a", r"(?=", r"(?!)", r"(?!)a", r"(*", r"(*FOO)", r"(*ACCEPT)", r"(*FAIL)", r"(*F)a", r"a(*COMMIT)b", r"(*PRUNE)a", r"(*THEN)a", r"(*MARK:x)a", r"(*:x)a", r"(*LF)a", r"(*CR)a", r"(*CRLF)a", r"(*ANY)a", r"(*BSR_ANYCRLF)\R", r"(*BSR_UNICODE)\R", r"(*NO_START_OPT)a", r"(*NO_AUTO_POSSESS)a+b", r"(*UCP)\w", r"(*UTF)a", r"(*LIMIT_MATCH=10)a", r"(*LIMIT_RECURSION=10)a",
+    r"\Qabc", r"\Qa\Eb\Qc", r"\E", r"a\E+", r"\Q\E", r"\Q\Ea", r"a\Q\E*", r"\Q*\E+", r"\Qa|b\E",
+    r"\p{Foo}", r"\p", r"\pZ", r"\p{Z}", r"\p{^Lu}", r"\P{^Lu}", r"\p{L&}", r"\p{Any}", r"\p{Xan}", r"\p{Xps}", r"\p{Xsp}", r"\p{Xwd}", r"\p{Latin}", r"\p{Greek}", r"\p{Nd}+", r"[\p{Lu}\d]+", r"[^\p{L}]",
+    r"(?C)a", r"(?C12)a", r"a(?C1)b", r"(?C256)a", r"\Ga", r"a\G", r"\G", r"(?:\Ga|b)c", r"\L", r"\l", r"\U", r"\u", r"\ua", r"\i", r"\j", r"\y", r"\_", r"\ ", r"\~", r"\%", r"(?X)\j", r"(?X)a",
+    r"(?x)a b", r"(?x)a\ b", r"(?x)[a b]", r"(?x)a#b\nc", r"(?x)a#b", r"(?x) ", r"(?x)(?# c) a", r"(?x)a {2}", r"(?x)a{ 2}", r"(?x)\Q a \E",
+    r"a\z", r"a\Z", r"\za", r"\Za", r"$a", r"a^", r"a^b", r"(?m)a$b", r"(?m)a$\nb", r"a$\n", r"(?m)$\n^", r"^^a", r"a$$", r"(?m)^$^$",
+    r"", r"(?i)", r"(?:)", r"a?", r"a*", r"\b", r"^", r"$", r"(?=a)", r"\K", r"a\Kb", r"(?<=\K)a",
 ]
 
 

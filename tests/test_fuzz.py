@@ -91,7 +91,7 @@ def check(liboracle, pat, texts):
     if liboracle.oracle_minlen(pb, C.byref(ml)) != 0:
         return None  # PCRE rejects it (FileGrep::prepare asks PCRE first and reports its error)
     try:
-        db = engine.Database(pat)
+        db = engine.Database(pat, pcre_checked=True)  # (FileGrep::prepare's sequence: pcre_compile first, then the engine's compiler)
     except engine.Unsupported:
         return None
     assert db.minlen == ml.value, (pat, db.minlen, ml.value)

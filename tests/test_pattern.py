@@ -525,6 +525,7 @@ def test_deep_group_repeats_and_small_stacks(built, liboracle):
 OCTAL = [  # (pattern, accepted by pcre_compile)
     (r"\101", True), (r"\377", True), (r"\400", False), (r"\777", False), (r"\12", True), (r"\1011", True), (r"x\1231", True), (r"[\101]x", True), (r"\18", True),
     (r"\7", False), (r"\8", True), (r"\9", True), (r"\81", True), (r"\80", True), (r"[\8]", True), (r"\08", True), (r"(a)\8", True), (r"(a)\11", True),
+    (r"\N{3}", True), (r"\N{2,}x", True), (r"\N{U+41}", False), (r"\N{a}", False), (r"\N{", False), (r"\N{,3}", False),  # \N{..}: a quantifier or nothing (pcre_compile's error 37)
     (r"(a)(b)(c)(d)(e)(f)(g)(h)\8", True), (r"(a)(b)(c)(d)(e)(f)(g)(h)(i)(j)\10", True), (r"(a)(b)(c)(d)(e)(f)(g)(h)(i)(j)\11", True), (r"\11(a)(b)(c)(d)(e)(f)(g)(h)(i)(j)(k)", True),
 ]
 
@@ -560,3 +561,66 @@ def test_octal_escapes_and_digits_that_are_no_back_references(pattern, ok, built
         want = C.string_at(out, n.value)
         liboracle.oracle_free(out)
         assert filegrep.report_chunk(db, flags, b"", text, 0, starts, ends=ends) == want, (pattern, flags)
+
+
+SYNTAX_CORNERS = [  # accepted by pcre_compile (8.34 and later) or not -- the product's compiler agrees, and where both accept, so do minlen and output
+    (r"\x{41}", True), (r"\x{041}", True), (r"\xg{", True), (r"\x{", False), (r"\x{}", False), (r"\x{41", False), (r"\x{4g}", False), (r"[\x{}]", False),
+    (r"[a-\d]", False), (r"[a-\w]", False), (r"[\x41-\d]", False), (r"[\d-z]", True), (r"[\w-a]", True), (r"[a-b-\d]", True), (r"[a-[:digit:]]", False), (r"[[:digit:]-z]", True),
+    (r"[A-[:x]", True), (r"[+--]", True), (r"[a-z-9]", True), (r"[--a]", True),
+    (r"[:alpha:]", False), (r"x[:alpha:]", False), (r"[=a=]", False), (r"[.a.]", False), (r"[::]", False), (r"[:a-z:]", False), (r"[:a\]:]", False), (r"[:]", True), (r"[a:alpha:]", True),
+    (r"[^:alpha:]", True), (r"[:ab[:digit:]]", True),
+    (r"a\Q\E*b", True), (r"a\Q\E\Q\E{2}", True), (r"a\E\Q\E?b", True), (r"\Q\E*a", False), (r"\Qab\E+c", True),
+]
+
+
+@pytest.mark.parametrize("pattern,ok", SYNTAX_CORNERS)
+def test_syntax_corners_follow_pcre_compile(pattern, ok, built, liboracle):
+    r"""Corners of pcre_compile's syntax the zoo (scripts/pattern_zoo.py) found handled the way libpcre < 8.34 did, or not at all:
+    \x{ must be well formed (error 79), a class escape or POSIX class cannot end a range (error 83), "[:alpha:]" outside a class is
+    an error (12), an empty \Q\E in front of a quantifier means nothing."""
+    test_octal_escapes_and_digits_that_are_no_back_references(pattern, ok, built, liboracle)
+
+
+LEFT_RECURSION = [  # pcre_compile's error 40 ("recursive call could loop indefinitely") and its corners, and quantified verbs; True: libpcre accepts
+    (r"(?R)?x", False), (r"(?R)", False), (r"(?0)", False), (r"a(?R)", True), (r"(?R)a", False), (r"(a|(?R))", False), (r"a(?R)?b", True),
+    (r"(?R)*a", False), (r"(?:(?R))", False), (r"((?1))", False), (r"(a(?1)?)", True), (r"((?1)a)", False), (r"(?1)(a)", True),
+    (r"((?2))((?1))", True), (r"(?:a|(?R))b", False), (r"^(?R)", False), (r"(?=(?R))a", False), (r"\b(?R)", False), (r"(a?(?1))", False),
+    (r"(a*(?1)b)", False), (r"(?<n>(?&n))", False), (r"(?<n>x(?&n)?)", True), (r"((a)|(?1))", False), (r"(a|b(?1))", True),
+    (r"(a|(?2))(b(?1)?)", True), (r"(\1(?1))", False), (r"(x)(\1?(?2))", False), (r"((?(1)a|b)(?1))", True), (r"(?|(?1))", False),
+    (r"(?>(?R))", False), (r"(?:a{0}(?R))", False), (r"((?=a)(?1))", False), (r"((?!a)(?1))", False), (r"(?i)((?1))", False), (r"(a(?R)b|c)", True),
+    (r"(\((?:[^()]|(?1))*\))", True), (r"\((?:[^()]++|(?R))*\)", True), (r"^(?:a(?R)?b)$", True), (r"(?<p>\((?:[^()]|(?&p))*\))", True),
+    (r"(x)(\1(?2))", False), (r"(x?)(\1(?2))", False), (r"(\1a(?1))", True), (r"()(\1(?2))", False), (r"(x)(\1+(?2))", False),
+    (r"(x)(\1{2}(?2))", False), (r"(x)((?1)(?2))", True), (r"(x?)((?1)(?2))", False), (r"(x)((?(1)a)(?2))", False), (r"(x)((?(1)a|b)(?2))", True),
+    (r"(x)((?(1)|b)(?2))", False), (r"(x)((?(?=a)a)(?2))", False), (r"(x)((?(?=a)a|b)(?2))", True), (r"(x)(y)((?1)?(?2)*(?3))", False),
+    (r"(x)(y)((?1)?(?2)(?3))", True), (r"(a|b*)((?1)(?2))", False), (r"((?2)(?1))(a?)", False), (r"((?2)(?1))(a)", False), (r"(a((?1)(?2)))", False),
+    (r"(a((?1)?(?2)))", False), (r"(a(b(?1)(?2)))", True), (r"(b(?2)(?1))(a)", True), (r"((?2)b(?1))(a)", False), (r"(?:(?1)(?R))(a)", False),
+    (r"(?:(?1)x(?R))(a)", False), (r"((?3)(?1))(x)(a)", False), (r"(?<a>(?&b)(?&a))(?<b>x)", False), (r"((?:(?2))b(?1))(a)", True),
+    (r"(?:(?1)|b)x(?R)(a)", True), (r"(x(?2))(a(?1)?)", True), (r"(?:x|(?1)y(?R))(a)", False), (r"((?2)|b(?1))(a)", True),
+    (r"(a(?2)b)(c(?1)?d)", True), (r"((?1)?a)", False), (r"(a|(?1)b)", False), (r"(a|(?1)?b)", False), (r"((?:a|(?1))b)", False),
+    (r"(?:(a)|b)(?1)", True), (r"(?1)(?:(a)|b)", True), (r"(?:(?1))(a)", True), (r"(?!a|(?R))b", True), (r"(?!(?R))a", False),
+    (r"(?(R)a|b)(?R)", True), (r"(?(R)a|)(?R)", False), (r"(?(1)a)(x)(?R)", True), (r"\w{2}(?(1)((?1))+x)", True), (r"(?|(x(?1)?)|((?1)y))", True),
+    (r"(*F){1,2}a", False), (r"a(*FAIL)+", False), (r"(*ACCEPT){2}", False),
+]
+
+
+@pytest.mark.parametrize("pattern,ok", LEFT_RECURSION)
+def test_left_recursion_is_diagnosed_the_way_pcre_compile_does(pattern, ok, built, liboracle):
+    r"""A call of a group from inside it that can be reached without consuming a byte: could_be_empty_branch's view of "may match
+    nothing" (assertions, back references, calls of groups that may, conditions without an else), an incomplete call ends the scan of
+    its branch, nothing inside a conditional group is checked, nor the later alternatives of an assertion; with (?| the first group
+    of a number is the one a call goes to.  With GSCAN_PCRE_CHECKED (what FileGrep::prepare passes once pcre_compile has accepted the
+    text) the diagnosis is not made at all."""
+    ml = C.c_int(-9)
+    assert (liboracle.oracle_minlen(pattern.encode(), C.byref(ml)) == 0) == ok
+    try:
+        db = engine.Database(pattern)
+        assert ok and db.minlen == ml.value, (pattern, db.minlen, ml.value)
+    except engine.Unsupported:
+        pass
+    except ValueError:
+        assert not ok, pattern
+    if ok:
+        try:
+            assert engine.Database(pattern, pcre_checked=True).minlen == ml.value
+        except engine.Unsupported:
+            pass
