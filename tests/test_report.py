@@ -55,7 +55,9 @@ def host_find(db, data, flags, chunk, path=b"", minimal=True):
 
 
 # (the 72 MB fixtures with 80+ byte windows cost 40-110 s each in the numpy stand-in for the kernels; the GPU suite runs them through the CLI)
-_CASES = [c for c in GOLDEN if not c["name"].startswith("syn256") and c["name"] not in ("big_lines_L5", "big_alt_Ol_L5", "cap_big_L5", "big_caret_L5")]
+# (round 6: three more of the 72 MB cases -- 27-66 s each here, a third of the CPU suite's wall clock between them; like the others they
+# run through the CLI on the GPU, tests/test_gpu_filegrep.py::test_cli_matches_reference, and through the oracle in tests/test_oracle.py)
+_CASES = [c for c in GOLDEN if not c["name"].startswith("syn256") and c["name"] not in ("big_lines_L5", "big_alt_Ol_L5", "cap_big_L5", "big_caret_L5", "big_inx_L5", "big_gap_L5", "big2_gap_L5")]
 
 
 @pytest.mark.parametrize("case", _CASES, ids=golden_ids(_CASES))
